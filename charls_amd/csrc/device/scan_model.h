@@ -1,0 +1,278 @@
+// scan_model.h -- JPEG-LS sample arithmetic and context model as device inlines (ISO/IEC 14495-1 annex A as the
+// reference implements it).  Shared by the serial scan kernels and the parallel lossless pipeline.  All int32, no floats.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "scan_types.h"
+
+namespace jls {
+
+#define JLS_DEV __device__ __forceinline__
+
+// J[] run-length order table (reference src/scan_codec.hpp:18-19), 4 bits per entry packed into two 64-bit words.
+JLS_DEV int run_j(int run_index)
+{
+    // {0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3} and {4,4,5,5,6,6,7,7,8,9,10,11,12,13,14,15}
+    const unsigned long long lo = 0x3333222211110000ull;
+    const unsigned long long hi = 0xFEDCBA9877665544ull;
+    const unsigned long long w = run_index < 16 ? lo : hi;
+    return (int)((w >> ((run_index & 15) * 4)) & 15u);
+}
+
+JLS_DEV int log2_ceiling(int n)
+{
+    int x = 0;
+    while (n > (1 << x))
+        ++x;
+    return x;
+}
+
+// reference src/make_scan_codec.cpp:40-156: RANGE/qbpp/LIMIT always derive from 2^bpp - 1.
+JLS_DEV Traits make_traits(const ScanDesc& d)
+{
+    Traits t;
+    t.bpp = d.bits_per_sample;
+    t.near = d.near_lossless;
+    t.maxval = (1 << d.bits_per_sample) - 1;
+    t.range = (t.maxval + 2 * t.near) / (2 * t.near + 1) + 1;
+    t.qbpp = log2_ceiling(t.range);
+    t.limit = 2 * (t.bpp + (t.bpp > 8 ? t.bpp : 8));
+    t.t1 = d.t1;
+    t.t2 = d.t2;
+    t.t3 = d.t3;
+    t.reset = d.reset;
+    return t;
+}
+
+JLS_DEV int initial_a(const Traits& t) // reference src/jpegls_algorithm.hpp:56-60
+{
+    const int a = (t.range + 32) / 64;
+    return a > 2 ? a : 2;
+}
+
+// Gradient quantisation, branch-free form of reference src/jpegls_algorithm.hpp:173-194 (note the asymmetric
+// <= / < on the two sides).
+JLS_DEV int quantize(const Traits& t, int d)
+{
+    const int pos = (d > t.near) + (d >= t.t1) + (d >= t.t2) + (d >= t.t3);
+    const int neg = (d < -t.near) + (d <= -t.t1) + (d <= -t.t2) + (d <= -t.t3);
+    return pos - neg;
+}
+
+JLS_DEV int context_id(const Traits& t, int ra, int rb, int rc, int rd) // src/jpegls_algorithm.hpp:165-168
+{
+    return (quantize(t, rd - rb) * 9 + quantize(t, rb - rc)) * 9 + quantize(t, rc - ra);
+}
+
+JLS_DEV int med_predict(int ra, int rb, int rc) // src/jpegls_algorithm.hpp:143-161
+{
+    const int lo = ra < rb ? ra : rb;
+    const int hi = ra < rb ? rb : ra;
+    const int grad = ra + rb - rc;
+    return rc >= hi ? lo : (rc <= lo ? hi : grad);
+}
+
+JLS_DEV int clamp_sample(const Traits& t, int v) // correct_prediction, src/default_traits.hpp:110-116
+{
+    return v < 0 ? 0 : (v > t.maxval ? t.maxval : v);
+}
+
+JLS_DEV int map_error(int e) // src/jpegls_algorithm.hpp:67-73
+{
+    return (e >> 30) ^ (2 * e);
+}
+
+JLS_DEV int unmap_error(int m) // src/jpegls_algorithm.hpp:80-86
+{
+    return (m >> 1) ^ -(m & 1);
+}
+
+// Errval quantisation + reduction modulo RANGE, src/default_traits.hpp:77-80,123-139,157-163.
+JLS_DEV int error_value(const Traits& t, int e)
+{
+    if (t.near != 0)
+    {
+        const int d = 2 * t.near + 1;
+        e = e > 0 ? (e + t.near) / d : -((t.near - e) / d);
+    }
+    if (e < 0)
+        e += t.range;
+    if (e >= (t.range + 1) / 2)
+        e -= t.range;
+    return e;
+}
+
+// Rx, src/default_traits.hpp:83-87,172-184.
+JLS_DEV int reconstruct(const Traits& t, int predicted, int e)
+{
+    const int step = 2 * t.near + 1;
+    int v = predicted + e * step;
+    if (v < -t.near)
+        v += t.range * step;
+    else if (v > t.maxval + t.near)
+        v -= t.range * step;
+    return clamp_sample(t, v);
+}
+
+JLS_DEV bool is_near(const Traits& t, int a, int b)
+{
+    const int d = a - b;
+    return (d < 0 ? -d : d) <= t.near;
+}
+
+// ---- regular-mode context {A,B,C,N}: src/regular_mode_context.hpp ----------------------------------------------
+struct RegCtx
+{
+    int a, b, c, n;
+};
+
+// k = min{k : N<<k >= A}; returns 16 when the reference raises invalid_data (src/regular_mode_context.hpp:99-136).
+JLS_DEV int regular_k(const RegCtx& x)
+{
+    int k = __clz(x.n) - __clz(x.a); // both > 0
+    k = k < 0 ? 0 : k;
+    k += ((x.n << k) < x.a);
+    return k > 16 ? 16 : k;
+}
+
+JLS_DEV int error_correction(const RegCtx& x, int k_or_near) // src/regular_mode_context.hpp:36-42
+{
+    return k_or_near != 0 ? 0 : ((2 * x.b + x.n - 1) >> 31);
+}
+
+// A.12/A.13 update; returns false when the reference raises invalid_data (src/regular_mode_context.hpp:45-93).
+JLS_DEV bool regular_update(RegCtx& x, int e, int near, int reset)
+{
+    x.a += e < 0 ? -e : e;
+    x.b += e * (2 * near + 1);
+    const int ab = x.b < 0 ? -x.b : x.b;
+    if (x.a >= (1 << 24) || ab >= (1 << 24))
+        return false;
+    if (x.n == reset)
+    {
+        x.a >>= 1;
+        x.b >>= 1;
+        x.n >>= 1;
+    }
+    ++x.n;
+    if (x.b + x.n <= 0)
+    {
+        x.b += x.n;
+        if (x.b <= -x.n)
+            x.b = -x.n + 1;
+        if (x.c > -128)
+            --x.c;
+    }
+    else if (x.b > 0)
+    {
+        x.b -= x.n;
+        if (x.b > 0)
+            x.b = 0;
+        if (x.c < 127)
+            ++x.c;
+    }
+    return true;
+}
+
+// ---- run-interruption context {RItype,A,N,Nn}: src/run_mode_context.hpp ----------------------------------------
+struct RunCtx
+{
+    int ritype, a, n, nn;
+};
+
+JLS_DEV int run_k(const RunCtx& x) // src/run_mode_context.hpp:34-62 (k > 32 -> 33 = invalid for the decoder)
+{
+    const long long temp = (long long)x.a + (long long)(x.n >> 1) * x.ritype;
+    long long n_test = x.n;
+    int k = 0;
+    while (n_test < temp && k <= 33)
+    {
+        n_test <<= 1;
+        ++k;
+    }
+    return k;
+}
+
+JLS_DEV int run_map(const RunCtx& x, int e, int k) // src/run_mode_context.hpp:103-115
+{
+    return (k == 0 && e > 0 && 2 * x.nn < x.n) || (e < 0 && 2 * x.nn >= x.n) || (e < 0 && k != 0);
+}
+
+JLS_DEV void run_update(RunCtx& x, int e, int em, int reset) // src/run_mode_context.hpp:65-83
+{
+    if (e < 0)
+        ++x.nn;
+    x.a += (em + 1 - x.ritype) >> 1;
+    if (x.n == reset)
+    {
+        x.a >>= 1;
+        x.n >>= 1;
+        x.nn >>= 1;
+    }
+    ++x.n;
+}
+
+JLS_DEV int run_error_value(const RunCtx& x, int temp, int k) // src/run_mode_context.hpp:86-99
+{
+    const int map = temp & 1;
+    const int ea = (temp + map) / 2;
+    const int neg = (k != 0 || (2 * x.nn >= x.n)) ? 1 : 0;
+    return neg == map ? -ea : ea;
+}
+
+// ---- colour transforms, src/color_transform.hpp:26-117 (modulo 2^(8*sizeof(sample))) -----------------------------
+JLS_DEV void hp_forward(int xform, bool wide, int r, int g, int b, unsigned out[3])
+{
+    const int range = wide ? 65536 : 256;
+    const int bias = range / 2;
+    const unsigned m = (unsigned)range - 1u;
+    if (xform == 1)
+    {
+        out[0] = (unsigned)(r - g + bias) & m;
+        out[1] = (unsigned)g & m;
+        out[2] = (unsigned)(b - g + bias) & m;
+    }
+    else if (xform == 2)
+    {
+        out[0] = (unsigned)(r - g + bias) & m;
+        out[1] = (unsigned)g & m;
+        out[2] = (unsigned)(b - ((r + g) / 2) + bias) & m;
+    }
+    else
+    {
+        const int v2 = (int)((unsigned)(b - g + bias) & m);
+        const int v3 = (int)((unsigned)(r - g + bias) & m);
+        out[0] = (unsigned)(g + ((v2 + v3) >> 2) - range / 4) & m;
+        out[1] = (unsigned)v2;
+        out[2] = (unsigned)v3;
+    }
+}
+
+JLS_DEV void hp_inverse(int xform, bool wide, int v1, int v2, int v3, unsigned out[3])
+{
+    const int range = wide ? 65536 : 256;
+    const int bias = range / 2;
+    const unsigned m = (unsigned)range - 1u;
+    if (xform == 1)
+    {
+        out[0] = (unsigned)(v1 + v2 - bias) & m;
+        out[1] = (unsigned)v2 & m;
+        out[2] = (unsigned)(v3 + v2 - bias) & m;
+    }
+    else if (xform == 2)
+    {
+        const int r = (int)((unsigned)(v1 + v2 - bias) & m);
+        out[0] = (unsigned)r;
+        out[1] = (unsigned)v2 & m;
+        out[2] = (unsigned)(v3 + ((r + (int)((unsigned)v2 & m)) >> 1) - bias) & m;
+    }
+    else
+    {
+        const int g = v1 - ((v3 + v2) >> 2) + range / 4;
+        out[0] = (unsigned)(v3 + g - bias) & m;
+        out[1] = (unsigned)g & m;
+        out[2] = (unsigned)(v2 + g - bias) & m;
+    }
+}
+
+} // namespace jls

@@ -1,0 +1,49 @@
+// TEST-ONLY: runs a __global__ function (compiled for the host against tests/emu/hip/hip_runtime.h) block by block,
+// one OS thread per GPU thread.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <thread>
+#include <vector>
+
+namespace emu {
+
+template <typename Kernel, typename... Args>
+void launch(Kernel kernel, dim3 grid, dim3 block, size_t dyn_shared_bytes, Args... args)
+{
+    const int n = (int)(block.x * block.y * block.z);
+    std::vector<unsigned char> dyn(dyn_shared_bytes + 16);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx)
+            {
+                BlockState st;
+                st.nthreads = n;
+                st.dyn_shared = dyn.data();
+                pthread_barrier_init(&st.block_barrier, nullptr, n);
+                const int waves = (n + kWave - 1) / kWave;
+                for (int w = 0; w < waves; ++w)
+                {
+                    const int in_wave = (w == waves - 1) ? n - w * kWave : kWave;
+                    pthread_barrier_init(&st.wave_barrier[w], nullptr, in_wave);
+                }
+                g_block = &st;
+                std::vector<std::thread> threads;
+                threads.reserve(n);
+                for (int t = 0; t < n; ++t)
+                    threads.emplace_back([=]() {
+                        t_threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                        t_blockIdx = dim3(bx, by, bz);
+                        t_blockDim = block;
+                        t_gridDim = grid;
+                        kernel(args...);
+                    });
+                for (auto& th : threads)
+                    th.join();
+                pthread_barrier_destroy(&st.block_barrier);
+                for (int w = 0; w < waves; ++w)
+                    pthread_barrier_destroy(&st.wave_barrier[w]);
+            }
+}
+
+} // namespace emu

@@ -1,0 +1,181 @@
+// tests/emu/hip/hip_runtime.h -- TEST-ONLY stand-in for <hip/hip_runtime.h>.
+//
+// There is no GPU in the build container.  To debug the gfx950 kernels' LOGIC before spending GPU minutes, the tests
+// compile the unmodified kernel sources (charls_amd/csrc/device/*.hip) with g++ against this header and run every
+// workgroup as a set of OS threads with real barriers (tests/emu/emu_driver.cpp).  It models: thread/block indices,
+// __shared__ (one workgroup runs at a time, so `static` is the right storage), __syncthreads, 64-lane wave shuffles /
+// ballots, and the atomics the kernels use.  It is never part of the product and says nothing about performance.
+#pragma once
+#include <pthread.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3
+{
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace emu {
+constexpr int kWave = 64;
+struct BlockState
+{
+    pthread_barrier_t block_barrier;
+    pthread_barrier_t wave_barrier[16];
+    unsigned long long xchg[16][kWave]; // per-wave exchange slots for shuffles / ballots
+    int nthreads;
+    unsigned char* dyn_shared;
+};
+extern BlockState* g_block;
+extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+} // namespace emu
+
+#define threadIdx (emu::t_threadIdx)
+#define blockIdx (emu::t_blockIdx)
+#define blockDim (emu::t_blockDim)
+#define gridDim (emu::t_gridDim)
+static const int warpSize = 64;
+
+inline void __syncthreads()
+{
+    pthread_barrier_wait(&emu::g_block->block_barrier);
+}
+
+inline int __clz(int x)
+{
+    return x == 0 ? 32 : __builtin_clz((unsigned)x);
+}
+inline int __clzll(long long x)
+{
+    return x == 0 ? 64 : __builtin_clzll((unsigned long long)x);
+}
+inline int __popc(unsigned x)
+{
+    return __builtin_popcount(x);
+}
+inline int __popcll(unsigned long long x)
+{
+    return __builtin_popcountll(x);
+}
+inline int __ffsll(unsigned long long x)
+{
+    return __builtin_ffsll((long long)x);
+}
+
+namespace emu {
+inline int lane_id()
+{
+    return (int)(t_threadIdx.x % kWave);
+}
+inline int wave_id()
+{
+    return (int)(t_threadIdx.x / kWave);
+}
+inline void wave_sync()
+{
+    pthread_barrier_wait(&g_block->wave_barrier[wave_id()]);
+}
+// All 64 lanes of the wave must call these convergently (the kernels are written that way).
+inline unsigned long long wave_exchange(unsigned long long mine, int src_lane)
+{
+    auto& slots = g_block->xchg[wave_id()];
+    slots[lane_id()] = mine;
+    wave_sync();
+    const unsigned long long v = slots[src_lane & (kWave - 1)];
+    wave_sync();
+    return v;
+}
+} // namespace emu
+
+template <typename T>
+inline T __shfl(T v, int src_lane, int = 64)
+{
+    unsigned long long raw = 0;
+    std::memcpy(&raw, &v, sizeof(T));
+    raw = emu::wave_exchange(raw, src_lane);
+    T out;
+    std::memcpy(&out, &raw, sizeof(T));
+    return out;
+}
+template <typename T>
+inline T __shfl_up(T v, unsigned delta, int = 64)
+{
+    const int l = emu::lane_id();
+    const int src = l - (int)delta;
+    const T got = __shfl(v, src < 0 ? l : src);
+    return src < 0 ? v : got;
+}
+template <typename T>
+inline T __shfl_down(T v, unsigned delta, int = 64)
+{
+    const int l = emu::lane_id();
+    const int src = l + (int)delta;
+    const T got = __shfl(v, src > 63 ? l : src);
+    return src > 63 ? v : got;
+}
+template <typename T>
+inline T __shfl_xor(T v, int mask, int = 64)
+{
+    return __shfl(v, emu::lane_id() ^ mask);
+}
+inline unsigned long long __ballot(int pred)
+{
+    auto& slots = emu::g_block->xchg[emu::wave_id()];
+    slots[emu::lane_id()] = pred ? 1ull : 0ull;
+    emu::wave_sync();
+    unsigned long long m = 0;
+    for (int i = 0; i < emu::kWave; ++i)
+        m |= slots[i] << i;
+    emu::wave_sync();
+    return m;
+}
+inline int __any(int pred)
+{
+    return __ballot(pred) != 0;
+}
+inline int __all(int pred)
+{
+    return __ballot(pred) == ~0ull;
+}
+
+template <typename T>
+inline T atomicAdd(T* p, T v)
+{
+    return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
+}
+template <typename T>
+inline T atomicOr(T* p, T v)
+{
+    return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST);
+}
+template <typename T>
+inline T atomicMax(T* p, T v)
+{
+    T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST))
+    {
+    }
+    return old;
+}
+template <typename T>
+inline T atomicExch(T* p, T v)
+{
+    return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST);
+}
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
+inline unsigned __builtin_amdgcn_readfirstlane(unsigned v)
+{
+    return __shfl(v, 0);
+}

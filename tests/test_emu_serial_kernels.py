@@ -1,0 +1,121 @@
+"""Kernel-logic check on the CPU: scan_serial.hip compiled for the host (tests/emu) vs the golden vectors, scan by scan.
+This is test infrastructure -- it proves the kernel source's logic, not the product path (see tests/test_gpu_*.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+import emu_bind
+import jls_container
+
+CASES = [c for c in common.cases() if c["errc"] == 0 and "file" in c and c["width"] * c["height"] <= 128 * 128]
+
+
+def _scan_views(c, img):
+    """Yield (pixels_view_bytes, stride) per scan of the frame in the user's layout."""
+    bytes_ps = 1 if c["bits_per_sample"] <= 8 else 2
+    raw = np.frombuffer(img.tobytes(), dtype=np.uint8)
+    w, h, nc = c["width"], c["height"], c["component_count"]
+    if c["interleave_mode"] == 0:
+        plane = w * h * bytes_ps
+        return [(raw[i * plane:(i + 1) * plane].copy(), w * bytes_ps) for i in range(nc)]
+    return [(raw.copy(), w * nc * bytes_ps)]
+
+
+@pytest.mark.parametrize("c", CASES, ids=lambda c: c["name"])
+def test_emulated_encode_kernel_matches_reference_scan_bytes(c):
+    L = emu_bind.lib()
+    with open(f"{common.GOLDEN}/{c['file']}", "rb") as f:
+        jls = f.read()
+    cont = jls_container.parse(jls)
+    pc = jls_container.validated_pc(tuple(c["preset"]) if c["preset"] else (0,) * 5, c["bits_per_sample"],
+                                    c["near_lossless"])
+    img = common.case_input(c)
+    views = _scan_views(c, img)
+    assert len(views) == len(cont.scans)
+    keep, descs, outs = [], [], []
+    for (pix, stride), scan in zip(views, cont.scans):
+        out = np.zeros(scan.data_end - scan.data_start + 64, dtype=np.uint8)
+        outs.append(out)
+        descs.append(emu_bind.make_desc(c["width"], c["height"], scan.components, scan.ilv, c["bits_per_sample"],
+                                        scan.near, c["color_transformation"], pc, 0, pix, stride, out, keep))
+    arr = (emu_bind.ScanDesc * len(descs))(*descs)
+    res = (emu_bind.ScanResult * len(descs))()
+    L.emu_encode_scans_serial(arr, res, len(descs))
+    for r, out, scan in zip(res, outs, cont.scans):
+        assert r.errc == 0
+        assert out[:r.bytes].tobytes() == jls[scan.data_start:scan.data_end]
+
+
+@pytest.mark.parametrize("c", CASES, ids=lambda c: c["name"])
+def test_emulated_decode_kernel_matches_reference_pixels(c):
+    L = emu_bind.lib()
+    with open(f"{common.GOLDEN}/{c['file']}", "rb") as f:
+        jls = f.read()
+    cont = jls_container.parse(jls)
+    pc = jls_container.validated_pc(cont.pc, cont.bits, c["near_lossless"])
+    bytes_ps = 1 if cont.bits <= 8 else 2
+    w, h = cont.width, cont.height
+    keep, descs, outs = [], [], []
+    for scan in cont.scans:
+        stride = w * bytes_ps * (1 if scan.ilv == 0 else scan.components)
+        pix = np.zeros(stride * h, dtype=np.uint8)
+        outs.append(pix)
+        src = np.frombuffer(jls[scan.data_start:], dtype=np.uint8).copy()
+        descs.append(emu_bind.make_desc(w, h, scan.components, scan.ilv, cont.bits, scan.near, cont.transform, pc,
+                                        cont.restart_interval, pix, stride, src, keep))
+    arr = (emu_bind.ScanDesc * len(descs))(*descs)
+    res = (emu_bind.ScanResult * len(descs))()
+    L.emu_decode_scans_serial(arr, res, len(descs))
+    got = b"".join(o.tobytes() for o in outs)
+    for r, scan in zip(res, cont.scans):
+        assert r.errc == 0
+        assert r.bytes == scan.data_end - scan.data_start
+    assert common.sha(got) == c["decoded_sha256"]
+
+
+@pytest.mark.parametrize("name,pnm,ilv", [("test8_ilv_none_rm_7", "test8.ppm", 0), ("test8_ilv_sample_rm_300", "test8.ppm", 2)])
+def test_emulated_decode_restart_markers(name, pnm, ilv):
+    L = emu_bind.lib()
+    jls = common.refdata(f"{name}.jls")
+    img, _ = common.read_pnm(pnm)
+    want = (common.planar(img) if ilv == 0 else img).tobytes()
+    cont = jls_container.parse(jls)
+    pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+    keep, descs, outs = [], [], []
+    for scan in cont.scans:
+        stride = cont.width * (1 if scan.ilv == 0 else scan.components)
+        pix = np.zeros(stride * cont.height, dtype=np.uint8)
+        outs.append(pix)
+        src = np.frombuffer(jls[scan.data_start:], dtype=np.uint8).copy()
+        descs.append(emu_bind.make_desc(cont.width, cont.height, scan.components, scan.ilv, cont.bits, scan.near,
+                                        cont.transform, pc, cont.restart_interval, pix, stride, src, keep))
+    arr = (emu_bind.ScanDesc * len(descs))(*descs)
+    res = (emu_bind.ScanResult * len(descs))()
+    L.emu_decode_scans_serial(arr, res, len(descs))
+    assert all(r.errc == 0 for r in res)
+    assert b"".join(o.tobytes() for o in outs) == want
+
+
+@pytest.mark.parametrize("name,errc", [("fuzzy-input-bad-run-mode-golomb-code.jls", 5),
+                                       ("fuzzy_input_golomb_16.jls", 5), ("fuzzy-input-no-valid-bits-at-the-end.jls", 5)])
+def test_emulated_decode_corrupt_streams(name, errc):
+    import oracle_bind as ob
+    L = emu_bind.lib()
+    jls = common.refdata(name)
+    p = ob.read_header(jls)
+    cont = jls_container.parse(jls)
+    pc = jls_container.validated_pc(cont.pc, cont.bits, cont.scans[0].near)
+    scan = cont.scans[0]
+    bytes_ps = 1 if cont.bits <= 8 else 2
+    stride = cont.width * bytes_ps * (1 if scan.ilv == 0 else scan.components)
+    keep = []
+    pix = np.zeros(stride * cont.height, dtype=np.uint8)
+    src = np.frombuffer(jls[scan.data_start:], dtype=np.uint8).copy()
+    d = emu_bind.make_desc(cont.width, cont.height, scan.components, scan.ilv, cont.bits, scan.near, cont.transform, pc,
+                           cont.restart_interval, pix, stride, src, keep)
+    arr = (emu_bind.ScanDesc * 1)(d)
+    res = (emu_bind.ScanResult * 1)()
+    L.emu_decode_scans_serial(arr, res, 1)
+    assert res[0].errc == errc
