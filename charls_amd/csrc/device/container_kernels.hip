@@ -1,0 +1,121 @@
+// container_kernels.hip -- placement of marker segments around device-resident entropy-coded segments (batch API).
+//
+// Every frame of a batch owns one fixed-pitch slot that will hold its complete .jls file.  A per-frame byte cursor lives
+// in device memory, so scans are written straight to their final position with exactly the capacity the reference's
+// writer would hand to scan_encoder::encode_scan (src/charls_jpegls_encoder.cpp:285-296: `writer_.remaining_destination()`):
+//   place_prologue : SOI .. LSE bytes (identical for all frames of a batch)            -> cursor = prologue size
+//   place_scan_header (per scan round): SOS bytes at the cursor, patch ScanDesc.stream/.stream_capacity
+//   <scan kernels>
+//   advance_cursor : cursor += SOS + entropy bytes, latch the first error of the frame
+//   place_epilogue : optional 0xFF fill + EOI (src/jpeg_stream_writer.cpp:26-35)       -> sizes[f]
+#include <hip/hip_runtime.h>
+
+#include "scan_types.h"
+
+namespace jls {
+
+struct FrameCursor
+{
+    uint64_t offset; // bytes of the slot already written
+    uint32_t errc;   // first error of this frame (charls_jpegls_errc), 0 while fine
+    uint32_t pad;
+};
+
+__global__ void place_prologue(uint8_t* __restrict__ slots, uint64_t slot_pitch, const uint8_t* __restrict__ prologue,
+                               uint32_t prologue_size, FrameCursor* __restrict__ cursors, uint32_t frames)
+{
+    const uint32_t f = blockIdx.x;
+    if (f >= frames)
+        return;
+    if (prologue_size > slot_pitch)
+    { // the reference's writer refuses a segment that does not fit (src/jpeg_stream_writer.cpp:229-243)
+        if (threadIdx.x == 0)
+            cursors[f] = FrameCursor{0, kDestinationTooSmall, 0};
+        return;
+    }
+    uint8_t* dst = slots + (uint64_t)f * slot_pitch;
+    for (uint32_t i = threadIdx.x; i < prologue_size; i += blockDim.x)
+        dst[i] = prologue[i];
+    if (threadIdx.x == 0)
+        cursors[f] = FrameCursor{prologue_size, kOk, 0};
+}
+
+// descs[f] describes the scan of this round for frame f; header = SOS segment bytes (same for all frames).
+__global__ void place_scan_header(uint8_t* __restrict__ slots, uint64_t slot_pitch, const uint8_t* __restrict__ header,
+                                  uint32_t header_size, FrameCursor* __restrict__ cursors, ScanDesc* __restrict__ descs,
+                                  uint32_t frames)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames)
+        return;
+    FrameCursor c = cursors[f];
+    uint8_t* slot = slots + (uint64_t)f * slot_pitch;
+    if (c.errc == kOk && c.offset + header_size > slot_pitch)
+    {
+        c.errc = kDestinationTooSmall;
+        cursors[f] = c;
+    }
+    if (c.errc != kOk)
+    { // make the scan kernel a no-op that fails fast without touching memory
+        descs[f].stream = slot;
+        descs[f].stream_capacity = 0;
+        descs[f].height = 0;
+        return;
+    }
+    for (uint32_t i = 0; i < header_size; ++i)
+        slot[c.offset + i] = header[i];
+    descs[f].stream = slot + c.offset + header_size;
+    descs[f].stream_capacity = slot_pitch - c.offset - header_size;
+}
+
+__global__ void advance_cursor(FrameCursor* __restrict__ cursors, const ScanResult* __restrict__ results,
+                               uint32_t header_size, uint32_t frames)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames)
+        return;
+    FrameCursor c = cursors[f];
+    if (c.errc != kOk)
+        return;
+    const ScanResult r = results[f];
+    if (r.errc != kOk)
+        c.errc = r.errc;
+    else
+        c.offset += header_size + r.bytes;
+    cursors[f] = c;
+}
+
+__global__ void place_epilogue(uint8_t* __restrict__ slots, uint64_t slot_pitch, FrameCursor* __restrict__ cursors,
+                               uint32_t even_size, uint64_t* __restrict__ sizes, uint32_t* __restrict__ errcs,
+                               uint32_t frames)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames)
+        return;
+    FrameCursor c = cursors[f];
+    uint8_t* slot = slots + (uint64_t)f * slot_pitch;
+    if (c.errc == kOk)
+    {
+        if (even_size && (c.offset & 1u))
+        {
+            if (c.offset + 1 > slot_pitch)
+                c.errc = kDestinationTooSmall;
+            else
+                slot[c.offset++] = 0xFF;
+        }
+    }
+    if (c.errc == kOk)
+    {
+        if (c.offset + 2 > slot_pitch)
+            c.errc = kDestinationTooSmall;
+        else
+        {
+            slot[c.offset++] = 0xFF;
+            slot[c.offset++] = 0xD9;
+        }
+    }
+    sizes[f] = c.errc == kOk ? c.offset : 0;
+    errcs[f] = c.errc;
+}
+
+} // namespace jls

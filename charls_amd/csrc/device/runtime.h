@@ -1,0 +1,119 @@
+// runtime.h -- host-side HIP plumbing of the engine: device discovery, per-handle stream + device arenas, kernel launches.
+// Compiled by hipcc together with the kernels; the C-ABI facade (host/*.cpp) only sees this interface.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../host/common.h"
+#include "scan_types.h"
+
+namespace jls::dev {
+
+// CHARLS_JPEGLS_ERRC_SUCCESS when a gfx950 device is usable by this process (lazy, thread-safe).
+charls_jpegls_errc device_status() noexcept;
+void require_device(); // raises CHARLS_AMD_ERRC_DEVICE_UNAVAILABLE
+
+inline void hip_check(hipError_t e)
+{
+    if (e != hipSuccess)
+        raise(e == hipErrorOutOfMemory ? CHARLS_JPEGLS_ERRC_NOT_ENOUGH_MEMORY : CHARLS_AMD_ERRC_DEVICE_FAILURE);
+}
+
+// Grow-only device allocation owned by a handle.
+class DeviceBuffer
+{
+public:
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    ~DeviceBuffer() { release(); }
+    void* ensure(size_t bytes);
+    void release() noexcept;
+    template <typename T>
+    T* as() const noexcept
+    {
+        return static_cast<T*>(ptr_);
+    }
+    size_t capacity() const noexcept { return cap_; }
+
+private:
+    void* ptr_{};
+    size_t cap_{};
+};
+
+// Pinned host allocation (descriptor upload / result download without staging copies).
+class PinnedBuffer
+{
+public:
+    PinnedBuffer() = default;
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    ~PinnedBuffer();
+    void* ensure(size_t bytes);
+    template <typename T>
+    T* as() const noexcept
+    {
+        return static_cast<T*>(ptr_);
+    }
+
+private:
+    void* ptr_{};
+    size_t cap_{};
+};
+
+enum class EncodeEngine : int32_t
+{
+    automatic = 0,
+    serial = 1,
+    pipeline = 2
+};
+EncodeEngine encode_engine() noexcept;
+void set_encode_engine(EncodeEngine e) noexcept;
+
+// Samples of line window needed by one scan: 2 * planes * (width + 2).
+inline size_t line_scratch_samples(uint32_t width, int32_t interleave_mode, int32_t components)
+{
+    return 2 * static_cast<size_t>(interleave_mode == 0 ? 1 : components) * (static_cast<size_t>(width) + 2);
+}
+
+// Upper bound of the entropy-coded bytes of one scan: every sample costs at most LIMIT bits (+1 stuffed bit per 8),
+// run-length codes at most 32 + 16 bits per run start; plus the end-of-scan padding.
+inline size_t worst_case_scan_bytes(uint32_t width, uint32_t height, int32_t components, int32_t bits)
+{
+    const size_t limit_bits = 2 * static_cast<size_t>(bits + (bits > 8 ? bits : 8));
+    const size_t samples = static_cast<size_t>(width) * height * static_cast<size_t>(components);
+    const size_t bits_total = samples * (limit_bits + 48);
+    return bits_total / 7 + 64;
+}
+
+// Kernel launches (descs/results are DEVICE pointers).
+void launch_encode_serial(const ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream);
+void launch_decode_serial(const ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream);
+
+// Container placement kernels (container_kernels.hip); all pointers are DEVICE pointers.
+struct FrameCursorPod
+{
+    uint64_t offset;
+    uint32_t errc;
+    uint32_t pad;
+};
+void launch_place_prologue(uint8_t* slots, uint64_t slot_pitch, const uint8_t* prologue, uint32_t prologue_size,
+                           FrameCursorPod* cursors, uint32_t frames, hipStream_t stream);
+void launch_place_scan_header(uint8_t* slots, uint64_t slot_pitch, const uint8_t* header, uint32_t header_size,
+                              FrameCursorPod* cursors, ScanDesc* descs, uint32_t frames, hipStream_t stream);
+void launch_advance_cursor(FrameCursorPod* cursors, const ScanResult* results, uint32_t header_size, uint32_t frames,
+                           hipStream_t stream);
+void launch_place_epilogue(uint8_t* slots, uint64_t slot_pitch, FrameCursorPod* cursors, bool even_size, uint64_t* sizes,
+                           uint32_t* errcs, uint32_t frames, hipStream_t stream);
+
+// Per-thread record of the last batch call's GPU time (charls_amd_last_timings).
+struct Timings
+{
+    double values[8];
+    int32_t count;
+};
+Timings& last_timings() noexcept;
+
+} // namespace jls::dev

@@ -1,0 +1,475 @@
+// batch_api.cpp -- charls_amd_encode_batch_device / charls_amd_decode_batch_device (charls_amd.h part 2).
+//
+// The batch is the engine's native unit: `frame_count` independent frames resident in HBM, every scan of every frame a
+// separate chain of work for the GPU (frames shard with no exchange).  The container bytes around the
+// entropy-coded segments are produced by the same StreamWriter the part-1 encoder uses, and parsed by the same
+// StreamReader the part-1 decoder uses, so each frame's .jls file / error code is what part 1 gives for that frame.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../device/runtime.h"
+#include "common.h"
+#include "preset.h"
+#include "stream_reader.h"
+#include "stream_writer.h"
+
+using namespace jls;
+using dev::hip_check;
+
+namespace {
+
+struct EventTimer
+{
+    hipEvent_t a{}, b{};
+    hipStream_t s;
+    explicit EventTimer(hipStream_t stream) : s(stream)
+    {
+        hip_check(hipEventCreate(&a));
+        hip_check(hipEventCreate(&b));
+    }
+    ~EventTimer()
+    {
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    }
+    void start() { hip_check(hipEventRecord(a, s)); }
+    void stop() { hip_check(hipEventRecord(b, s)); }
+    double ms()
+    {
+        float v = 0;
+        hip_check(hipEventSynchronize(b));
+        hip_check(hipEventElapsedTime(&v, a, b));
+        return v;
+    }
+};
+
+// Validation of the coding parameters: the checks charls_jpegls_encoder::encode_components performs before any scan
+// is coded (reference src/charls_jpegls_encoder.cpp:182-207, 298-358).
+void validate_encode(const charls_amd_codec_params& p, size_t frame_pitch, uint32_t stride_arg, size_t* stride_out,
+                     charls_jpegls_pc_parameters* pc_out)
+{
+    const charls_frame_info& f = p.frame_info;
+    check_argument(f.width >= 1 && f.width <= kMaxDimension, CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_WIDTH);
+    check_argument(f.height >= 1 && f.height <= kMaxDimension, CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_HEIGHT);
+    check_argument(f.bits_per_sample >= kMinBits && f.bits_per_sample <= kMaxBits,
+                   CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_BITS_PER_SAMPLE);
+    check_argument(f.component_count >= 1 && f.component_count <= kMaxComponents,
+                   CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_COMPONENT_COUNT);
+    check_argument(p.near_lossless >= 0 && p.near_lossless <= kMaxNear, CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_NEAR_LOSSLESS);
+    check_argument(p.interleave_mode >= 0 && p.interleave_mode <= 2, CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_INTERLEAVE_MODE);
+    check_argument(p.color_transformation >= 0 && p.color_transformation <= 3,
+                   CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_COLOR_TRANSFORMATION);
+    check_argument(p.encoding_options <= 7u, CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_ENCODING_OPTIONS);
+    if (f.component_count == 1 && p.interleave_mode != 0)
+        raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_INTERLEAVE_MODE);
+    if (p.interleave_mode != 0 && f.component_count > kMaxComponentsInScan)
+        raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_COMPONENT_COUNT);
+    const int32_t bit_maxval = bit_max_value(f.bits_per_sample);
+    int32_t maxval = bit_maxval;
+    if (p.preset_coding_parameters.maximum_sample_value != 0)
+    {
+        if (p.preset_coding_parameters.maximum_sample_value < 1 || p.preset_coding_parameters.maximum_sample_value > bit_maxval)
+            raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_JPEGLS_PC_PARAMETERS);
+        maxval = p.preset_coding_parameters.maximum_sample_value;
+    }
+    if (p.near_lossless > max_near_for(maxval))
+        raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_NEAR_LOSSLESS);
+    const size_t row = static_cast<size_t>(f.width) * bytes_per_sample(f.bits_per_sample) *
+                       (p.interleave_mode == 0 ? 1u : static_cast<size_t>(f.component_count));
+    size_t stride = stride_arg;
+    if (stride == 0)
+        stride = row;
+    else if (stride < row)
+        raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_STRIDE);
+    const size_t need = (p.interleave_mode == 0 ? checked_mul(stride * static_cast<size_t>(f.component_count), f.height)
+                                                : checked_mul(stride, f.height)) -
+                        (stride - row);
+    if (frame_pitch < need)
+        raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
+    if (!pc_validate(p.preset_coding_parameters, bit_maxval, p.near_lossless, pc_out))
+        raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_JPEGLS_PC_PARAMETERS);
+    if (p.color_transformation != 0 && !color_transformation_possible(f, p.near_lossless, p.interleave_mode))
+        raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_COLOR_TRANSFORMATION);
+    *stride_out = stride;
+}
+
+ScanDesc base_desc(const charls_frame_info& f, int32_t components, int32_t ilv, int32_t near, int32_t xform,
+                   const charls_jpegls_pc_parameters& pc, uint32_t restart)
+{
+    ScanDesc d{};
+    d.width = f.width;
+    d.height = f.height;
+    d.components = components;
+    d.interleave_mode = ilv;
+    d.bits_per_sample = f.bits_per_sample;
+    d.near_lossless = near;
+    d.color_transformation = xform;
+    d.t1 = pc.threshold1;
+    d.t2 = pc.threshold2;
+    d.t3 = pc.threshold3;
+    d.reset = static_cast<uint8_t>(pc.reset_value);
+    d.restart_interval = restart;
+    return d;
+}
+
+} // namespace
+
+extern "C" charls_jpegls_errc charls_amd_encode_batch_device(const charls_amd_codec_params* params, uint32_t frame_count,
+                                                             const void* d_frames, size_t frame_pitch_bytes,
+                                                             uint32_t stride_arg, void* d_streams,
+                                                             size_t stream_pitch_bytes, uint64_t* sizes,
+                                                             charls_jpegls_errc* errcs, void* hip_stream)
+try
+{
+    check_pointer(params);
+    check_pointer(sizes);
+    check_pointer(errcs);
+    if (frame_count == 0)
+        return CHARLS_JPEGLS_ERRC_SUCCESS;
+    check_pointer(d_frames);
+    check_pointer(d_streams);
+    dev::require_device();
+    const charls_amd_codec_params& p = *params;
+    size_t stride = 0;
+    charls_jpegls_pc_parameters pc{};
+    validate_encode(p, frame_pitch_bytes, stride_arg, &stride, &pc);
+    const charls_frame_info& f = p.frame_info;
+    auto stream = static_cast<hipStream_t>(hip_stream);
+
+    // ---- container bytes, produced once on the host by the writer of part 1
+    uint8_t prologue[512];
+    StreamWriter w;
+    w.set_destination(prologue, sizeof prologue);
+    w.start_of_image();
+    if (p.encoding_options & 2u)
+    {
+        static const char version[] = "charls 3.0.0";
+        w.comment(reinterpret_cast<const uint8_t*>(version), sizeof version);
+    }
+    if (p.color_transformation != 0)
+        w.color_transform(p.color_transformation);
+    if (f.component_count * 3 + 32 > 400)
+        raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_COMPONENT_COUNT); // batch API: at most ~120 components
+    if (w.start_of_frame(f))
+        w.oversize_dimensions(f.height, f.width);
+    if (!pc_is_default(p.preset_coding_parameters, default_pc(bit_max_value(f.bits_per_sample), p.near_lossless)) ||
+        ((p.encoding_options & 4u) && f.bits_per_sample > 12))
+        w.preset_coding_parameters(pc);
+    const uint32_t prologue_size = static_cast<uint32_t>(w.bytes_written());
+
+    const uint32_t rounds = p.interleave_mode == 0 ? static_cast<uint32_t>(f.component_count) : 1u;
+    const int32_t comps_per_scan = p.interleave_mode == 0 ? 1 : f.component_count;
+    std::vector<std::vector<uint8_t>> sos(rounds);
+    {
+        std::vector<uint8_t> tmp(static_cast<size_t>(rounds) * 16);
+        StreamWriter ws; // one writer for all scans: component identifiers keep counting across scans
+        ws.set_destination(tmp.data(), tmp.size());
+        for (uint32_t r = 0; r < rounds; ++r)
+        {
+            const size_t before = ws.bytes_written();
+            ws.start_of_scan(comps_per_scan, p.near_lossless, p.interleave_mode);
+            sos[r].assign(tmp.data() + before, tmp.data() + ws.bytes_written());
+        }
+    }
+
+    // ---- device work areas
+    const size_t scratch_samples = dev::line_scratch_samples(f.width, p.interleave_mode, comps_per_scan);
+    dev::DeviceBuffer d_descs, d_results, d_cursors, d_scratch, d_blob, d_sizes, d_errcs;
+    d_descs.ensure(sizeof(ScanDesc) * frame_count);
+    d_results.ensure(sizeof(ScanResult) * frame_count);
+    d_cursors.ensure(sizeof(dev::FrameCursorPod) * frame_count);
+    d_scratch.ensure(scratch_samples * sizeof(uint16_t) * frame_count);
+    d_sizes.ensure(sizeof(uint64_t) * frame_count);
+    d_errcs.ensure(sizeof(uint32_t) * frame_count);
+    size_t blob_bytes = prologue_size;
+    for (auto& s : sos)
+        blob_bytes += s.size();
+    std::vector<uint8_t> blob(blob_bytes);
+    std::memcpy(blob.data(), prologue, prologue_size);
+    {
+        size_t o = prologue_size;
+        for (auto& s : sos)
+        {
+            std::memcpy(blob.data() + o, s.data(), s.size());
+            o += s.size();
+        }
+    }
+    d_blob.ensure(blob_bytes);
+    hip_check(hipMemcpyAsync(d_blob.as<uint8_t>(), blob.data(), blob_bytes, hipMemcpyHostToDevice, stream));
+
+    std::vector<ScanDesc> descs(frame_count);
+    auto* slots = static_cast<uint8_t*>(d_streams);
+    const auto* frames = static_cast<const uint8_t*>(d_frames);
+
+    EventTimer total(stream), scans(stream);
+    double scan_ms = 0;
+    total.start();
+    dev::launch_place_prologue(slots, stream_pitch_bytes, d_blob.as<uint8_t>(), prologue_size,
+                               d_cursors.as<dev::FrameCursorPod>(), frame_count, stream);
+    size_t blob_offset = prologue_size;
+    for (uint32_t r = 0; r < rounds; ++r)
+    {
+        for (uint32_t i = 0; i < frame_count; ++i)
+        {
+            ScanDesc d = base_desc(f, comps_per_scan, p.interleave_mode, p.near_lossless, p.color_transformation, pc, 0);
+            d.pixels = const_cast<uint8_t*>(frames) + i * frame_pitch_bytes + (p.interleave_mode == 0 ? r * stride * f.height : 0);
+            d.pixel_stride = stride;
+            d.line_scratch = d_scratch.as<uint16_t>() + i * scratch_samples;
+            descs[i] = d;
+        }
+        hip_check(hipMemcpyAsync(d_descs.as<ScanDesc>(), descs.data(), sizeof(ScanDesc) * frame_count,
+                                 hipMemcpyHostToDevice, stream));
+        hip_check(hipStreamSynchronize(stream)); // descs is reused by the next round
+        const uint32_t sos_size = static_cast<uint32_t>(sos[r].size());
+        dev::launch_place_scan_header(slots, stream_pitch_bytes, d_blob.as<uint8_t>() + blob_offset, sos_size,
+                                      d_cursors.as<dev::FrameCursorPod>(), d_descs.as<ScanDesc>(), frame_count, stream);
+        scans.start();
+        dev::launch_encode_serial(d_descs.as<ScanDesc>(), d_results.as<ScanResult>(), frame_count, stream);
+        scans.stop();
+        dev::launch_advance_cursor(d_cursors.as<dev::FrameCursorPod>(), d_results.as<ScanResult>(), sos_size, frame_count,
+                                   stream);
+        scan_ms += scans.ms();
+        blob_offset += sos_size;
+    }
+    dev::launch_place_epilogue(slots, stream_pitch_bytes, d_cursors.as<dev::FrameCursorPod>(),
+                               (p.encoding_options & 1u) != 0, d_sizes.as<uint64_t>(), d_errcs.as<uint32_t>(),
+                               frame_count, stream);
+    total.stop();
+    hip_check(hipMemcpyAsync(sizes, d_sizes.as<uint64_t>(), sizeof(uint64_t) * frame_count, hipMemcpyDeviceToHost, stream));
+    static_assert(sizeof(charls_jpegls_errc) == sizeof(uint32_t), "errc size");
+    hip_check(hipMemcpyAsync(errcs, d_errcs.as<uint32_t>(), sizeof(uint32_t) * frame_count, hipMemcpyDeviceToHost, stream));
+    hip_check(hipStreamSynchronize(stream));
+    dev::Timings& t = dev::last_timings();
+    t.values[0] = total.ms();
+    t.values[1] = scan_ms;
+    t.count = 2;
+    return CHARLS_JPEGLS_ERRC_SUCCESS;
+}
+catch (...)
+{
+    return current_exception_to_errc();
+}
+
+extern "C" charls_jpegls_errc charls_amd_decode_batch_device(uint32_t frame_count, const void* d_streams,
+                                                             size_t stream_pitch_bytes, const uint64_t* sizes,
+                                                             void* d_frames, size_t frame_pitch_bytes,
+                                                             uint32_t stride_arg, charls_amd_codec_params* params_out,
+                                                             charls_jpegls_errc* errcs, void* hip_stream)
+try
+{
+    check_pointer(sizes);
+    check_pointer(errcs);
+    if (frame_count == 0)
+        return CHARLS_JPEGLS_ERRC_SUCCESS;
+    check_pointer(d_streams);
+    check_pointer(d_frames);
+    dev::require_device();
+    auto stream = static_cast<hipStream_t>(hip_stream);
+    const auto* slots = static_cast<const uint8_t*>(d_streams);
+    auto* frames = static_cast<uint8_t*>(d_frames);
+
+    // Every frame's marker segments are parsed on the host by the part-1 reader.  Only a window of each stream is
+    // fetched: the first `kWindow` bytes up front, later windows at the position each scan ended.
+    constexpr size_t kWindow = 2048;
+    struct Frame
+    {
+        StreamReader reader;
+        std::vector<uint8_t> window; // host copy of [window_base, window_base + window.size())
+        size_t window_base{};
+        size_t cursor{};             // absolute offset of the next unparsed byte
+        size_t plane_offset{};       // destination offset of the next scan
+        uint32_t decoded_components{};
+        charls_jpegls_errc errc{};
+        bool done{};
+    };
+    std::vector<Frame> fr(frame_count);
+
+    auto fetch = [&](uint32_t i, size_t base, size_t bytes) {
+        Frame& x = fr[i];
+        const size_t avail = base < sizes[i] ? static_cast<size_t>(sizes[i]) - base : 0;
+        const size_t n = std::min(bytes, avail);
+        x.window.resize(n);
+        x.window_base = base;
+        if (n)
+            hip_check(hipMemcpyAsync(x.window.data(), slots + i * stream_pitch_bytes + base, n, hipMemcpyDeviceToHost, stream));
+    };
+    // A parse that runs off the end of the window while the stream has more bytes is retried with a larger window.
+    auto parse = [&](uint32_t i, auto&& body) {
+        Frame& x = fr[i];
+        size_t want = kWindow;
+        const StreamReader snapshot = x.reader; // a failed attempt may have advanced the reader's state machine
+        for (;;)
+        {
+            try
+            {
+                body(x);
+                x.errc = CHARLS_JPEGLS_ERRC_SUCCESS;
+                return;
+            }
+            catch (const error& e)
+            {
+                const bool truncated = x.window_base + x.window.size() < sizes[i];
+                if (!truncated || (e.code != CHARLS_JPEGLS_ERRC_NEED_MORE_DATA &&
+                                   e.code != CHARLS_JPEGLS_ERRC_INVALID_MARKER_SEGMENT_SIZE &&
+                                   e.code != CHARLS_JPEGLS_ERRC_DEFINE_NUMBER_OF_LINES_MARKER_NOT_FOUND))
+                {
+                    x.errc = e.code;
+                    x.done = true;
+                    return;
+                }
+            }
+            want *= 8;
+            fetch(i, x.window_base, want);
+            hip_check(hipStreamSynchronize(stream));
+            x.reader = snapshot;
+        }
+    };
+
+    if (stream_pitch_bytes == 0)
+        raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
+    for (uint32_t i = 0; i < frame_count; ++i)
+    {
+        if (sizes[i] > stream_pitch_bytes)
+            raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
+        fetch(i, 0, kWindow);
+    }
+    hip_check(hipStreamSynchronize(stream));
+    for (uint32_t i = 0; i < frame_count; ++i)
+        parse(i, [&](Frame& x) {
+            x.reader.set_source(x.window.data(), x.window.size());
+            x.reader.read_header();
+            if (x.reader.end_of_image())
+                raise(CHARLS_JPEGLS_ERRC_INVALID_OPERATION); // abbreviated table stream: nothing to decode
+            x.cursor = x.window_base + static_cast<size_t>(x.reader.position() - x.window.data());
+        });
+
+    dev::DeviceBuffer d_descs, d_results, d_scratch;
+    d_descs.ensure(sizeof(ScanDesc) * frame_count);
+    d_results.ensure(sizeof(ScanResult) * frame_count);
+    std::vector<ScanDesc> descs(frame_count);
+    std::vector<ScanResult> results(frame_count);
+    std::vector<uint32_t> active;
+    EventTimer total(stream);
+    double scan_ms = 0;
+    bool first_params = true;
+
+    for (;;)
+    {
+        active.clear();
+        size_t scratch_total = 0;
+        for (uint32_t i = 0; i < frame_count; ++i)
+        {
+            Frame& x = fr[i];
+            if (x.done)
+                continue;
+            try
+            {
+                const charls_frame_info& f = x.reader.frame_info();
+                const int32_t ilv = x.reader.scan_interleave_mode();
+                const uint32_t nc = x.reader.scan_component_count();
+                const size_t row = (ilv == 0 ? 1u : nc) * static_cast<size_t>(f.width) * bytes_per_sample(f.bits_per_sample);
+                size_t stride = stride_arg;
+                if (stride == 0)
+                    stride = row;
+                else if (stride < row)
+                    raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_STRIDE);
+                const size_t need = (ilv == 0 ? stride * nc * f.height : stride * f.height) - (stride - row);
+                if (frame_pitch_bytes < x.plane_offset + need)
+                    raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
+                if (params_out && first_params)
+                {
+                    *params_out = charls_amd_codec_params{f, x.reader.parameters().near_lossless, ilv,
+                                                          x.reader.parameters().transformation,
+                                                          x.reader.preset_coding_parameters(), 0};
+                    first_params = false;
+                }
+                ScanDesc d = base_desc(f, static_cast<int32_t>(nc), ilv, x.reader.parameters().near_lossless,
+                                       x.reader.parameters().transformation, x.reader.validated_pc(),
+                                       x.reader.parameters().restart_interval);
+                d.pixels = frames + i * frame_pitch_bytes + x.plane_offset;
+                d.pixel_stride = stride;
+                d.stream = const_cast<uint8_t*>(slots) + i * stream_pitch_bytes + x.cursor;
+                d.stream_capacity = sizes[i] - x.cursor;
+                d.line_scratch = reinterpret_cast<uint16_t*>(scratch_total); // patched below
+                scratch_total += dev::line_scratch_samples(f.width, ilv, static_cast<int32_t>(nc)) * sizeof(uint16_t);
+                scratch_total = (scratch_total + 255) & ~size_t{255};
+                descs[active.size()] = d;
+                active.push_back(i);
+            }
+            catch (const error& e)
+            {
+                x.errc = e.code;
+                x.done = true;
+            }
+        }
+        if (active.empty())
+            break;
+        auto* scratch = static_cast<uint8_t*>(d_scratch.ensure(scratch_total));
+        for (size_t k = 0; k < active.size(); ++k)
+            descs[k].line_scratch = reinterpret_cast<uint16_t*>(scratch + reinterpret_cast<size_t>(descs[k].line_scratch));
+        const uint32_t n = static_cast<uint32_t>(active.size());
+        hip_check(hipMemcpyAsync(d_descs.as<ScanDesc>(), descs.data(), sizeof(ScanDesc) * n, hipMemcpyHostToDevice, stream));
+        total.start();
+        dev::launch_decode_serial(d_descs.as<ScanDesc>(), d_results.as<ScanResult>(), n, stream);
+        total.stop();
+        hip_check(hipMemcpyAsync(results.data(), d_results.as<ScanResult>(), sizeof(ScanResult) * n, hipMemcpyDeviceToHost, stream));
+        hip_check(hipStreamSynchronize(stream));
+        scan_ms += total.ms();
+
+        // advance every frame past its scan; fetch the bytes that follow (next SOS or EOI)
+        for (uint32_t k = 0; k < n; ++k)
+        {
+            Frame& x = fr[active[k]];
+            if (results[k].errc != kOk)
+            {
+                x.errc = static_cast<charls_jpegls_errc>(results[k].errc);
+                x.done = true;
+                continue;
+            }
+            x.cursor += results[k].bytes;
+            fetch(active[k], x.cursor, kWindow);
+        }
+        hip_check(hipStreamSynchronize(stream));
+        for (uint32_t k = 0; k < n; ++k)
+        {
+            const uint32_t i = active[k];
+            Frame& x = fr[i];
+            if (x.done)
+                continue;
+            const charls_frame_info f = x.reader.frame_info();
+            const uint32_t nc = x.reader.scan_component_count();
+            const int32_t ilv = x.reader.scan_interleave_mode();
+            x.decoded_components += nc;
+            const bool last = x.decoded_components == x.reader.component_count();
+            if (!last)
+            {
+                const size_t row = (ilv == 0 ? 1u : nc) * static_cast<size_t>(f.width) * bytes_per_sample(f.bits_per_sample);
+                const size_t stride = stride_arg ? stride_arg : row;
+                x.plane_offset += stride * f.height;
+            }
+            parse(i, [&](Frame& y) {
+                // continue the same reader on the freshly fetched window
+                y.reader.set_source(y.window.data(), y.window.size());
+                if (last)
+                    y.reader.read_end_of_image();
+                else
+                    y.reader.read_next_start_of_scan();
+                y.cursor = y.window_base + static_cast<size_t>(y.reader.position() - y.window.data());
+            });
+            if (last)
+                x.done = true;
+        }
+    }
+    for (uint32_t i = 0; i < frame_count; ++i)
+        errcs[i] = fr[i].errc;
+    dev::Timings& t = dev::last_timings();
+    t.values[0] = scan_ms;
+    t.values[1] = scan_ms;
+    t.count = 2;
+    return CHARLS_JPEGLS_ERRC_SUCCESS;
+}
+catch (...)
+{
+    return current_exception_to_errc();
+}

@@ -1,0 +1,311 @@
+// decoder_api.cpp -- `struct charls_jpegls_decoder` and its 20 extern "C" entry points.
+//
+// Same state machine, checks and error codes as the reference facade (src/charls_jpegls_decoder.cpp:21-533); the scan
+// itself (`make_scan_codec<scan_decoder>()->decode_scan`, :186-189) runs on the GPU through ScanEngine.
+#include <new>
+
+#include "common.h"
+#include "scan_engine.h"
+#include "stream_reader.h"
+
+using namespace jls;
+
+struct charls_jpegls_decoder
+{
+    enum class State
+    {
+        initial,
+        source_set,
+        spiff_header_read,
+        spiff_header_not_found,
+        header_read,
+        completed
+    };
+
+    void check_header_read() const { check_operation(state >= State::header_read); }
+    void check_completed() const { check_operation(state == State::completed); }
+
+    size_t minimum_stride() const noexcept // reference :238-244
+    {
+        const size_t planes = reader.scan_interleave_mode() == 0 ? 1u : static_cast<size_t>(reader.scan_component_count());
+        return planes * reader.frame_info().width * bytes_per_sample(reader.frame_info().bits_per_sample);
+    }
+
+    size_t destination_size(size_t stride) const // reference :92-121
+    {
+        check_header_read();
+        const charls_frame_info& f = reader.frame_info();
+        if (stride == 0)
+            return checked_mul(checked_mul(checked_mul(static_cast<size_t>(f.component_count), f.height), f.width),
+                               bytes_per_sample(f.bits_per_sample));
+        check_argument(reader.component_count() > 0);
+        if (reader.interleave_mode(0) == 0)
+        {
+            const size_t min_stride = static_cast<size_t>(f.width) * bytes_per_sample(f.bits_per_sample);
+            check_argument(stride >= min_stride, CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_STRIDE);
+            return checked_mul(checked_mul(stride, static_cast<size_t>(f.component_count)), f.height) - (stride - min_stride);
+        }
+        const size_t min_stride =
+            static_cast<size_t>(f.width) * static_cast<size_t>(f.component_count) * bytes_per_sample(f.bits_per_sample);
+        check_argument(stride >= min_stride, CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_STRIDE);
+        return checked_mul(stride, f.height) - (stride - min_stride);
+    }
+
+    void decode(void* destination, size_t destination_size_bytes, size_t stride_arg) // reference :177-201
+    {
+        check_buffer(destination, destination_size_bytes);
+        check_operation(state == State::header_read);
+        auto* dst = static_cast<uint8_t*>(destination);
+        size_t dst_left = destination_size_bytes;
+        const uint8_t* base = reader.position();
+        bool uploaded = false;
+
+        for (size_t component = 0;;)
+        {
+            // reference :211-236
+            const size_t min_stride = minimum_stride();
+            size_t stride = stride_arg;
+            if (stride == 0)
+                stride = min_stride;
+            else if (stride < min_stride)
+                raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_STRIDE);
+            const size_t unused = stride - min_stride;
+            const uint32_t height = reader.frame_info().height;
+            const size_t needed = (reader.scan_interleave_mode() == 0
+                                       ? stride * reader.scan_component_count() * height
+                                       : stride * height) -
+                                  unused;
+            if (dst_left < needed)
+                raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
+
+            const charls_frame_info& f = reader.frame_info();
+            const ScanSpec spec{f.width,
+                                f.height,
+                                static_cast<int32_t>(reader.scan_component_count()),
+                                reader.parameters().interleave_mode,
+                                f.bits_per_sample,
+                                reader.parameters().near_lossless,
+                                reader.parameters().transformation,
+                                reader.validated_pc(),
+                                reader.parameters().restart_interval};
+            if (!uploaded)
+            { // everything from the first entropy-coded byte to the end of the source goes to the device once
+                engine.upload_stream(base, reader.remaining());
+                uploaded = true;
+            }
+            const size_t used = engine.decode_scan(spec, static_cast<size_t>(reader.position() - base), dst, stride);
+            reader.advance(used);
+
+            component += reader.scan_component_count();
+            if (component == reader.component_count())
+                break;
+            dst += stride * height;
+            dst_left -= stride * height;
+            reader.read_next_start_of_scan();
+        }
+        reader.read_end_of_image();
+        state = State::completed;
+    }
+
+    State state{State::initial};
+    StreamReader reader;
+    ScanEngine engine;
+};
+
+#define JLS_THUNK_BEGIN try {
+#define JLS_THUNK_END                          \
+    return CHARLS_JPEGLS_ERRC_SUCCESS;         \
+    }                                          \
+    catch (...) { return current_exception_to_errc(); }
+
+using D = charls_jpegls_decoder;
+
+extern "C" {
+
+charls_jpegls_decoder* charls_jpegls_decoder_create(void)
+{
+    return new (std::nothrow) charls_jpegls_decoder;
+}
+
+void charls_jpegls_decoder_destroy(const charls_jpegls_decoder* decoder)
+{
+    delete decoder;
+}
+
+charls_jpegls_errc charls_jpegls_decoder_set_source_buffer(charls_jpegls_decoder* d, const void* source, size_t size)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d);
+    check_buffer(source, size);
+    check_operation(d->state == D::State::initial);
+    d->reader.set_source(static_cast<const uint8_t*>(source), size);
+    d->state = D::State::source_set;
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_jpegls_decoder_read_spiff_header(charls_jpegls_decoder* d, charls_spiff_header* header,
+                                                           int32_t* header_found)
+{
+    JLS_THUNK_BEGIN
+    // C++17 evaluates the right side of the reference's `*check_pointer(header_found) = ...->read_header(...)` first:
+    // the header is parsed (and the state advanced) before a null `header_found` is reported.
+    check_pointer(d);
+    check_pointer(header);
+    check_operation(d->state == D::State::source_set);
+    bool found = false;
+    d->reader.read_header(header, &found);
+    d->state = found ? D::State::spiff_header_read : D::State::spiff_header_not_found;
+    *check_pointer(header_found) = found ? 1 : 0;
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_jpegls_decoder_read_header(charls_jpegls_decoder* d)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d);
+    check_operation(d->state >= D::State::source_set && d->state < D::State::header_read);
+    if (d->state != D::State::spiff_header_not_found)
+        d->reader.read_header();
+    d->state = d->reader.end_of_image() ? D::State::completed : D::State::header_read;
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_jpegls_decoder_get_frame_info(const charls_jpegls_decoder* d, charls_frame_info* frame_info)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->check_header_read(); // value first, output pointer second (reference evaluation order)
+    *check_pointer(frame_info) = d->reader.frame_info();
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_jpegls_decoder_get_near_lossless(const charls_jpegls_decoder* d, int32_t component_index,
+                                                           int32_t* near_lossless)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->check_header_read();
+    check_argument(static_cast<size_t>(component_index) < d->reader.component_count());
+    *check_pointer(near_lossless) = d->reader.near_lossless(static_cast<size_t>(component_index));
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_jpegls_decoder_get_interleave_mode(const charls_jpegls_decoder* d, int32_t component_index,
+                                                             charls_interleave_mode* mode)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->check_header_read();
+    check_argument(static_cast<size_t>(component_index) < d->reader.component_count());
+    *check_pointer(mode) = d->reader.interleave_mode(static_cast<size_t>(component_index));
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_jpegls_decoder_get_preset_coding_parameters(const charls_jpegls_decoder* d, int32_t /*reserved*/,
+                                                                      charls_jpegls_pc_parameters* pc)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->check_header_read();
+    *check_pointer(pc) = d->reader.preset_coding_parameters();
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_jpegls_decoder_get_color_transformation(const charls_jpegls_decoder* d,
+                                                                  charls_color_transformation* transformation)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->check_header_read();
+    *check_pointer(transformation) = d->reader.parameters().transformation;
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_jpegls_decoder_get_destination_size(const charls_jpegls_decoder* d, uint32_t stride,
+                                                              size_t* size)
+{
+    JLS_THUNK_BEGIN
+    const size_t value = check_pointer(d)->destination_size(stride);
+    *check_pointer(size) = value;
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_jpegls_decoder_decode_to_buffer(charls_jpegls_decoder* d, void* destination, size_t size,
+                                                          uint32_t stride)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->decode(destination, size, stride);
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_jpegls_decoder_at_comment(charls_jpegls_decoder* d, charls_at_comment_handler handler,
+                                                    void* user_context)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->reader.at_comment(handler, user_context);
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_jpegls_decoder_at_application_data(charls_jpegls_decoder* d,
+                                                             charls_at_application_data_handler handler,
+                                                             void* user_context)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->reader.at_application_data(handler, user_context);
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_decoder_get_compressed_data_format(const charls_jpegls_decoder* d,
+                                                             charls_compressed_data_format* format)
+{
+    JLS_THUNK_BEGIN
+    const charls_compressed_data_format value = check_pointer(d)->reader.compressed_data_format();
+    *check_pointer(format) = value;
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_decoder_get_mapping_table_id(const charls_jpegls_decoder* d, int32_t component_index,
+                                                       int32_t* table_id)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->check_completed();
+    check_argument(static_cast<size_t>(component_index) < d->reader.component_count());
+    *check_pointer(table_id) = d->reader.mapping_table_id(static_cast<size_t>(component_index));
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_decoder_find_mapping_table_index(const charls_jpegls_decoder* d, int32_t mapping_table_id,
+                                                           int32_t* index)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->check_completed();
+    check_argument(mapping_table_id >= 1 && mapping_table_id <= 255);
+    *check_pointer(index) = d->reader.find_mapping_table_index(static_cast<uint8_t>(mapping_table_id));
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_decoder_get_mapping_table_count(const charls_jpegls_decoder* d, int32_t* count)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->check_completed();
+    *check_pointer(count) = static_cast<int32_t>(d->reader.mapping_table_count());
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_decoder_get_mapping_table_info(const charls_jpegls_decoder* d, int32_t index,
+                                                         charls_mapping_table_info* info)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->check_completed();
+    check_argument(static_cast<size_t>(index) < d->reader.mapping_table_count());
+    *check_pointer(info) = d->reader.mapping_table_info(static_cast<size_t>(index));
+    JLS_THUNK_END
+}
+
+charls_jpegls_errc charls_decoder_get_mapping_table_data(const charls_jpegls_decoder* d, int32_t index, void* data,
+                                                         size_t size)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(d)->check_completed();
+    check_argument(static_cast<size_t>(index) < d->reader.mapping_table_count());
+    check_buffer(data, size);
+    d->reader.mapping_table_data(static_cast<size_t>(index), static_cast<uint8_t*>(data), size);
+    JLS_THUNK_END
+}
+
+} // extern "C"

@@ -1,0 +1,316 @@
+/*
+ * charls_amd.h -- C ABI of the MI355X-native JPEG-LS engine.
+ *
+ * Part 1 is the drop-in boundary: the 48 entry points, enums and four POD structs of team-charls/charls 3.0, with the
+ * same names, argument meaning, state machines and error codes, so that a program built against the reference's own
+ * <charls/charls.h> runs unchanged when libcharls_amd.so is loaded in place of libcharls.so.3.  Each declaration cites
+ * the reference interface it replaces (paths relative to the reference tree).  Source/destination buffers passed to
+ * part 1 are HOST memory, borrowed for the duration of the call exactly as in the reference.
+ *
+ * Part 2 (prefix charls_amd_) is additive: batch entry points working on DEVICE-resident frames, which is how the
+ * engine is meant to be fed at scale (independent frames / scans are the sharding unit across wavefronts and GPUs).
+ *
+ * Plain C: opaque handles, plain pointers and sizes, no C++ or torch types cross this boundary
+ * (the one exception, charls_get_jpegls_category, is inherited from the reference and documented there).
+ */
+#ifndef CHARLS_AMD_H
+#define CHARLS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define CHARLS_AMD_API __attribute__((visibility("default")))
+#else
+#define CHARLS_AMD_API
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Types: include/charls/public_types.h:28-187 (enums), :934-1034 (structs; sizes 40/16/20/12 asserted at :1075-1078)
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef int32_t charls_jpegls_errc; /* enum charls_jpegls_errc, int32-sized; values below */
+enum
+{
+    CHARLS_JPEGLS_ERRC_SUCCESS = 0,
+    CHARLS_JPEGLS_ERRC_NOT_ENOUGH_MEMORY = 1,
+    CHARLS_JPEGLS_ERRC_CALLBACK_FAILED = 2,
+    CHARLS_JPEGLS_ERRC_DESTINATION_TOO_SMALL = 3,
+    CHARLS_JPEGLS_ERRC_NEED_MORE_DATA = 4,
+    CHARLS_JPEGLS_ERRC_INVALID_DATA = 5,
+    CHARLS_JPEGLS_ERRC_ENCODING_NOT_SUPPORTED = 6,
+    CHARLS_JPEGLS_ERRC_PARAMETER_VALUE_NOT_SUPPORTED = 7,
+    CHARLS_JPEGLS_ERRC_COLOR_TRANSFORM_NOT_SUPPORTED = 8,
+    CHARLS_JPEGLS_ERRC_JPEGLS_PRESET_EXTENDED_PARAMETER_TYPE_NOT_SUPPORTED = 9,
+    CHARLS_JPEGLS_ERRC_JPEG_MARKER_START_BYTE_NOT_FOUND = 10,
+    CHARLS_JPEGLS_ERRC_START_OF_IMAGE_MARKER_NOT_FOUND = 11,
+    CHARLS_JPEGLS_ERRC_INVALID_SPIFF_HEADER = 12,
+    CHARLS_JPEGLS_ERRC_UNKNOWN_JPEG_MARKER_FOUND = 13,
+    CHARLS_JPEGLS_ERRC_UNEXPECTED_START_OF_SCAN_MARKER = 14,
+    CHARLS_JPEGLS_ERRC_INVALID_MARKER_SEGMENT_SIZE = 15,
+    CHARLS_JPEGLS_ERRC_DUPLICATE_START_OF_IMAGE_MARKER = 16,
+    CHARLS_JPEGLS_ERRC_DUPLICATE_START_OF_FRAME_MARKER = 17,
+    CHARLS_JPEGLS_ERRC_DUPLICATE_COMPONENT_ID_IN_SOF_SEGMENT = 18,
+    CHARLS_JPEGLS_ERRC_UNEXPECTED_END_OF_IMAGE_MARKER = 19,
+    CHARLS_JPEGLS_ERRC_INVALID_JPEGLS_PRESET_PARAMETER_TYPE = 20,
+    CHARLS_JPEGLS_ERRC_MISSING_END_OF_SPIFF_DIRECTORY = 21,
+    CHARLS_JPEGLS_ERRC_UNEXPECTED_RESTART_MARKER = 22,
+    CHARLS_JPEGLS_ERRC_RESTART_MARKER_NOT_FOUND = 23,
+    CHARLS_JPEGLS_ERRC_END_OF_IMAGE_MARKER_NOT_FOUND = 24,
+    CHARLS_JPEGLS_ERRC_UNEXPECTED_DEFINE_NUMBER_OF_LINES_MARKER = 25,
+    CHARLS_JPEGLS_ERRC_DEFINE_NUMBER_OF_LINES_MARKER_NOT_FOUND = 26,
+    CHARLS_JPEGLS_ERRC_UNKNOWN_COMPONENT_ID = 27,
+    CHARLS_JPEGLS_ERRC_ABBREVIATED_FORMAT_AND_SPIFF_HEADER_MISMATCH = 28,
+    CHARLS_JPEGLS_ERRC_INVALID_PARAMETER_WIDTH = 29,
+    CHARLS_JPEGLS_ERRC_INVALID_PARAMETER_HEIGHT = 30,
+    CHARLS_JPEGLS_ERRC_INVALID_PARAMETER_BITS_PER_SAMPLE = 31,
+    CHARLS_JPEGLS_ERRC_INVALID_PARAMETER_COMPONENT_COUNT = 32,
+    CHARLS_JPEGLS_ERRC_INVALID_PARAMETER_INTERLEAVE_MODE = 33,
+    CHARLS_JPEGLS_ERRC_INVALID_PARAMETER_NEAR_LOSSLESS = 34,
+    CHARLS_JPEGLS_ERRC_INVALID_PARAMETER_JPEGLS_PRESET_PARAMETERS = 35,
+    CHARLS_JPEGLS_ERRC_INVALID_PARAMETER_COLOR_TRANSFORMATION = 36,
+    CHARLS_JPEGLS_ERRC_INVALID_PARAMETER_MAPPING_TABLE_ID = 37,
+    CHARLS_JPEGLS_ERRC_INVALID_PARAMETER_MAPPING_TABLE_CONTINUATION = 38,
+    CHARLS_JPEGLS_ERRC_INVALID_OPERATION = 100,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT = 101,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_WIDTH = 102,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_HEIGHT = 103,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_BITS_PER_SAMPLE = 104,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_COMPONENT_COUNT = 105,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_INTERLEAVE_MODE = 106,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_NEAR_LOSSLESS = 107,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_JPEGLS_PC_PARAMETERS = 108,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_COLOR_TRANSFORMATION = 109,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE = 110,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_STRIDE = 111,
+    CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_ENCODING_OPTIONS = 112,
+    /* additive, never produced by the reference: the engine has no CPU fallback, so a missing / failing GPU is an error */
+    CHARLS_AMD_ERRC_DEVICE_UNAVAILABLE = 200,
+    CHARLS_AMD_ERRC_DEVICE_FAILURE = 201
+};
+
+typedef int32_t charls_interleave_mode; /* 0 none, 1 line, 2 sample */
+typedef int32_t charls_color_transformation; /* 0 none, 1 HP1, 2 HP2, 3 HP3 */
+typedef uint32_t charls_encoding_options; /* 1 even size, 2 version comment, 4 pc parameters (JAI) */
+typedef int32_t charls_compressed_data_format; /* 0 unknown, 1 interchange, 2 abbreviated image, 3 abbreviated tables */
+typedef int32_t charls_spiff_profile_id;
+typedef int32_t charls_spiff_color_space;
+typedef int32_t charls_spiff_compression_type;
+typedef int32_t charls_spiff_resolution_units;
+
+typedef struct charls_spiff_header
+{
+    charls_spiff_profile_id profile_id;
+    int32_t component_count;
+    uint32_t height;
+    uint32_t width;
+    charls_spiff_color_space color_space;
+    int32_t bits_per_sample;
+    charls_spiff_compression_type compression_type;
+    charls_spiff_resolution_units resolution_units;
+    uint32_t vertical_resolution;
+    uint32_t horizontal_resolution;
+} charls_spiff_header;
+
+typedef struct charls_frame_info
+{
+    uint32_t width;
+    uint32_t height;
+    int32_t bits_per_sample;
+    int32_t component_count;
+} charls_frame_info;
+
+typedef struct charls_jpegls_pc_parameters
+{
+    int32_t maximum_sample_value;
+    int32_t threshold1;
+    int32_t threshold2;
+    int32_t threshold3;
+    int32_t reset_value;
+} charls_jpegls_pc_parameters;
+
+typedef struct charls_mapping_table_info
+{
+    int32_t table_id;
+    int32_t entry_size;
+    uint32_t data_size;
+} charls_mapping_table_info;
+
+typedef int32_t (*charls_at_comment_handler)(const void* data, size_t size, void* user_context);
+typedef int32_t (*charls_at_application_data_handler)(int32_t application_data_id, const void* data, size_t size,
+                                                      void* user_context);
+
+typedef struct charls_jpegls_encoder charls_jpegls_encoder;
+typedef struct charls_jpegls_decoder charls_jpegls_decoder;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Part 1a -- encoder: include/charls/charls_jpegls_encoder.h:25-318, implemented by src/charls_jpegls_encoder.cpp
+ * ---------------------------------------------------------------------------------------------------------------- */
+CHARLS_AMD_API charls_jpegls_encoder* charls_jpegls_encoder_create(void);                                   /* :25 */
+CHARLS_AMD_API void charls_jpegls_encoder_destroy(const charls_jpegls_encoder* encoder);                    /* :33 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_set_frame_info(charls_jpegls_encoder* encoder,
+                                                                       const charls_frame_info* frame_info); /* :42 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_set_near_lossless(charls_jpegls_encoder* encoder,
+                                                                          int32_t near_lossless);            /* :52 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_set_encoding_options(charls_jpegls_encoder* encoder,
+                                                                             charls_encoding_options options); /* :61 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_set_interleave_mode(charls_jpegls_encoder* encoder,
+                                                                            charls_interleave_mode mode);    /* :72 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_set_preset_coding_parameters(
+    charls_jpegls_encoder* encoder, const charls_jpegls_pc_parameters* preset_coding_parameters);           /* :85 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_set_color_transformation(
+    charls_jpegls_encoder* encoder, charls_color_transformation color_transformation);                      /* :99 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_set_mapping_table_id(charls_jpegls_encoder* encoder,
+                                                                             int32_t component_index,
+                                                                             int32_t table_id);             /* :110 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_get_estimated_destination_size(
+    const charls_jpegls_encoder* encoder, size_t* size_in_bytes);                                           /* :123 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_set_destination_buffer(charls_jpegls_encoder* encoder,
+                                                                               void* destination_buffer,
+                                                                               size_t destination_size_bytes); /* :136 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_write_standard_spiff_header(
+    charls_jpegls_encoder* encoder, charls_spiff_color_space color_space, charls_spiff_resolution_units resolution_units,
+    uint32_t vertical_resolution, uint32_t horizontal_resolution);                                          /* :152 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_write_spiff_header(charls_jpegls_encoder* encoder,
+                                                                           const charls_spiff_header* spiff_header); /* :166 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_write_spiff_entry(charls_jpegls_encoder* encoder,
+                                                                          uint32_t entry_tag, const void* entry_data,
+                                                                          size_t entry_data_size_bytes);    /* :182 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_write_spiff_end_of_directory_entry(
+    charls_jpegls_encoder* encoder);                                                                        /* :197 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_write_comment(charls_jpegls_encoder* encoder,
+                                                                      const void* comment, size_t comment_size_bytes); /* :211 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_write_application_data(charls_jpegls_encoder* encoder,
+                                                                               int32_t application_data_id,
+                                                                               const void* application_data,
+                                                                               size_t application_data_size_bytes); /* :228 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_write_mapping_table(charls_jpegls_encoder* encoder,
+                                                                            int32_t table_id, int32_t entry_size,
+                                                                            const void* table_data,
+                                                                            size_t table_data_size_bytes);  /* :247 */
+/* HOT PATH: :264-268 -> charls_jpegls_encoder::encode -> make_scan_codec<scan_encoder>()->encode_scan (src/...encoder.cpp:182-296) */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_encode_from_buffer(charls_jpegls_encoder* encoder,
+                                                                           const void* source_buffer,
+                                                                           size_t source_size_bytes, uint32_t stride);
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_encode_components_from_buffer(
+    charls_jpegls_encoder* encoder, const void* source_buffer, size_t source_size_bytes, int32_t source_component_count,
+    uint32_t stride);                                                                                       /* :284 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_create_abbreviated_format(charls_jpegls_encoder* encoder); /* :297 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_get_bytes_written(const charls_jpegls_encoder* encoder,
+                                                                          size_t* bytes_written);           /* :306 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_encoder_rewind(charls_jpegls_encoder* encoder);             /* :316 */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Part 1b -- decoder: include/charls/charls_jpegls_decoder.h:25-295, implemented by src/charls_jpegls_decoder.cpp
+ * ---------------------------------------------------------------------------------------------------------------- */
+CHARLS_AMD_API charls_jpegls_decoder* charls_jpegls_decoder_create(void);                                   /* :25 */
+CHARLS_AMD_API void charls_jpegls_decoder_destroy(const charls_jpegls_decoder* decoder);                    /* :33 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_set_source_buffer(charls_jpegls_decoder* decoder,
+                                                                          const void* source_buffer,
+                                                                          size_t source_size_bytes);        /* :45 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_read_spiff_header(charls_jpegls_decoder* decoder,
+                                                                          charls_spiff_header* spiff_header,
+                                                                          int32_t* header_found);           /* :59 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_read_header(charls_jpegls_decoder* decoder);        /* :69 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_get_frame_info(const charls_jpegls_decoder* decoder,
+                                                                       charls_frame_info* frame_info);      /* :81 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_get_near_lossless(const charls_jpegls_decoder* decoder,
+                                                                          int32_t component_index,
+                                                                          int32_t* near_lossless);          /* :95 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_get_interleave_mode(const charls_jpegls_decoder* decoder,
+                                                                            int32_t component_index,
+                                                                            charls_interleave_mode* interleave_mode); /* :109 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_get_preset_coding_parameters(
+    const charls_jpegls_decoder* decoder, int32_t reserved, charls_jpegls_pc_parameters* preset_coding_parameters); /* :123 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_get_color_transformation(
+    const charls_jpegls_decoder* decoder, charls_color_transformation* color_transformation);               /* :137 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_get_destination_size(const charls_jpegls_decoder* decoder,
+                                                                             uint32_t stride,
+                                                                             size_t* destination_size_bytes); /* :151 */
+/* HOT PATH: :170-174 -> charls_jpegls_decoder::decode -> make_scan_codec<scan_decoder>()->decode_scan (src/...decoder.cpp:177-201) */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_decode_to_buffer(charls_jpegls_decoder* decoder,
+                                                                         void* destination_buffer,
+                                                                         size_t destination_size_bytes, uint32_t stride);
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_at_comment(charls_jpegls_decoder* decoder,
+                                                                   charls_at_comment_handler handler,
+                                                                   void* user_context);                     /* :186 */
+CHARLS_AMD_API charls_jpegls_errc charls_jpegls_decoder_at_application_data(
+    charls_jpegls_decoder* decoder, charls_at_application_data_handler handler, void* user_context);        /* :201 */
+CHARLS_AMD_API charls_jpegls_errc charls_decoder_get_compressed_data_format(
+    const charls_jpegls_decoder* decoder, charls_compressed_data_format* compressed_data_format);           /* :215 */
+CHARLS_AMD_API charls_jpegls_errc charls_decoder_get_mapping_table_id(const charls_jpegls_decoder* decoder,
+                                                                      int32_t component_index, int32_t* table_id); /* :229 */
+CHARLS_AMD_API charls_jpegls_errc charls_decoder_find_mapping_table_index(const charls_jpegls_decoder* decoder,
+                                                                          int32_t mapping_table_id, int32_t* index); /* :244 */
+CHARLS_AMD_API charls_jpegls_errc charls_decoder_get_mapping_table_count(const charls_jpegls_decoder* decoder,
+                                                                         int32_t* count);                   /* :257 */
+CHARLS_AMD_API charls_jpegls_errc charls_decoder_get_mapping_table_info(const charls_jpegls_decoder* decoder,
+                                                                        int32_t mapping_table_index,
+                                                                        charls_mapping_table_info* mapping_table_info); /* :273 */
+CHARLS_AMD_API charls_jpegls_errc charls_decoder_get_mapping_table_data(const charls_jpegls_decoder* decoder,
+                                                                        int32_t mapping_table_index,
+                                                                        void* mapping_table_data,
+                                                                        size_t mapping_table_size_bytes);   /* :291 */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Part 1c -- misc: include/charls/jpegls_error.h:12, jpegls_error.hpp:10, version.h:43-54, validate_spiff_header.h:23
+ * ---------------------------------------------------------------------------------------------------------------- */
+CHARLS_AMD_API const char* charls_get_error_message(charls_jpegls_errc error_value);
+CHARLS_AMD_API const void* charls_get_jpegls_category(void); /* really `const std::error_category*`, as in the reference */
+CHARLS_AMD_API const char* charls_get_version_string(void);
+CHARLS_AMD_API void charls_get_version_number(int32_t* major, int32_t* minor, int32_t* patch);
+CHARLS_AMD_API charls_jpegls_errc charls_validate_spiff_header(const charls_spiff_header* spiff_header,
+                                                               const charls_frame_info* frame_info);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Part 2 -- additive batch API on DEVICE memory (no reference counterpart; never changes part 1 semantics).
+ *
+ * A batch is `frame_count` independent frames with identical coding parameters.  Frame f's pixels start at
+ * d_frames + f * frame_pitch_bytes in the reference's user layout (planar for ILV_NONE, pixel-interleaved otherwise,
+ * `stride` bytes between rows, 0 = minimal).  Frame f's complete .jls file is produced at / read from
+ * d_streams + f * stream_pitch_bytes.  `sizes` and `errcs` are HOST arrays of frame_count elements.
+ * `hip_stream` is a hipStream_t (NULL = default stream); the calls return after the stream work has completed.
+ * Every frame gets the bytes and the errc the part-1 encoder/decoder would give it with a destination buffer of
+ * stream_pitch_bytes (encode) or a source buffer of sizes[f] bytes (decode).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct charls_amd_codec_params
+{
+    charls_frame_info frame_info;
+    int32_t near_lossless;
+    charls_interleave_mode interleave_mode;
+    charls_color_transformation color_transformation;
+    charls_jpegls_pc_parameters preset_coding_parameters; /* all zero = defaults */
+    charls_encoding_options encoding_options;
+} charls_amd_codec_params;
+
+CHARLS_AMD_API charls_jpegls_errc charls_amd_encode_batch_device(const charls_amd_codec_params* params,
+                                                                 uint32_t frame_count, const void* d_frames,
+                                                                 size_t frame_pitch_bytes, uint32_t stride,
+                                                                 void* d_streams, size_t stream_pitch_bytes,
+                                                                 uint64_t* sizes, charls_jpegls_errc* errcs,
+                                                                 void* hip_stream);
+
+CHARLS_AMD_API charls_jpegls_errc charls_amd_decode_batch_device(uint32_t frame_count, const void* d_streams,
+                                                                 size_t stream_pitch_bytes, const uint64_t* sizes,
+                                                                 void* d_frames, size_t frame_pitch_bytes,
+                                                                 uint32_t stride, charls_amd_codec_params* params_out,
+                                                                 charls_jpegls_errc* errcs, void* hip_stream);
+
+/* Engine selection for the lossless single-component encoder: 0 = automatic, 1 = force the one-wavefront-per-scan
+ * kernel, 2 = force the parallel pipeline (returns invalid_argument when the scan is not eligible). Process-wide. */
+CHARLS_AMD_API charls_jpegls_errc charls_amd_set_encode_engine(int32_t engine);
+
+/* Milliseconds of GPU time (hipEvent) the last batch call on this thread spent in its kernels, by stage:
+ * out[0] total, out[1] dominant kernel, out[2..7] stage breakdown. Returns the number of values. */
+CHARLS_AMD_API int32_t charls_amd_last_timings(double* out, int32_t capacity);
+
+/* 0 when a gfx950 device is usable, otherwise CHARLS_AMD_ERRC_DEVICE_UNAVAILABLE. */
+CHARLS_AMD_API charls_jpegls_errc charls_amd_device_status(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
