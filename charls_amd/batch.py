@@ -1,0 +1,157 @@
+"""Device-resident batch encode/decode (charls_amd.h part 2) on torch tensors, plus frame sharding across ranks.
+
+torch supplies HBM allocations, the current HIP stream and torch.distributed (backend "nccl" = RCCL over xGMI);
+all coding work happens inside libcharls_amd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+
+
+class CodecParams(C.Structure):  # charls_amd_codec_params (include/charls_amd.h)
+    _fields_ = [("frame_info", capi.FrameInfo), ("near_lossless", C.c_int32), ("interleave_mode", C.c_int32),
+                ("color_transformation", C.c_int32), ("preset_coding_parameters", capi.PcParameters),
+                ("encoding_options", C.c_uint32)]
+
+
+def _bind(lib):
+    l = lib.lib
+    if getattr(l, "_batch_bound", False):
+        return l
+    l.charls_amd_encode_batch_device.argtypes = [C.POINTER(CodecParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32,
+                                                 C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
+                                                 C.c_void_p]
+    l.charls_amd_encode_batch_device.restype = C.c_int32
+    l.charls_amd_decode_batch_device.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_void_p,
+                                                 C.c_size_t, C.c_uint32, C.POINTER(CodecParams), C.POINTER(C.c_int32),
+                                                 C.c_void_p]
+    l.charls_amd_decode_batch_device.restype = C.c_int32
+    l.charls_amd_last_timings.argtypes = [C.POINTER(C.c_double), C.c_int32]
+    l.charls_amd_last_timings.restype = C.c_int32
+    l.charls_amd_set_encode_engine.argtypes = [C.c_int32]
+    l.charls_amd_set_encode_engine.restype = C.c_int32
+    l._batch_bound = True
+    return l
+
+
+def estimated_destination_size(width, height, bits, components) -> int:
+    """charls_jpegls_encoder_get_estimated_destination_size (reference src/charls_jpegls_encoder.cpp:103-114)."""
+    raw = width * height * components * ((bits + 7) // 8)
+    return raw + raw // 16 + 1024 + 34
+
+
+@dataclass
+class EncodedBatch:
+    streams: "torch.Tensor"  # (frames, pitch) uint8 on the device; frame f's .jls is streams[f, :sizes[f]]
+    sizes: np.ndarray        # uint64, host
+    errcs: np.ndarray        # int32, host
+    gpu_ms: tuple            # (total, dominant kernel)
+
+
+def last_timings(lib=None):
+    l = _bind(lib or capi.load_product())
+    buf = (C.c_double * 8)()
+    n = l.charls_amd_last_timings(buf, 8)
+    return tuple(buf[i] for i in range(n))
+
+
+def encode_batch(frames, *, bits_per_sample=8, component_count=1, interleave_mode=0, near_lossless=0,
+                 color_transformation=0, preset=(0, 0, 0, 0, 0), encoding_options=0, streams=None, lib=None) -> EncodedBatch:
+    """frames: contiguous torch tensor on the GPU, (F, H, W) / (F, C, H, W) for ILV_NONE or (F, H, W, C) otherwise,
+    dtype uint8 (<= 8 bit) or int16/uint16 (9..16 bit)."""
+    import torch
+    lib = lib or capi.load_product()
+    l = _bind(lib)
+    assert frames.is_cuda and frames.is_contiguous()
+    count = frames.shape[0]
+    if component_count == 1 or interleave_mode == 0:
+        height, width = frames.shape[-2], frames.shape[-1]
+    else:
+        height, width = frames.shape[1], frames.shape[2]
+    frame_pitch = frames[0].numel() * frames.element_size()
+    if streams is None:
+        pitch = (estimated_destination_size(width, height, bits_per_sample, component_count) + 255) & ~255
+        streams = torch.empty((count, pitch), dtype=torch.uint8, device=frames.device)
+    assert streams.is_contiguous() and streams.shape[0] == count
+    p = CodecParams(capi.FrameInfo(width, height, bits_per_sample, component_count), near_lossless, interleave_mode,
+                    color_transformation, capi.PcParameters(*preset), encoding_options)
+    sizes = np.zeros(count, dtype=np.uint64)
+    errcs = np.zeros(count, dtype=np.int32)
+    stream = torch.cuda.current_stream(frames.device).cuda_stream
+    rc = l.charls_amd_encode_batch_device(C.byref(p), count, frames.data_ptr(), frame_pitch, 0, streams.data_ptr(),
+                                          streams.shape[1], sizes.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          errcs.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(stream))
+    if rc != 0:
+        raise capi.JpegLSError(rc, "charls_amd_encode_batch_device")
+    return EncodedBatch(streams, sizes, errcs, last_timings(lib))
+
+
+def decode_batch(streams, sizes, out, *, lib=None):
+    """streams: (F, pitch) uint8 device tensor; sizes: host uint64 array; out: preallocated device tensor whose [f] slice
+    receives frame f in the reference's user layout. Returns (params, errcs, gpu_ms)."""
+    import torch
+    lib = lib or capi.load_product()
+    l = _bind(lib)
+    assert streams.is_cuda and streams.is_contiguous() and out.is_cuda and out.is_contiguous()
+    count = streams.shape[0]
+    sizes = np.ascontiguousarray(sizes, dtype=np.uint64)
+    errcs = np.zeros(count, dtype=np.int32)
+    p = CodecParams()
+    frame_pitch = out[0].numel() * out.element_size()
+    stream = torch.cuda.current_stream(streams.device).cuda_stream
+    rc = l.charls_amd_decode_batch_device(count, streams.data_ptr(), streams.shape[1],
+                                          sizes.ctypes.data_as(C.POINTER(C.c_uint64)), out.data_ptr(), frame_pitch, 0,
+                                          C.byref(p), errcs.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(stream))
+    if rc != 0:
+        raise capi.JpegLSError(rc, "charls_amd_decode_batch_device")
+    return p, errcs, last_timings(lib)
+
+
+def set_encode_engine(engine: int, lib=None):
+    """0 automatic, 1 one-wavefront-per-scan kernel, 2 parallel lossless pipeline."""
+    rc = _bind(lib or capi.load_product()).charls_amd_set_encode_engine(engine)
+    if rc:
+        raise capi.JpegLSError(rc, "charls_amd_set_encode_engine")
+
+
+# ---- multi-GPU: frames are the sharding unit; the only exchange is the final bitstream gather -------------
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous block of frame indices owned by `rank` (sizes differ by at most one)."""
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def gather_streams(streams, sizes, dst=0, group=None):
+    """Variable-length gather of the encoded frames to rank `dst`: all-gather of the per-frame byte counts, then one
+    padded gather of the payload trimmed to the batch maximum (RCCL on GPU tensors, gloo on CPU tensors).
+    Returns on dst: (list of per-rank uint8 tensors (frames_r, max_len), list of per-rank size arrays); else (None, all_sizes)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = streams.device
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([len(sizes)], dtype=torch.int64, device=dev), group=group)
+    counts = [int(c.item()) for c in counts]
+    max_count = max(counts)
+    mine = torch.zeros(max_count, dtype=torch.int64, device=dev)
+    mine[:len(sizes)] = torch.as_tensor(np.asarray(sizes, dtype=np.int64), device=dev)
+    all_sizes = [torch.zeros(max_count, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, mine, group=group)
+    all_sizes = [s[:c].cpu().numpy().astype(np.uint64) for s, c in zip(all_sizes, counts)]
+    max_len = int(max((int(s.max()) if len(s) else 0) for s in all_sizes))
+    payload = torch.zeros((max_count, max_len), dtype=torch.uint8, device=dev)
+    payload[:streams.shape[0]] = streams[:, :max_len]
+    if rank == dst:
+        parts = [torch.empty_like(payload) for _ in range(world)]
+        dist.gather(payload, parts, dst=dst, group=group)
+        return [p[:c] for p, c in zip(parts, counts)], all_sizes
+    dist.gather(payload, None, dst=dst, group=group)
+    return None, all_sizes

@@ -1,0 +1,90 @@
+"""Batch API on device-resident frames (charls_amd.h part 2): every frame bit-exact, round-trip properties at scale."""
+import numpy as np
+import pytest
+
+import common
+import oracle_bind as ob
+from charls_amd import batch, capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("bits,kind", [(8, "mixed"), (8, "gradient"), (16, "mixed"), (12, "gradient")])
+def test_batch_frames_equal_oracle(torch, bits, kind):
+    n, w, h = 5, 200, 120
+    frames = synth.frames_torch(n, w, h, seed0=40, bits=bits, kind=kind, device="cuda:0")
+    enc = batch.encode_batch(frames, bits_per_sample=bits)
+    host = enc.streams.cpu().numpy()
+    for f in range(n):
+        want = ob.encode(synth.frame_numpy(w, h, seed=40 + f, bits=bits, kind=kind), width=w, height=h, bits_per_sample=bits)
+        assert enc.errcs[f] == 0
+        assert host[f, :int(enc.sizes[f])].tobytes() == want
+    out = torch.empty_like(frames)
+    p, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+    assert (errcs == 0).all() and torch.equal(out, frames)
+    assert (p.frame_info.width, p.frame_info.height, p.frame_info.bits_per_sample) == (w, h, bits)
+
+
+def test_batch_rgb_modes(torch):
+    n, w, h = 3, 96, 64
+    for ilv, near, ct in [(0, 0, 0), (1, 0, 0), (2, 0, 1), (2, 2, 0), (1, 0, 3)]:
+        imgs = [synth.frame_numpy(w, h, seed=60 + f, components=3, kind="mixed", interleaved=(ilv != 0)) for f in range(n)]
+        frames = torch.from_numpy(np.stack(imgs)).cuda()
+        enc = batch.encode_batch(frames, component_count=3, interleave_mode=ilv, near_lossless=near, color_transformation=ct)
+        host = enc.streams.cpu().numpy()
+        for f in range(n):
+            want = ob.encode(imgs[f], width=w, height=h, component_count=3, interleave_mode=ilv, near_lossless=near,
+                             color_transformation=ct)
+            assert enc.errcs[f] == 0 and host[f, :int(enc.sizes[f])].tobytes() == want, (ilv, near, ct, f)
+        out = torch.empty_like(frames)
+        _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+        assert (errcs == 0).all()
+        if near == 0:
+            assert torch.equal(out, frames)
+        else:
+            assert (out.int() - frames.int()).abs().max().item() <= near
+
+
+def test_batch_destination_too_small_is_per_frame(torch):
+    w, h = 64, 64
+    frames = torch.stack([synth.frames_torch(1, w, h, seed0=1, kind="noise", device="cuda:0")[0],
+                          synth.frames_torch(1, w, h, seed0=2, kind="zero", device="cuda:0")[0]])
+    streams = torch.zeros((2, 2048), dtype=torch.uint8, device="cuda:0")
+    enc = batch.encode_batch(frames, streams=streams)
+    assert enc.errcs[0] == 3 and enc.errcs[1] == 0  # noise does not fit 2 KiB, zeros do
+    assert enc.sizes[0] == 0 and enc.sizes[1] > 0
+
+
+def test_batch_corrupt_stream_is_per_frame(torch):
+    w, h = 64, 48
+    frames = synth.frames_torch(3, w, h, seed0=9, kind="mixed", device="cuda:0")
+    enc = batch.encode_batch(frames)
+    bad = enc.streams.clone()
+    bad[1, 40:60] = 0xFF  # destroy part of the entropy-coded segment of frame 1
+    out = torch.zeros_like(frames)
+    _, errcs, _ = batch.decode_batch(bad, enc.sizes, out)
+    assert errcs[0] == 0 and errcs[2] == 0 and errcs[1] != 0
+    assert torch.equal(out[0], frames[0]) and torch.equal(out[2], frames[2])
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("bits", [8, 16])
+def test_full_size_roundtrip_properties(torch, bits):
+    """BASELINE.json sizes: lossless round trip restores every sample; sizes equal the golden manifest."""
+    cases = {c["name"]: c for c in common.cases()}
+    c = cases["cfg2_full" if bits == 8 else "cfg3_full"]
+    frames = synth.frames_torch(2, 4096, 4096, seed0=c["seed"], bits=bits, device="cuda:0")
+    enc = batch.encode_batch(frames, bits_per_sample=bits)
+    assert (enc.errcs == 0).all()
+    assert int(enc.sizes[0]) == c["jls_size"]
+    assert common.sha(enc.streams[0, :int(enc.sizes[0])].cpu().numpy().tobytes()) == c["jls_sha256"]
+    out = torch.empty_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+    assert (errcs == 0).all() and torch.equal(out, frames)
