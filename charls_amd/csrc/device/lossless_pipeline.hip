@@ -1,0 +1,647 @@
+// lossless_pipeline.hip -- parallel JPEG-LS encoder for lossless single-component scans (the BASELINE headline path).
+//
+// In lossless mode the causal template holds SOURCE samples, so everything except the adaptive statistics is a pure
+// function of the image (reference src/scan_encoder_impl.hpp:109-144).  The scan is therefore coded in
+// stages that each expose the parallelism they really have:
+//
+//   A  analyze_rows      one wavefront per scan line: context id, sign, MED prediction for every sample (coalesced,
+//                        HBM-bound); run-mode segmentation of the line resolved as a carry chain over ballot masks
+//   B1 chain_offsets     per-line histograms of the 365 statistic chains (364 regular contexts + the run chain) ->
+//                        exclusive offsets (a stable counting sort by context, raster order kept inside a chain)
+//   B2 scatter_events    events move to their chain, lane-order ranks from ballots (deterministic, no atomics on order)
+//   C  code_chains       one LANE per chain: A/B/C/N recurrence + Golomb code for the chain's samples in raster order;
+//                        the run chain carries RUNindex and the two run-interruption contexts.  Chains of different
+//                        contexts never interact in lossless mode, so 365 x scans lanes run concurrently.
+//   D1 sum/scan          code lengths -> bit offsets (two-level prefix sum per scan)
+//   D2 write_raw_bits    codes are concatenated MSB-first into the unstuffed bit stream (plain stores for owned words)
+//   D3 stuff_scan        JPEG-LS 0xFF bit stuffing + end-of-scan padding (src/scan_encoder.hpp:103-180), one wavefront
+//                        per scan streaming through LDS
+//
+// Output is byte-identical to scan_encoder::encode_scan.  MFMA is not used anywhere: nothing here is a contraction.
+#include <hip/hip_runtime.h>
+
+#include "scan_model.h"
+
+namespace jls {
+namespace pipe {
+
+constexpr int kChains = 365;          // 0 = run chain, 1..364 = regular contexts
+constexpr uint16_t kNoEvent = 0xFFFF; // key of a sample that produces no code of its own
+constexpr uint32_t kPackBlock = 4096; // samples per D1/D2 workgroup (256 threads x 16)
+constexpr uint32_t kStatusInvalid = 1u;
+
+// Per-scan work areas (device pointers), parallel to the ScanDesc array.
+struct Work
+{
+    uint16_t* key;         // [H*W] chain | sign << 9, or kNoEvent
+    uint32_t* val;         // [H*W] x | Px << 16   (run start: run length | end-of-line << 31)
+    uint32_t* hist;        // [H][kChains] events per line and chain -> exclusive prefix over lines
+    uint32_t* chain_total; // [kChains]
+    uint32_t* chain_base;  // [kChains] offset of the chain in sval/spos
+    uint32_t* sval;        // [H*W] events grouped by chain, raster order inside a chain
+    uint32_t* spos;        // [H*W] raster index of the event | sign << 31
+    uint8_t* len;          // [H*W] code length of the sample (0 = none)
+    uint64_t* code;        // [H*W] code bits, right aligned
+    uint32_t* blocksum;    // [ceil(H*W / kPackBlock)]
+    uint64_t* blockbase;   // same count: exclusive bit offsets
+    uint32_t* raw;         // unstuffed bit stream, 32-bit words in big-endian bit order; zeroed before D2
+    uint64_t raw_words;    // capacity of raw
+    uint64_t* total_bits;  // [1]
+    uint32_t* status;      // [1] kStatusInvalid when the reference would raise invalid_data
+};
+
+template <typename S>
+JLS_DEV int load_sample(const ScanDesc& d, uint32_t y, uint32_t x, int mask)
+{
+    const S* row = reinterpret_cast<const S*>(d.pixels + (size_t)y * d.pixel_stride);
+    return (int)row[x] & mask;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A: grid (height, scans), one wavefront per line.  Dynamic LDS: chunks * (8 + 8 + 4) bytes + kChains * 4.
+template <typename S>
+__global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    JLS_DYNAMIC_LDS(smem);
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const Traits t = make_traits(d);
+    const uint32_t y = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t width = d.width;
+    const uint32_t chunks = (width + 63) / 64;
+    uint64_t* s_eq = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* s_q0 = s_eq + chunks;
+    uint32_t* s_next = reinterpret_cast<uint32_t*>(s_q0 + chunks);
+    uint32_t* s_hist = s_next + chunks;
+    const int mask = (1 << d.bits_per_sample) - 1;
+
+    for (int c = lane; c < kChains; c += 64)
+        s_hist[c] = 0;
+
+    // edge samples of the line (src/scan_codec.hpp:189-195 and the two-line ping-pong of src/scan_encoder_impl.hpp:55-106)
+    const int edge_a = y > 0 ? load_sample<S>(d, y - 1, 0, mask) : 0;           // cur[0]  = prev[1]
+    const int edge_c = y > 1 ? load_sample<S>(d, y - 2, 0, mask) : 0;           // prev[0] = line y-2, first sample
+    uint16_t* key_row = w.key + (size_t)y * width;
+    uint32_t* val_row = w.val + (size_t)y * width;
+
+    // ---- pass 1: every sample as if coded in regular mode; equality / zero-context masks per 64-sample chunk
+    for (uint32_t k = 0; k < chunks; ++k)
+    {
+        const uint32_t x = k * 64 + lane;
+        bool eq = false, q0 = false;
+        if (x < width)
+        {
+            const int v = load_sample<S>(d, y, x, mask);
+            const int ra = x > 0 ? load_sample<S>(d, y, x - 1, mask) : edge_a;
+            int rb = 0, rc = 0, rd = 0;
+            if (y > 0)
+            {
+                rb = load_sample<S>(d, y - 1, x, mask);
+                rc = x > 0 ? load_sample<S>(d, y - 1, x - 1, mask) : edge_c;
+                rd = load_sample<S>(d, y - 1, x + 1 < width ? x + 1 : width - 1, mask);
+            }
+            else
+                rc = x > 0 ? 0 : edge_c;
+            const int qs = context_id(t, ra, rb, rc, rd);
+            const int sg = qs >> 31;
+            const int ctx = (qs ^ sg) - sg;
+            const int px = med_predict(ra, rb, rc);
+            key_row[x] = (uint16_t)(ctx | ((sg & 1) << 9));
+            val_row[x] = (uint32_t)v | ((uint32_t)px << 16);
+            eq = v == ra;
+            q0 = qs == 0;
+        }
+        const unsigned long long m_eq = __ballot(eq);
+        const unsigned long long m_q0 = __ballot(q0);
+        if (lane == 0)
+        {
+            s_eq[k] = m_eq;
+            s_q0[k] = m_q0;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 2 (reverse): column of the first sample at or after the NEXT chunk that differs from its left neighbour
+    if (lane == 0)
+    {
+        uint32_t carry = width;
+        for (uint32_t k = chunks; k-- > 0;)
+        {
+            s_next[k] = carry;
+            const uint32_t valid = width - k * 64 >= 64 ? 64 : width - k * 64;
+            const unsigned long long vm = valid == 64 ? ~0ull : ((1ull << valid) - 1ull);
+            const unsigned long long neq = ~s_eq[k] & vm;
+            if (neq)
+                carry = k * 64 + (uint32_t)__ffsll(neq) - 1;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 3: run-mode state before every sample.  s' = eq & (s | q0) is a carry chain: generate = eq & q0,
+    // propagate = eq, so one 64-bit addition per chunk resolves 64 samples (src/scan_encoder_impl.hpp:249-275).
+    unsigned long long carry = 0;
+    for (uint32_t k = 0; k < chunks; ++k)
+    {
+        const unsigned long long a = s_eq[k];
+        const unsigned long long b = s_eq[k] & s_q0[k];
+        const unsigned long long sum = a + b + carry;
+        const unsigned long long st = sum ^ a ^ b; // bit i: in-run state before sample i
+        carry = (((a & b) | ((a | b) & st)) >> 63) & 1ull;
+        const uint32_t x = k * 64 + lane;
+        if (x < width)
+        {
+            const bool s = (st >> lane) & 1ull;
+            const bool q0 = (s_q0[k] >> lane) & 1ull;
+            const bool eq = (a >> lane) & 1ull;
+            if (!(s || q0))
+                atomicAdd(&s_hist[key_row[x] & 0x1FF], 1u); // regular sample, key already written by this lane
+            else if (s)
+                key_row[x] = kNoEvent; // inside a run, or the interruption sample of a run started earlier
+            else
+            { // a run starts here (possibly of length 0)
+                uint32_t run = 0, eol = 0;
+                if (eq)
+                {
+                    const uint32_t valid = width - k * 64 >= 64 ? 64 : width - k * 64;
+                    const unsigned long long vm = valid == 64 ? ~0ull : ((1ull << valid) - 1ull);
+                    const unsigned long long neq = (~a & vm) >> lane;
+                    const uint32_t end = neq ? x + (uint32_t)__ffsll(neq) - 1 : s_next[k];
+                    run = end - x;
+                    eol = end == width ? 1u : 0u;
+                }
+                key_row[x] = 0;
+                val_row[x] = run | (eol << 31);
+                atomicAdd(&s_hist[0], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* hist_row = w.hist + (size_t)y * kChains;
+    for (int c = lane; c < kChains; c += 64)
+        hist_row[c] = s_hist[c];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// B1: one workgroup of 384 threads per scan.
+__global__ void __launch_bounds__(384) chain_offsets(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    __shared__ uint32_t s_total[384];
+    const ScanDesc d = descs[blockIdx.x];
+    const Work w = works[blockIdx.x];
+    const int c = threadIdx.x;
+    uint32_t running = 0;
+    if (c < kChains)
+    {
+        for (uint32_t y = 0; y < d.height; ++y)
+        {
+            const uint32_t n = w.hist[(size_t)y * kChains + c];
+            w.hist[(size_t)y * kChains + c] = running;
+            running += n;
+        }
+        w.chain_total[c] = running;
+    }
+    s_total[c] = c < kChains ? running : 0;
+    __syncthreads();
+    if (c == 0)
+    { // 365 values: a serial scan is cheaper than its synchronisation
+        uint32_t acc = 0;
+        for (int i = 0; i < kChains; ++i)
+        {
+            w.chain_base[i] = acc;
+            acc += s_total[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// B2: grid (height, scans), one wavefront per line; stable scatter of the line's events to their chains.
+__global__ void __launch_bounds__(64) scatter_events(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    __shared__ uint32_t s_cnt[kChains];
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const uint32_t y = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t width = d.width;
+    for (int c = lane; c < kChains; c += 64)
+        s_cnt[c] = w.chain_base[c] + w.hist[(size_t)y * kChains + c];
+    __syncthreads();
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (uint32_t k = 0; k < (width + 63) / 64; ++k)
+    {
+        const uint32_t x = k * 64 + lane;
+        uint16_t key = kNoEvent;
+        uint32_t v = 0;
+        if (x < width)
+        {
+            key = w.key[(size_t)y * width + x];
+            v = w.val[(size_t)y * width + x];
+        }
+        const bool has = key != kNoEvent;
+        const int chain = key & 0x1FF;
+        uint32_t dest = 0;
+        unsigned long long remaining = __ballot(has);
+        while (remaining) // one iteration per distinct chain present in the chunk
+        {
+            const int leader = __ffsll(remaining) - 1;
+            const int kc = __shfl(chain, leader);
+            const unsigned long long same = __ballot(has && chain == kc);
+            JLS_LOCKSTEP();
+            if (has && chain == kc)
+                dest = s_cnt[kc] + (uint32_t)__popcll(same & below);
+            JLS_LOCKSTEP();
+            if (lane == leader)
+                s_cnt[kc] += (uint32_t)__popcll(same);
+            JLS_LOCKSTEP();
+            remaining &= ~same;
+        }
+        if (has)
+        {
+            w.sval[dest] = v;
+            w.spos[dest] = (uint32_t)((size_t)y * width + x) | ((uint32_t)(key >> 9) << 31);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C: one lane per (chain, scan).  Thread t codes chain t / scans of scan t % scans, so that the lanes of a wavefront
+// work on the SAME context of different frames (similar chain lengths -> little idle time).
+
+struct CodeWord
+{
+    uint64_t bits;
+    int len;
+};
+
+// Limited-length Golomb code as (bits, length): src/scan_encoder_core.hpp:69-103.
+JLS_DEV CodeWord golomb_word(const Traits& t, int k, int m, int limit)
+{
+    CodeWord c;
+    const int hb = m >> k;
+    if (hb < limit - t.qbpp - 1)
+    {
+        c.len = hb + 1 + k;
+        c.bits = (1ull << k) | (uint64_t)((uint32_t)m & ((1u << k) - 1u));
+    }
+    else
+    {
+        c.len = limit;
+        c.bits = (1ull << t.qbpp) | (uint64_t)((uint32_t)(m - 1) & ((1u << t.qbpp) - 1u));
+    }
+    return c;
+}
+
+template <typename S>
+__global__ void __launch_bounds__(64) code_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works,
+                                                  uint32_t scans)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= scans * (uint32_t)kChains)
+        return;
+    const uint32_t chain = tid / scans;
+    const ScanDesc d = descs[tid % scans];
+    const Work w = works[tid % scans];
+    const Traits t = make_traits(d);
+    const uint32_t n = w.chain_total[chain];
+    const uint32_t* sval = w.sval + w.chain_base[chain];
+    const uint32_t* spos = w.spos + w.chain_base[chain];
+    bool invalid = false;
+
+    if (chain != 0)
+    { // ---- regular mode: src/scan_encoder_core.hpp:57-67
+        RegCtx ctx{initial_a(t), 0, 0, 1};
+        for (uint32_t e = 0; e < n; ++e)
+        {
+            const uint32_t v = sval[e];
+            const uint32_t ps = spos[e];
+            const int s = (int)ps >> 31; // 0 or -1
+            const int x = (int)(v & 0xFFFFu);
+            const int pred = (int)(v >> 16);
+            const int k = regular_k(ctx);
+            if (k >= 16)
+            {
+                invalid = true;
+                break;
+            }
+            const int px = clamp_sample(t, pred + ((ctx.c ^ s) - s));
+            const int err = error_value(t, ((x - px) ^ s) - s);
+            const CodeWord c = golomb_word(t, k, map_error(error_correction(ctx, k) ^ err), t.limit);
+            if (!regular_update(ctx, err, 0, t.reset))
+            {
+                invalid = true;
+                break;
+            }
+            const uint32_t p = ps & 0x7FFFFFFFu;
+            w.code[p] = c.bits;
+            w.len[p] = (uint8_t)c.len;
+        }
+    }
+    else
+    { // ---- run mode: src/scan_encoder.hpp:53-73, src/scan_encoder_impl.hpp:249-275, src/scan_encoder_core.hpp:105-125
+        RunCtx rc[2] = {RunCtx{0, initial_a(t), 1, 0}, RunCtx{1, initial_a(t), 1, 0}};
+        int run_index = 0;
+        const int mask = (1 << d.bits_per_sample) - 1;
+        for (uint32_t e = 0; e < n; ++e)
+        {
+            const uint32_t v = sval[e];
+            const uint32_t p = spos[e] & 0x7FFFFFFFu;
+            uint32_t run = v & 0x7FFFFFFFu;
+            const bool eol = (v >> 31) != 0;
+            const uint32_t y = p / d.width;
+            const uint32_t x0 = p - y * d.width;
+            const uint32_t full = run;
+            // run-length part: ones for every completed 2^J block, then either the end-of-line one or 0 + remainder
+            uint64_t bits = 0;
+            int len = 0;
+            while (run >= (1u << run_j(run_index)))
+            {
+                bits = (bits << 1) | 1ull;
+                ++len;
+                run -= 1u << run_j(run_index);
+                if (run_index < 31)
+                    ++run_index;
+            }
+            if (eol)
+            {
+                if (run != 0)
+                {
+                    bits = (bits << 1) | 1ull;
+                    ++len;
+                }
+                w.code[p] = bits;
+                w.len[p] = (uint8_t)len;
+                continue;
+            }
+            const int jb = run_j(run_index);
+            bits = (bits << (jb + 1)) | run;
+            len += jb + 1;
+            // run interruption sample at x0 + full
+            const uint32_t xi = x0 + full;
+            const int xv = load_sample<S>(d, y, xi, mask);
+            const int ra = xi > 0 ? load_sample<S>(d, y, xi - 1, mask) : (y > 0 ? load_sample<S>(d, y - 1, 0, mask) : 0);
+            const int rb = y > 0 ? load_sample<S>(d, y - 1, xi, mask) : 0;
+            const int which = ra == rb ? 1 : 0;
+            int err;
+            if (which)
+                err = error_value(t, xv - ra);
+            else
+                err = error_value(t, (xv - rb) * ((rb - ra) < 0 ? -1 : 1));
+            RunCtx& ctx = rc[which];
+            const int k = run_k(ctx);
+            const int map = run_map(ctx, err, k);
+            const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - map;
+            const CodeWord c = golomb_word(t, k, em, t.limit - jb - 1);
+            run_update(ctx, err, em, t.reset);
+            if (run_index > 0)
+                --run_index;
+            if (full == 0)
+            { // both codes belong to the same sample: J+1 zero bits followed by the interruption code (<= LIMIT bits)
+                w.code[p] = (bits << c.len) | c.bits;
+                w.len[p] = (uint8_t)(len + c.len);
+            }
+            else
+            {
+                w.code[p] = bits;
+                w.len[p] = (uint8_t)len;
+                w.code[p + full] = c.bits;
+                w.len[p + full] = (uint8_t)c.len;
+            }
+        }
+    }
+    if (invalid)
+        atomicOr(w.status, kStatusInvalid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// D1a: grid (blocks, scans), 256 threads: bits of each 4096-sample block.
+__global__ void __launch_bounds__(256) sum_code_lengths(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    __shared__ uint32_t s_part[256];
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const uint64_t total = (uint64_t)d.width * d.height;
+    const uint64_t base = (uint64_t)blockIdx.x * kPackBlock + (uint64_t)threadIdx.x * 16;
+    uint32_t sum = 0;
+    for (int i = 0; i < 16; ++i)
+        if (base + i < total)
+            sum += w.len[base + i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1)
+    {
+        if ((int)threadIdx.x < stride)
+            s_part[threadIdx.x] += s_part[threadIdx.x + stride];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        w.blocksum[blockIdx.x] = s_part[0];
+}
+
+// D1b: one wavefront per scan: exclusive scan of the block sums.
+__global__ void __launch_bounds__(64) scan_block_sums(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    const ScanDesc d = descs[blockIdx.x];
+    const Work w = works[blockIdx.x];
+    const uint64_t total = (uint64_t)d.width * d.height;
+    const uint32_t blocks = (uint32_t)((total + kPackBlock - 1) / kPackBlock);
+    const int lane = threadIdx.x;
+    uint64_t carry = 0;
+    for (uint32_t b0 = 0; b0 < blocks; b0 += 64)
+    {
+        const uint32_t b = b0 + lane;
+        const uint64_t v = b < blocks ? w.blocksum[b] : 0;
+        uint64_t inc = v;
+        for (int delta = 1; delta < 64; delta <<= 1)
+        {
+            const uint64_t up = __shfl_up(inc, delta);
+            if (lane >= delta)
+                inc += up;
+        }
+        if (b < blocks)
+            w.blockbase[b] = carry + inc - v;
+        carry += __shfl(inc, 63);
+    }
+    if (lane == 0)
+        *w.total_bits = carry;
+}
+
+// D2: grid (blocks, scans), 256 threads x 16 samples: concatenate the codes into the raw bit stream.
+__global__ void __launch_bounds__(256) write_raw_bits(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    __shared__ uint32_t s_scan[256];
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const uint64_t total = (uint64_t)d.width * d.height;
+    const uint64_t base = (uint64_t)blockIdx.x * kPackBlock + (uint64_t)threadIdx.x * 16;
+    int lens[16];
+    uint32_t sum = 0;
+    for (int i = 0; i < 16; ++i)
+    {
+        lens[i] = base + i < total ? w.len[base + i] : 0;
+        sum += (uint32_t)lens[i];
+    }
+    s_scan[threadIdx.x] = sum;
+    __syncthreads();
+    for (int stride = 1; stride < 256; stride <<= 1) // Hillis-Steele inclusive scan
+    {
+        const uint32_t add = (int)threadIdx.x >= stride ? s_scan[threadIdx.x - stride] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint64_t bitpos = w.blockbase[blockIdx.x] + s_scan[threadIdx.x] - sum;
+    if (sum == 0)
+        return;
+    uint64_t word = bitpos >> 5;
+    const uint64_t first_word = word;
+    int acc_bits = (int)(bitpos & 31); // the leading bits of the first word belong to the previous thread
+    uint64_t acc = 0;
+    for (int i = 0; i < 16; ++i)
+    {
+        int left = lens[i];
+        if (left == 0)
+            continue;
+        const uint64_t v = w.code[base + i];
+        while (left > 0)
+        {
+            const int room = 64 - acc_bits;
+            const int n = left < room ? left : room;
+            const uint64_t piece = n == 64 ? v : ((v >> (left - n)) & ((1ull << n) - 1ull));
+            acc |= piece << (room - n);
+            acc_bits += n;
+            left -= n;
+            while (acc_bits >= 32)
+            {
+                const uint32_t out = __builtin_bswap32((uint32_t)(acc >> 32));
+                if (word < w.raw_words)
+                {
+                    if (word == first_word)
+                        atomicOr(&w.raw[word], out); // shared with the previous thread's tail
+                    else
+                        w.raw[word] = out;           // entirely ours
+                }
+                acc <<= 32;
+                acc_bits -= 32;
+                ++word;
+            }
+        }
+    }
+    if (acc_bits > 0 && word < w.raw_words)
+        atomicOr(&w.raw[word], __builtin_bswap32((uint32_t)(acc >> 32))); // tail shared with the next thread
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// D3: one wavefront per scan, wave-uniform: raw bits -> stuffed bytes.  After a 0xFF byte the next byte carries 7 bits
+// (MSB 0); a final 0xFF is followed by 0x00; the last partial byte is zero padded (src/scan_encoder.hpp:103-180).
+// Result flags: bit 1 = the capacity is within 3 bytes of the output size, where the reference's accept/reject
+// decision depends on its 32-bit flush history; the host then re-runs the exact serial kernel.
+constexpr uint32_t kOutStage = 1024;
+
+__global__ void __launch_bounds__(64) stuff_scan(const ScanDesc* __restrict__ descs, const Work* __restrict__ works,
+                                                 ScanResult* __restrict__ results)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[2048];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[kOutStage + 16];
+    const ScanDesc d = descs[blockIdx.x];
+    const Work w = works[blockIdx.x];
+    const int lane = threadIdx.x;
+    const uint64_t total_bits = *w.total_bits;
+    const uint64_t raw_bytes_cap = w.raw_words * 4;
+    const uint8_t* raw = reinterpret_cast<const uint8_t*>(w.raw);
+    ScanResult r{kOk, 0, 0};
+
+    if ((*w.status & kStatusInvalid) != 0)
+        r.errc = kInvalidData;
+    else if ((total_bits + 7) / 8 > raw_bytes_cap)
+        r.errc = kDestinationTooSmall; // the unstuffed stream alone exceeds the destination
+    if (r.errc != kOk)
+    {
+        if (lane == 0)
+            results[blockIdx.x] = r;
+        return;
+    }
+
+    uint64_t loaded = 0;   // raw bytes [loaded - 2048, loaded) are in s_in (ring)
+    uint64_t bp = 0;       // next raw bit
+    uint64_t written = 0;  // bytes already copied to the destination
+    uint32_t staged = 0;   // bytes waiting in s_out
+    bool prev_ff = false;
+    bool overflow = false;
+
+    auto flush_out = [&]() {
+        __syncthreads();
+        for (uint32_t i = lane; i < staged; i += 64)
+            if (written + i < d.stream_capacity)
+                d.stream[written + i] = s_out[i];
+        if (written + staged > d.stream_capacity)
+            overflow = true;
+        written += staged;
+        staged = 0;
+        __syncthreads();
+    };
+    auto ensure_in = [&](uint64_t byte_needed_end) { // make raw bytes up to byte_needed_end (exclusive) resident
+        while (loaded < byte_needed_end && loaded < raw_bytes_cap)
+        {
+            const uint64_t o = loaded + (uint64_t)lane * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (o + 16 <= raw_bytes_cap)
+                v = *reinterpret_cast<const uint4*>(raw + o);
+            *reinterpret_cast<uint4*>(s_in + (o & 2047)) = v;
+            loaded += 1024;
+            __syncthreads();
+        }
+    };
+    auto peek64 = [&](uint64_t bit) -> uint64_t { // 64 raw bits starting at `bit`, MSB first (zeros past the end)
+        const uint64_t* in64 = reinterpret_cast<const uint64_t*>(s_in);
+        const uint64_t w0 = __builtin_bswap64(in64[(bit >> 6) & 255]);
+        const uint64_t w1 = __builtin_bswap64(in64[((bit >> 6) + 1) & 255]);
+        const int s = (int)(bit & 63);
+        return s ? ((w0 << s) | (w1 >> (64 - s))) : w0;
+    };
+
+    while (bp < total_bits)
+    {
+        JLS_LOCKSTEP();
+        ensure_in((bp >> 3) + 24);
+        if (staged + 9 > kOutStage)
+            flush_out();
+        const uint64_t v = peek64(bp);
+        if (prev_ff)
+        { // 7 payload bits, stuffed zero on top
+            s_out[staged++] = (uint8_t)(v >> 57);
+            bp += 7;
+            prev_ff = false;
+            continue;
+        }
+        const uint64_t inv = ~v;
+        const uint64_t ffm = (inv - 0x0101010101010101ull) & ~inv & 0x8080808080808080ull;
+        if (ffm == 0 && bp + 64 <= total_bits)
+        { // eight ordinary bytes
+            const uint64_t le = __builtin_bswap64(v);
+            for (int i = 0; i < 8; ++i)
+                s_out[staged + i] = (uint8_t)(le >> (8 * i));
+            staged += 8;
+            bp += 64;
+            continue;
+        }
+        const uint32_t b = (uint32_t)(v >> 56); // one byte (zero padded past the end by construction of the raw buffer)
+        s_out[staged++] = (uint8_t)b;
+        bp += 8;
+        prev_ff = b == 0xFFu;
+    }
+    if (prev_ff)
+        s_out[staged++] = 0; // src/scan_encoder.hpp:107-112
+    flush_out();
+
+    r.bytes = written;
+    if (overflow || written > d.stream_capacity)
+        r.errc = kDestinationTooSmall;
+    else if (d.stream_capacity - written < 4)
+        r.flags = 2; // undecidable here, see above
+    if (lane == 0)
+        results[blockIdx.x] = r;
+}
+
+} // namespace pipe
+} // namespace jls

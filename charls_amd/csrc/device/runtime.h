@@ -92,6 +92,20 @@ inline size_t worst_case_scan_bytes(uint32_t width, uint32_t height, int32_t com
 void launch_encode_serial(const ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream);
 void launch_decode_serial(const ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream);
 
+// Decoder dispatch.  All `count` scans must share the geometry / coding mode of `proto` (a HOST copy of one of them):
+// the wave-uniform LDS decoder (scan_wave_decode.hip) when the scan qualifies, the global-memory fallback otherwise.
+// The key groups scans that can share one launch.
+uint64_t decode_launch_key(const ScanDesc& d) noexcept;
+void launch_decode(const ScanDesc& proto, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count,
+                   hipStream_t stream);
+
+// Encoder dispatch.  All `count` scans share the geometry / coding mode of `proto` (HOST copy of one of them; its
+// stream_capacity is an upper bound of every scan's capacity).  Lossless single-component scans go through the
+// parallel pipeline (lossless_pipeline.hip) unless the engine is forced to serial; everything else, and the rare scan
+// whose destination is within 3 bytes of its output size, runs the exact one-wavefront-per-scan kernel.
+bool pipeline_eligible(const ScanDesc& proto) noexcept;
+void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream);
+
 // Container placement kernels (container_kernels.hip); all pointers are DEVICE pointers.
 struct FrameCursorPod
 {

@@ -5,10 +5,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "runtime.h"
 #include "scan_serial.hip"
 #include "container_kernels.hip"
+#include "scan_wave_decode.hip"
+#include "lossless_pipeline.hip"
 
 namespace jls::dev {
 
@@ -118,6 +121,264 @@ void launch_decode_serial(const ScanDesc* d_descs, ScanResult* d_results, uint32
         return;
     hipLaunchKernelGGL(decode_scans_serial, dim3(count), dim3(64), 0, stream, d_descs, d_results);
     hip_check(hipGetLastError());
+}
+
+namespace {
+constexpr size_t kMaxDynamicLds = 64 * 1024;
+
+size_t wave_decode_lds(const ScanDesc& d)
+{
+    const size_t planes = d.interleave_mode == 0 ? 1 : static_cast<size_t>(d.components);
+    return wave::kFixedLds + planes * (static_cast<size_t>(d.width) + 2) * (d.bits_per_sample > 8 ? 2 : 1);
+}
+
+bool wave_decode_eligible(const ScanDesc& d)
+{
+    if (wave_decode_lds(d) > kMaxDynamicLds)
+        return false; // line does not fit LDS
+    if (d.reset == 0)
+        return false; // RESET = 256*m is stored as 0 by the reference: N is never halved and outgrows the packed context
+    if (d.bits_per_sample > 8 && d.interleave_mode == 0 &&
+        ((reinterpret_cast<uintptr_t>(d.pixels) | d.pixel_stride) & 1u) != 0)
+        return false; // odd row address for 16-bit samples
+    return true;
+}
+
+template <typename S>
+void launch_wave_decode(int nc, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count, size_t lds,
+                        hipStream_t stream)
+{
+    switch (nc)
+    {
+    case 1:
+        hipLaunchKernelGGL((decode_scans_wave<S, 1>), dim3(count), dim3(64), lds, stream, d_descs, d_results);
+        break;
+    case 2:
+        hipLaunchKernelGGL((decode_scans_wave<S, 2>), dim3(count), dim3(64), lds, stream, d_descs, d_results);
+        break;
+    case 3:
+        hipLaunchKernelGGL((decode_scans_wave<S, 3>), dim3(count), dim3(64), lds, stream, d_descs, d_results);
+        break;
+    default:
+        hipLaunchKernelGGL((decode_scans_wave<S, 4>), dim3(count), dim3(64), lds, stream, d_descs, d_results);
+        break;
+    }
+}
+} // namespace
+
+uint64_t decode_launch_key(const ScanDesc& d) noexcept
+{
+    // width | components | interleave | wide | eligible : scans with equal keys can share a launch
+    return (static_cast<uint64_t>(d.width) << 16) | (static_cast<uint64_t>(d.components & 0xFF) << 8) |
+           (static_cast<uint64_t>(d.interleave_mode & 3) << 4) | (d.bits_per_sample > 8 ? 2u : 0u) |
+           (wave_decode_eligible(d) ? 1u : 0u);
+}
+
+void launch_decode(const ScanDesc& proto, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count,
+                   hipStream_t stream)
+{
+    if (count == 0)
+        return;
+    if (!wave_decode_eligible(proto))
+    {
+        launch_decode_serial(d_descs, d_results, count, stream);
+        return;
+    }
+    const int nc = proto.interleave_mode == 2 ? proto.components : 1;
+    const size_t lds = wave_decode_lds(proto);
+    if (proto.bits_per_sample > 8)
+        launch_wave_decode<uint16_t>(nc, d_descs, d_results, count, lds, stream);
+    else
+        launch_wave_decode<uint8_t>(nc, d_descs, d_results, count, lds, stream);
+    hip_check(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Lossless pipeline orchestration.
+namespace {
+
+struct StageTimer
+{
+    hipEvent_t ev[10]{};
+    int n = 0;
+    hipStream_t s;
+    explicit StageTimer(hipStream_t stream) : s(stream) {}
+    ~StageTimer()
+    {
+        for (int i = 0; i < n; ++i)
+            (void)hipEventDestroy(ev[i]);
+    }
+    void mark()
+    {
+        hip_check(hipEventCreate(&ev[n]));
+        hip_check(hipEventRecord(ev[n], s));
+        ++n;
+    }
+    double between(int a, int b)
+    {
+        float ms = 0;
+        hip_check(hipEventSynchronize(ev[b]));
+        hip_check(hipEventElapsedTime(&ms, ev[a], ev[b]));
+        return ms;
+    }
+};
+
+size_t align_up(size_t v, size_t a)
+{
+    return (v + a - 1) / a * a;
+}
+
+// Bytes of work area one scan needs (23 B per sample + per-line histograms + the unstuffed stream).
+struct PipeLayout
+{
+    size_t samples, blocks, raw_bytes;
+    size_t off_key, off_val, off_hist, off_total, off_base, off_sval, off_spos, off_len, off_code, off_bsum, off_bbase,
+        off_raw, off_bits, off_status, bytes;
+    PipeLayout(const ScanDesc& d, size_t capacity_hint)
+    {
+        samples = static_cast<size_t>(d.width) * d.height;
+        blocks = (samples + pipe::kPackBlock - 1) / pipe::kPackBlock;
+        const size_t worst = worst_case_scan_bytes(d.width, d.height, 1, d.bits_per_sample);
+        raw_bytes = align_up((capacity_hint < worst ? capacity_hint : worst) + 64, 16);
+        size_t o = 0;
+        auto take = [&](size_t n) {
+            const size_t at = o;
+            o = align_up(o + n, 256);
+            return at;
+        };
+        off_key = take(samples * 2);
+        off_val = take(samples * 4);
+        off_hist = take(static_cast<size_t>(d.height) * pipe::kChains * 4);
+        off_total = take(pipe::kChains * 4);
+        off_base = take(pipe::kChains * 4);
+        off_sval = take(samples * 4);
+        off_spos = take(samples * 4);
+        off_len = take(samples);
+        off_code = take(samples * 8);
+        off_bsum = take(blocks * 4);
+        off_bbase = take(blocks * 8);
+        off_raw = take(raw_bytes);
+        off_bits = take(8);
+        off_status = take(4);
+        bytes = o;
+    }
+};
+
+DeviceBuffer& pipeline_arena()
+{
+    static thread_local DeviceBuffer arena;
+    return arena;
+}
+
+constexpr size_t kArenaBudget = size_t{96} << 30; // bytes of HBM the pipeline may use for work areas per call
+
+template <typename S>
+void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
+{
+    const PipeLayout lay(proto, proto.stream_capacity);
+    const uint32_t per_pass = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, kArenaBudget / lay.bytes)));
+    auto* arena = static_cast<uint8_t*>(pipeline_arena().ensure(lay.bytes * per_pass + per_pass * sizeof(pipe::Work)));
+    auto* d_works = reinterpret_cast<pipe::Work*>(arena + lay.bytes * per_pass);
+    std::vector<pipe::Work> works(per_pass);
+    Timings& tm = last_timings();
+    double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (uint32_t first = 0; first < count; first += per_pass)
+    {
+        const uint32_t n = std::min(per_pass, count - first);
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            uint8_t* base = arena + lay.bytes * i;
+            pipe::Work& w = works[i];
+            w.key = reinterpret_cast<uint16_t*>(base + lay.off_key);
+            w.val = reinterpret_cast<uint32_t*>(base + lay.off_val);
+            w.hist = reinterpret_cast<uint32_t*>(base + lay.off_hist);
+            w.chain_total = reinterpret_cast<uint32_t*>(base + lay.off_total);
+            w.chain_base = reinterpret_cast<uint32_t*>(base + lay.off_base);
+            w.sval = reinterpret_cast<uint32_t*>(base + lay.off_sval);
+            w.spos = reinterpret_cast<uint32_t*>(base + lay.off_spos);
+            w.len = base + lay.off_len;
+            w.code = reinterpret_cast<uint64_t*>(base + lay.off_code);
+            w.blocksum = reinterpret_cast<uint32_t*>(base + lay.off_bsum);
+            w.blockbase = reinterpret_cast<uint64_t*>(base + lay.off_bbase);
+            w.raw = reinterpret_cast<uint32_t*>(base + lay.off_raw);
+            w.raw_words = lay.raw_bytes / 4;
+            w.total_bits = reinterpret_cast<uint64_t*>(base + lay.off_bits);
+            w.status = reinterpret_cast<uint32_t*>(base + lay.off_status);
+            // len, raw, total_bits and status start at zero (contiguous at the end of the layout apart from code)
+            hip_check(hipMemsetAsync(w.len, 0, lay.samples, stream));
+            hip_check(hipMemsetAsync(w.raw, 0, lay.off_status + 4 - lay.off_raw, stream));
+        }
+        hip_check(hipMemcpyAsync(d_works, works.data(), sizeof(pipe::Work) * n, hipMemcpyHostToDevice, stream));
+        hip_check(hipStreamSynchronize(stream)); // `works` is reused by the next pass
+
+        const ScanDesc* descs = d_descs + first;
+        const uint32_t chunks = (proto.width + 63) / 64;
+        const size_t lds_a = static_cast<size_t>(chunks) * 20 + pipe::kChains * 4;
+        const uint32_t blocks = static_cast<uint32_t>(lay.blocks);
+        StageTimer t(stream);
+        t.mark();
+        hipLaunchKernelGGL((pipe::analyze_rows<S>), dim3(proto.height, n), dim3(64), lds_a, stream, descs, d_works);
+        t.mark();
+        hipLaunchKernelGGL(pipe::chain_offsets, dim3(n), dim3(384), 0, stream, descs, d_works);
+        hipLaunchKernelGGL(pipe::scatter_events, dim3(proto.height, n), dim3(64), 0, stream, descs, d_works);
+        t.mark();
+        hipLaunchKernelGGL((pipe::code_chains<S>), dim3((n * pipe::kChains + 63) / 64), dim3(64), 0, stream, descs, d_works, n);
+        t.mark();
+        hipLaunchKernelGGL(pipe::sum_code_lengths, dim3(blocks, n), dim3(256), 0, stream, descs, d_works);
+        hipLaunchKernelGGL(pipe::scan_block_sums, dim3(n), dim3(64), 0, stream, descs, d_works);
+        hipLaunchKernelGGL(pipe::write_raw_bits, dim3(blocks, n), dim3(256), 0, stream, descs, d_works);
+        t.mark();
+        hipLaunchKernelGGL(pipe::stuff_scan, dim3(n), dim3(64), 0, stream, descs, d_works, d_results + first);
+        t.mark();
+        hip_check(hipGetLastError());
+        for (int i = 0; i < 5; ++i)
+            stage_ms[i] += t.between(i, i + 1);
+    }
+    // values[2..6]: analyze, partition, chains, pack, stuff (ms); filled in by the batch API with totals in [0],[1]
+    for (int i = 0; i < 5; ++i)
+        tm.values[2 + i] = stage_ms[i];
+    tm.count = 7;
+}
+
+} // namespace
+
+bool pipeline_eligible(const ScanDesc& d) noexcept
+{
+    if (encode_engine() == EncodeEngine::serial)
+        return false;
+    if (d.near_lossless != 0 || d.interleave_mode != 0 || d.components != 1 || d.color_transformation != 0)
+        return false;
+    if (static_cast<uint64_t>(d.width) * d.height >= (uint64_t{1} << 31) || d.width > 65536)
+        return false;
+    if (d.bits_per_sample > 8 && ((reinterpret_cast<uintptr_t>(d.pixels) | d.pixel_stride) & 1u) != 0)
+        return false;
+    return true;
+}
+
+void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
+{
+    if (count == 0)
+        return;
+    if (!pipeline_eligible(proto))
+    {
+        if (encode_engine() == EncodeEngine::pipeline)
+            raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT);
+        launch_encode_serial(d_descs, d_results, count, stream);
+        return;
+    }
+    if (proto.bits_per_sample > 8)
+        run_pipeline<uint16_t>(proto, d_descs, d_results, count, stream);
+    else
+        run_pipeline<uint8_t>(proto, d_descs, d_results, count, stream);
+    // Scans whose destination is within 3 bytes of their size: the reference's verdict depends on its flush history
+    // (src/scan_encoder.hpp:117-120), so those few are re-coded by the kernel that restates that history.
+    std::vector<ScanResult> results(count);
+    hip_check(hipMemcpyAsync(results.data(), d_results, sizeof(ScanResult) * count, hipMemcpyDeviceToHost, stream));
+    hip_check(hipStreamSynchronize(stream));
+    for (uint32_t i = 0; i < count; ++i)
+        if (results[i].errc == kOk && (results[i].flags & 2u) != 0)
+            launch_encode_serial(d_descs + i, d_results + i, 1, stream);
 }
 
 static_assert(sizeof(FrameCursorPod) == sizeof(FrameCursor), "cursor layout");

@@ -9,6 +9,18 @@ namespace jls {
 
 #define JLS_DEV __device__ __forceinline__
 
+// The wave-uniform kernels rely on the 64 lanes of a wavefront executing in lockstep (all lanes read a shared LDS word
+// before any lane of the same wavefront overwrites it).  On gfx950 that is how a wavefront executes; this marker only
+// stops the compiler from reordering across it (no instruction is emitted).  The CPU test harness maps it to a real
+// barrier between the lane threads.
+#define JLS_LOCKSTEP() __builtin_amdgcn_wave_barrier()
+
+// Launch-time sized LDS (Guideline 17 of the CDNA guide: everything carved from one 16-byte aligned dynamic region).
+// The CPU test harness pre-defines this to point at its per-workgroup buffer.
+#ifndef JLS_DYNAMIC_LDS
+#define JLS_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
 // J[] run-length order table (reference src/scan_codec.hpp:18-19), 4 bits per entry packed into two 64-bit words.
 JLS_DEV int run_j(int run_index)
 {

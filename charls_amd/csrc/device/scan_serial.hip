@@ -23,13 +23,6 @@ namespace {
 
 constexpr int kWave = 64;
 
-struct LineWindow
-{
-    uint16_t* prev;
-    uint16_t* cur;
-    size_t plane_stride; // width + 2
-};
-
 // ---------------------------------------------------------------------------------------------------------------
 // Bit writer: the reference's 32-bit accumulator and flush policy (src/scan_encoder.hpp:75-186), kept identical so
 // that destination_too_small is raised for exactly the same destination sizes.
@@ -161,8 +154,7 @@ struct BitWriter
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// Bit reader: the reference's 64-bit cache with its refill / marker rules (src/scan_decoder.hpp:250-322).  The
-// reference's 8-byte "optimistic" refill is a pure speed-up of the byte loop, so only the byte loop is restated.
+// Bit reader: the reference's 64-bit cache with its refill / marker rules (src/scan_decoder.hpp:250-322).
 struct BitReader
 {
     const uint8_t* pos;
@@ -176,6 +168,28 @@ struct BitReader
     {
         if (err)
             return;
+        // The reference's fast refill (src/scan_decoder.hpp:286-308): taken exactly when none of the next 8 bytes is
+        // 0xFF.  It may load up to 64 bits where the byte loop stops at 56..63, which is observable through the read
+        // position at the end of a scan, so it is restated rather than treated as an optimisation.
+        if (end - pos >= 8 && valid >= 0)
+        {
+            uint64_t v = 0;
+            bool any_ff = false;
+            for (int i = 0; i < 8; ++i)
+            {
+                const uint64_t b = pos[i];
+                any_ff = any_ff || b == 0xFFu;
+                v = (v << 8) | b;
+            }
+            if (!any_ff)
+            {
+                cache |= v >> valid;
+                const int consumed = (64 - valid) / 8;
+                pos += consumed;
+                valid += consumed * 8;
+                return;
+            }
+        }
         do
         {
             if (pos >= end)

@@ -225,7 +225,11 @@ try
         dev::launch_place_scan_header(slots, stream_pitch_bytes, d_blob.as<uint8_t>() + blob_offset, sos_size,
                                       d_cursors.as<dev::FrameCursorPod>(), d_descs.as<ScanDesc>(), frame_count, stream);
         scans.start();
-        dev::launch_encode_serial(d_descs.as<ScanDesc>(), d_results.as<ScanResult>(), frame_count, stream);
+        {
+            ScanDesc proto = descs[0];
+            proto.stream_capacity = stream_pitch_bytes; // upper bound of every frame's remaining capacity
+            dev::launch_encode(proto, d_descs.as<ScanDesc>(), d_results.as<ScanResult>(), frame_count, stream);
+        }
         scans.stop();
         dev::launch_advance_cursor(d_cursors.as<dev::FrameCursorPod>(), d_results.as<ScanResult>(), sos_size, frame_count,
                                    stream);
@@ -409,9 +413,35 @@ try
         for (size_t k = 0; k < active.size(); ++k)
             descs[k].line_scratch = reinterpret_cast<uint16_t*>(scratch + reinterpret_cast<size_t>(descs[k].line_scratch));
         const uint32_t n = static_cast<uint32_t>(active.size());
+        // scans that can share a kernel specialisation are made contiguous (stable), one launch per group
+        {
+            std::vector<uint32_t> order(n);
+            for (uint32_t k = 0; k < n; ++k)
+                order[k] = k;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+                return dev::decode_launch_key(descs[a]) < dev::decode_launch_key(descs[b]);
+            });
+            std::vector<ScanDesc> d2(n);
+            std::vector<uint32_t> a2(n);
+            for (uint32_t k = 0; k < n; ++k)
+            {
+                d2[k] = descs[order[k]];
+                a2[k] = active[order[k]];
+            }
+            std::copy(d2.begin(), d2.end(), descs.begin());
+            active = a2;
+        }
         hip_check(hipMemcpyAsync(d_descs.as<ScanDesc>(), descs.data(), sizeof(ScanDesc) * n, hipMemcpyHostToDevice, stream));
         total.start();
-        dev::launch_decode_serial(d_descs.as<ScanDesc>(), d_results.as<ScanResult>(), n, stream);
+        for (uint32_t first = 0; first < n;)
+        {
+            uint32_t last = first + 1;
+            while (last < n && dev::decode_launch_key(descs[last]) == dev::decode_launch_key(descs[first]))
+                ++last;
+            dev::launch_decode(descs[first], d_descs.as<ScanDesc>() + first, d_results.as<ScanResult>() + first, last - first,
+                               stream);
+            first = last;
+        }
         total.stop();
         hip_check(hipMemcpyAsync(results.data(), d_results.as<ScanResult>(), sizeof(ScanResult) * n, hipMemcpyDeviceToHost, stream));
         hip_check(hipStreamSynchronize(stream));

@@ -50,9 +50,9 @@ ScanResult ScanEngine::run(const ScanDesc& desc, bool decode)
     auto* d_result = static_cast<ScanResult*>(result_.ensure(sizeof(ScanResult)));
     hip_check(hipMemcpyAsync(d_desc, staged, sizeof desc, hipMemcpyHostToDevice, stream_));
     if (decode)
-        dev::launch_decode_serial(d_desc, d_result, 1, stream_);
+        dev::launch_decode(desc, d_desc, d_result, 1, stream_);
     else
-        dev::launch_encode_serial(d_desc, d_result, 1, stream_);
+        dev::launch_encode(desc, d_desc, d_result, 1, stream_);
     hip_check(hipMemcpyAsync(staged + sizeof desc, d_result, sizeof(ScanResult), hipMemcpyDeviceToHost, stream_));
     hip_check(hipStreamSynchronize(stream_));
     ScanResult r;
@@ -92,7 +92,7 @@ size_t ScanEngine::encode_scan(const ScanSpec& spec, size_t pixel_offset, size_t
 void ScanEngine::upload_stream(const uint8_t* source, size_t bytes)
 {
     ensure_stream();
-    bits_.ensure(bytes);
+    bits_.ensure(bytes + 16); // the ring refill of the wave decoder reads whole 16-byte groups
     stream_bytes_ = bytes;
     hip_check(hipMemcpyAsync(bits_.as<uint8_t>(), source, bytes, hipMemcpyHostToDevice, stream_));
 }

@@ -7,6 +7,11 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 } // namespace emu
 
 #include "../../charls_amd/csrc/device/scan_serial.hip"
+#include "../../charls_amd/csrc/device/scan_wave_decode.hip"
+#include "../../charls_amd/csrc/device/lossless_pipeline.hip"
+
+#include <cstdlib>
+#include <vector>
 
 extern "C" {
 
@@ -18,6 +23,89 @@ void emu_encode_scans_serial(const jls::ScanDesc* descs, jls::ScanResult* result
 void emu_decode_scans_serial(const jls::ScanDesc* descs, jls::ScanResult* results, int count)
 {
     emu::launch(jls::decode_scans_serial, dim3(count), dim3(64), 0, descs, results);
+}
+
+// NC co-sited components / sample width chosen exactly as the host dispatcher does (runtime.hip: launch_decode).
+int emu_decode_scans_wave(const jls::ScanDesc* descs, jls::ScanResult* results, int count)
+{
+    const jls::ScanDesc& d = descs[0];
+    const int planes = d.interleave_mode == 0 ? 1 : d.components;
+    const bool wide = d.bits_per_sample > 8;
+    const size_t lds = jls::wave::kFixedLds + (size_t)planes * (d.width + 2) * (wide ? 2 : 1);
+    const int nc = d.interleave_mode == 2 ? d.components : 1;
+#define EMU_CASE(S, N) emu::launch(jls::decode_scans_wave<S, N>, dim3(count), dim3(64), lds, descs, results)
+    if (!wide)
+    {
+        if (nc == 1) EMU_CASE(uint8_t, 1); else if (nc == 2) EMU_CASE(uint8_t, 2); else if (nc == 3) EMU_CASE(uint8_t, 3); else EMU_CASE(uint8_t, 4);
+    }
+    else
+    {
+        if (nc == 1) EMU_CASE(uint16_t, 1); else if (nc == 2) EMU_CASE(uint16_t, 2); else if (nc == 3) EMU_CASE(uint16_t, 3); else EMU_CASE(uint16_t, 4);
+    }
+#undef EMU_CASE
+    return 0;
+}
+
+} // extern "C"
+
+// The lossless pipeline, kernel by kernel, in the order and with the launch geometry runtime.hip uses.
+template <typename S>
+static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count)
+{
+    using namespace jls;
+    const ScanDesc& p = descs[0];
+    const size_t samples = (size_t)p.width * p.height;
+    const size_t blocks = (samples + pipe::kPackBlock - 1) / pipe::kPackBlock;
+    std::vector<pipe::Work> works(count);
+    std::vector<void*> allocs;
+    auto zalloc = [&](size_t bytes) {
+        void* q = std::calloc(bytes + 64, 1);
+        allocs.push_back(q);
+        return q;
+    };
+    for (int i = 0; i < count; ++i)
+    {
+        pipe::Work& w = works[i];
+        const size_t raw_bytes = ((size_t)descs[i].stream_capacity + 64 + 15) / 16 * 16;
+        w.key = (uint16_t*)zalloc(samples * 2);
+        w.val = (uint32_t*)zalloc(samples * 4);
+        w.hist = (uint32_t*)zalloc((size_t)p.height * pipe::kChains * 4);
+        w.chain_total = (uint32_t*)zalloc(pipe::kChains * 4);
+        w.chain_base = (uint32_t*)zalloc(pipe::kChains * 4);
+        w.sval = (uint32_t*)zalloc(samples * 4);
+        w.spos = (uint32_t*)zalloc(samples * 4);
+        w.len = (uint8_t*)zalloc(samples);
+        w.code = (uint64_t*)zalloc(samples * 8);
+        w.blocksum = (uint32_t*)zalloc(blocks * 4);
+        w.blockbase = (uint64_t*)zalloc(blocks * 8);
+        w.raw = (uint32_t*)zalloc(raw_bytes);
+        w.raw_words = raw_bytes / 4;
+        w.total_bits = (uint64_t*)zalloc(8);
+        w.status = (uint32_t*)zalloc(4);
+    }
+    const uint32_t chunks = (p.width + 63) / 64;
+    const size_t lds_a = (size_t)chunks * 20 + pipe::kChains * 4;
+    const pipe::Work* wk = works.data();
+    emu::launch(pipe::analyze_rows<S>, dim3(p.height, count), dim3(64), lds_a, descs, wk);
+    emu::launch(pipe::chain_offsets, dim3(count), dim3(384), 0, descs, wk);
+    emu::launch(pipe::scatter_events, dim3(p.height, count), dim3(64), 0, descs, wk);
+    emu::launch(pipe::code_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    emu::launch(pipe::sum_code_lengths, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
+    emu::launch(pipe::scan_block_sums, dim3(count), dim3(64), 0, descs, wk);
+    emu::launch(pipe::write_raw_bits, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
+    emu::launch(pipe::stuff_scan, dim3(count), dim3(64), 0, descs, wk, results);
+    for (void* q : allocs)
+        std::free(q);
+}
+
+extern "C" {
+
+void emu_encode_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count)
+{
+    if (descs[0].bits_per_sample > 8)
+        emu_pipeline<uint16_t>(descs, results, count);
+    else
+        emu_pipeline<uint8_t>(descs, results, count);
 }
 
 size_t emu_sizeof_scan_desc() { return sizeof(jls::ScanDesc); }

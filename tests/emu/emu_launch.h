@@ -12,14 +12,15 @@ template <typename Kernel, typename... Args>
 void launch(Kernel kernel, dim3 grid, dim3 block, size_t dyn_shared_bytes, Args... args)
 {
     const int n = (int)(block.x * block.y * block.z);
-    std::vector<unsigned char> dyn(dyn_shared_bytes + 16);
+    std::vector<unsigned char> dyn_store(dyn_shared_bytes + 64);
+    unsigned char* dyn_aligned = dyn_store.data() + (64 - (reinterpret_cast<uintptr_t>(dyn_store.data()) & 63)) % 64;
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx)
             {
                 BlockState st;
                 st.nthreads = n;
-                st.dyn_shared = dyn.data();
+                st.dyn_shared = dyn_aligned;
                 pthread_barrier_init(&st.block_barrier, nullptr, n);
                 const int waves = (n + kWave - 1) / kWave;
                 for (int w = 0; w < waves; ++w)

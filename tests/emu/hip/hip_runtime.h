@@ -16,6 +16,7 @@
 #define __device__
 #define __host__
 #define __shared__ static
+#define JLS_DYNAMIC_LDS(name) unsigned char* name = emu::g_block->dyn_shared
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __restrict__
@@ -174,6 +175,20 @@ inline T atomicExch(T* p, T v)
 }
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
+inline void __builtin_amdgcn_wave_barrier()
+{
+    emu::wave_sync();
+}
+
+struct uint4
+{
+    unsigned x, y, z, w;
+};
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w)
+{
+    return uint4{x, y, z, w};
+}
 
 inline unsigned __builtin_amdgcn_readfirstlane(unsigned v)
 {

@@ -1,0 +1,92 @@
+"""Kernel-logic check on the CPU for the parallel lossless encoder (lossless_pipeline.hip compiled for the host by
+tests/emu): every stage runs with the launch geometry of the product, the final scan bytes must equal the reference's."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+import emu_bind
+import jls_container
+import oracle_bind as ob
+from charls_amd import synth
+
+ELIGIBLE = [c for c in common.cases()
+            if c["errc"] == 0 and "file" in c and c["near_lossless"] == 0 and c["width"] * c["height"] <= 128 * 128 and
+            (c["component_count"] == 1 or c["interleave_mode"] == 0)]
+
+
+def _encode_planes(L, planes, width, height, bits, pc, capacity_slack=64):
+    """planes: list of 2-D arrays (one scan each). Returns list of (errc, flags, bytes)."""
+    keep, descs, outs = [], [], []
+    for pl in planes:
+        pix = np.frombuffer(np.ascontiguousarray(pl).tobytes(), dtype=np.uint8).copy()
+        out = np.zeros(width * height * 4 + 1024 if capacity_slack is None else capacity_slack, dtype=np.uint8)
+        outs.append(out)
+        descs.append(emu_bind.make_desc(width, height, 1, 0, bits, 0, 0, pc, 0, pix, width * (1 if bits <= 8 else 2), out, keep))
+    arr = (emu_bind.ScanDesc * len(descs))(*descs)
+    res = (emu_bind.ScanResult * len(descs))()
+    L.emu_encode_pipeline(arr, res, len(descs))
+    return [(r.errc, r.flags, o[:r.bytes].tobytes()) for r, o in zip(res, outs)]
+
+
+@pytest.mark.parametrize("c", ELIGIBLE, ids=lambda c: c["name"])
+def test_pipeline_matches_reference_scan_bytes(c):
+    L = emu_bind.lib()
+    with open(f"{common.GOLDEN}/{c['file']}", "rb") as f:
+        jls = f.read()
+    cont = jls_container.parse(jls)
+    pc = jls_container.validated_pc(tuple(c["preset"]) if c["preset"] else (0,) * 5, c["bits_per_sample"], 0)
+    img = common.case_input(c)
+    planes = [img] if img.ndim == 2 else [img[i] for i in range(img.shape[0])]
+    size = max(s.data_end - s.data_start for s in cont.scans) + 64
+    got = _encode_planes(L, planes, c["width"], c["height"], c["bits_per_sample"], pc, capacity_slack=size)
+    for (errc, flags, data), scan in zip(got, cont.scans):
+        assert errc == 0
+        assert data == jls[scan.data_start:scan.data_end]
+
+
+@pytest.mark.parametrize("kind,bits,w,h,seed", [("mixed", 8, 200, 37, 1), ("zero", 8, 130, 9, 2), ("noise", 8, 70, 20, 3),
+                                                ("hard", 12, 65, 33, 4), ("mixed", 16, 129, 17, 5), ("gradient", 8, 64, 64, 6),
+                                                ("mixed", 8, 1, 50, 7), ("mixed", 8, 63, 1, 8), ("noise", 16, 40, 12, 9)])
+def test_pipeline_batch_of_seeded_frames(kind, bits, w, h, seed):
+    """Several frames in one launch (lanes of the chain kernel interleave frames): each equals the oracle."""
+    L = emu_bind.lib()
+    frames = [synth.frame_numpy(w, h, seed=seed * 10 + f, bits=bits, kind=kind) for f in range(3)]
+    pc = jls_container.validated_pc((0,) * 5, bits, 0)
+    got = _encode_planes(L, frames, w, h, bits, pc, capacity_slack=w * h * 4 + 1024)
+    for img, (errc, flags, data) in zip(frames, got):
+        want = ob.encode(img, width=w, height=h, bits_per_sample=bits)
+        cont = jls_container.parse(want)
+        assert errc == 0
+        assert data == want[cont.scans[0].data_start:cont.scans[0].data_end]
+
+
+def test_pipeline_long_runs_cross_run_index_31():
+    """Runs long enough to walk RUNindex up to 31 and back (J = 15): src/scan_encoder.hpp:53-73."""
+    L = emu_bind.lib()
+    w, h = 70000, 3  # one line of 70000 equal samples needs 2^15 blocks
+    img = np.zeros((h, w), dtype=np.uint8)
+    img[1, 50000:] = 9
+    img[2, ::2] = 3
+    pc = jls_container.validated_pc((0,) * 5, 8, 0)
+    (errc, flags, data), = _encode_planes(L, [img], w, h, 8, pc, capacity_slack=w * h * 2 + 1024)
+    want = ob.encode(img, width=w, height=h)
+    cont = jls_container.parse(want)
+    assert errc == 0 and data == want[cont.scans[0].data_start:cont.scans[0].data_end]
+
+
+def test_pipeline_destination_too_small_and_knife_edge():
+    L = emu_bind.lib()
+    img = synth.frame_numpy(64, 64, seed=3, kind="mixed")
+    want = ob.encode(img, width=64, height=64)
+    cont = jls_container.parse(want)
+    n = cont.scans[0].data_end - cont.scans[0].data_start
+    pc = jls_container.validated_pc((0,) * 5, 8, 0)
+    (errc, flags, data), = _encode_planes(L, [img], 64, 64, 8, pc, capacity_slack=n - 1)
+    assert errc == 3
+    for slack in (0, 1, 3):
+        (errc, flags, data), = _encode_planes(L, [img], 64, 64, 8, pc, capacity_slack=n + slack)
+        assert errc == 0 and flags == 2  # host re-runs the exact serial kernel for these
+    (errc, flags, data), = _encode_planes(L, [img], 64, 64, 8, pc, capacity_slack=n + 4)
+    assert errc == 0 and flags == 0 and len(data) == n

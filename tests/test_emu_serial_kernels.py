@@ -48,8 +48,20 @@ def test_emulated_encode_kernel_matches_reference_scan_bytes(c):
         assert out[:r.bytes].tobytes() == jls[scan.data_start:scan.data_end]
 
 
+DECODERS = ["emu_decode_scans_serial", "emu_decode_scans_wave"]
+
+
+def _stream_copy(jls, start):
+    """Source bytes of a scan placed at a deliberately odd offset of a padded buffer (the ring refill aligns down)."""
+    raw = np.zeros(len(jls) - start + 64 + 32, dtype=np.uint8)
+    view = raw[19:19 + len(jls) - start]
+    view[:] = np.frombuffer(jls[start:], dtype=np.uint8)
+    return view
+
+
+@pytest.mark.parametrize("kernel", DECODERS)
 @pytest.mark.parametrize("c", CASES, ids=lambda c: c["name"])
-def test_emulated_decode_kernel_matches_reference_pixels(c):
+def test_emulated_decode_kernel_matches_reference_pixels(c, kernel):
     L = emu_bind.lib()
     with open(f"{common.GOLDEN}/{c['file']}", "rb") as f:
         jls = f.read()
@@ -62,12 +74,12 @@ def test_emulated_decode_kernel_matches_reference_pixels(c):
         stride = w * bytes_ps * (1 if scan.ilv == 0 else scan.components)
         pix = np.zeros(stride * h, dtype=np.uint8)
         outs.append(pix)
-        src = np.frombuffer(jls[scan.data_start:], dtype=np.uint8).copy()
+        src = _stream_copy(jls, scan.data_start)
         descs.append(emu_bind.make_desc(w, h, scan.components, scan.ilv, cont.bits, scan.near, cont.transform, pc,
                                         cont.restart_interval, pix, stride, src, keep))
-    arr = (emu_bind.ScanDesc * len(descs))(*descs)
     res = (emu_bind.ScanResult * len(descs))()
-    L.emu_decode_scans_serial(arr, res, len(descs))
+    for k, dsc in enumerate(descs):  # one launch per scan: the wave kernel is specialised per geometry
+        getattr(L, kernel)((emu_bind.ScanDesc * 1)(dsc), C.byref(res[k]), 1)
     got = b"".join(o.tobytes() for o in outs)
     for r, scan in zip(res, cont.scans):
         assert r.errc == 0
@@ -75,8 +87,10 @@ def test_emulated_decode_kernel_matches_reference_pixels(c):
     assert common.sha(got) == c["decoded_sha256"]
 
 
-@pytest.mark.parametrize("name,pnm,ilv", [("test8_ilv_none_rm_7", "test8.ppm", 0), ("test8_ilv_sample_rm_300", "test8.ppm", 2)])
-def test_emulated_decode_restart_markers(name, pnm, ilv):
+@pytest.mark.parametrize("kernel", DECODERS)
+@pytest.mark.parametrize("name,pnm,ilv", [("test8_ilv_none_rm_7", "test8.ppm", 0), ("test8_ilv_sample_rm_300", "test8.ppm", 2),
+                                          ("test8_ilv_line_rm_7", "test8.ppm", 1)])
+def test_emulated_decode_restart_markers(name, pnm, ilv, kernel):
     L = emu_bind.lib()
     jls = common.refdata(f"{name}.jls")
     img, _ = common.read_pnm(pnm)
@@ -88,19 +102,21 @@ def test_emulated_decode_restart_markers(name, pnm, ilv):
         stride = cont.width * (1 if scan.ilv == 0 else scan.components)
         pix = np.zeros(stride * cont.height, dtype=np.uint8)
         outs.append(pix)
-        src = np.frombuffer(jls[scan.data_start:], dtype=np.uint8).copy()
+        src = _stream_copy(jls, scan.data_start)
         descs.append(emu_bind.make_desc(cont.width, cont.height, scan.components, scan.ilv, cont.bits, scan.near,
                                         cont.transform, pc, cont.restart_interval, pix, stride, src, keep))
     arr = (emu_bind.ScanDesc * len(descs))(*descs)
     res = (emu_bind.ScanResult * len(descs))()
-    L.emu_decode_scans_serial(arr, res, len(descs))
+    getattr(L, kernel)(arr, res, len(descs))
     assert all(r.errc == 0 for r in res)
     assert b"".join(o.tobytes() for o in outs) == want
 
 
 @pytest.mark.parametrize("name,errc", [("fuzzy-input-bad-run-mode-golomb-code.jls", 5),
-                                       ("fuzzy_input_golomb_16.jls", 5), ("fuzzy-input-no-valid-bits-at-the-end.jls", 5)])
-def test_emulated_decode_corrupt_streams(name, errc):
+                                       ("fuzzy_input_golomb_16.jls", 5), ("fuzzy-input-no-valid-bits-at-the-end.jls", 5),
+                                       ("no_start_byte_after_encoded_scan.jls", 4)])
+@pytest.mark.parametrize("kernel", DECODERS)
+def test_emulated_decode_corrupt_streams(name, errc, kernel):
     import oracle_bind as ob
     L = emu_bind.lib()
     jls = common.refdata(name)
@@ -112,10 +128,10 @@ def test_emulated_decode_corrupt_streams(name, errc):
     stride = cont.width * bytes_ps * (1 if scan.ilv == 0 else scan.components)
     keep = []
     pix = np.zeros(stride * cont.height, dtype=np.uint8)
-    src = np.frombuffer(jls[scan.data_start:], dtype=np.uint8).copy()
+    src = _stream_copy(jls, scan.data_start)
     d = emu_bind.make_desc(cont.width, cont.height, scan.components, scan.ilv, cont.bits, scan.near, cont.transform, pc,
                            cont.restart_interval, pix, stride, src, keep)
     arr = (emu_bind.ScanDesc * 1)(d)
     res = (emu_bind.ScanResult * 1)()
-    L.emu_decode_scans_serial(arr, res, 1)
+    getattr(L, kernel)(arr, res, 1)
     assert res[0].errc == errc
