@@ -193,6 +193,9 @@ def main():
             "decode_mpix_s": round(frames_n * pixels / 1e6 / (np.mean(dec_ms) * 1e-3), 2),
             "encode_ms": round(float(np.mean(enc_ms)), 3),
             "decode_ms": round(float(np.mean(dec_ms)), 3),
+            "encode_stage_ms": dict(zip(["analyze", "partition", "chains", "pack", "stuff"],
+                                        [round(float(v), 3) for v in np.mean([k[2:7] for k in enc_kernel_ms], axis=0)]))
+            if enc_kernel_ms and len(enc_kernel_ms[0]) >= 7 else None,
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "kernel_ms_per_launch": round(dom_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes)},

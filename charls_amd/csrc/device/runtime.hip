@@ -270,7 +270,7 @@ DeviceBuffer& pipeline_arena()
     return arena;
 }
 
-constexpr size_t kArenaBudget = size_t{96} << 30; // bytes of HBM the pipeline may use for work areas per call
+constexpr size_t kArenaBudget = size_t{64} << 30; // bytes of HBM the pipeline may use for work areas per call
 
 template <typename S>
 void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)

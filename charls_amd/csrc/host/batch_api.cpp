@@ -204,6 +204,7 @@ try
 
     EventTimer total(stream), scans(stream);
     double scan_ms = 0;
+    dev::last_timings().count = 0;
     total.start();
     dev::launch_place_prologue(slots, stream_pitch_bytes, d_blob.as<uint8_t>(), prologue_size,
                                d_cursors.as<dev::FrameCursorPod>(), frame_count, stream);
@@ -247,7 +248,8 @@ try
     dev::Timings& t = dev::last_timings();
     t.values[0] = total.ms();
     t.values[1] = scan_ms;
-    t.count = 2;
+    if (t.count < 2)
+        t.count = 2; // the pipeline adds its stage breakdown in values[2..6]
     return CHARLS_JPEGLS_ERRC_SUCCESS;
 }
 catch (...)
