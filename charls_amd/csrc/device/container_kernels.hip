@@ -8,6 +8,7 @@
 //   <scan kernels>
 //   advance_cursor : cursor += SOS + entropy bytes, latch the first error of the frame
 //   place_epilogue : optional 0xFF fill + EOI (src/jpeg_stream_writer.cpp:26-35)       -> sizes[f]
+#pragma once
 #include <hip/hip_runtime.h>
 
 #include "scan_types.h"

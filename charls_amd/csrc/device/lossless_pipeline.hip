@@ -18,6 +18,7 @@
 //                        per scan streaming through LDS
 //
 // Output is byte-identical to scan_encoder::encode_scan.  MFMA is not used anywhere: nothing here is a contraction.
+#pragma once
 #include <hip/hip_runtime.h>
 
 #include "scan_model.h"

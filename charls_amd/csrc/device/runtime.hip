@@ -12,6 +12,7 @@
 #include "container_kernels.hip"
 #include "scan_wave_decode.hip"
 #include "lossless_pipeline.hip"
+#include "scan_fast_decode.hip"
 
 namespace jls::dev {
 
@@ -144,6 +145,20 @@ bool wave_decode_eligible(const ScanDesc& d)
     return true;
 }
 
+size_t fast_decode_lds(const ScanDesc& d)
+{
+    const size_t line_bytes = ((static_cast<size_t>(d.width) + 2) * (d.bits_per_sample > 8 ? 2 : 1) + 3) & ~size_t{3};
+    return fast::kFixedLds + line_bytes + (static_cast<size_t>(d.width) + 2) * 4;
+}
+
+// Lossless single-component scans take the speed path (scan_fast_decode.hip); it defers to the exact kernels whenever
+// the scan does not end cleanly.
+bool fast_decode_eligible(const ScanDesc& d)
+{
+    return wave_decode_eligible(d) && d.near_lossless == 0 && d.interleave_mode == 0 && d.components == 1 &&
+           fast_decode_lds(d) <= kMaxDynamicLds && std::getenv("CHARLS_AMD_EXACT_DECODER") == nullptr;
+}
+
 template <typename S>
 void launch_wave_decode(int nc, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count, size_t lds,
                         hipStream_t stream)
@@ -170,8 +185,8 @@ uint64_t decode_launch_key(const ScanDesc& d) noexcept
 {
     // width | components | interleave | wide | eligible : scans with equal keys can share a launch
     return (static_cast<uint64_t>(d.width) << 16) | (static_cast<uint64_t>(d.components & 0xFF) << 8) |
-           (static_cast<uint64_t>(d.interleave_mode & 3) << 4) | (d.bits_per_sample > 8 ? 2u : 0u) |
-           (wave_decode_eligible(d) ? 1u : 0u);
+           (static_cast<uint64_t>(d.interleave_mode & 3) << 4) | (fast_decode_eligible(d) ? 4u : 0u) |
+           (d.bits_per_sample > 8 ? 2u : 0u) | (wave_decode_eligible(d) ? 1u : 0u);
 }
 
 void launch_decode(const ScanDesc& proto, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count,
@@ -186,11 +201,30 @@ void launch_decode(const ScanDesc& proto, const ScanDesc* d_descs, ScanResult* d
     }
     const int nc = proto.interleave_mode == 2 ? proto.components : 1;
     const size_t lds = wave_decode_lds(proto);
+    auto exact = [&](const ScanDesc* descs, ScanResult* results, uint32_t n) {
+        if (proto.bits_per_sample > 8)
+            launch_wave_decode<uint16_t>(nc, descs, results, n, lds, stream);
+        else
+            launch_wave_decode<uint8_t>(nc, descs, results, n, lds, stream);
+        hip_check(hipGetLastError());
+    };
+    if (!fast_decode_eligible(proto))
+    {
+        exact(d_descs, d_results, count);
+        return;
+    }
     if (proto.bits_per_sample > 8)
-        launch_wave_decode<uint16_t>(nc, d_descs, d_results, count, lds, stream);
+        hipLaunchKernelGGL((decode_scans_fast<uint16_t>), dim3(count), dim3(64), fast_decode_lds(proto), stream, d_descs, d_results);
     else
-        launch_wave_decode<uint8_t>(nc, d_descs, d_results, count, lds, stream);
+        hipLaunchKernelGGL((decode_scans_fast<uint8_t>), dim3(count), dim3(64), fast_decode_lds(proto), stream, d_descs, d_results);
     hip_check(hipGetLastError());
+    // scans that did not end cleanly are decided by the exact decoder (error codes and byte counts of the reference)
+    std::vector<ScanResult> results(count);
+    hip_check(hipMemcpyAsync(results.data(), d_results, sizeof(ScanResult) * count, hipMemcpyDeviceToHost, stream));
+    hip_check(hipStreamSynchronize(stream));
+    for (uint32_t i = 0; i < count; ++i)
+        if ((results[i].flags & fast::kFastRetry) != 0)
+            exact(d_descs + i, d_results + i, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

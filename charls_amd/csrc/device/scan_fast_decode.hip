@@ -1,0 +1,474 @@
+// scan_fast_decode.hip -- speed path of the scan decoder for lossless single-component scans (the BASELINE workload).
+//
+// Same one-wavefront-per-scan, wave-uniform organisation as scan_wave_decode.hip, with the per-sample dependency chain
+// cut down to what is truly serial (bit position -> k -> context -> reconstructed sample):
+//
+//   * un-stuffing is hoisted out of the chain.  JPEG-LS stuffing is byte aligned in the coded stream (the byte after a
+//     0xFF carries 7 payload bits), so each 1 KB refill is un-stuffed by all 64 lanes at once (16 bytes per lane, a
+//     wave prefix sum of the 7/8-bit contributions, LDS atomic OR into a dense bit ring); marker detection (0xFF followed
+//     by a byte >= 0x80) happens there as well.  The serial reader then only does aligned 64-bit reads of dense bits.
+//   * the part of the context that depends on the previous LINE only (81*Q1 + 9*Q2 and the sample Rd) is computed for a
+//     whole line by all lanes right after the previous line is complete and parked in LDS next to it, so the serial
+//     loop needs one LDS word, one gradient quantisation (Rc - Ra) and the context table per sample.
+//   * contexts are the packed 8-byte form of scan_wave_decode.hip; run mode is kept out of line.
+//
+// This kernel is not a restatement of the reference's bit reader; it decodes the same bit sequence.  Its result is used
+// only when the scan ends cleanly (all samples decoded inside the entropy-coded segment, zero padding, marker next).
+// In every other case it reports flags = kFastRetry and the host re-runs the exact decoder (scan_wave_decode.hip /
+// scan_serial.hip), which reproduces the reference's error codes and byte counts.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "scan_model.h"
+#include "scan_wave_decode.hip"
+
+namespace jls {
+namespace fast {
+
+constexpr uint32_t kBitRingBytes = 4096;          // dense (un-stuffed) bits resident in LDS
+constexpr uint32_t kBitRingBits = kBitRingBytes * 8;
+constexpr uint32_t kSrcChunk = 1024;              // coded bytes consumed per cooperative refill
+constexpr uint32_t kFixedLds = wave::kCtxBytes + wave::kRunBytes + kBitRingBytes;
+constexpr uint32_t kFastRetry = 4u;               // ScanResult.flags: decode again with the exact kernel
+
+// Producer/consumer state of the dense bit ring (wave-uniform).
+struct DenseBits
+{
+    const uint8_t* gbase; // 16-byte aligned origin of the coded stream
+    uint64_t u_next;      // next coded byte to un-stuff (u = offset + misalignment)
+    uint64_t u_end;       // end of the source
+    uint64_t u_begin;
+    uint64_t produced;    // dense bits written so far
+    uint64_t u_marker;    // position of the terminating marker once seen (else ~0)
+    uint32_t prev_byte;   // last coded byte of the previous refill
+    uint32_t* ring;       // kBitRingBytes / 4 words; bit p lives in word ((p >> 5) ^ 1) (64-bit words, MSB first)
+    bool ended;           // marker or end of source reached: `produced` is final
+    int lane;
+
+    // OR `n` (1..32) bits, right aligned in v, at dense bit position p (MSB first).
+    JLS_DEV void put(uint64_t p, uint32_t v, int n)
+    {
+        const uint32_t q = (uint32_t)((p & (kBitRingBits - 1)) >> 5);
+        const int off = (int)(p & 31);
+        const int room = 32 - off;
+        if (n <= room)
+            atomicOr(&ring[q ^ 1u], v << (room - n));
+        else
+        {
+            atomicOr(&ring[q ^ 1u], v >> (n - room));
+            const uint32_t q2 = (q + 1) & (kBitRingBits / 32 - 1);
+            atomicOr(&ring[q2 ^ 1u], v << (32 - (n - room)));
+        }
+    }
+
+    // Un-stuffs up to kSrcChunk coded bytes.  All 64 lanes.
+    JLS_DEV void refill()
+    {
+        // 1) clear the words this refill may touch (everything after the word holding `produced`)
+        {
+            const uint32_t first = (uint32_t)((produced + 31) >> 5);
+            for (uint32_t i = lane; i < kSrcChunk * 8 / 32 + 2; i += 64)
+            {
+                const uint32_t q = (first + i) & (kBitRingBits / 32 - 1);
+                ring[q ^ 1u] = 0;
+            }
+        }
+        __syncthreads();
+        // 2) every lane takes 16 coded bytes
+        const uint64_t u0 = u_next + (uint64_t)lane * 16;
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (u0 < u_end)
+            raw = *reinterpret_cast<const uint4*>(gbase + u0);
+        const uint32_t words[4] = {raw.x, raw.y, raw.z, raw.w};
+        uint32_t next_first = 0; // coded byte following this lane's 16 (for the marker test of its last byte)
+        if (u0 + 16 < u_end)
+            next_first = gbase[u0 + 16];
+        uint32_t last = words[3] >> 24;
+        uint32_t before = __shfl_up(last, 1);
+        if (lane == 0)
+            before = prev_byte;
+        // bits contributed by each byte and the first marker inside this lane's bytes
+        int nbits[16];
+        uint32_t bytes[16];
+        int marker_at = 16;
+        uint32_t prev = before;
+        int total = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+        {
+            const uint32_t b = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+            const uint64_t u = u0 + (uint64_t)j;
+            bytes[j] = b;
+            int n = 0;
+            if (u == u_begin)
+                prev = 0; // the first coded byte has no predecessor
+            if (u >= u_begin && u < u_end && marker_at == 16)
+            {
+                const uint32_t nb = j < 15 ? ((words[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 0xFFu) : next_first;
+                const bool is_marker = b == 0xFFu && (u + 1 >= u_end || (nb & 0x80u) != 0);
+                if (is_marker)
+                    marker_at = j;
+                else
+                    n = prev == 0xFFu ? 7 : 8;
+            }
+            nbits[j] = n;
+            total += n;
+            prev = b;
+        }
+        // lanes after the first marker (or past the end) contribute nothing
+        const unsigned long long has_marker = __ballot(marker_at < 16);
+        const int first_marker_lane = has_marker ? __ffsll(has_marker) - 1 : 64;
+        if (lane > first_marker_lane)
+            total = 0;
+        // exclusive prefix sum of the lanes' bit counts
+        int inc = total;
+        for (int delta = 1; delta < 64; delta <<= 1)
+        {
+            const int up = __shfl_up(inc, delta);
+            if (lane >= delta)
+                inc += up;
+        }
+        uint64_t p = produced + (uint64_t)(inc - total);
+        if (lane <= first_marker_lane)
+        {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (nbits[j] != 0)
+                {
+                    put(p, nbits[j] == 7 ? (bytes[j] & 0x7Fu) : bytes[j], nbits[j]);
+                    p += (uint64_t)nbits[j];
+                }
+        }
+        const int chunk_bits = __shfl(inc, 63);
+        produced += (uint64_t)chunk_bits;
+        prev_byte = __shfl(last, 63);
+        if (has_marker)
+        {
+            const int at = __shfl(marker_at, first_marker_lane);
+            u_marker = u_next + (uint64_t)first_marker_lane * 16 + (uint64_t)at;
+            ended = true;
+        }
+        u_next += kSrcChunk;
+        if (u_next >= u_end)
+            ended = true;
+        __syncthreads();
+    }
+
+    JLS_DEV void init(const uint8_t* stream, uint64_t size, uint32_t* ring_, int lane_)
+    {
+        const uint64_t mis = (uint64_t)(reinterpret_cast<uintptr_t>(stream) & 15u);
+        gbase = stream - mis;
+        u_begin = mis;
+        u_next = 0;
+        u_end = mis + size;
+        produced = 0;
+        u_marker = ~0ull;
+        prev_byte = 0;
+        ring = ring_;
+        ended = size == 0;
+        lane = lane_;
+        for (uint32_t i = lane; i < kBitRingBits / 32; i += 64)
+            ring[i] = 0;
+        __syncthreads();
+    }
+
+    // 64 dense bits starting at bit p, MSB first (zeros beyond `produced`).
+    JLS_DEV uint64_t peek64(uint64_t p) const
+    {
+        const uint64_t* ring64 = reinterpret_cast<const uint64_t*>(ring);
+        const uint32_t w = (uint32_t)((p & (kBitRingBits - 1)) >> 6);
+        const uint64_t w0 = ring64[w];
+        const uint64_t w1 = ring64[(w + 1) & (kBitRingBits / 64 - 1)];
+        const int s = (int)(p & 63);
+        return s ? ((w0 << s) | (w1 >> (64 - s))) : w0;
+    }
+};
+
+// Serial reader over the dense ring: cache holds the next `valid` bits MSB-aligned (bits below are zero or real).
+struct FastReader
+{
+    DenseBits src;
+    uint64_t cache;
+    uint64_t bp; // dense bits consumed
+    int valid;
+
+    JLS_DEV void refill_cache()
+    {
+        // keep at least 4096 un-stuffed bits ahead of the reader (or everything there is)
+        while (!src.ended && src.produced < bp + 4096)
+            src.refill();
+        cache = src.peek64(bp);
+        valid = 64;
+    }
+    JLS_DEV void skip(int n)
+    {
+        cache <<= n;
+        bp += (uint64_t)n;
+        valid -= n;
+    }
+    JLS_DEV void need(int n)
+    {
+        if (valid < n)
+            refill_cache();
+    }
+};
+
+template <typename S>
+JLS_DEV void prepare_line(const Traits& t, const S* line, uint32_t* aux, uint32_t width, int corner, int lane)
+{
+    // aux[i] = (81*Q1 + 9*Q2 of sample i) & 0xFFFF | prev[i+1] << 16, i = 0..width (i = 0 carries prev[1] only)
+    for (uint32_t i = lane; i <= width; i += 64)
+    {
+        const int rd = (int)line[i + 1 <= width ? i + 1 : width];
+        int pre = 0;
+        if (i >= 1)
+        {
+            const int rb = (int)line[i];
+            const int rc = i >= 2 ? (int)line[i - 1] : corner;
+            pre = 81 * quantize(t, rd - rb) + 9 * quantize(t, rb - rc);
+        }
+        aux[i] = ((uint32_t)pre & 0xFFFFu) | ((uint32_t)rd << 16);
+    }
+}
+
+// Run mode, out of the hot loop.  Returns false when the scan must be retried by the exact decoder.
+template <typename S>
+__device__ __attribute__((noinline)) bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& br, S* line,
+                                                      const uint32_t* aux, uint32_t width, uint32_t& i, int& ra, int& rb,
+                                                      int& run_index, int lane)
+{
+    const uint32_t remaining = width - (i - 1);
+    uint32_t run = 0;
+    for (;;)
+    {
+        br.need(1);
+        const int bit = (int)(br.cache >> 63);
+        br.skip(1);
+        if (!bit)
+            break;
+        const uint32_t block = 1u << run_j(run_index);
+        const uint32_t count = block < remaining - run ? block : remaining - run;
+        run += count;
+        if (count == block && run_index < 31)
+            ++run_index;
+        if (run == remaining)
+            break;
+    }
+    if (run != remaining)
+    {
+        const int jb = run_j(run_index);
+        if (jb > 0)
+        {
+            br.need(jb);
+            run += (uint32_t)(br.cache >> (64 - jb));
+            br.skip(jb);
+        }
+        if (run > remaining)
+            return false;
+    }
+    JLS_LOCKSTEP();
+    for (uint32_t r = lane; r < run; r += 64)
+        line[i + r] = (S)ra;
+    if (run == remaining)
+    {
+        i = width + 1;
+        return true;
+    }
+    const uint32_t at = i + run;
+    const int rb_at = (int)(aux[at - 1] >> 16); // prev[at]
+    const int which = ra == rb_at ? 1 : 0;
+    JLS_LOCKSTEP();
+    RunCtx ctx = m.run[which];
+    const int k = run_k(ctx);
+    if (k > 24)
+        return false;
+    const int limit = t.limit - run_j(run_index) - 1;
+    br.need(64);
+    const int u = br.cache == 0 ? 64 : __clzll((long long)br.cache);
+    if (u >= 48)
+        return false; // longer than any valid prefix: let the exact decoder classify it
+    br.skip(u + 1);
+    int em;
+    if (u < limit - t.qbpp - 1)
+    {
+        em = u << k;
+        if (k)
+        {
+            br.need(k);
+            em += (int)(br.cache >> (64 - k));
+            br.skip(k);
+        }
+    }
+    else
+    {
+        br.need(t.qbpp);
+        em = (int)(br.cache >> (64 - t.qbpp)) + 1;
+        br.skip(t.qbpp);
+    }
+    const int e = run_error_value(ctx, em + ctx.ritype, k);
+    run_update(ctx, e, em, t.reset);
+    JLS_LOCKSTEP();
+    m.run[which] = ctx;
+    const int rx = which ? ((ra + e) & t.maxval) : ((rb_at + e * ((rb_at - ra) < 0 ? -1 : 1)) & t.maxval);
+    line[at] = (S)rx;
+    ra = rx;
+    rb = rb_at; // becomes Rc of the next sample; its Rb comes from aux[at]
+    if (run_index > 0)
+        --run_index;
+    i = at + 1;
+    return true;
+}
+
+} // namespace fast
+
+// Dynamic LDS: fast::kFixedLds + (width + 2) * sizeof(S) rounded to 4 + (width + 2) * 4.
+template <typename S>
+__global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restrict__ descs, ScanResult* __restrict__ results)
+{
+    using namespace fast;
+    JLS_DYNAMIC_LDS(smem);
+    const int lane = threadIdx.x;
+    const ScanDesc d = descs[blockIdx.x];
+    const Traits t = make_traits(d);
+    const wave::WaveModel m{reinterpret_cast<wave::PackedCtx*>(smem), reinterpret_cast<RunCtx*>(smem + wave::kCtxBytes)};
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem + wave::kCtxBytes + wave::kRunBytes);
+    const uint32_t width = d.width;
+    const uint32_t line_bytes = ((width + 2) * (uint32_t)sizeof(S) + 3u) & ~3u;
+    S* line = reinterpret_cast<S*>(smem + kFixedLds);
+    uint32_t* aux = reinterpret_cast<uint32_t*>(smem + kFixedLds + line_bytes);
+
+    wave::init_model(t, m, lane);
+    for (uint32_t i = lane; i < width + 2; i += 64)
+        line[i] = 0;
+    FastReader br;
+    br.src.init(d.stream, d.stream_capacity, ring, lane);
+    br.bp = 0;
+    br.refill_cache();
+
+    int corner = 0;
+    int run_index = 0;
+    bool retry = false;
+    const int t1 = t.t1, t2 = t.t2, t3 = t.t3;
+    const int limit_m = t.limit - t.qbpp - 1;
+
+    for (uint32_t y = 0; y < d.height && !retry; ++y)
+    {
+        prepare_line<S>(t, line, aux, width, corner, lane);
+        __syncthreads();
+        int rb = corner;                                             // prev[0]
+        int ra = (int)(__builtin_amdgcn_readfirstlane(aux[0]) >> 16); // cur[0] = prev[1]
+        int rd = ra;                                                 // prev[1]
+        const int first = ra;
+        uint32_t i = 1;
+        while (i <= width)
+        {
+            JLS_LOCKSTEP();
+            const uint32_t a = __builtin_amdgcn_readfirstlane(aux[i]);
+            const int rc = rb;
+            rb = rd;
+            rd = (int)(a >> 16);
+            // Q3 = quantised (Rc - Ra); the quantiser is odd-symmetric (reference src/jpegls_algorithm.hpp:173-194)
+            const int d3 = rc - ra;
+            const int ad = d3 < 0 ? -d3 : d3;
+            int q3 = (ad > 0) + (ad >= t1) + (ad >= t2) + (ad >= t3);
+            q3 = d3 < 0 ? -q3 : q3;
+            const int qs = (int)(short)(a & 0xFFFFu) + q3;
+            if (qs == 0)
+            {
+                int rb_next = rb; // decode_run reads its neighbourhood from aux and returns prev[at] here
+                if (!decode_run<S>(t, m, br, line, aux, width, i, ra, rb_next, run_index, lane))
+                {
+                    retry = true;
+                    break;
+                }
+                rb = rb_next;
+                if (i <= width)
+                    rd = (int)(__builtin_amdgcn_readfirstlane(aux[i - 1]) >> 16); // prev[i]: Rb of the next sample
+                continue;
+            }
+            // ---- regular mode
+            const int s = qs >> 31;
+            const int idx = (qs ^ s) - s;
+            const wave::PackedCtx packed = m.reg[idx];
+            RegCtx ctx = wave::unpack(wave::PackedCtx{__builtin_amdgcn_readfirstlane(packed.a),
+                                                      __builtin_amdgcn_readfirstlane(packed.bcn)});
+            const int k = regular_k(ctx);
+            int px = med_predict(ra, rb, rc) + ((ctx.c ^ s) - s);
+            px = px < 0 ? 0 : (px > t.maxval ? t.maxval : px);
+            br.need(48);
+            const int u = br.cache == 0 ? 64 : __clzll((long long)br.cache);
+            if (u >= 48 || k >= 16)
+            {
+                retry = true;
+                break;
+            }
+            br.skip(u + 1);
+            int mm;
+            if (u < limit_m)
+            {
+                mm = u << k;
+                if (k)
+                {
+                    br.need(k);
+                    mm |= (int)(br.cache >> (64 - k));
+                    br.skip(k);
+                }
+            }
+            else
+            { // escape: MErrval - 1 in qbpp bits (src/scan_decoder.hpp:113-125)
+                br.need(t.qbpp);
+                mm = (int)(br.cache >> (64 - t.qbpp)) + 1;
+                br.skip(t.qbpp);
+            }
+            int e = unmap_error(mm);
+            if (k == 0)
+                e ^= error_correction(ctx, 0);
+            if (!regular_update(ctx, e, 0, t.reset))
+            {
+                retry = true;
+                break;
+            }
+            JLS_LOCKSTEP();
+            m.reg[idx] = wave::pack(ctx);
+            const int x = (px + ((e ^ s) - s)) & t.maxval;
+            line[i] = (S)x;
+            ra = x;
+            ++i;
+        }
+        corner = first;
+        __syncthreads();
+        if (retry)
+            break;
+        // finished line -> user's row
+        uint8_t* row = d.pixels + (size_t)y * d.pixel_stride;
+        if (sizeof(S) == 1)
+            for (uint32_t x = lane; x < width; x += 64)
+                row[x] = (uint8_t)line[1 + x];
+        else
+            for (uint32_t x = lane; x < width; x += 64)
+                reinterpret_cast<uint16_t*>(row)[x] = (uint16_t)line[1 + x];
+        JLS_LOCKSTEP();
+    }
+
+    // Clean end of scan: nothing consumed past the coded segment, only zero padding left (at most the rest of a byte
+    // plus the 7-bit byte that follows a trailing 0xFF), marker found right behind it.
+    ScanResult r{kOk, 0, 0};
+    if (!retry)
+    {
+        while (!br.src.ended)
+            br.src.refill();
+        const bool inside = br.bp <= br.src.produced;
+        const uint64_t left = inside ? br.src.produced - br.bp : 0;
+        const bool clean = inside && br.src.u_marker != ~0ull && left < 15 && (left == 0 || (br.src.peek64(br.bp) >> (64 - left)) == 0);
+        if (clean)
+            r.bytes = br.src.u_marker - br.src.u_begin;
+        else
+            retry = true;
+    }
+    if (retry)
+        r.flags = kFastRetry;
+    if (lane == 0)
+        results[blockIdx.x] = r;
+}
+
+} // namespace jls

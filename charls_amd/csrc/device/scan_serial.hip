@@ -13,6 +13,7 @@
 //
 // The lossless single-component encoder has a far more parallel formulation (lossless_pipeline.hip); this file is the
 // general path and the decoder.  Results are bit-exact with the reference, including the error codes of appendix D.
+#pragma once
 #include <hip/hip_runtime.h>
 
 #include "scan_model.h"

@@ -15,6 +15,7 @@
 //     consumed and error codes match on valid, truncated and corrupt streams alike.
 // decode_scans_serial (scan_serial.hip) remains the fallback for scans whose line does not fit LDS or whose RESET makes
 // N exceed 8 bits.
+#pragma once
 #include <hip/hip_runtime.h>
 
 #include "scan_model.h"

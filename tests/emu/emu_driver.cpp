@@ -7,8 +7,8 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 } // namespace emu
 
 #include "../../charls_amd/csrc/device/scan_serial.hip"
-#include "../../charls_amd/csrc/device/scan_wave_decode.hip"
 #include "../../charls_amd/csrc/device/lossless_pipeline.hip"
+#include "../../charls_amd/csrc/device/scan_fast_decode.hip"
 
 #include <cstdlib>
 #include <vector>
@@ -106,6 +106,19 @@ void emu_encode_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
         emu_pipeline<uint16_t>(descs, results, count);
     else
         emu_pipeline<uint8_t>(descs, results, count);
+}
+
+int emu_decode_scans_fast(const jls::ScanDesc* descs, jls::ScanResult* results, int count)
+{
+    const jls::ScanDesc& d = descs[0];
+    const bool wide = d.bits_per_sample > 8;
+    const size_t line_bytes = (((size_t)d.width + 2) * (wide ? 2 : 1) + 3) & ~size_t{3};
+    const size_t lds = jls::fast::kFixedLds + line_bytes + ((size_t)d.width + 2) * 4;
+    if (wide)
+        emu::launch(jls::decode_scans_fast<uint16_t>, dim3(count), dim3(64), lds, descs, results);
+    else
+        emu::launch(jls::decode_scans_fast<uint8_t>, dim3(count), dim3(64), lds, descs, results);
+    return 0;
 }
 
 size_t emu_sizeof_scan_desc() { return sizeof(jls::ScanDesc); }

@@ -135,3 +135,51 @@ def test_emulated_decode_corrupt_streams(name, errc, kernel):
     res = (emu_bind.ScanResult * 1)()
     getattr(L, kernel)(arr, res, 1)
     assert res[0].errc == errc
+
+
+# ---- speed path of the decoder (scan_fast_decode.hip): lossless single-component scans ---------------------------------
+FAST_CASES = [c for c in CASES if c["near_lossless"] == 0 and (c["component_count"] == 1 or c["interleave_mode"] == 0)]
+
+
+@pytest.mark.parametrize("c", FAST_CASES, ids=lambda c: c["name"])
+def test_emulated_fast_decoder_matches_reference_pixels(c):
+    L = emu_bind.lib()
+    with open(f"{common.GOLDEN}/{c['file']}", "rb") as f:
+        jls = f.read()
+    cont = jls_container.parse(jls)
+    pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+    bytes_ps = 1 if cont.bits <= 8 else 2
+    w, h = cont.width, cont.height
+    keep, outs = [], []
+    for scan in cont.scans:
+        stride = w * bytes_ps
+        pix = np.zeros(stride * h, dtype=np.uint8)
+        outs.append(pix)
+        src = _stream_copy(jls, scan.data_start)
+        d = emu_bind.make_desc(w, h, 1, 0, cont.bits, 0, 0, pc, 0, pix, stride, src, keep)
+        res = (emu_bind.ScanResult * 1)()
+        L.emu_decode_scans_fast((emu_bind.ScanDesc * 1)(d), res, 1)
+        assert res[0].errc == 0 and res[0].flags == 0, "a valid stream must not need the exact decoder"
+        assert res[0].bytes == scan.data_end - scan.data_start
+    assert common.sha(b"".join(o.tobytes() for o in outs)) == c["decoded_sha256"]
+
+
+@pytest.mark.parametrize("name", ["fuzzy-input-bad-run-mode-golomb-code.jls", "fuzzy_input_golomb_16.jls",
+                                  "fuzzy-input-no-valid-bits-at-the-end.jls", "no_start_byte_after_encoded_scan.jls"])
+def test_emulated_fast_decoder_defers_on_corrupt_streams(name):
+    """The speed path never reports an error itself: anything unusual is handed to the exact decoder."""
+    L = emu_bind.lib()
+    jls = common.refdata(name)
+    cont = jls_container.parse(jls)
+    scan = cont.scans[0]
+    if scan.near != 0 or scan.ilv != 0:
+        pytest.skip("not a scan the speed path takes")
+    pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+    bytes_ps = 1 if cont.bits <= 8 else 2
+    keep = []
+    pix = np.zeros(cont.width * bytes_ps * cont.height, dtype=np.uint8)
+    src = _stream_copy(jls, scan.data_start)
+    d = emu_bind.make_desc(cont.width, cont.height, 1, 0, cont.bits, 0, 0, pc, 0, pix, cont.width * bytes_ps, src, keep)
+    res = (emu_bind.ScanResult * 1)()
+    L.emu_decode_scans_fast((emu_bind.ScanDesc * 1)(d), res, 1)
+    assert res[0].errc == 0 and res[0].flags == 4
