@@ -356,14 +356,14 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
         prepare_line<S>(t, line, aux, width, corner, lane);
         __syncthreads();
         int rb = corner;                                             // prev[0]
-        int ra = (int)(__builtin_amdgcn_readfirstlane(aux[0]) >> 16); // cur[0] = prev[1]
+        int ra = (int)(uniform(aux[0]) >> 16); // cur[0] = prev[1]
         int rd = ra;                                                 // prev[1]
         const int first = ra;
         uint32_t i = 1;
         while (i <= width)
         {
             JLS_LOCKSTEP();
-            const uint32_t a = __builtin_amdgcn_readfirstlane(aux[i]);
+            const uint32_t a = uniform(aux[i]);
             const int rc = rb;
             rb = rd;
             rd = (int)(a >> 16);
@@ -383,15 +383,15 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
                 }
                 rb = rb_next;
                 if (i <= width)
-                    rd = (int)(__builtin_amdgcn_readfirstlane(aux[i - 1]) >> 16); // prev[i]: Rb of the next sample
+                    rd = (int)(uniform(aux[i - 1]) >> 16); // prev[i]: Rb of the next sample
                 continue;
             }
             // ---- regular mode
             const int s = qs >> 31;
             const int idx = (qs ^ s) - s;
             const wave::PackedCtx packed = m.reg[idx];
-            RegCtx ctx = wave::unpack(wave::PackedCtx{__builtin_amdgcn_readfirstlane(packed.a),
-                                                      __builtin_amdgcn_readfirstlane(packed.bcn)});
+            RegCtx ctx = wave::unpack(wave::PackedCtx{uniform(packed.a),
+                                                      uniform(packed.bcn)});
             const int k = regular_k(ctx);
             int px = med_predict(ra, rb, rc) + ((ctx.c ^ s) - s);
             px = px < 0 ? 0 : (px > t.maxval ? t.maxval : px);

@@ -21,6 +21,12 @@ namespace jls {
 #define JLS_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
 
+// Value of lane 0, as a scalar: tells the compiler a value read from LDS / memory is wave-uniform.
+JLS_DEV uint32_t uniform(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // J[] run-length order table (reference src/scan_codec.hpp:18-19), 4 bits per entry packed into two 64-bit words.
 JLS_DEV int run_j(int run_index)
 {
