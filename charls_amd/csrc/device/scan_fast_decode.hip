@@ -231,9 +231,10 @@ JLS_DEV void prepare_line(const Traits& t, const S* line, uint32_t* aux, uint32_
     }
 }
 
-// Run mode, out of the hot loop.  Returns false when the scan must be retried by the exact decoder.
+// Run mode.  Returns false when the scan must be retried by the exact decoder.  Inlined on purpose: an out-of-line
+// call would force the reader state (cache, bit position) out of registers into scratch memory.
 template <typename S>
-__device__ __attribute__((noinline)) bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& br, S* line,
+JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& br, S* line,
                                                       const uint32_t* aux, uint32_t width, uint32_t& i, int& ra, int& rb,
                                                       int& run_index, int lane)
 {
