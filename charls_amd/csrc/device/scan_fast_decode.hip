@@ -177,8 +177,10 @@ struct DenseBits
     {
         const uint64_t* ring64 = reinterpret_cast<const uint64_t*>(ring);
         const uint32_t w = (uint32_t)((p & (kBitRingBits - 1)) >> 6);
-        const uint64_t w0 = ring64[w];
-        const uint64_t w1 = ring64[(w + 1) & (kBitRingBits / 64 - 1)];
+        const uint64_t r0 = ring64[w];
+        const uint64_t r1 = ring64[(w + 1) & (kBitRingBits / 64 - 1)];
+        const uint64_t w0 = ((uint64_t)uniform((uint32_t)(r0 >> 32)) << 32) | uniform((uint32_t)r0); // scalar registers
+        const uint64_t w1 = ((uint64_t)uniform((uint32_t)(r1 >> 32)) << 32) | uniform((uint32_t)r1);
         const int s = (int)(p & 63);
         return s ? ((w0 << s) | (w1 >> (64 - s))) : w0;
     }
@@ -276,10 +278,14 @@ JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& b
         return true;
     }
     const uint32_t at = i + run;
-    const int rb_at = (int)(aux[at - 1] >> 16); // prev[at]
+    const int rb_at = (int)(uniform(aux[at - 1]) >> 16); // prev[at]
     const int which = ra == rb_at ? 1 : 0;
     JLS_LOCKSTEP();
     RunCtx ctx = m.run[which];
+    ctx.ritype = (int)uniform((uint32_t)ctx.ritype);
+    ctx.a = (int)uniform((uint32_t)ctx.a);
+    ctx.n = (int)uniform((uint32_t)ctx.n);
+    ctx.nn = (int)uniform((uint32_t)ctx.nn);
     const int k = run_k(ctx);
     if (k > 24)
         return false;
