@@ -311,31 +311,60 @@ __global__ void __launch_bounds__(64) code_chains(const ScanDesc* __restrict__ d
 
     if (chain != 0)
     { // ---- regular mode: src/scan_encoder_core.hpp:57-67
+        // The recurrence on {A,B,C,N} is the only true dependency; the event records are fetched one group of four
+        // ahead so that their memory latency overlaps the arithmetic of the previous group.
         RegCtx ctx{initial_a(t), 0, 0, 1};
-        for (uint32_t e = 0; e < n; ++e)
+        uint32_t vb[4], pb[4];
+        auto fetch = [&](uint32_t base, uint32_t* v, uint32_t* p) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const uint32_t idx = base + j < n ? base + j : n - 1;
+                v[j] = sval[idx];
+                p[j] = spos[idx];
+            }
+        };
+        if (n != 0)
+            fetch(0, vb, pb);
+        for (uint32_t e0 = 0; e0 < n && !invalid; e0 += 4)
         {
-            const uint32_t v = sval[e];
-            const uint32_t ps = spos[e];
-            const int s = (int)ps >> 31; // 0 or -1
-            const int x = (int)(v & 0xFFFFu);
-            const int pred = (int)(v >> 16);
-            const int k = regular_k(ctx);
-            if (k >= 16)
+            uint32_t vn[4] = {0, 0, 0, 0}, pn[4] = {0, 0, 0, 0};
+            if (e0 + 4 < n)
+                fetch(e0 + 4, vn, pn);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
             {
-                invalid = true;
-                break;
+                if (e0 + j >= n || invalid)
+                    break;
+                const uint32_t v = vb[j];
+                const uint32_t ps = pb[j];
+                const int s = (int)ps >> 31; // 0 or -1
+                const int x = (int)(v & 0xFFFFu);
+                const int pred = (int)(v >> 16);
+                const int k = regular_k(ctx);
+                if (k >= 16)
+                {
+                    invalid = true;
+                    break;
+                }
+                const int px = clamp_sample(t, pred + ((ctx.c ^ s) - s));
+                const int err = error_value(t, ((x - px) ^ s) - s);
+                const CodeWord c = golomb_word(t, k, map_error(error_correction(ctx, k) ^ err), t.limit);
+                if (!regular_update(ctx, err, 0, t.reset))
+                {
+                    invalid = true;
+                    break;
+                }
+                const uint32_t p = ps & 0x7FFFFFFFu;
+                w.code[p] = c.bits;
+                w.len[p] = (uint8_t)c.len;
             }
-            const int px = clamp_sample(t, pred + ((ctx.c ^ s) - s));
-            const int err = error_value(t, ((x - px) ^ s) - s);
-            const CodeWord c = golomb_word(t, k, map_error(error_correction(ctx, k) ^ err), t.limit);
-            if (!regular_update(ctx, err, 0, t.reset))
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
             {
-                invalid = true;
-                break;
+                vb[j] = vn[j];
+                pb[j] = pn[j];
             }
-            const uint32_t p = ps & 0x7FFFFFFFu;
-            w.code[p] = c.bits;
-            w.len[p] = (uint8_t)c.len;
         }
     }
     else
@@ -533,17 +562,18 @@ __global__ void __launch_bounds__(256) write_raw_bits(const ScanDesc* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// D3: one wavefront per scan, wave-uniform: raw bits -> stuffed bytes.  After a 0xFF byte the next byte carries 7 bits
-// (MSB 0); a final 0xFF is followed by 0x00; the last partial byte is zero padded (src/scan_encoder.hpp:103-180).
-// Result flags: bit 1 = the capacity is within 3 bytes of the output size, where the reference's accept/reject
-// decision depends on its 32-bit flush history; the host then re-runs the exact serial kernel.
-constexpr uint32_t kOutStage = 1024;
-
+// D3: one wavefront per scan: raw bits -> stuffed bytes.  After a 0xFF byte the next byte carries 7 bits (MSB 0); a final
+// 0xFF is followed by 0x00; the last partial byte is zero padded (src/scan_encoder.hpp:103-180).
+//
+// Stuffing is sequential only through the (rare) 0xFF bytes, so the wavefront speculates: lane l cuts output byte l of
+// the next 64 out of the raw bit stream assuming no 0xFF occurs before it; a ballot finds the first 0xFF, everything up
+// to and including it is final and is stored with one coalesced write, and the next round starts behind it with a
+// 7-bit first byte.  Result flags: bit 1 = the capacity is within 3 bytes of the output size, where the reference's
+// accept/reject decision depends on its 32-bit flush history; the host then re-runs the exact serial kernel.
 __global__ void __launch_bounds__(64) stuff_scan(const ScanDesc* __restrict__ descs, const Work* __restrict__ works,
                                                  ScanResult* __restrict__ results)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[2048];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[kOutStage + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[4096];
     const ScanDesc d = descs[blockIdx.x];
     const Work w = works[blockIdx.x];
     const int lane = threadIdx.x;
@@ -563,80 +593,54 @@ __global__ void __launch_bounds__(64) stuff_scan(const ScanDesc* __restrict__ de
         return;
     }
 
-    uint64_t loaded = 0;   // raw bytes [loaded - 2048, loaded) are in s_in (ring)
-    uint64_t bp = 0;       // next raw bit
-    uint64_t written = 0;  // bytes already copied to the destination
-    uint32_t staged = 0;   // bytes waiting in s_out
-    bool prev_ff = false;
-    bool overflow = false;
+    uint64_t loaded = 0;  // raw bytes [loaded - 4096, loaded) are resident in s_in (ring)
+    uint64_t bp = 0;      // next raw bit
+    uint64_t written = 0; // output bytes so far
+    bool first_short = false; // the next output byte follows a 0xFF: 7 payload bits
+    bool last_ff = false;
 
-    auto flush_out = [&]() {
-        __syncthreads();
-        for (uint32_t i = lane; i < staged; i += 64)
-            if (written + i < d.stream_capacity)
-                d.stream[written + i] = s_out[i];
-        if (written + staged > d.stream_capacity)
-            overflow = true;
-        written += staged;
-        staged = 0;
-        __syncthreads();
-    };
-    auto ensure_in = [&](uint64_t byte_needed_end) { // make raw bytes up to byte_needed_end (exclusive) resident
-        while (loaded < byte_needed_end && loaded < raw_bytes_cap)
+    while (bp < total_bits)
+    {
+        JLS_LOCKSTEP();
+        // raw bytes needed by this round: 64 output bytes + slack
+        while (loaded < (bp >> 3) + 80 && loaded < raw_bytes_cap)
         {
             const uint64_t o = loaded + (uint64_t)lane * 16;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (o + 16 <= raw_bytes_cap)
                 v = *reinterpret_cast<const uint4*>(raw + o);
-            *reinterpret_cast<uint4*>(s_in + (o & 2047)) = v;
+            *reinterpret_cast<uint4*>(s_in + (o & 4095)) = v;
             loaded += 1024;
             __syncthreads();
         }
-    };
-    auto peek64 = [&](uint64_t bit) -> uint64_t { // 64 raw bits starting at `bit`, MSB first (zeros past the end)
-        const uint64_t* in64 = reinterpret_cast<const uint64_t*>(s_in);
-        const uint64_t w0 = __builtin_bswap64(in64[(bit >> 6) & 255]);
-        const uint64_t w1 = __builtin_bswap64(in64[((bit >> 6) + 1) & 255]);
-        const int s = (int)(bit & 63);
-        return s ? ((w0 << s) | (w1 >> (64 - s))) : w0;
-    };
-
-    while (bp < total_bits)
-    {
-        JLS_LOCKSTEP();
-        ensure_in((bp >> 3) + 24);
-        if (staged + 9 > kOutStage)
-            flush_out();
-        const uint64_t v = peek64(bp);
-        if (prev_ff)
-        { // 7 payload bits, stuffed zero on top
-            s_out[staged++] = (uint8_t)(v >> 57);
-            bp += 7;
-            prev_ff = false;
-            continue;
-        }
-        const uint64_t inv = ~v;
-        const uint64_t ffm = (inv - 0x0101010101010101ull) & ~inv & 0x8080808080808080ull;
-        if (ffm == 0 && bp + 64 <= total_bits)
-        { // eight ordinary bytes
-            const uint64_t le = __builtin_bswap64(v);
-            for (int i = 0; i < 8; ++i)
-                s_out[staged + i] = (uint8_t)(le >> (8 * i));
-            staged += 8;
-            bp += 64;
-            continue;
-        }
-        const uint32_t b = (uint32_t)(v >> 56); // one byte (zero padded past the end by construction of the raw buffer)
-        s_out[staged++] = (uint8_t)b;
-        bp += 8;
-        prev_ff = b == 0xFFu;
+        // lane l: bits [start, start + n) with n = 7 for a byte that follows a 0xFF
+        const int n = (lane == 0 && first_short) ? 7 : 8;
+        const uint64_t start = bp + (uint64_t)lane * 8 - ((lane != 0 && first_short) ? 1 : 0);
+        const bool active = start < total_bits;
+        const uint32_t b0 = s_in[(start >> 3) & 4095];
+        const uint32_t b1 = s_in[((start >> 3) + 1) & 4095];
+        const uint32_t two = (b0 << 8) | b1; // 16 raw bits, MSB first (zeros beyond the end of the stream)
+        const uint32_t byte = (two >> (16 - (int)(start & 7) - n)) & ((1u << n) - 1u);
+        const unsigned long long act = __ballot(active);
+        const unsigned long long ffm = __ballot(active && byte == 0xFFu);
+        const int count = __popcll(act);                              // active lanes are a prefix
+        const int upto = ffm ? (int)__ffsll(ffm) : count;             // bytes that are final in this round
+        if (lane < upto && written + (uint64_t)lane < d.stream_capacity)
+            d.stream[written + lane] = (uint8_t)byte;
+        written += (uint64_t)upto;
+        bp = bp + (uint64_t)upto * 8 - (first_short ? 1 : 0);
+        first_short = ffm != 0 && upto <= count;
+        last_ff = ffm != 0;
     }
-    if (prev_ff)
-        s_out[staged++] = 0; // src/scan_encoder.hpp:107-112
-    flush_out();
+    if (last_ff)
+    { // src/scan_encoder.hpp:107-112: a trailing 0xFF is followed by a byte of seven zero bits
+        if (lane == 0 && written < d.stream_capacity)
+            d.stream[written] = 0;
+        ++written;
+    }
 
     r.bytes = written;
-    if (overflow || written > d.stream_capacity)
+    if (written > d.stream_capacity)
         r.errc = kDestinationTooSmall;
     else if (d.stream_capacity - written < 4)
         r.flags = 2; // undecidable here, see above
