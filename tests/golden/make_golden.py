@@ -111,6 +111,20 @@ def main():
     add("c4_ilv2", 64, 64, comps=4, ilv=2, near=1, kind="mixed", seed=93)
     add("c5_ilv0", 32, 32, comps=5, ilv=0, kind="mixed", seed=94)
     add("config5_literal_rejected", 64, 64, comps=3, ilv=2, ct=1, near=2, seed=95)    # errc 109
+    # tiny cases: every coding mode once, cheap enough for the thread-per-lane kernel emulation of the CPU suite
+    for ilv in (0, 1, 2):
+        add(f"tiny_rgb8_ilv{ilv}", 24, 16, comps=3, ilv=ilv, kind="mixed", seed=110 + ilv)
+    add("tiny_rgb8_ilv2_near2", 24, 16, comps=3, ilv=2, near=2, kind="mixed", seed=114)
+    add("tiny_rgb8_ilv1_near1", 24, 16, comps=3, ilv=1, near=1, kind="mixed", seed=115)
+    add("tiny_rgb16_line_hp3", 24, 16, bits=16, comps=3, ilv=1, ct=3, kind="mixed", seed=116)
+    add("tiny_rgb8_sample_hp1", 24, 16, comps=3, ilv=2, ct=1, kind="mixed", seed=117)
+    add("tiny_c4_ilv2_near1", 16, 16, comps=4, ilv=2, near=1, kind="mixed", seed=118)
+    add("tiny_c2_ilv1", 20, 12, comps=2, ilv=1, kind="mixed", seed=119)
+    add("tiny_gray12", 40, 24, bits=12, kind="mixed", seed=120)
+    add("tiny_gray16_noise", 24, 24, bits=16, kind="noise", seed=121)
+    add("tiny_gray2", 40, 24, bits=2, kind="mixed", seed=122)
+    add("tiny_gray8_near3", 40, 24, near=3, kind="mixed", seed=123)
+    add("tiny_gray8_noise", 32, 32, kind="noise", seed=124)
     # BASELINE.json configs at crop sizes (bytes) and full size (hash only) -----------------------------------------
     add("cfg1_512", 512, 512, seed=1, keep=False)
     add("cfg2_crop256", 256, 256, seed=2)

@@ -9,7 +9,18 @@ import common
 import emu_bind
 import jls_container
 
+import os
+
+FULL = os.environ.get("CHARLS_AMD_FULL_EMU") == "1"  # every golden case through every kernel (tens of minutes)
 CASES = [c for c in common.cases() if c["errc"] == 0 and "file" in c and c["width"] * c["height"] <= 128 * 128]
+# The thread-per-lane emulation of the wave-uniform kernels costs seconds per case: by default they run a subset that
+# covers every coding mode once; the one-lane kernel (cheap to emulate) always runs everything.
+_WAVE_SUBSET = {"gray8_64x48", "gray8_w1", "gray8_h1", "gray8_1x1", "tiny_rgb8_ilv0", "tiny_rgb8_ilv1", "tiny_rgb8_ilv2",
+                "tiny_rgb8_ilv2_near2", "tiny_rgb8_ilv1_near1", "tiny_rgb16_line_hp3", "tiny_rgb8_sample_hp1",
+                "tiny_c4_ilv2_near1", "tiny_c2_ilv1", "tiny_gray12", "tiny_gray16_noise", "tiny_gray2", "tiny_gray8_near3"}
+_FAST_SUBSET = {"gray8_64x48", "gray8_w1", "gray8_h1", "gray8_1x1", "tiny_gray12", "tiny_gray16_noise", "tiny_gray2",
+                "tiny_gray8_noise", "tiny_rgb8_ilv0"}
+WAVE_CASES = CASES if FULL else [c for c in CASES if c["name"] in _WAVE_SUBSET]
 
 
 def _scan_views(c, img):
@@ -59,8 +70,13 @@ def _stream_copy(jls, start):
     return view
 
 
-@pytest.mark.parametrize("kernel", DECODERS)
-@pytest.mark.parametrize("c", CASES, ids=lambda c: c["name"])
+def _decode_params():
+    out = [pytest.param(c, "emu_decode_scans_serial", id=f"{c['name']}-serial") for c in CASES]
+    out += [pytest.param(c, "emu_decode_scans_wave", id=f"{c['name']}-wave") for c in WAVE_CASES]
+    return out
+
+
+@pytest.mark.parametrize("c,kernel", _decode_params())
 def test_emulated_decode_kernel_matches_reference_pixels(c, kernel):
     L = emu_bind.lib()
     with open(f"{common.GOLDEN}/{c['file']}", "rb") as f:
@@ -87,7 +103,7 @@ def test_emulated_decode_kernel_matches_reference_pixels(c, kernel):
     assert common.sha(got) == c["decoded_sha256"]
 
 
-@pytest.mark.parametrize("kernel", DECODERS)
+@pytest.mark.parametrize("kernel", DECODERS if FULL else DECODERS[:1])
 @pytest.mark.parametrize("name,pnm,ilv", [("test8_ilv_none_rm_7", "test8.ppm", 0), ("test8_ilv_sample_rm_300", "test8.ppm", 2),
                                           ("test8_ilv_line_rm_7", "test8.ppm", 1)])
 def test_emulated_decode_restart_markers(name, pnm, ilv, kernel):
@@ -138,7 +154,8 @@ def test_emulated_decode_corrupt_streams(name, errc, kernel):
 
 
 # ---- speed path of the decoder (scan_fast_decode.hip): lossless single-component scans ---------------------------------
-FAST_CASES = [c for c in CASES if c["near_lossless"] == 0 and (c["component_count"] == 1 or c["interleave_mode"] == 0)]
+FAST_CASES = [c for c in CASES if c["near_lossless"] == 0 and (c["component_count"] == 1 or c["interleave_mode"] == 0) and
+              (FULL or c["name"] in _FAST_SUBSET)]
 
 
 @pytest.mark.parametrize("c", FAST_CASES, ids=lambda c: c["name"])

@@ -1,0 +1,76 @@
+"""N > 1 path on the CPU: frames are sharded over ranks with no exchange, the only collective is the final gather of the
+variable-length bitstreams (charls_amd/batch.py).  world_size 2, gloo backend, spawned processes."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from charls_amd import batch
+
+
+def test_shard_range_covers_all_frames_once():
+    for total in (0, 1, 7, 8, 256, 1001):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                a, b = batch.shard_range(total, r, world)
+                assert 0 <= a <= b <= total
+                seen.extend(range(a, b))
+            assert seen == list(range(total))
+            sizes = [batch.shard_range(total, r, world)[1] - batch.shard_range(total, r, world)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total_frames, result_queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = batch.shard_range(total_frames, rank, world)
+        rng = np.random.default_rng(1234)
+        all_sizes = rng.integers(5, 200, size=total_frames)
+        pitch = 256
+        # every rank fabricates the "encoded" frames it owns: frame f is sizes[f] bytes of value f
+        mine = torch.zeros((hi - lo, pitch), dtype=torch.uint8)
+        for i, f in enumerate(range(lo, hi)):
+            mine[i, :all_sizes[f]] = f % 251
+        parts, sizes = batch.gather_streams(mine, all_sizes[lo:hi].astype(np.uint64), dst=0)
+        assert [len(s) for s in sizes] == [batch.shard_range(total_frames, r, world)[1] - batch.shard_range(total_frames, r, world)[0]
+                                           for r in range(world)]
+        if rank == 0:
+            f = 0
+            for part, sz in zip(parts, sizes):
+                for i in range(len(sz)):
+                    assert int(sz[i]) == all_sizes[f]
+                    assert (part[i, :int(sz[i])] == f % 251).all()
+                    f += 1
+            assert f == total_frames
+            result_queue.put("ok")
+        else:
+            assert parts is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total_frames", [5, 8])
+def test_gather_streams_world_size_2(total_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == "ok"

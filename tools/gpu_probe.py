@@ -1,7 +1,7 @@
 """Scratch GPU probe used during development: times the C-ABI and batch paths at a few sizes."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 from charls_amd import batch, capi, synth
 lib = capi.load_product()

@@ -1,6 +1,6 @@
 """Scratch: one encode + one decode of a small batch, for rocprofv3 counter collection."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from charls_amd import batch, capi, synth
 n, w = int(sys.argv[1]), int(sys.argv[2])

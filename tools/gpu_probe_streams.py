@@ -1,6 +1,6 @@
 """Scratch: decode scaling with the number of concurrent streams (2048x2048 frames)."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from charls_amd import batch, capi, synth
 lib = capi.load_product()
