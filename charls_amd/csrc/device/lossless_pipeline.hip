@@ -42,7 +42,7 @@ struct Work
     uint32_t* sval;        // [H*W] events grouped by chain, raster order inside a chain
     uint32_t* spos;        // [H*W] raster index of the event | sign << 31
     uint8_t* len;          // [H*W] code length of the sample (0 = none)
-    uint64_t* code;        // [H*W] code bits, right aligned
+    uint64_t* code;        // [H*W] code bits, right aligned (re-uses the storage of key/val, dead after B2)
     uint32_t* blocksum;    // [ceil(H*W / kPackBlock)]
     uint64_t* blockbase;   // same count: exclusive bit offsets
     uint32_t* raw;         // unstuffed bit stream, 32-bit words in big-endian bit order; zeroed before D2
@@ -50,6 +50,16 @@ struct Work
     uint64_t* total_bits;  // [1]
     uint32_t* status;      // [1] kStatusInvalid when the reference would raise invalid_data
 };
+
+// Workgroup -> scan line.  Workgroup b runs on XCD b % 8 (each XCD has its own L2): giving every XCD a contiguous band of
+// lines keeps the short per-chain segments that neighbouring lines append to the same cache lines in ONE L2, where they
+// merge before they are written back.  Launch with grid.x = 8 * ceil(height / 8); returns height for idle workgroups.
+JLS_DEV uint32_t xcd_band_row(uint32_t block, uint32_t height)
+{
+    const uint32_t band = (height + 7) / 8;
+    const uint32_t y = (block & 7u) * band + (block >> 3);
+    return (block >> 3) < band && y < height ? y : height;
+}
 
 template <typename S>
 JLS_DEV int load_sample(const ScanDesc& d, uint32_t y, uint32_t x, int mask)
@@ -59,7 +69,7 @@ JLS_DEV int load_sample(const ScanDesc& d, uint32_t y, uint32_t x, int mask)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// A: grid (height, scans), one wavefront per line.  Dynamic LDS: chunks * (8 + 8 + 4) bytes + kChains * 4.
+// A: grid (8 * ceil(height / 8), scans), one wavefront per line (see xcd_band_row).  Dynamic LDS: chunks * (8 + 8 + 4) bytes + kChains * 4.
 template <typename S>
 __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
@@ -67,7 +77,9 @@ __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ 
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const Traits t = make_traits(d);
-    const uint32_t y = blockIdx.x;
+    const uint32_t y = xcd_band_row(blockIdx.x, d.height);
+    if (y >= d.height)
+        return;
     const int lane = threadIdx.x;
     const uint32_t width = d.width;
     const uint32_t chunks = (width + 63) / 64;
@@ -216,13 +228,15 @@ __global__ void __launch_bounds__(384) chain_offsets(const ScanDesc* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// B2: grid (height, scans), one wavefront per line; stable scatter of the line's events to their chains.
+// B2: grid (8 * ceil(height / 8), scans), one wavefront per line; stable scatter of the line's events to their chains.
 __global__ void __launch_bounds__(64) scatter_events(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
     __shared__ uint32_t s_cnt[kChains];
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
-    const uint32_t y = blockIdx.x;
+    const uint32_t y = xcd_band_row(blockIdx.x, d.height);
+    if (y >= d.height)
+        return;
     const int lane = threadIdx.x;
     const uint32_t width = d.width;
     for (int c = lane; c < kChains; c += 64)

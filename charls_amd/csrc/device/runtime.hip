@@ -262,7 +262,7 @@ size_t align_up(size_t v, size_t a)
     return (v + a - 1) / a * a;
 }
 
-// Bytes of work area one scan needs (23 B per sample + per-line histograms + the unstuffed stream).
+// Bytes of work area one scan needs (17 B per sample + per-line histograms + the unstuffed stream).
 struct PipeLayout
 {
     size_t samples, blocks, raw_bytes;
@@ -280,15 +280,17 @@ struct PipeLayout
             o = align_up(o + n, 256);
             return at;
         };
-        off_key = take(samples * 2);
-        off_val = take(samples * 4);
+        // key (2 B) + val (4 B) are dead once the events are scattered; the 8-byte codes written by stage C re-use them
+        const size_t val_at = align_up(samples * 2, 256);
+        off_code = take(std::max(samples * 8, val_at + samples * 4));
+        off_key = off_code;
+        off_val = off_code + val_at;
         off_hist = take(static_cast<size_t>(d.height) * pipe::kChains * 4);
         off_total = take(pipe::kChains * 4);
         off_base = take(pipe::kChains * 4);
         off_sval = take(samples * 4);
         off_spos = take(samples * 4);
         off_len = take(samples);
-        off_code = take(samples * 8);
         off_bsum = take(blocks * 4);
         off_bbase = take(blocks * 8);
         off_raw = take(raw_bytes);
@@ -304,7 +306,7 @@ DeviceBuffer& pipeline_arena()
     return arena;
 }
 
-constexpr size_t kArenaBudget = size_t{64} << 30; // bytes of HBM the pipeline may use for work areas per call
+constexpr size_t kArenaBudget = size_t{96} << 30; // bytes of HBM the pipeline may use for work areas per call
 
 template <typename S>
 void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
@@ -350,12 +352,13 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         const uint32_t chunks = (proto.width + 63) / 64;
         const size_t lds_a = static_cast<size_t>(chunks) * 20 + pipe::kChains * 4;
         const uint32_t blocks = static_cast<uint32_t>(lay.blocks);
+        const uint32_t rows_grid = 8 * ((proto.height + 7) / 8);
         StageTimer t(stream);
         t.mark();
-        hipLaunchKernelGGL((pipe::analyze_rows<S>), dim3(proto.height, n), dim3(64), lds_a, stream, descs, d_works);
+        hipLaunchKernelGGL((pipe::analyze_rows<S>), dim3(rows_grid, n), dim3(64), lds_a, stream, descs, d_works);
         t.mark();
         hipLaunchKernelGGL(pipe::chain_offsets, dim3(n), dim3(384), 0, stream, descs, d_works);
-        hipLaunchKernelGGL(pipe::scatter_events, dim3(proto.height, n), dim3(64), 0, stream, descs, d_works);
+        hipLaunchKernelGGL(pipe::scatter_events, dim3(rows_grid, n), dim3(64), 0, stream, descs, d_works);
         t.mark();
         hipLaunchKernelGGL((pipe::code_chains<S>), dim3((n * pipe::kChains + 63) / 64), dim3(64), 0, stream, descs, d_works, n);
         t.mark();

@@ -67,15 +67,15 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
     {
         pipe::Work& w = works[i];
         const size_t raw_bytes = ((size_t)descs[i].stream_capacity + 64 + 15) / 16 * 16;
-        w.key = (uint16_t*)zalloc(samples * 2);
-        w.val = (uint32_t*)zalloc(samples * 4);
+        w.code = (uint64_t*)zalloc(samples * 8 + 512);  // stage C re-uses the storage of key/val, as in runtime.hip
+        w.key = (uint16_t*)w.code;
+        w.val = (uint32_t*)((unsigned char*)w.code + ((samples * 2 + 255) / 256) * 256);
         w.hist = (uint32_t*)zalloc((size_t)p.height * pipe::kChains * 4);
         w.chain_total = (uint32_t*)zalloc(pipe::kChains * 4);
         w.chain_base = (uint32_t*)zalloc(pipe::kChains * 4);
         w.sval = (uint32_t*)zalloc(samples * 4);
         w.spos = (uint32_t*)zalloc(samples * 4);
         w.len = (uint8_t*)zalloc(samples);
-        w.code = (uint64_t*)zalloc(samples * 8);
         w.blocksum = (uint32_t*)zalloc(blocks * 4);
         w.blockbase = (uint64_t*)zalloc(blocks * 8);
         w.raw = (uint32_t*)zalloc(raw_bytes);
@@ -86,9 +86,10 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
     const uint32_t chunks = (p.width + 63) / 64;
     const size_t lds_a = (size_t)chunks * 20 + pipe::kChains * 4;
     const pipe::Work* wk = works.data();
-    emu::launch(pipe::analyze_rows<S>, dim3(p.height, count), dim3(64), lds_a, descs, wk);
+    const unsigned rows_grid = 8 * ((p.height + 7) / 8);
+    emu::launch(pipe::analyze_rows<S>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
     emu::launch(pipe::chain_offsets, dim3(count), dim3(384), 0, descs, wk);
-    emu::launch(pipe::scatter_events, dim3(p.height, count), dim3(64), 0, descs, wk);
+    emu::launch(pipe::scatter_events, dim3(rows_grid, count), dim3(64), 0, descs, wk);
     emu::launch(pipe::code_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
     emu::launch(pipe::sum_code_lengths, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
     emu::launch(pipe::scan_block_sums, dim3(count), dim3(64), 0, descs, wk);
