@@ -35,10 +35,15 @@ def lib():
         srcs = glob.glob(os.path.join(EMU_DIR, "*")) + glob.glob(os.path.join(EMU_DIR, "hip", "*")) + \
             glob.glob(os.path.join(DEV, "*"))
         newest = max(os.path.getmtime(s) for s in srcs)
-        if not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
-            os.makedirs(os.path.dirname(OUT), exist_ok=True)
-            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + EMU_DIR,
-                                   "-I" + DEV, "-x", "c++", os.path.join(EMU_DIR, "emu_driver.cpp"), "-o", OUT])
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        import fcntl
+        with open(OUT + ".lock", "w") as lock:  # pytest-xdist workers must not rebuild / replace the library concurrently
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
+                tmp = OUT + f".{os.getpid()}.tmp"
+                subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + EMU_DIR,
+                                       "-I" + DEV, "-x", "c++", os.path.join(EMU_DIR, "emu_driver.cpp"), "-o", tmp])
+                os.replace(tmp, OUT)
         L = C.CDLL(OUT)
         assert L.emu_sizeof_scan_desc() == C.sizeof(ScanDesc)
         _lib = L
