@@ -128,10 +128,14 @@ def shard_range(total: int, rank: int, world: int):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def gather_streams(streams, sizes, dst=0, group=None):
-    """Variable-length gather of the encoded frames to rank `dst`: all-gather of the per-frame byte counts, then one
-    padded gather of the payload trimmed to the batch maximum (RCCL on GPU tensors, gloo on CPU tensors).
-    Returns on dst: (list of per-rank uint8 tensors (frames_r, max_len), list of per-rank size arrays); else (None, all_sizes)."""
+def gather_streams(streams, sizes, dst=0, group=None, chunk_frames=128, sink=None):
+    """Variable-length gather of the encoded frames to rank `dst` (RCCL on GPU tensors, gloo on CPU tensors):
+    an all-gather of the per-frame byte counts, then the payload in rounds of `chunk_frames` frames per rank, each round
+    one padded `gather` trimmed to the round's maximum length into a receive buffer that is re-used (the payload of a
+    big batch does not have to fit rank dst's HBM at once).  `sink(rank, first_frame, tensor, sizes)` is called on dst for
+    every received piece; without a sink the pieces are kept and returned.
+    Returns on dst: (list of per-rank lists of (first_frame, uint8 tensor (n, max_len)), per-rank size arrays);
+    elsewhere: (None, per-rank size arrays)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -146,12 +150,26 @@ def gather_streams(streams, sizes, dst=0, group=None):
     all_sizes = [torch.zeros(max_count, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_sizes, mine, group=group)
     all_sizes = [s[:c].cpu().numpy().astype(np.uint64) for s, c in zip(all_sizes, counts)]
-    max_len = int(max((int(s.max()) if len(s) else 0) for s in all_sizes))
-    payload = torch.zeros((max_count, max_len), dtype=torch.uint8, device=dev)
-    payload[:streams.shape[0]] = streams[:, :max_len]
-    if rank == dst:
-        parts = [torch.empty_like(payload) for _ in range(world)]
-        dist.gather(payload, parts, dst=dst, group=group)
-        return [p[:c] for p, c in zip(parts, counts)], all_sizes
-    dist.gather(payload, None, dst=dst, group=group)
-    return None, all_sizes
+    kept = [[] for _ in range(world)] if rank == dst else None
+    for first in range(0, max_count, chunk_frames):
+        n = min(chunk_frames, max_count - first)
+        max_len = int(max((int(s[first:first + n].max()) if len(s) > first else 0) for s in all_sizes))
+        max_len = max(max_len, 1)
+        payload = torch.zeros((n, max_len), dtype=torch.uint8, device=dev)
+        have = max(0, min(n, streams.shape[0] - first))
+        if have:
+            payload[:have] = streams[first:first + have, :max_len]
+        if rank == dst:
+            parts = [torch.empty_like(payload) for _ in range(world)]
+            dist.gather(payload, parts, dst=dst, group=group)
+            for r, part in enumerate(parts):
+                m = max(0, min(n, counts[r] - first))
+                if m == 0:
+                    continue
+                if sink is not None:
+                    sink(r, first, part[:m], all_sizes[r][first:first + m])
+                else:
+                    kept[r].append((first, part[:m]))
+        else:
+            dist.gather(payload, None, dst=dst, group=group)
+    return kept, all_sizes

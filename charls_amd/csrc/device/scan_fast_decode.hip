@@ -25,7 +25,7 @@
 namespace jls {
 namespace fast {
 
-constexpr uint32_t kBitRingBytes = 4096;          // dense (un-stuffed) bits resident in LDS
+constexpr uint32_t kBitRingBytes = 2048;          // dense (un-stuffed) bits resident in LDS (>= 8256 + 4096 bits, see refill)
 constexpr uint32_t kBitRingBits = kBitRingBytes * 8;
 constexpr uint32_t kSrcChunk = 1024;              // coded bytes consumed per cooperative refill
 constexpr uint32_t kFixedLds = wave::kCtxBytes + wave::kRunBytes + kBitRingBytes;
@@ -139,12 +139,12 @@ struct DenseBits
                     p += (uint64_t)nbits[j];
                 }
         }
-        const int chunk_bits = __shfl(inc, 63);
+        const int chunk_bits = (int)uniform((uint32_t)__shfl(inc, 63));
         produced += (uint64_t)chunk_bits;
-        prev_byte = __shfl(last, 63);
+        prev_byte = uniform(__shfl(last, 63));
         if (has_marker)
         {
-            const int at = __shfl(marker_at, first_marker_lane);
+            const int at = (int)uniform((uint32_t)__shfl(marker_at, first_marker_lane));
             u_marker = u_next + (uint64_t)first_marker_lane * 16 + (uint64_t)at;
             ended = true;
         }
@@ -215,10 +215,36 @@ struct FastReader
     }
 };
 
+// Per-sample record prepared from the previous line: low half = 9*Q1 + Q2 (|.| <= 40, signed), high half = prev[i+1].
+// 8-bit samples pack it in 16 bits, wider samples in 32.
 template <typename S>
-JLS_DEV void prepare_line(const Traits& t, const S* line, uint32_t* aux, uint32_t width, int corner, int lane)
+struct AuxOf
 {
-    // aux[i] = (81*Q1 + 9*Q2 of sample i) & 0xFFFF | prev[i+1] << 16, i = 0..width (i = 0 carries prev[1] only)
+    using type = uint32_t;
+    static constexpr int kShift = 16;
+};
+template <>
+struct AuxOf<uint8_t>
+{
+    using type = uint16_t;
+    static constexpr int kShift = 8;
+};
+
+template <typename S>
+JLS_DEV int aux_rd(uint32_t a)
+{
+    return (int)(a >> AuxOf<S>::kShift);
+}
+template <typename S>
+JLS_DEV int aux_pre(uint32_t a)
+{
+    return AuxOf<S>::kShift == 8 ? (int)(signed char)(a & 0xFFu) : (int)(short)(a & 0xFFFFu);
+}
+
+template <typename S>
+JLS_DEV void prepare_line(const Traits& t, const S* line, typename AuxOf<S>::type* aux, uint32_t width, int corner, int lane)
+{
+    // aux[i] for i = 0..width (i = 0 carries prev[1] only)
     for (uint32_t i = lane; i <= width; i += 64)
     {
         const int rd = (int)line[i + 1 <= width ? i + 1 : width];
@@ -227,9 +253,10 @@ JLS_DEV void prepare_line(const Traits& t, const S* line, uint32_t* aux, uint32_
         {
             const int rb = (int)line[i];
             const int rc = i >= 2 ? (int)line[i - 1] : corner;
-            pre = 81 * quantize(t, rd - rb) + 9 * quantize(t, rb - rc);
+            pre = 9 * quantize(t, rd - rb) + quantize(t, rb - rc);
         }
-        aux[i] = ((uint32_t)pre & 0xFFFFu) | ((uint32_t)rd << 16);
+        const uint32_t low = (uint32_t)pre & ((1u << AuxOf<S>::kShift) - 1u);
+        aux[i] = (typename AuxOf<S>::type)(low | ((uint32_t)rd << AuxOf<S>::kShift));
     }
 }
 
@@ -237,8 +264,8 @@ JLS_DEV void prepare_line(const Traits& t, const S* line, uint32_t* aux, uint32_
 // call would force the reader state (cache, bit position) out of registers into scratch memory.
 template <typename S>
 JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& br, S* line,
-                                                      const uint32_t* aux, uint32_t width, uint32_t& i, int& ra, int& rb,
-                                                      int& run_index, int lane)
+                        const typename AuxOf<S>::type* aux, uint32_t width, uint32_t& i, int& ra, int& rb, int& run_index,
+                        int lane)
 {
     const uint32_t remaining = width - (i - 1);
     uint32_t run = 0;
@@ -278,7 +305,7 @@ JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& b
         return true;
     }
     const uint32_t at = i + run;
-    const int rb_at = (int)(uniform(aux[at - 1]) >> 16); // prev[at]
+    const int rb_at = aux_rd<S>(uniform(aux[at - 1])); // prev[at]
     const int which = ra == rb_at ? 1 : 0;
     JLS_LOCKSTEP();
     RunCtx ctx = m.run[which];
@@ -328,7 +355,7 @@ JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& b
 
 } // namespace fast
 
-// Dynamic LDS: fast::kFixedLds + (width + 2) * sizeof(S) rounded to 4 + (width + 2) * 4.
+// Dynamic LDS: fast::kFixedLds + (width + 2) * sizeof(S) rounded to 4 + (width + 2) * sizeof(AuxOf<S>::type).
 template <typename S>
 __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restrict__ descs, ScanResult* __restrict__ results)
 {
@@ -342,7 +369,8 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
     const uint32_t width = d.width;
     const uint32_t line_bytes = ((width + 2) * (uint32_t)sizeof(S) + 3u) & ~3u;
     S* line = reinterpret_cast<S*>(smem + kFixedLds);
-    uint32_t* aux = reinterpret_cast<uint32_t*>(smem + kFixedLds + line_bytes);
+    using Aux = typename AuxOf<S>::type;
+    Aux* aux = reinterpret_cast<Aux*>(smem + kFixedLds + line_bytes);
 
     wave::init_model(t, m, lane);
     for (uint32_t i = lane; i < width + 2; i += 64)
@@ -363,7 +391,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
         prepare_line<S>(t, line, aux, width, corner, lane);
         __syncthreads();
         int rb = corner;                                             // prev[0]
-        int ra = (int)(uniform(aux[0]) >> 16); // cur[0] = prev[1]
+        int ra = aux_rd<S>(uniform(aux[0])); // cur[0] = prev[1]
         int rd = ra;                                                 // prev[1]
         const int first = ra;
         uint32_t i = 1;
@@ -373,13 +401,13 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             const uint32_t a = uniform(aux[i]);
             const int rc = rb;
             rb = rd;
-            rd = (int)(a >> 16);
+            rd = aux_rd<S>(a);
             // Q3 = quantised (Rc - Ra); the quantiser is odd-symmetric (reference src/jpegls_algorithm.hpp:173-194)
             const int d3 = rc - ra;
             const int ad = d3 < 0 ? -d3 : d3;
             int q3 = (ad > 0) + (ad >= t1) + (ad >= t2) + (ad >= t3);
             q3 = d3 < 0 ? -q3 : q3;
-            const int qs = (int)(short)(a & 0xFFFFu) + q3;
+            const int qs = 9 * aux_pre<S>(a) + q3;
             if (qs == 0)
             {
                 int rb_next = rb; // decode_run reads its neighbourhood from aux and returns prev[at] here
@@ -390,7 +418,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
                 }
                 rb = rb_next;
                 if (i <= width)
-                    rd = (int)(uniform(aux[i - 1]) >> 16); // prev[i]: Rb of the next sample
+                    rd = aux_rd<S>(uniform(aux[i - 1])); // prev[i]: Rb of the next sample
                 continue;
             }
             // ---- regular mode

@@ -44,16 +44,21 @@ def _worker(rank, world, port, total_frames, result_queue):
         mine = torch.zeros((hi - lo, pitch), dtype=torch.uint8)
         for i, f in enumerate(range(lo, hi)):
             mine[i, :all_sizes[f]] = f % 251
-        parts, sizes = batch.gather_streams(mine, all_sizes[lo:hi].astype(np.uint64), dst=0)
+        parts, sizes = batch.gather_streams(mine, all_sizes[lo:hi].astype(np.uint64), dst=0, chunk_frames=3)
         assert [len(s) for s in sizes] == [batch.shard_range(total_frames, r, world)[1] - batch.shard_range(total_frames, r, world)[0]
                                            for r in range(world)]
         if rank == 0:
             f = 0
-            for part, sz in zip(parts, sizes):
-                for i in range(len(sz)):
-                    assert int(sz[i]) == all_sizes[f]
-                    assert (part[i, :int(sz[i])] == f % 251).all()
-                    f += 1
+            for pieces, sz in zip(parts, sizes):
+                got = 0
+                for first, part in pieces:
+                    assert first == got
+                    for i in range(part.shape[0]):
+                        assert int(sz[first + i]) == all_sizes[f]
+                        assert (part[i, :int(sz[first + i])] == f % 251).all()
+                        f += 1
+                    got += part.shape[0]
+                assert got == len(sz)
             assert f == total_frames
             result_queue.put("ok")
         else:
