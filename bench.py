@@ -81,9 +81,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=int(os.environ.get("CHARLS_AMD_BENCH_FRAMES", "1024")),
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("CHARLS_AMD_BENCH_FRAMES", "2048")),
                     help="frames per GPU per step (decoding is one serial chain per frame: throughput comes from "
-                         "the number of concurrent frames, 1024 = one wavefront per SIMD)")
+                         "the number of concurrent frames, 2048 = two wavefronts per SIMD, about what fits LDS and HBM)")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 serial kernel, 2 pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
