@@ -187,28 +187,25 @@ struct DenseBits
 };
 
 // Serial reader over the dense ring: cache holds the next `valid` bits MSB-aligned (bits below are zero or real).
-// `base` is the dense bit position of the cache's MSB at the last refill, so the hot path only shifts the cache and
-// decrements `valid`; the consumed position is base + (64 - valid).
 struct FastReader
 {
     DenseBits src;
     uint64_t cache;
-    uint64_t base;
+    uint64_t bp; // dense bits consumed
     int valid;
 
-    JLS_DEV uint64_t position() const { return base + (uint64_t)(64 - valid); }
     JLS_DEV void refill_cache()
     {
-        base = position();
         // keep at least 4096 un-stuffed bits ahead of the reader (or everything there is)
-        while (!src.ended && src.produced < base + 4096)
+        while (!src.ended && src.produced < bp + 4096)
             src.refill();
-        cache = src.peek64(base);
+        cache = src.peek64(bp);
         valid = 64;
     }
     JLS_DEV void skip(int n)
     {
         cache <<= n;
+        bp += (uint64_t)n;
         valid -= n;
     }
     JLS_DEV void need(int n)
@@ -380,8 +377,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
         line[i] = 0;
     FastReader br;
     br.src.init(d.stream, d.stream_capacity, ring, lane);
-    br.base = 0;
-    br.valid = 64;
+    br.bp = 0;
     br.refill_cache();
 
     int corner = 0;
@@ -399,23 +395,18 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
         int rd = ra;                                                 // prev[1]
         const int first = ra;
         uint32_t i = 1;
-        uint32_t a_raw = aux[1 <= width ? 1 : 0]; // the record of the NEXT sample is always in flight
         while (i <= width)
         {
             JLS_LOCKSTEP();
-            const uint32_t a = uniform(a_raw);
-            a_raw = aux[i + 1 <= width ? i + 1 : width];
+            const uint32_t a = uniform(aux[i]);
             const int rc = rb;
             rb = rd;
             rd = aux_rd<S>(a);
-            // Q3 = quantised (Rc - Ra); the quantiser is odd-symmetric (reference src/jpegls_algorithm.hpp:173-194).
-            // (c - |d|) >> 31 is 1 exactly when |d| > c: sign-bit arithmetic keeps this on the scalar ALU.
+            // Q3 = quantised (Rc - Ra); the quantiser is odd-symmetric (reference src/jpegls_algorithm.hpp:173-194)
             const int d3 = rc - ra;
             const int ad = d3 < 0 ? -d3 : d3;
-            int q3 = (int)(((uint32_t)(0 - ad) >> 31) + ((uint32_t)(t1 - 1 - ad) >> 31) + ((uint32_t)(t2 - 1 - ad) >> 31) +
-                           ((uint32_t)(t3 - 1 - ad) >> 31));
-            const int sd = d3 >> 31;
-            q3 = (q3 ^ sd) - sd;
+            int q3 = (ad > 0) + (ad >= t1) + (ad >= t2) + (ad >= t3);
+            q3 = d3 < 0 ? -q3 : q3;
             const int qs = 9 * aux_pre<S>(a) + q3;
             if (qs == 0)
             {
@@ -427,10 +418,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
                 }
                 rb = rb_next;
                 if (i <= width)
-                {
                     rd = aux_rd<S>(uniform(aux[i - 1])); // prev[i]: Rb of the next sample
-                    a_raw = aux[i];
-                }
                 continue;
             }
             // ---- regular mode
@@ -444,37 +432,28 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             px = px < 0 ? 0 : (px > t.maxval ? t.maxval : px);
             br.need(48);
             const int u = br.cache == 0 ? 64 : __clzll((long long)br.cache);
+            if (u >= 48 || k >= 16)
+            {
+                retry = true;
+                break;
+            }
+            br.skip(u + 1);
             int mm;
-            if (u < limit_m && u + 1 + k <= 48 && k < 16)
-            { // the whole code word is in the cache: one extraction, one shift
-                const uint64_t rest = (br.cache << (u + 1)) >> 1;
-                mm = (u << k) | (int)(rest >> (63 - k));
-                br.skip(u + 1 + k);
+            if (u < limit_m)
+            {
+                mm = u << k;
+                if (k)
+                {
+                    br.need(k);
+                    mm |= (int)(br.cache >> (64 - k));
+                    br.skip(k);
+                }
             }
             else
-            {
-                if (u >= 48 || k >= 16)
-                {
-                    retry = true;
-                    break;
-                }
-                br.skip(u + 1);
-                if (u < limit_m)
-                {
-                    mm = u << k;
-                    if (k)
-                    {
-                        br.need(k);
-                        mm |= (int)(br.cache >> (64 - k));
-                        br.skip(k);
-                    }
-                }
-                else
-                { // escape: MErrval - 1 in qbpp bits (src/scan_decoder.hpp:113-125)
-                    br.need(t.qbpp);
-                    mm = (int)(br.cache >> (64 - t.qbpp)) + 1;
-                    br.skip(t.qbpp);
-                }
+            { // escape: MErrval - 1 in qbpp bits (src/scan_decoder.hpp:113-125)
+                br.need(t.qbpp);
+                mm = (int)(br.cache >> (64 - t.qbpp)) + 1;
+                br.skip(t.qbpp);
             }
             int e = unmap_error(mm);
             if (k == 0)
@@ -513,10 +492,9 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
     {
         while (!br.src.ended)
             br.src.refill();
-        const uint64_t bp = br.position();
-        const bool inside = bp <= br.src.produced;
-        const uint64_t left = inside ? br.src.produced - bp : 0;
-        const bool clean = inside && br.src.u_marker != ~0ull && left < 15 && (left == 0 || (br.src.peek64(bp) >> (64 - left)) == 0);
+        const bool inside = br.bp <= br.src.produced;
+        const uint64_t left = inside ? br.src.produced - br.bp : 0;
+        const bool clean = inside && br.src.u_marker != ~0ull && left < 15 && (left == 0 || (br.src.peek64(br.bp) >> (64 - left)) == 0);
         if (clean)
             r.bytes = br.src.u_marker - br.src.u_begin;
         else
