@@ -319,67 +319,73 @@ __global__ void __launch_bounds__(64) code_chains(const ScanDesc* __restrict__ d
     const Work w = works[tid % scans];
     const Traits t = make_traits(d);
     const uint32_t n = w.chain_total[chain];
-    const uint32_t* sval = w.sval + w.chain_base[chain];
-    const uint32_t* spos = w.spos + w.chain_base[chain];
+    const JLS_GLOBAL_AS uint32_t* sval = (const JLS_GLOBAL_AS uint32_t*)(w.sval + w.chain_base[chain]);
+    const JLS_GLOBAL_AS uint32_t* spos = (const JLS_GLOBAL_AS uint32_t*)(w.spos + w.chain_base[chain]);
+    JLS_GLOBAL_AS uint64_t* code_out = (JLS_GLOBAL_AS uint64_t*)w.code;
+    JLS_GLOBAL_AS uint8_t* len_out = (JLS_GLOBAL_AS uint8_t*)w.len;
     bool invalid = false;
 
     if (chain != 0)
     { // ---- regular mode: src/scan_encoder_core.hpp:57-67
-        // The recurrence on {A,B,C,N} is the only true dependency; the event records are fetched one group of four
-        // ahead so that their memory latency overlaps the arithmetic of the previous group.
+        // The recurrence on {A,B,C,N} is the only true dependency.  On gfx950 stores and loads share one in-order
+        // counter (vmcnt), so the loop body is kept straight-line (no divergent branch around a memory operation): the
+        // records of group g+2 are requested while group g is coded, and the compiler can wait for exactly the records
+        // it needs instead of draining the scattered code stores of the previous group.
         RegCtx ctx{initial_a(t), 0, 0, 1};
-        uint32_t vb[4], pb[4];
-        auto fetch = [&](uint32_t base, uint32_t* v, uint32_t* p) {
+        uint32_t bad = 0;
+        auto step = [&](uint32_t v, uint32_t ps) {
+            const int s = (int)ps >> 31; // 0 or -1
+            const int x = (int)(v & 0xFFFFu);
+            const int pred = (int)(v >> 16);
+            int k = regular_k(ctx);
+            bad |= (uint32_t)(k >= 16);
+            k = k > 15 ? 15 : k;
+            const int px = clamp_sample(t, pred + ((ctx.c ^ s) - s));
+            const int err = error_value(t, ((x - px) ^ s) - s);
+            const CodeWord c = golomb_word(t, k, map_error(error_correction(ctx, k) ^ err), t.limit);
+            bad |= (uint32_t)!regular_update(ctx, err, 0, t.reset);
+            const uint32_t p = ps & 0x7FFFFFFFu;
+            code_out[p] = c.bits;
+            len_out[p] = (uint8_t)c.len;
+        };
+        const uint32_t groups = n / 4;
+        uint32_t v0[4], p0[4], v1[4], p1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        { // prologue: groups 0 and 1 (clamped reads keep it branch-free; n >= 1 whenever this code matters)
+            const uint32_t i0 = (uint32_t)j < n ? (uint32_t)j : (n ? n - 1 : 0);
+            const uint32_t i1 = 4u + j < n ? 4u + j : (n ? n - 1 : 0);
+            v0[j] = n ? sval[i0] : 0;
+            p0[j] = n ? spos[i0] : 0;
+            v1[j] = n ? sval[i1] : 0;
+            p1[j] = n ? spos[i1] : 0;
+        }
+        for (uint32_t g = 0; g < groups; ++g)
+        {
+            uint32_t v2[4], p2[4];
+            const uint32_t base = (g + 2) * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
             {
                 const uint32_t idx = base + j < n ? base + j : n - 1;
-                v[j] = sval[idx];
-                p[j] = spos[idx];
-            }
-        };
-        if (n != 0)
-            fetch(0, vb, pb);
-        for (uint32_t e0 = 0; e0 < n && !invalid; e0 += 4)
-        {
-            uint32_t vn[4] = {0, 0, 0, 0}, pn[4] = {0, 0, 0, 0};
-            if (e0 + 4 < n)
-                fetch(e0 + 4, vn, pn);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-            {
-                if (e0 + j >= n || invalid)
-                    break;
-                const uint32_t v = vb[j];
-                const uint32_t ps = pb[j];
-                const int s = (int)ps >> 31; // 0 or -1
-                const int x = (int)(v & 0xFFFFu);
-                const int pred = (int)(v >> 16);
-                const int k = regular_k(ctx);
-                if (k >= 16)
-                {
-                    invalid = true;
-                    break;
-                }
-                const int px = clamp_sample(t, pred + ((ctx.c ^ s) - s));
-                const int err = error_value(t, ((x - px) ^ s) - s);
-                const CodeWord c = golomb_word(t, k, map_error(error_correction(ctx, k) ^ err), t.limit);
-                if (!regular_update(ctx, err, 0, t.reset))
-                {
-                    invalid = true;
-                    break;
-                }
-                const uint32_t p = ps & 0x7FFFFFFFu;
-                w.code[p] = c.bits;
-                w.len[p] = (uint8_t)c.len;
+                v2[j] = sval[idx];
+                p2[j] = spos[idx];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
+                step(v0[j], p0[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
             {
-                vb[j] = vn[j];
-                pb[j] = pn[j];
+                v0[j] = v1[j];
+                p0[j] = p1[j];
+                v1[j] = v2[j];
+                p1[j] = p2[j];
             }
         }
+        for (uint32_t e = groups * 4; e < n; ++e) // at most three events
+            step(sval[e], spos[e]);
+        invalid = bad != 0;
     }
     else
     { // ---- run mode: src/scan_encoder.hpp:53-73, src/scan_encoder_impl.hpp:249-275, src/scan_encoder_core.hpp:105-125

@@ -15,6 +15,13 @@ namespace jls {
 // barrier between the lane threads.
 #define JLS_LOCKSTEP() __builtin_amdgcn_wave_barrier()
 
+// Pointers that are loaded from a descriptor in memory are "generic" to the compiler, which then emits flat_* memory
+// instructions; those tick both wait counters and force conservative s_waitcnt 0.  Declaring them global lets the
+// compiler use global_* instructions and count outstanding loads exactly.  (Empty in the CPU test harness.)
+#ifndef JLS_GLOBAL_AS
+#define JLS_GLOBAL_AS __attribute__((address_space(1)))
+#endif
+
 // Launch-time sized LDS (Guideline 17 of the CDNA guide: everything carved from one 16-byte aligned dynamic region).
 // The CPU test harness pre-defines this to point at its per-workgroup buffer.
 #ifndef JLS_DYNAMIC_LDS

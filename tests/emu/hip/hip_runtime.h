@@ -16,6 +16,7 @@
 #define __device__
 #define __host__
 #define __shared__ static
+#define JLS_GLOBAL_AS
 #define JLS_DYNAMIC_LDS(name) unsigned char* name = emu::g_block->dyn_shared
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
