@@ -34,6 +34,12 @@ JLS_DEV uint32_t uniform(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+// Value held by lane `l` (wave-uniform l), as a scalar.
+JLS_DEV uint32_t from_lane(uint32_t v, int l)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+
 // J[] run-length order table (reference src/scan_codec.hpp:18-19), 4 bits per entry packed into two 64-bit words.
 JLS_DEV int run_j(int run_index)
 {

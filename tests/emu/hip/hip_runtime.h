@@ -191,6 +191,11 @@ inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w)
     return uint4{x, y, z, w};
 }
 
+inline int __builtin_amdgcn_readlane(int v, int lane)
+{
+    return __shfl(v, lane);
+}
+
 inline unsigned __builtin_amdgcn_readfirstlane(unsigned v)
 {
     return __shfl(v, 0);
