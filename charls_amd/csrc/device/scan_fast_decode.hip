@@ -395,30 +395,10 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
         int rd = ra;                                                 // prev[1]
         const int first = ra;
         uint32_t i = 1;
-        // Software pipeline of the LDS reads that do not depend on the sample being decoded:
-        //   a_cur / a_nxt : the per-sample records of samples i and i+1
-        //   cand          : the contexts sample i can select.  Its context is 9*pre + Q3 with Q3 in -4..4 unknown until
-        //                   sample i-1 is reconstructed, so lanes 0..8 fetch the nine candidates one sample ahead and the
-        //                   right one is picked with a lane read; the table read leaves the critical path.
-        // A context written by sample i-1 may be stale in `cand`: it is forwarded from registers instead.
-        uint32_t a_cur = uniform(aux[i <= width ? i : width]);
-        uint32_t a_nxt = aux[i + 1 <= width ? i + 1 : width];
-        auto fetch_candidates = [&](uint32_t a) {
-            const int c9 = 9 * aux_pre<S>(a) + (lane < 9 ? lane - 4 : 0);
-            return m.reg[c9 < 0 ? -c9 : c9];
-        };
-        wave::PackedCtx cand = fetch_candidates(a_cur);
-        int last_idx = -1;
-        wave::PackedCtx last_ctx{0, 0};
         while (i <= width)
         {
             JLS_LOCKSTEP();
-            const uint32_t a = a_cur;
-            const wave::PackedCtx cand_now = cand;
-            // start the reads for the next sample before anything of this sample is waited for
-            a_cur = uniform(a_nxt);
-            a_nxt = aux[i + 2 <= width ? i + 2 : width];
-            cand = fetch_candidates(a_cur);
+            const uint32_t a = uniform(aux[i]);
             const int rc = rb;
             rb = rd;
             rd = aux_rd<S>(a);
@@ -437,23 +417,16 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
                     break;
                 }
                 rb = rb_next;
-                last_idx = -1;
                 if (i <= width)
-                { // re-prime the pipeline at the sample after the run
                     rd = aux_rd<S>(uniform(aux[i - 1])); // prev[i]: Rb of the next sample
-                    a_cur = uniform(aux[i]);
-                    a_nxt = aux[i + 1 <= width ? i + 1 : width];
-                    cand = fetch_candidates(a_cur);
-                }
                 continue;
             }
             // ---- regular mode
             const int s = qs >> 31;
             const int idx = (qs ^ s) - s;
-            wave::PackedCtx packed{from_lane(cand_now.a, q3 + 4), from_lane(cand_now.bcn, q3 + 4)};
-            if (idx == last_idx)
-                packed = last_ctx;
-            RegCtx ctx = wave::unpack(packed);
+            const wave::PackedCtx packed = m.reg[idx];
+            RegCtx ctx = wave::unpack(wave::PackedCtx{uniform(packed.a),
+                                                      uniform(packed.bcn)});
             const int k = regular_k(ctx);
             int px = med_predict(ra, rb, rc) + ((ctx.c ^ s) - s);
             px = px < 0 ? 0 : (px > t.maxval ? t.maxval : px);
@@ -491,9 +464,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
                 break;
             }
             JLS_LOCKSTEP();
-            last_ctx = wave::pack(ctx);
-            last_idx = idx;
-            m.reg[idx] = last_ctx;
+            m.reg[idx] = wave::pack(ctx);
             const int x = (px + ((e ^ s) - s)) & t.maxval;
             line[i] = (S)x;
             ra = x;
