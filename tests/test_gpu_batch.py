@@ -88,3 +88,48 @@ def test_full_size_roundtrip_properties(torch, bits):
     out = torch.empty_like(frames)
     _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
     assert (errcs == 0).all() and torch.equal(out, frames)
+
+
+@pytest.mark.slow
+def test_config4_frames_equal_reference_hashes(torch):
+    """BASELINE configs[3]: independent 2048x2048 8-bit frames with per-frame seeds (100 + f); the first four are pinned
+    by hashes of the reference's output, all must round-trip."""
+    cases = {c["name"]: c for c in common.cases()}
+    n = 8
+    frames = synth.frames_torch(n, 2048, 2048, seed0=100, device="cuda:0")
+    enc = batch.encode_batch(frames)
+    assert (enc.errcs == 0).all()
+    host = enc.streams.cpu().numpy()
+    for f in range(4):
+        c = cases[f"cfg4_frame{f}"]
+        data = host[f, :int(enc.sizes[f])].tobytes()
+        assert (len(data), common.sha(data)) == (c["jls_size"], c["jls_sha256"])
+    assert len(set(int(s) for s in enc.sizes)) > 1  # the frames really differ in length (variable-size gather)
+    out = torch.empty_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+    assert (errcs == 0).all() and torch.equal(out, frames)
+
+
+def test_exact_decoder_agrees_with_speed_path(torch, monkeypatch):
+    """CHARLS_AMD_EXACT_DECODER=1 forces the reference-policy decoder; both must give the same pixels and byte counts."""
+    frames = synth.frames_torch(4, 333, 77, seed0=5, kind="mixed", device="cuda:0")
+    enc = batch.encode_batch(frames)
+    out_fast = torch.empty_like(frames)
+    batch.decode_batch(enc.streams, enc.sizes, out_fast)
+    monkeypatch.setenv("CHARLS_AMD_EXACT_DECODER", "1")
+    out_exact = torch.empty_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out_exact)
+    assert (errcs == 0).all() and torch.equal(out_fast, out_exact) and torch.equal(out_exact, frames)
+
+
+def test_serial_and_pipeline_encoders_agree(torch):
+    frames = synth.frames_torch(3, 257, 65, seed0=8, kind="mixed", device="cuda:0")
+    batch.set_encode_engine(1)
+    a = batch.encode_batch(frames)
+    batch.set_encode_engine(2)
+    b = batch.encode_batch(frames)
+    batch.set_encode_engine(0)
+    assert (a.sizes == b.sizes).all()
+    for f in range(3):
+        n = int(a.sizes[f])
+        assert torch.equal(a.streams[f, :n], b.streams[f, :n])
