@@ -9,9 +9,12 @@
 //   B1 chain_offsets     per-line histograms of the 365 statistic chains (364 regular contexts + the run chain) ->
 //                        exclusive offsets (a stable counting sort by context, raster order kept inside a chain)
 //   B2 scatter_events    events move to their chain, lane-order ranks from ballots (deterministic, no atomics on order)
-//   C  code_chains       one LANE per chain: A/B/C/N recurrence + Golomb code for the chain's samples in raster order;
-//                        the run chain carries RUNindex and the two run-interruption contexts.  Chains of different
-//                        contexts never interact in lossless mode, so 365 x scans lanes run concurrently.
+//   C1 bias_chains       one LANE per chain: the {B,C,N} recurrence turns the chain's samples into Errval (the only
+//                        serial dependency of regular mode); the run chain carries RUNindex and the two run-interruption
+//                        contexts and codes its events directly.  Chains of different contexts never interact in
+//                        lossless mode, so 365 x scans lanes run concurrently.
+//   C2 code_events       one wavefront per chain: A is a segmented prefix sum of |Errval|, N a function of the event
+//                        index -> k and the Golomb words of 64 events per step, scattered back to raster order
 //   D1 sum/scan          code lengths -> bit offsets (two-level prefix sum per scan)
 //   D2 write_raw_bits    codes are concatenated MSB-first into the unstuffed bit stream (plain stores for owned words)
 //   D3 stuff_scan        JPEG-LS 0xFF bit stuffing + end-of-scan padding (src/scan_encoder.hpp:103-180), one wavefront
@@ -30,6 +33,8 @@ constexpr int kChains = 365;          // 0 = run chain, 1..364 = regular context
 constexpr uint16_t kNoEvent = 0xFFFF; // key of a sample that produces no code of its own
 constexpr uint32_t kPackBlock = 4096; // samples per D1/D2 workgroup (256 threads x 16)
 constexpr uint32_t kStatusInvalid = 1u;
+constexpr uint32_t kChainPad = 12;    // chains start on multiples of 12 records (three 16-byte groups), see bias_chains
+constexpr uint32_t kChainSlack = kChains * kChainPad + 64; // spare records of sval/spos: padding + read-ahead
 
 // Per-scan work areas (device pointers), parallel to the ScanDesc array.
 struct Work
@@ -39,8 +44,8 @@ struct Work
     uint32_t* hist;        // [H][kChains] events per line and chain -> exclusive prefix over lines
     uint32_t* chain_total; // [kChains]
     uint32_t* chain_base;  // [kChains] offset of the chain in sval/spos
-    uint32_t* sval;        // [H*W] events grouped by chain, raster order inside a chain
-    uint32_t* spos;        // [H*W] raster index of the event | sign << 31
+    uint32_t* sval;        // [H*W + kChainSlack] events grouped by chain, raster order inside a chain; 16-byte aligned
+    uint32_t* spos;        // [H*W + kChainSlack] raster index of the event | sign << 31; 16-byte aligned
     uint8_t* len;          // [H*W] code length of the sample (0 = none)
     uint64_t* code;        // [H*W] code bits, right aligned (re-uses the storage of key/val, dead after B2)
     uint32_t* blocksum;    // [ceil(H*W / kPackBlock)]
@@ -222,7 +227,7 @@ __global__ void __launch_bounds__(384) chain_offsets(const ScanDesc* __restrict_
         for (int i = 0; i < kChains; ++i)
         {
             w.chain_base[i] = acc;
-            acc += s_total[i];
+            acc += (s_total[i] + kChainPad - 1) / kChainPad * kChainPad;
         }
     }
 }
@@ -308,7 +313,7 @@ JLS_DEV CodeWord golomb_word(const Traits& t, int k, int m, int limit)
 }
 
 template <typename S>
-__global__ void __launch_bounds__(64) code_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works,
+__global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works,
                                                   uint32_t scans)
 {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,73 +324,67 @@ __global__ void __launch_bounds__(64) code_chains(const ScanDesc* __restrict__ d
     const Work w = works[tid % scans];
     const Traits t = make_traits(d);
     const uint32_t n = w.chain_total[chain];
-    const JLS_GLOBAL_AS uint32_t* sval = (const JLS_GLOBAL_AS uint32_t*)(w.sval + w.chain_base[chain]);
+    JLS_GLOBAL_AS uint32_t* sval = (JLS_GLOBAL_AS uint32_t*)(w.sval + w.chain_base[chain]);
     const JLS_GLOBAL_AS uint32_t* spos = (const JLS_GLOBAL_AS uint32_t*)(w.spos + w.chain_base[chain]);
-    JLS_GLOBAL_AS uint64_t* code_out = (JLS_GLOBAL_AS uint64_t*)w.code;
-    JLS_GLOBAL_AS uint8_t* len_out = (JLS_GLOBAL_AS uint8_t*)w.len;
-    bool invalid = false;
 
     if (chain != 0)
-    { // ---- regular mode: src/scan_encoder_core.hpp:57-67
-        // The recurrence on {A,B,C,N} is the only true dependency.  On gfx950 stores and loads share one in-order
-        // counter (vmcnt), so the loop body is kept straight-line (no divergent branch around a memory operation): the
-        // records of group g+2 are requested while group g is coded, and the compiler can wait for exactly the records
-        // it needs instead of draining the scattered code stores of the previous group.
-        RegCtx ctx{initial_a(t), 0, 0, 1};
-        uint32_t bad = 0;
-        auto step = [&](uint32_t v, uint32_t ps) {
+    { // ---- regular mode, serial half: src/scan_encoder_core.hpp:57-67, src/regular_mode_context.hpp:45-93
+        // Of {A,B,C,N} only B and C feed back into the VALUE that is coded (through the bias-corrected prediction); N is
+        // a function of the event index alone and A is a (periodically halved) running sum of |Errval| that only picks
+        // the Golomb parameter.  The serial chain therefore carries just {B,C,N}: it turns each (x, Px, sign) record
+        // into Errval plus the sign of 2B+N-1 (the k=0 error-correction condition, src/regular_mode_context.hpp:36-42),
+        // in place.  A, k and the code words are then computed 64 events at a time by code_events.
+        //
+        // Memory: every chain starts on a multiple of kChainPad (= 12) records and the buffers carry kChainSlack spare
+        // records, so a lane streams its chain with aligned 16-byte loads/stores (4 records) and no bounds logic: records
+        // past the end of a chain are garbage that is processed into the chain's own padding.  Three register sets rotate
+        // (loads run two groups ahead of the in-place store), so no register copies and no full vmcnt drains are needed.
+        int b = 0, c = 0, nn = 1;
+        const int reset = t.reset, range = t.range, half_range = (t.range + 1) / 2, maxval = t.maxval;
+        auto step = [&](uint32_t v, uint32_t ps) -> uint32_t {
             const int s = (int)ps >> 31; // 0 or -1
-            const int x = (int)(v & 0xFFFFu);
-            const int pred = (int)(v >> 16);
-            int k = regular_k(ctx);
-            bad |= (uint32_t)(k >= 16);
-            k = k > 15 ? 15 : k;
-            const int px = clamp_sample(t, pred + ((ctx.c ^ s) - s));
-            const int err = error_value(t, ((x - px) ^ s) - s);
-            const CodeWord c = golomb_word(t, k, map_error(error_correction(ctx, k) ^ err), t.limit);
-            bad |= (uint32_t)!regular_update(ctx, err, 0, t.reset);
-            const uint32_t p = ps & 0x7FFFFFFFu;
-            code_out[p] = c.bits;
-            len_out[p] = (uint8_t)c.len;
+            int px = (int)(v >> 16) + ((c ^ s) - s);
+            px = px < 0 ? 0 : px;
+            px = px > maxval ? maxval : px;
+            int err = (((int)(v & 0xFFFFu) - px) ^ s) - s;
+            err += (err >> 31) & range; // modulo RANGE, src/default_traits.hpp:123-139
+            err -= err >= half_range ? range : 0;
+            const uint32_t out = ((uint32_t)err << 1) | ((uint32_t)(2 * b + nn - 1) >> 31);
+            b += err; // |B| < N + RANGE/2: cannot reach 2^24
+            const int sh = nn == reset;
+            b >>= sh;
+            nn = (nn >> sh) + 1;
+            const bool low = b + nn <= 0, high = b > 0;
+            const int b_low = b + nn > 1 - nn ? b + nn : 1 - nn;
+            const int b_high = b - nn < 0 ? b - nn : 0;
+            const int c_low = c - 1 > -128 ? c - 1 : -128;
+            const int c_high = c + 1 < 127 ? c + 1 : 127;
+            b = low ? b_low : (high ? b_high : b);
+            c = low ? c_low : (high ? c_high : c);
+            return out;
         };
-        const uint32_t groups = n / 4;
-        uint32_t v0[4], p0[4], v1[4], p1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-        { // prologue: groups 0 and 1 (clamped reads keep it branch-free; n >= 1 whenever this code matters)
-            const uint32_t i0 = (uint32_t)j < n ? (uint32_t)j : (n ? n - 1 : 0);
-            const uint32_t i1 = 4u + j < n ? 4u + j : (n ? n - 1 : 0);
-            v0[j] = n ? sval[i0] : 0;
-            p0[j] = n ? spos[i0] : 0;
-            v1[j] = n ? sval[i1] : 0;
-            p1[j] = n ? spos[i1] : 0;
-        }
-        for (uint32_t g = 0; g < groups; ++g)
+        typedef uint32_t u32x4 __attribute__((vector_size(16)));
+        const JLS_GLOBAL_AS u32x4* vin = (const JLS_GLOBAL_AS u32x4*)sval;
+        const JLS_GLOBAL_AS u32x4* pin = (const JLS_GLOBAL_AS u32x4*)spos;
+        JLS_GLOBAL_AS u32x4* vout = (JLS_GLOBAL_AS u32x4*)sval;
+        auto phase = [&](uint32_t g, const u32x4& v, const u32x4& q, u32x4& v_next, u32x4& q_next) {
+            v_next = vin[g + 2];
+            q_next = pin[g + 2];
+            u32x4 o;
+            o[0] = step(v[0], q[0]);
+            o[1] = step(v[1], q[1]);
+            o[2] = step(v[2], q[2]);
+            o[3] = step(v[3], q[3]);
+            vout[g] = o;
+        };
+        const uint32_t groups = (n + kChainPad - 1) / kChainPad * 3; // a multiple of three, into the padding
+        u32x4 va = vin[0], qa = pin[0], vb = vin[1], qb = pin[1], vc, qc;
+        for (uint32_t g = 0; g < groups; g += 3)
         {
-            uint32_t v2[4], p2[4];
-            const uint32_t base = (g + 2) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-            {
-                const uint32_t idx = base + j < n ? base + j : n - 1;
-                v2[j] = sval[idx];
-                p2[j] = spos[idx];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                step(v0[j], p0[j]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-            {
-                v0[j] = v1[j];
-                p0[j] = p1[j];
-                v1[j] = v2[j];
-                p1[j] = p2[j];
-            }
+            phase(g, va, qa, vc, qc);
+            phase(g + 1, vb, qb, va, qa);
+            phase(g + 2, vc, qc, vb, qb);
         }
-        for (uint32_t e = groups * 4; e < n; ++e) // at most three events
-            step(sval[e], spos[e]);
-        invalid = bad != 0;
     }
     else
     { // ---- run mode: src/scan_encoder.hpp:53-73, src/scan_encoder_impl.hpp:249-275, src/scan_encoder_core.hpp:105-125
@@ -459,7 +458,90 @@ __global__ void __launch_bounds__(64) code_chains(const ScanDesc* __restrict__ d
             }
         }
     }
-    if (invalid)
+}
+
+// C2: grid (364, scans), one wavefront per regular chain: 64 consecutive events of the chain per step.
+//
+// Before event i of a chain, N_i depends on i only (it counts 1..RESET, then cycles RESET/2+1..RESET) and
+// A_i = A_seg + (sum of |Errval| since the last halving), where A_seg changes only at the events with N_i == RESET
+// (src/regular_mode_context.hpp:45-63).  Inside a step the sums are a wavefront prefix sum; the halvings (two per 64
+// events for RESET = 64) are walked in a short uniform loop.  Then k, the error correction and the limited-length Golomb
+// word (src/regular_mode_context.hpp:99-136, src/scan_encoder_core.hpp:57-103) are independent per event.
+__global__ void __launch_bounds__(64) code_events(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const Traits t = make_traits(d);
+    const uint32_t chain = blockIdx.x + 1;
+    const uint32_t n = w.chain_total[chain];
+    if (n == 0)
+        return;
+    const JLS_GLOBAL_AS uint32_t* serr = (const JLS_GLOBAL_AS uint32_t*)(w.sval + w.chain_base[chain]);
+    const JLS_GLOBAL_AS uint32_t* spos = (const JLS_GLOBAL_AS uint32_t*)(w.spos + w.chain_base[chain]);
+    JLS_GLOBAL_AS uint64_t* code_out = (JLS_GLOBAL_AS uint64_t*)w.code;
+    JLS_GLOBAL_AS uint8_t* len_out = (JLS_GLOBAL_AS uint8_t*)w.len;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t reset = (uint32_t)t.reset;          // 0: N never matches (RESET = 256*m stored through uint8)
+    const uint32_t half = reset >> 1;
+    const uint32_t period = reset - half;              // events between two halvings once N cycles
+    uint32_t a_seg = (uint32_t)initial_a(t);           // A before the first event of the current segment (uniform)
+    uint32_t bad = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64)
+    {
+        const uint32_t i = i0 + lane;
+        const bool live = i < n;
+        const uint32_t rec = live ? serr[i] : 0;
+        const uint32_t ps = live ? spos[i] : 0;
+        const int err = (int)rec >> 1;
+        const uint32_t mag = (uint32_t)(err < 0 ? -err : err);
+        uint32_t incl = mag; // inclusive prefix sum of |Errval| over the lanes
+        for (int delta = 1; delta < 64; delta <<= 1)
+        {
+            const uint32_t up = __shfl_up(incl, delta);
+            if ((int)lane >= delta)
+                incl += up;
+        }
+        // N before event i
+        uint32_t n_i = i + 1;
+        if (reset != 0 && i >= reset)
+            n_i = half + 1 + (i - reset) % period;
+        // walk the halving events inside [i0, i0+64): they are at i = reset-1 + j*period
+        uint32_t my_a = a_seg, my_base = 0, seg_base = 0;
+        if (reset != 0 && i0 + 64 > reset - 1)
+        {
+            uint32_t r = reset - 1;
+            if (i0 > r)
+                r += (i0 - r + period - 1) / period * period;
+            for (; r < i0 + 64 && r < n; r += period)
+            {
+                const uint32_t at = (uint32_t)__shfl((int)incl, (int)(r - i0)); // sum up to and including the halving event
+                a_seg = (a_seg + at - seg_base) >> 1;
+                seg_base = at;
+                if (i > r)
+                {
+                    my_a = a_seg;
+                    my_base = at;
+                }
+            }
+        }
+        const uint32_t a_i = my_a + (incl - mag - my_base);
+        bad |= (uint32_t)(live && a_i + mag >= (1u << 24)); // src/regular_mode_context.hpp:56-61
+        if (live)
+        {
+            const RegCtx ctx{(int)a_i, 0, 0, (int)n_i};
+            int k = regular_k(ctx);
+            bad |= (uint32_t)(k >= 16);
+            k = k > 15 ? 15 : k;
+            const int corr = k == 0 ? -(int)(rec & 1u) : 0;
+            const CodeWord c = golomb_word(t, k, map_error(corr ^ err), t.limit);
+            const uint32_t p = ps & 0x7FFFFFFFu;
+            code_out[p] = c.bits;
+            len_out[p] = (uint8_t)c.len;
+        }
+        // A before the first event of the next step: everything after the last halving of this step
+        a_seg += (uint32_t)__shfl((int)incl, 63) - seg_base;
+    }
+    if (bad)
         atomicOr(w.status, kStatusInvalid);
 }
 

@@ -288,8 +288,8 @@ struct PipeLayout
         off_hist = take(static_cast<size_t>(d.height) * pipe::kChains * 4);
         off_total = take(pipe::kChains * 4);
         off_base = take(pipe::kChains * 4);
-        off_sval = take(samples * 4);
-        off_spos = take(samples * 4);
+        off_sval = take((samples + pipe::kChainSlack) * 4);
+        off_spos = take((samples + pipe::kChainSlack) * 4);
         off_len = take(samples);
         off_bsum = take(blocks * 4);
         off_bbase = take(blocks * 8);
@@ -360,7 +360,8 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         hipLaunchKernelGGL(pipe::chain_offsets, dim3(n), dim3(384), 0, stream, descs, d_works);
         hipLaunchKernelGGL(pipe::scatter_events, dim3(rows_grid, n), dim3(64), 0, stream, descs, d_works);
         t.mark();
-        hipLaunchKernelGGL((pipe::code_chains<S>), dim3((n * pipe::kChains + 63) / 64), dim3(64), 0, stream, descs, d_works, n);
+        hipLaunchKernelGGL((pipe::bias_chains<S>), dim3((n * pipe::kChains + 63) / 64), dim3(64), 0, stream, descs, d_works, n);
+        hipLaunchKernelGGL(pipe::code_events, dim3(pipe::kChains - 1, n), dim3(64), 0, stream, descs, d_works);
         t.mark();
         hipLaunchKernelGGL(pipe::sum_code_lengths, dim3(blocks, n), dim3(256), 0, stream, descs, d_works);
         hipLaunchKernelGGL(pipe::scan_block_sums, dim3(n), dim3(64), 0, stream, descs, d_works);

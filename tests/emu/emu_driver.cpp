@@ -73,8 +73,8 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
         w.hist = (uint32_t*)zalloc((size_t)p.height * pipe::kChains * 4);
         w.chain_total = (uint32_t*)zalloc(pipe::kChains * 4);
         w.chain_base = (uint32_t*)zalloc(pipe::kChains * 4);
-        w.sval = (uint32_t*)zalloc(samples * 4);
-        w.spos = (uint32_t*)zalloc(samples * 4);
+        w.sval = (uint32_t*)zalloc((samples + pipe::kChainSlack) * 4);
+        w.spos = (uint32_t*)zalloc((samples + pipe::kChainSlack) * 4);
         w.len = (uint8_t*)zalloc(samples);
         w.blocksum = (uint32_t*)zalloc(blocks * 4);
         w.blockbase = (uint64_t*)zalloc(blocks * 8);
@@ -90,7 +90,8 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
     emu::launch(pipe::analyze_rows<S>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
     emu::launch(pipe::chain_offsets, dim3(count), dim3(384), 0, descs, wk);
     emu::launch(pipe::scatter_events, dim3(rows_grid, count), dim3(64), 0, descs, wk);
-    emu::launch(pipe::code_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    emu::launch(pipe::bias_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    emu::launch(pipe::code_events, dim3(pipe::kChains - 1, count), dim3(64), 0, descs, wk);
     emu::launch(pipe::sum_code_lengths, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
     emu::launch(pipe::scan_block_sums, dim3(count), dim3(64), 0, descs, wk);
     emu::launch(pipe::write_raw_bits, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);

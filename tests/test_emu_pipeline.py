@@ -110,3 +110,23 @@ def test_pipeline_destination_too_small_and_knife_edge():
         assert errc == 0 and flags == 2  # host re-runs the exact serial kernel for these
     (errc, flags, data), = _encode_planes(L, [img], 64, 64, 8, pc, capacity_slack=n + 4)
     assert errc == 0 and flags == 0 and len(data) == n
+
+
+@pytest.mark.parametrize("bits,reset", [(8, 3), (8, 4), (8, 31), (8, 64), (8, 255), (16, 256), (16, 257), (16, 258),
+                                        (16, 300)])
+def test_pipeline_reset_values_with_long_chains(bits, reset):
+    """Few contexts, chains of thousands of events: the code_events stage crosses many halving points (RESET is stored
+    through a uint8 by the reference, so 256/257/258 behave as 0/1/2 -- SURVEY F8)."""
+    L = emu_bind.lib()
+    w, h = 96, 48
+    rng = np.random.default_rng(reset)
+    base = (np.arange(w)[None, :] // 7 + np.arange(h)[:, None] // 5) * (3 if bits == 8 else 700)
+    noise = rng.integers(-2, 3, size=(h, w)) * (1 if bits == 8 else 900)
+    img = np.clip(base + noise + (40 if bits == 8 else 9000), 0, (1 << bits) - 1).astype(np.uint8 if bits == 8 else np.uint16)
+    preset = (0, 0, 0, 0, reset)
+    pc = jls_container.validated_pc(preset, bits, 0)
+    want = ob.encode(img, width=w, height=h, bits_per_sample=bits, preset=preset)
+    cont = jls_container.parse(want)
+    (errc, flags, data), = _encode_planes(L, [img], w, h, bits, pc, capacity_slack=w * h * 4 + 1024)
+    assert errc == 0
+    assert data == want[cont.scans[0].data_start:cont.scans[0].data_end]
