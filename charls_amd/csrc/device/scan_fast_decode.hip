@@ -186,34 +186,75 @@ struct DenseBits
     }
 };
 
-// Serial reader over the dense ring: cache holds the next `valid` bits MSB-aligned (bits below are zero or real).
-struct FastReader
+// Consumer side of the dense ring (wave-uniform, lives in scalar registers): the next `valid` bits MSB-aligned in
+// `cache` (bits below are zero), topped up 32 bits at a time from ring word `next_word`.  `safe_words` counts the words
+// the producer has completed beyond next_word; the scan loop keeps it >= kHandlerWords before it enters the out-of-line
+// handlers (a run or a long code consumes far fewer bits), so these never have to call the producer themselves.
+struct BitWindow
 {
-    DenseBits src;
     uint64_t cache;
-    uint64_t bp; // dense bits consumed
     int valid;
-
-    JLS_DEV void refill_cache()
-    {
-        // keep at least 4096 un-stuffed bits ahead of the reader (or everything there is)
-        while (!src.ended && src.produced < bp + 4096)
-            src.refill();
-        cache = src.peek64(bp);
-        valid = 64;
-    }
-    JLS_DEV void skip(int n)
-    {
-        cache <<= n;
-        bp += (uint64_t)n;
-        valid -= n;
-    }
-    JLS_DEV void need(int n)
-    {
-        if (valid < n)
-            refill_cache();
-    }
+    uint32_t next_word;
+    uint32_t safe_words;
+    bool starved; // a handler ran past the producer: the scan is retried by the exact decoder
 };
+
+constexpr uint32_t kRingWords = kBitRingBits / 32;
+constexpr uint32_t kHandlerWords = 16;
+constexpr uint32_t kUnlimitedWords = 0x40000000u;
+
+JLS_DEV void top_up(BitWindow& w, const uint32_t* ring) // requires valid <= 32
+{
+    uint32_t word = 0;
+    if (w.safe_words != 0)
+    {
+        word = uniform(ring[(w.next_word & (kRingWords - 1)) ^ 1u]);
+        --w.safe_words;
+    }
+    else
+        w.starved = true;
+    ++w.next_word;
+    w.cache |= (uint64_t)word << (32 - w.valid);
+    w.valid += 32;
+}
+
+JLS_DEV void fill(BitWindow& w, const uint32_t* ring) // afterwards valid >= 33
+{
+    while (w.valid <= 32)
+        top_up(w, ring);
+}
+
+JLS_DEV uint32_t take_bits(BitWindow& w, const uint32_t* ring, int n) // 0 <= n <= 32
+{
+    fill(w, ring);
+    const uint32_t v = (uint32_t)((w.cache >> 1) >> (63 - n));
+    w.cache <<= n;
+    w.valid -= n;
+    return v;
+}
+
+// Number of zero bits before the next one bit, which is consumed as well; -1 when it exceeds `most`.
+JLS_DEV int take_unary(BitWindow& w, const uint32_t* ring, int most)
+{
+    int total = 0;
+    for (;;)
+    {
+        fill(w, ring);
+        const int u = w.cache == 0 ? 64 : __clzll((long long)w.cache);
+        if (u < w.valid)
+        {
+            w.cache <<= u + 1;
+            w.valid -= u + 1;
+            total += u;
+            return total > most ? -1 : total;
+        }
+        total += w.valid;
+        w.cache = 0;
+        w.valid = 0;
+        if (total > most)
+            return -1;
+    }
+}
 
 // Per-sample record prepared from the previous line: low half = 9*Q1 + Q2 (|.| <= 40, signed), high half = prev[i+1].
 // 8-bit samples pack it in 16 bits, wider samples in 32.
@@ -260,10 +301,10 @@ JLS_DEV void prepare_line(const Traits& t, const S* line, typename AuxOf<S>::typ
     }
 }
 
-// Run mode.  Returns false when the scan must be retried by the exact decoder.  Inlined on purpose: an out-of-line
-// call would force the reader state (cache, bit position) out of registers into scratch memory.
+// Run mode (reference src/scan_decoder_impl.hpp:270-330, src/scan_decoder_core.hpp:71-101).  Returns false when the scan
+// must be retried by the exact decoder.
 template <typename S>
-JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& br, S* line,
+JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, BitWindow& w, const uint32_t* ring, S* line,
                         const typename AuxOf<S>::type* aux, uint32_t width, uint32_t& i, int& ra, int& rb, int& run_index,
                         int lane)
 {
@@ -271,10 +312,7 @@ JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& b
     uint32_t run = 0;
     for (;;)
     {
-        br.need(1);
-        const int bit = (int)(br.cache >> 63);
-        br.skip(1);
-        if (!bit)
+        if (!take_bits(w, ring, 1))
             break;
         const uint32_t block = 1u << run_j(run_index);
         const uint32_t count = block < remaining - run ? block : remaining - run;
@@ -286,13 +324,7 @@ JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& b
     }
     if (run != remaining)
     {
-        const int jb = run_j(run_index);
-        if (jb > 0)
-        {
-            br.need(jb);
-            run += (uint32_t)(br.cache >> (64 - jb));
-            br.skip(jb);
-        }
+        run += take_bits(w, ring, run_j(run_index));
         if (run > remaining)
             return false;
     }
@@ -317,28 +349,14 @@ JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& b
     if (k > 24)
         return false;
     const int limit = t.limit - run_j(run_index) - 1;
-    br.need(64);
-    const int u = br.cache == 0 ? 64 : __clzll((long long)br.cache);
-    if (u >= 48)
-        return false; // longer than any valid prefix: let the exact decoder classify it
-    br.skip(u + 1);
+    const int u = take_unary(w, ring, 47); // anything longer: let the exact decoder classify it
+    if (u < 0)
+        return false;
     int em;
     if (u < limit - t.qbpp - 1)
-    {
-        em = u << k;
-        if (k)
-        {
-            br.need(k);
-            em += (int)(br.cache >> (64 - k));
-            br.skip(k);
-        }
-    }
+        em = (u << k) + (int)take_bits(w, ring, k);
     else
-    {
-        br.need(t.qbpp);
-        em = (int)(br.cache >> (64 - t.qbpp)) + 1;
-        br.skip(t.qbpp);
-    }
+        em = (int)take_bits(w, ring, t.qbpp) + 1;
     const int e = run_error_value(ctx, em + ctx.ritype, k);
     run_update(ctx, e, em, t.reset);
     JLS_LOCKSTEP();
@@ -353,9 +371,49 @@ JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, FastReader& b
     return true;
 }
 
+// One regular-mode sample with every case the inner loop leaves out (escape codes, prefixes longer than the window):
+// src/scan_decoder_core.hpp:38-69, src/scan_decoder.hpp:99-125.  Returns false -> retry with the exact decoder.
+JLS_DEV bool decode_regular_slow(const Traits& t, const wave::WaveModel& m, BitWindow& w, const uint32_t* ring, int qs,
+                                 int pred, int& x_out)
+{
+    const int s = qs >> 31;
+    const int idx = (qs ^ s) - s;
+    JLS_LOCKSTEP();
+    const wave::PackedCtx packed = m.reg[idx];
+    RegCtx ctx = wave::unpack(wave::PackedCtx{uniform(packed.a), uniform(packed.bcn)});
+    const int k = regular_k(ctx);
+    if (k >= 16)
+        return false;
+    const int px = clamp_sample(t, pred + ((ctx.c ^ s) - s));
+    const int u = take_unary(w, ring, 47);
+    if (u < 0)
+        return false;
+    int mm;
+    if (u < t.limit - t.qbpp - 1)
+        mm = (u << k) | (int)take_bits(w, ring, k);
+    else
+        mm = (int)take_bits(w, ring, t.qbpp) + 1;
+    int e = unmap_error(mm);
+    if (k == 0)
+        e ^= error_correction(ctx, 0);
+    if (!regular_update(ctx, e, 0, t.reset))
+        return false;
+    JLS_LOCKSTEP();
+    m.reg[idx] = wave::pack(ctx);
+    x_out = (px + ((e ^ s) - s)) & t.maxval;
+    return true;
+}
+
 } // namespace fast
 
 // Dynamic LDS: fast::kFixedLds + (width + 2) * sizeof(S) rounded to 4 + (width + 2) * sizeof(AuxOf<S>::type).
+//
+// Control structure: ONE loop whose body visits a 64-sample chunk of the current line.  The chunk's records (aux) are
+// loaded into a VGPR once and read per sample with v_readlane; decoded samples are collected with v_writelane and
+// written back to the line in one LDS store, so the per-sample LDS traffic is the context record only.  The inner loop
+// handles nothing but plain regular-mode samples whose code fits the bit window; everything else leaves it with an event
+// code and is handled once, out of line: producer refill (the only call site of DenseBits::refill), run mode, long or
+// escape codes.  That keeps the inner loop short, straight and free of cold code.
 template <typename S>
 __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restrict__ descs, ScanResult* __restrict__ results)
 {
@@ -375,114 +433,188 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
     wave::init_model(t, m, lane);
     for (uint32_t i = lane; i < width + 2; i += 64)
         line[i] = 0;
-    FastReader br;
-    br.src.init(d.stream, d.stream_capacity, ring, lane);
-    br.bp = 0;
-    br.refill_cache();
+    DenseBits src;
+    src.init(d.stream, d.stream_capacity, ring, lane);
+    BitWindow w{0, 0, 0, 0, false};
 
-    int corner = 0;
+    enum : int { kNone = 0, kRefill, kRun, kSlow, kRetry };
+    enum : int { kLineStart = 0, kInLine, kDrain };
+    int phase = d.height == 0 ? kDrain : kLineStart;
+    int corner = 0, first = 0;
     int run_index = 0;
     bool retry = false;
-    const int t1 = t.t1, t2 = t.t2, t3 = t.t3;
+    const int t1 = t.t1, t2 = t.t2, t3 = t.t3, maxval = t.maxval, reset = t.reset;
     const int limit_m = t.limit - t.qbpp - 1;
+    uint32_t y = 0, i = 1;
+    int ra = 0, rb = 0, rd = 0;
 
-    for (uint32_t y = 0; y < d.height && !retry; ++y)
+    for (;;)
     {
-        prepare_line<S>(t, line, aux, width, corner, lane);
-        __syncthreads();
-        int rb = corner;                                             // prev[0]
-        int ra = aux_rd<S>(uniform(aux[0])); // cur[0] = prev[1]
-        int rd = ra;                                                 // prev[1]
-        const int first = ra;
-        uint32_t i = 1;
-        while (i <= width)
+        // ---- producer: the one place where coded bytes are un-stuffed into the ring
+        if (!src.ended && (phase == kDrain || w.safe_words < kHandlerWords))
         {
-            JLS_LOCKSTEP();
-            const uint32_t a = uniform(aux[i]);
-            const int rc = rb;
-            rb = rd;
-            rd = aux_rd<S>(a);
+            src.refill();
+            w.safe_words = src.ended ? kUnlimitedWords : (uint32_t)(src.produced >> 5) - w.next_word;
+            continue;
+        }
+        if (src.ended)
+            w.safe_words = kUnlimitedWords;
+        if (phase == kDrain)
+            break;
+        if (phase == kLineStart)
+        {
+            prepare_line<S>(t, line, aux, width, corner, lane);
+            __syncthreads();
+            rb = corner;                         // prev[0]
+            ra = aux_rd<S>(uniform(aux[0]));     // cur[0] = prev[1]
+            rd = ra;                             // prev[1]
+            first = ra;
+            i = 1;
+            phase = kInLine;
+        }
+
+        // ---- one visit of the chunk that holds sample i
+        const uint32_t chunk_base = (i - 1) & ~63u;
+        const uint32_t chunk_last = chunk_base + 64 < width ? chunk_base + 64 : width;
+        const uint32_t pos = chunk_base + 1 + lane;
+        const uint32_t v_aux = aux[pos <= width ? pos : width];
+        uint32_t v_out = 0;
+        const uint32_t flush_from = i;
+        int event = kNone;
+        int qs = 0;
+        while (i <= chunk_last)
+        {
+            if (w.valid <= 32)
+            {
+                if (w.safe_words == 0)
+                {
+                    event = kRefill;
+                    break;
+                }
+                const uint32_t word = uniform(ring[(w.next_word & (kRingWords - 1)) ^ 1u]);
+                w.cache |= (uint64_t)word << (32 - w.valid);
+                w.valid += 32;
+                ++w.next_word;
+                --w.safe_words;
+            }
+            const int sel = (int)((i - 1) & 63u);
+            const uint32_t a = from_lane(v_aux, sel);
+            const int rd_next = aux_rd<S>(a);
             // Q3 = quantised (Rc - Ra); the quantiser is odd-symmetric (reference src/jpegls_algorithm.hpp:173-194)
-            const int d3 = rc - ra;
+            const int d3 = rb - ra;
             const int ad = d3 < 0 ? -d3 : d3;
             int q3 = (ad > 0) + (ad >= t1) + (ad >= t2) + (ad >= t3);
             q3 = d3 < 0 ? -q3 : q3;
-            const int qs = 9 * aux_pre<S>(a) + q3;
+            qs = 9 * aux_pre<S>(a) + q3;
             if (qs == 0)
             {
-                int rb_next = rb; // decode_run reads its neighbourhood from aux and returns prev[at] here
-                if (!decode_run<S>(t, m, br, line, aux, width, i, ra, rb_next, run_index, lane))
-                {
-                    retry = true;
-                    break;
-                }
-                rb = rb_next;
-                if (i <= width)
-                    rd = aux_rd<S>(uniform(aux[i - 1])); // prev[i]: Rb of the next sample
-                continue;
+                event = kRun;
+                break;
             }
-            // ---- regular mode
             const int s = qs >> 31;
             const int idx = (qs ^ s) - s;
-            const wave::PackedCtx packed = m.reg[idx];
-            RegCtx ctx = wave::unpack(wave::PackedCtx{uniform(packed.a),
-                                                      uniform(packed.bcn)});
-            const int k = regular_k(ctx);
-            int px = med_predict(ra, rb, rc) + ((ctx.c ^ s) - s);
-            px = px < 0 ? 0 : (px > t.maxval ? t.maxval : px);
-            br.need(48);
-            const int u = br.cache == 0 ? 64 : __clzll((long long)br.cache);
-            if (u >= 48 || k >= 16)
-            {
-                retry = true;
-                break;
-            }
-            br.skip(u + 1);
-            int mm;
-            if (u < limit_m)
-            {
-                mm = u << k;
-                if (k)
-                {
-                    br.need(k);
-                    mm |= (int)(br.cache >> (64 - k));
-                    br.skip(k);
-                }
-            }
-            else
-            { // escape: MErrval - 1 in qbpp bits (src/scan_decoder.hpp:113-125)
-                br.need(t.qbpp);
-                mm = (int)(br.cache >> (64 - t.qbpp)) + 1;
-                br.skip(t.qbpp);
-            }
-            int e = unmap_error(mm);
-            if (k == 0)
-                e ^= error_correction(ctx, 0);
-            if (!regular_update(ctx, e, 0, t.reset))
-            {
-                retry = true;
-                break;
-            }
             JLS_LOCKSTEP();
-            m.reg[idx] = wave::pack(ctx);
-            const int x = (px + ((e ^ s) - s)) & t.maxval;
-            line[i] = (S)x;
+            const wave::PackedCtx packed = m.reg[idx];
+            const uint32_t ca = uniform(packed.a), bcn = uniform(packed.bcn);
+            int a_acc = (int)ca;
+            int b = -(int)(bcn & 0xFFu);
+            int c = (int)(signed char)((bcn >> 8) & 0xFFu);
+            int n = (int)(bcn >> 16);
+            int k = __clz(n) - __clz(a_acc);
+            k = k < 0 ? 0 : k;
+            k += ((n << k) < a_acc);
+            const int u = w.cache == 0 ? 64 : __clzll((long long)w.cache);
+            if (u >= limit_m || u + 1 + k > w.valid || k >= 16)
+            {
+                event = kSlow;
+                break;
+            }
+            int px = med_predict(ra, rd, rb) + ((c ^ s) - s);
+            px = px < 0 ? 0 : px;
+            px = px > maxval ? maxval : px;
+            const uint64_t after = w.cache << (u + 1);
+            const int mm = (u << k) | (int)((after >> 1) >> (63 - k));
+            w.cache = after << k;
+            w.valid -= u + 1 + k;
+            int e = (mm >> 1) ^ -(mm & 1);
+            e ^= k == 0 ? ((2 * b + n - 1) >> 31) : 0;
+            // A.12/A.13, src/regular_mode_context.hpp:45-93 (|B| cannot overflow in lossless mode)
+            a_acc += e < 0 ? -e : e;
+            if (a_acc >= (1 << 24))
+            {
+                event = kRetry;
+                break;
+            }
+            b += e;
+            const int sh = n == reset;
+            a_acc >>= sh;
+            b >>= sh;
+            n = (n >> sh) + 1;
+            const bool low = b + n <= 0, high = b > 0;
+            const int b_low = b + n > 1 - n ? b + n : 1 - n;
+            const int b_high = b - n < 0 ? b - n : 0;
+            const int c_low = c - 1 > -128 ? c - 1 : -128;
+            const int c_high = c + 1 < 127 ? c + 1 : 127;
+            b = low ? b_low : (high ? b_high : b);
+            c = low ? c_low : (high ? c_high : c);
+            JLS_LOCKSTEP();
+            m.reg[idx] = wave::PackedCtx{(uint32_t)a_acc, (uint32_t)(-b) | (((uint32_t)c & 0xFFu) << 8) | ((uint32_t)n << 16)};
+            const int x = (px + ((e ^ s) - s)) & maxval;
+            v_out = to_lane(v_out, (uint32_t)x, sel);
+            rb = rd;
+            rd = rd_next;
             ra = x;
             ++i;
         }
-        corner = first;
-        __syncthreads();
-        if (retry)
-            break;
-        // finished line -> user's row
-        uint8_t* row = d.pixels + (size_t)y * d.pixel_stride;
-        if (sizeof(S) == 1)
-            for (uint32_t x = lane; x < width; x += 64)
-                row[x] = (uint8_t)line[1 + x];
-        else
-            for (uint32_t x = lane; x < width; x += 64)
-                reinterpret_cast<uint16_t*>(row)[x] = (uint16_t)line[1 + x];
+        // samples decoded by the inner loop -> line
+        if (pos >= flush_from && pos < i)
+            line[pos] = (S)v_out;
         JLS_LOCKSTEP();
+        if (event == kRun)
+        {
+            // the inner loop had not advanced its neighbourhood yet: Rc = rb, Rb = rd as for any sample at i
+            int rb_next = rd;
+            rb = rd;
+            if (!decode_run<S>(t, m, w, ring, line, aux, width, i, ra, rb_next, run_index, lane))
+                retry = true;
+            rb = rb_next;
+            if (i <= width)
+                rd = aux_rd<S>(uniform(aux[i - 1])); // prev[i]: Rb of the next sample
+        }
+        else if (event == kSlow)
+        {
+            int x = 0;
+            if (!decode_regular_slow(t, m, w, ring, qs, med_predict(ra, rd, rb), x))
+                retry = true;
+            if (lane == 0)
+                line[i] = (S)x;
+            rb = rd;
+            rd = aux_rd<S>(uniform(aux[i]));
+            ra = x;
+            ++i;
+        }
+        else if (event == kRetry)
+            retry = true;
+        if (retry || w.starved)
+        {
+            retry = true;
+            break;
+        }
+        if (i > width)
+        { // finished line -> user's row
+            corner = first;
+            __syncthreads();
+            uint8_t* row = d.pixels + (size_t)y * d.pixel_stride;
+            if (sizeof(S) == 1)
+                for (uint32_t x = lane; x < width; x += 64)
+                    row[x] = (uint8_t)line[1 + x];
+            else
+                for (uint32_t x = lane; x < width; x += 64)
+                    reinterpret_cast<uint16_t*>(row)[x] = (uint16_t)line[1 + x];
+            JLS_LOCKSTEP();
+            ++y;
+            phase = y == d.height ? kDrain : kLineStart;
+        }
     }
 
     // Clean end of scan: nothing consumed past the coded segment, only zero padding left (at most the rest of a byte
@@ -490,13 +622,13 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
     ScanResult r{kOk, 0, 0};
     if (!retry)
     {
-        while (!br.src.ended)
-            br.src.refill();
-        const bool inside = br.bp <= br.src.produced;
-        const uint64_t left = inside ? br.src.produced - br.bp : 0;
-        const bool clean = inside && br.src.u_marker != ~0ull && left < 15 && (left == 0 || (br.src.peek64(br.bp) >> (64 - left)) == 0);
+        const uint64_t consumed = (uint64_t)w.next_word * 32 - (uint64_t)w.valid;
+        const bool inside = consumed <= src.produced;
+        const uint64_t left = inside ? src.produced - consumed : 0;
+        const bool clean = inside && src.u_marker != ~0ull && left < 15 &&
+                           (left == 0 || (src.peek64(consumed) >> (64 - left)) == 0);
         if (clean)
-            r.bytes = br.src.u_marker - br.src.u_begin;
+            r.bytes = src.u_marker - src.u_begin;
         else
             retry = true;
     }
