@@ -447,6 +447,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
     const int limit_m = t.limit - t.qbpp - 1;
     uint32_t y = 0, i = 1;
     int ra = 0, rb = 0, rd = 0;
+    const int vz = vector_zero();
 
     for (;;)
     {
@@ -482,6 +483,14 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
         const uint32_t flush_from = i;
         int event = kNone;
         int qs = 0;
+        // Work split of the inner loop.  One CU has ONE scalar unit for its four SIMDs but a vector ALU per SIMD, and a
+        // loop that is all scalar instructions is bound by that shared unit (measured: two wavefronts per SIMD were barely
+        // faster than one).  So only the bit window and the loop control are kept on the scalar unit; the sample
+        // arithmetic (gradient, context record, prediction, A/B/C/N update) is done by the vector ALU on values that
+        // are equal in all lanes -- Ra and the context record simply stay in vector registers -- and k is the one value
+        // that crosses back per sample.  Wavefronts sharing a SIMD then overlap scalar and vector work.
+        int ra_v = ra | vz;     // equal in all lanes, kept in a VGPR
+        uint32_t a_seen = 0;    // OR of every updated A: the 2^24 overflow test is done once per chunk visit
         while (i <= chunk_last)
         {
             if (w.valid <= 32)
@@ -501,35 +510,40 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             const uint32_t a = from_lane(v_aux, sel);
             const int rd_next = aux_rd<S>(a);
             // Q3 = quantised (Rc - Ra); the quantiser is odd-symmetric (reference src/jpegls_algorithm.hpp:173-194)
-            const int d3 = rb - ra;
+            const int d3 = rb - ra_v;
             const int ad = d3 < 0 ? -d3 : d3;
             int q3 = (ad > 0) + (ad >= t1) + (ad >= t2) + (ad >= t3);
             q3 = d3 < 0 ? -q3 : q3;
-            qs = 9 * aux_pre<S>(a) + q3;
-            if (qs == 0)
+            const int qs_v = 9 * aux_pre<S>(a) + q3;
+            const int s = qs_v >> 31;
+            const int idx = (qs_v ^ s) - s;
+            JLS_LOCKSTEP();
+            const wave::PackedCtx packed = m.reg[idx]; // idx 0 (run mode) reads a valid, unused slot
+            if (uniform((uint32_t)qs_v) == 0)
             {
+                qs = 0;
                 event = kRun;
                 break;
             }
-            const int s = qs >> 31;
-            const int idx = (qs ^ s) - s;
-            JLS_LOCKSTEP();
-            const wave::PackedCtx packed = m.reg[idx];
-            const uint32_t ca = uniform(packed.a), bcn = uniform(packed.bcn);
-            int a_acc = (int)ca;
-            int b = -(int)(bcn & 0xFFu);
-            int c = (int)(signed char)((bcn >> 8) & 0xFFu);
-            int n = (int)(bcn >> 16);
-            int k = __clz(n) - __clz(a_acc);
-            k = k < 0 ? 0 : k;
-            k += ((n << k) < a_acc);
+            int a_acc = (int)packed.a;
+            int b = -(int)(packed.bcn & 0xFFu);
+            int c = (int)(signed char)((packed.bcn >> 8) & 0xFFu);
+            int n = (int)(packed.bcn >> 16);
+            int k_v = __clz(n) - __clz(a_acc);
+            k_v = k_v < 0 ? 0 : k_v;
+            k_v += ((n << k_v) < a_acc);
+            const int k = (int)uniform((uint32_t)k_v);
             const int u = w.cache == 0 ? 64 : __clzll((long long)w.cache);
             if (u >= limit_m || u + 1 + k > w.valid || k >= 16)
             {
+                qs = (int)uniform((uint32_t)qs_v);
                 event = kSlow;
                 break;
             }
-            int px = med_predict(ra, rd, rb) + ((c ^ s) - s);
+            // MED predictor = median of (Ra, Rb, Ra + Rb - Rc): src/jpegls_algorithm.hpp:143-161
+            const int grad = ra_v + rd - rb;
+            const int lo = ra_v < rd ? ra_v : rd, hi = ra_v < rd ? rd : ra_v;
+            int px = (grad < lo ? lo : (grad > hi ? hi : grad)) + ((c ^ s) - s);
             px = px < 0 ? 0 : px;
             px = px > maxval ? maxval : px;
             const uint64_t after = w.cache << (u + 1);
@@ -537,14 +551,10 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             w.cache = after << k;
             w.valid -= u + 1 + k;
             int e = (mm >> 1) ^ -(mm & 1);
-            e ^= k == 0 ? ((2 * b + n - 1) >> 31) : 0;
+            e ^= k_v == 0 ? ((2 * b + n - 1) >> 31) : 0;
             // A.12/A.13, src/regular_mode_context.hpp:45-93 (|B| cannot overflow in lossless mode)
             a_acc += e < 0 ? -e : e;
-            if (a_acc >= (1 << 24))
-            {
-                event = kRetry;
-                break;
-            }
+            a_seen |= (uint32_t)a_acc;
             b += e;
             const int sh = n == reset;
             a_acc >>= sh;
@@ -560,12 +570,15 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             JLS_LOCKSTEP();
             m.reg[idx] = wave::PackedCtx{(uint32_t)a_acc, (uint32_t)(-b) | (((uint32_t)c & 0xFFu) << 8) | ((uint32_t)n << 16)};
             const int x = (px + ((e ^ s) - s)) & maxval;
-            v_out = to_lane(v_out, (uint32_t)x, sel);
+            v_out = lane == sel ? (uint32_t)x : v_out;
             rb = rd;
             rd = rd_next;
-            ra = x;
+            ra_v = x;
             ++i;
         }
+        ra = (int)uniform((uint32_t)ra_v);
+        if (uniform(a_seen) >= (1u << 24))
+            event = kRetry;
         // samples decoded by the inner loop -> line
         if (pos >= flush_from && pos < i)
             line[pos] = (S)v_out;

@@ -55,6 +55,22 @@ JLS_DEV uint32_t to_lane(uint32_t old, uint32_t value, int l)
 }
 #endif
 
+// Zero in a vector register that the compiler cannot see through.  OR-ing it into a wave-uniform value keeps that value
+// and everything computed from it on the vector ALU (the compiler would otherwise move uniform work to the scalar unit).
+#ifndef JLS_EMULATED_VECTOR_ZERO
+JLS_DEV int vector_zero()
+{
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+#else
+JLS_DEV int vector_zero()
+{
+    return 0;
+}
+#endif
+
 // J[] run-length order table (reference src/scan_codec.hpp:18-19), 4 bits per entry packed into two 64-bit words.
 JLS_DEV int run_j(int run_index)
 {
