@@ -81,9 +81,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=int(os.environ.get("CHARLS_AMD_BENCH_FRAMES", "2048")),
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("CHARLS_AMD_BENCH_FRAMES", "4096")),
                     help="frames per GPU per step (decoding is one serial chain per frame: throughput comes from "
-                         "the number of concurrent frames, 2048 = two wavefronts per SIMD, about what fits LDS and HBM)")
+                         "the number of concurrent frames; 4096 = four wavefronts per SIMD = what LDS holds, and with "
+                         "their bitstreams and decoded copies 210 GB of the 288 GB of HBM)")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 serial kernel, 2 pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -151,7 +152,8 @@ def main():
 
     # ---- correctness, outside the timed region
     assert (enc.errcs == 0).all() and (errcs == 0).all(), "a frame failed"
-    assert torch.equal(out, frames), "round trip is not lossless"
+    for f0 in range(0, frames_n, 128):  # chunked: torch.equal materialises a mask as large as its inputs
+        assert torch.equal(out[f0:f0 + 128], frames[f0:f0 + 128]), "round trip is not lossless"
     bit_exact = None
     if rank == 0:
         with open(os.path.join(ROOT, "tests", "golden", "cases.json")) as f:

@@ -148,7 +148,7 @@ bool wave_decode_eligible(const ScanDesc& d)
 size_t fast_decode_lds(const ScanDesc& d)
 {
     const size_t line_bytes = ((static_cast<size_t>(d.width) + 2) * (d.bits_per_sample > 8 ? 2 : 1) + 3) & ~size_t{3};
-    return fast::kFixedLds + line_bytes + (static_cast<size_t>(d.width) + 2) * (d.bits_per_sample > 8 ? 4 : 2);
+    return fast::kFixedLds + line_bytes;
 }
 
 // Lossless single-component scans take the speed path (scan_fast_decode.hip); it defers to the exact kernels whenever
@@ -306,13 +306,29 @@ DeviceBuffer& pipeline_arena()
     return arena;
 }
 
-constexpr size_t kArenaBudget = size_t{96} << 30; // bytes of HBM the pipeline may use for work areas per call
+constexpr size_t kArenaBudget = size_t{96} << 30; // most HBM the pipeline uses for work areas per call
+constexpr size_t kArenaReserve = size_t{4} << 30; // HBM left to the caller when the device is nearly full
+
+// Work-area budget of this call: what is free now (plus what the arena already holds), capped by kArenaBudget.
+size_t arena_budget(size_t held)
+{
+    size_t free_bytes = 0, total_bytes = 0;
+    if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return kArenaBudget;
+    }
+    const size_t reachable = free_bytes + held;
+    const size_t usable = reachable > kArenaReserve ? reachable - kArenaReserve : 0;
+    return std::min(kArenaBudget, usable);
+}
 
 template <typename S>
 void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
 {
     const PipeLayout lay(proto, proto.stream_capacity);
-    const uint32_t per_pass = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, kArenaBudget / lay.bytes)));
+    const size_t budget = arena_budget(pipeline_arena().capacity());
+    const uint32_t per_pass = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, budget / (lay.bytes + sizeof(pipe::Work)))));
     auto* arena = static_cast<uint8_t*>(pipeline_arena().ensure(lay.bytes * per_pass + per_pass * sizeof(pipe::Work)));
     auto* d_works = reinterpret_cast<pipe::Work*>(arena + lay.bytes * per_pass);
     std::vector<pipe::Work> works(per_pass);

@@ -7,9 +7,11 @@
 //     0xFF carries 7 payload bits), so each 1 KB refill is un-stuffed by all 64 lanes at once (16 bytes per lane, a
 //     wave prefix sum of the 7/8-bit contributions, LDS atomic OR into a dense bit ring); marker detection (0xFF followed
 //     by a byte >= 0x80) happens there as well.  The serial reader then only does aligned 64-bit reads of dense bits.
-//   * the part of the context that depends on the previous LINE only (81*Q1 + 9*Q2 and the sample Rd) is computed for a
-//     whole line by all lanes right after the previous line is complete and parked in LDS next to it, so the serial
-//     loop needs one LDS word, one gradient quantisation (Rc - Ra) and the context table per sample.
+//   * the part of the context that depends on the previous LINE only (81*Q1 + 9*Q2 and the sample Rd) is computed by
+//     all lanes for 64 samples at a time, straight from the line buffer (samples at and after the decoding position
+//     still hold the previous line), and kept in a vector register; the serial loop reads it with v_readlane and
+//     needs one gradient quantisation (Rc - Ra) and the context table per sample.  LDS per scan is the context
+//     table, the bit ring and ONE line: 9 KB for 4096 8-bit samples, i.e. four wavefronts per SIMD.
 //   * contexts are the packed 8-byte form of scan_wave_decode.hip; run mode is kept out of line.
 //
 // This kernel is not a restatement of the reference's bit reader; it decodes the same bit sequence.  Its result is used
@@ -256,19 +258,12 @@ JLS_DEV int take_unary(BitWindow& w, const uint32_t* ring, int most)
     }
 }
 
-// Per-sample record prepared from the previous line: low half = 9*Q1 + Q2 (|.| <= 40, signed), high half = prev[i+1].
+// Per-sample record derived from the previous line: low half = 9*Q1 + Q2 (|.| <= 40, signed), high half = prev[i+1].
 // 8-bit samples pack it in 16 bits, wider samples in 32.
 template <typename S>
 struct AuxOf
 {
-    using type = uint32_t;
-    static constexpr int kShift = 16;
-};
-template <>
-struct AuxOf<uint8_t>
-{
-    using type = uint16_t;
-    static constexpr int kShift = 8;
+    static constexpr int kShift = sizeof(S) == 1 ? 8 : 16;
 };
 
 template <typename S>
@@ -282,31 +277,25 @@ JLS_DEV int aux_pre(uint32_t a)
     return AuxOf<S>::kShift == 8 ? (int)(signed char)(a & 0xFFu) : (int)(short)(a & 0xFFFFu);
 }
 
+// Record of position `pos` (1-based).  line[p] holds the previous line for p >= i (the decoding position); the sample
+// left of position i has already been overwritten, its previous-line value is `rc_at_i`.  line[width + 1] replicates
+// line[width].  Lanes left of i or right of the line produce records nobody reads.
 template <typename S>
-JLS_DEV void prepare_line(const Traits& t, const S* line, typename AuxOf<S>::type* aux, uint32_t width, int corner, int lane)
+JLS_DEV uint32_t chunk_record(const Traits& t, const S* line, uint32_t pos, uint32_t i, uint32_t width, int rc_at_i)
 {
-    // aux[i] for i = 0..width (i = 0 carries prev[1] only)
-    for (uint32_t i = lane; i <= width; i += 64)
-    {
-        const int rd = (int)line[i + 1 <= width ? i + 1 : width];
-        int pre = 0;
-        if (i >= 1)
-        {
-            const int rb = (int)line[i];
-            const int rc = i >= 2 ? (int)line[i - 1] : corner;
-            pre = 9 * quantize(t, rd - rb) + quantize(t, rb - rc);
-        }
-        const uint32_t low = (uint32_t)pre & ((1u << AuxOf<S>::kShift) - 1u);
-        aux[i] = (typename AuxOf<S>::type)(low | ((uint32_t)rd << AuxOf<S>::kShift));
-    }
+    const uint32_t p = pos <= width ? pos : width;
+    const int rb = (int)line[p];
+    const int rd = (int)line[p + 1];
+    const int rc = pos == i ? rc_at_i : (int)line[p - 1];
+    const int pre = 9 * quantize(t, rd - rb) + quantize(t, rb - rc);
+    return ((uint32_t)pre & ((1u << AuxOf<S>::kShift) - 1u)) | ((uint32_t)rd << AuxOf<S>::kShift);
 }
 
 // Run mode (reference src/scan_decoder_impl.hpp:270-330, src/scan_decoder_core.hpp:71-101).  Returns false when the scan
 // must be retried by the exact decoder.
 template <typename S>
 JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, BitWindow& w, const uint32_t* ring, S* line,
-                        const typename AuxOf<S>::type* aux, uint32_t width, uint32_t& i, int& ra, int& rb, int& run_index,
-                        int lane)
+                        uint32_t width, uint32_t& i, int& ra, int& rb, int& run_index, int lane)
 {
     const uint32_t remaining = width - (i - 1);
     uint32_t run = 0;
@@ -337,7 +326,8 @@ JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, BitWindow& w,
         return true;
     }
     const uint32_t at = i + run;
-    const int rb_at = aux_rd<S>(uniform(aux[at - 1])); // prev[at]
+    JLS_LOCKSTEP();
+    const int rb_at = (int)uniform((uint32_t)line[at]); // prev[at]: not overwritten yet
     const int which = ra == rb_at ? 1 : 0;
     JLS_LOCKSTEP();
     RunCtx ctx = m.run[which];
@@ -364,7 +354,7 @@ JLS_DEV bool decode_run(const Traits& t, const wave::WaveModel& m, BitWindow& w,
     const int rx = which ? ((ra + e) & t.maxval) : ((rb_at + e * ((rb_at - ra) < 0 ? -1 : 1)) & t.maxval);
     line[at] = (S)rx;
     ra = rx;
-    rb = rb_at; // becomes Rc of the next sample; its Rb comes from aux[at]
+    rb = rb_at; // becomes Rc of the next sample
     if (run_index > 0)
         --run_index;
     i = at + 1;
@@ -406,7 +396,7 @@ JLS_DEV bool decode_regular_slow(const Traits& t, const wave::WaveModel& m, BitW
 
 } // namespace fast
 
-// Dynamic LDS: fast::kFixedLds + (width + 2) * sizeof(S) rounded to 4 + (width + 2) * sizeof(AuxOf<S>::type).
+// Dynamic LDS: fast::kFixedLds + (width + 2) * sizeof(S) rounded up to 4.
 //
 // Control structure: ONE loop whose body visits a 64-sample chunk of the current line.  The chunk's records (aux) are
 // loaded into a VGPR once and read per sample with v_readlane; decoded samples are collected with v_writelane and
@@ -425,10 +415,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
     const wave::WaveModel m{reinterpret_cast<wave::PackedCtx*>(smem), reinterpret_cast<RunCtx*>(smem + wave::kCtxBytes)};
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem + wave::kCtxBytes + wave::kRunBytes);
     const uint32_t width = d.width;
-    const uint32_t line_bytes = ((width + 2) * (uint32_t)sizeof(S) + 3u) & ~3u;
     S* line = reinterpret_cast<S*>(smem + kFixedLds);
-    using Aux = typename AuxOf<S>::type;
-    Aux* aux = reinterpret_cast<Aux*>(smem + kFixedLds + line_bytes);
 
     wave::init_model(t, m, lane);
     for (uint32_t i = lane; i < width + 2; i += 64)
@@ -464,11 +451,12 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             break;
         if (phase == kLineStart)
         {
-            prepare_line<S>(t, line, aux, width, corner, lane);
+            if (lane == 0)
+                line[width + 1] = line[width];
             __syncthreads();
-            rb = corner;                         // prev[0]
-            ra = aux_rd<S>(uniform(aux[0]));     // cur[0] = prev[1]
-            rd = ra;                             // prev[1]
+            rb = corner;                                  // prev[0]
+            ra = (int)uniform((uint32_t)line[1]);         // cur[0] = prev[1]
+            rd = ra;                                      // prev[1]
             first = ra;
             i = 1;
             phase = kInLine;
@@ -478,7 +466,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
         const uint32_t chunk_base = (i - 1) & ~63u;
         const uint32_t chunk_last = chunk_base + 64 < width ? chunk_base + 64 : width;
         const uint32_t pos = chunk_base + 1 + lane;
-        const uint32_t v_aux = aux[pos <= width ? pos : width];
+        const uint32_t v_aux = chunk_record<S>(t, line, pos, i, width, rb);
         uint32_t v_out = 0;
         const uint32_t flush_from = i;
         int event = kNone;
@@ -588,21 +576,25 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             // the inner loop had not advanced its neighbourhood yet: Rc = rb, Rb = rd as for any sample at i
             int rb_next = rd;
             rb = rd;
-            if (!decode_run<S>(t, m, w, ring, line, aux, width, i, ra, rb_next, run_index, lane))
+            if (!decode_run<S>(t, m, w, ring, line, width, i, ra, rb_next, run_index, lane))
                 retry = true;
             rb = rb_next;
+            JLS_LOCKSTEP();
             if (i <= width)
-                rd = aux_rd<S>(uniform(aux[i - 1])); // prev[i]: Rb of the next sample
+                rd = (int)uniform((uint32_t)line[i]); // prev[i]: Rb of the next sample
         }
         else if (event == kSlow)
         {
             int x = 0;
             if (!decode_regular_slow(t, m, w, ring, qs, med_predict(ra, rd, rb), x))
                 retry = true;
+            JLS_LOCKSTEP();
+            const int rd_after = (int)uniform((uint32_t)line[i + 1]); // prev[i + 1]
+            JLS_LOCKSTEP();
             if (lane == 0)
                 line[i] = (S)x;
             rb = rd;
-            rd = aux_rd<S>(uniform(aux[i]));
+            rd = rd_after;
             ra = x;
             ++i;
         }
