@@ -148,7 +148,7 @@ bool wave_decode_eligible(const ScanDesc& d)
 size_t fast_decode_lds(const ScanDesc& d)
 {
     const size_t line_bytes = ((static_cast<size_t>(d.width) + 2) * (d.bits_per_sample > 8 ? 2 : 1) + 3) & ~size_t{3};
-    return fast::kFixedLds + line_bytes;
+    return (d.bits_per_sample > 8 ? fast::fixed_lds<uint16_t>() : fast::fixed_lds<uint8_t>()) + line_bytes;
 }
 
 // Lossless single-component scans take the speed path (scan_fast_decode.hip); it defers to the exact kernels whenever

@@ -31,6 +31,12 @@ constexpr uint32_t kBitRingBytes = 2048;          // dense (un-stuffed) bits res
 constexpr uint32_t kBitRingBits = kBitRingBytes * 8;
 constexpr uint32_t kSrcChunk = 1024;              // coded bytes consumed per cooperative refill
 constexpr uint32_t kFixedLds = wave::kCtxBytes + wave::kRunBytes + kBitRingBytes;
+constexpr uint32_t kGradientLutBytes = 512;       // 8-bit samples only: quantised gradient for d = -255..255
+template <typename S>
+constexpr uint32_t fixed_lds()
+{
+    return kFixedLds + (sizeof(S) == 1 ? kGradientLutBytes : 0u);
+}
 constexpr uint32_t kFastRetry = 4u;               // ScanResult.flags: decode again with the exact kernel
 
 // Producer/consumer state of the dense bit ring (wave-uniform).
@@ -291,6 +297,25 @@ JLS_DEV uint32_t chunk_record(const Traits& t, const S* line, uint32_t pos, uint
     return ((uint32_t)pre & ((1u << AuxOf<S>::kShift) - 1u)) | ((uint32_t)rd << AuxOf<S>::kShift);
 }
 
+// Regular-mode context record of this kernel: word 0 = A | N << 24, word 1 = (B & 0xFFFF) | C << 16.  A < 2^24 is
+// checked at every update, N <= RESET <= 255 (the reference stores RESET through a uint8_t, src/scan_codec.hpp:142),
+// -N < B <= 0 and -128 <= C <= 127 after A.13, so the record is exact and packs/unpacks in one or two instructions.
+struct CtxRecord
+{
+    uint32_t an;
+    uint32_t bc;
+};
+
+JLS_DEV RegCtx open_record(const CtxRecord r)
+{
+    return RegCtx{(int)(r.an & 0xFFFFFFu), (int)(short)(r.bc & 0xFFFFu), (int)r.bc >> 16, (int)(r.an >> 24)};
+}
+
+JLS_DEV CtxRecord close_record(const RegCtx& x)
+{
+    return CtxRecord{(uint32_t)x.a | ((uint32_t)x.n << 24), ((uint32_t)x.b & 0xFFFFu) | ((uint32_t)x.c << 16)};
+}
+
 // Run mode (reference src/scan_decoder_impl.hpp:270-330, src/scan_decoder_core.hpp:71-101).  Returns false when the scan
 // must be retried by the exact decoder.
 template <typename S>
@@ -369,8 +394,9 @@ JLS_DEV bool decode_regular_slow(const Traits& t, const wave::WaveModel& m, BitW
     const int s = qs >> 31;
     const int idx = (qs ^ s) - s;
     JLS_LOCKSTEP();
-    const wave::PackedCtx packed = m.reg[idx];
-    RegCtx ctx = wave::unpack(wave::PackedCtx{uniform(packed.a), uniform(packed.bcn)});
+    CtxRecord* records = reinterpret_cast<CtxRecord*>(m.reg);
+    const CtxRecord packed = records[idx];
+    RegCtx ctx = open_record(CtxRecord{uniform(packed.an), uniform(packed.bc)});
     const int k = regular_k(ctx);
     if (k >= 16)
         return false;
@@ -389,14 +415,14 @@ JLS_DEV bool decode_regular_slow(const Traits& t, const wave::WaveModel& m, BitW
     if (!regular_update(ctx, e, 0, t.reset))
         return false;
     JLS_LOCKSTEP();
-    m.reg[idx] = wave::pack(ctx);
+    records[idx] = close_record(ctx);
     x_out = (px + ((e ^ s) - s)) & t.maxval;
     return true;
 }
 
 } // namespace fast
 
-// Dynamic LDS: fast::kFixedLds + (width + 2) * sizeof(S) rounded up to 4.
+// Dynamic LDS: fast::fixed_lds<S>() + (width + 2) * sizeof(S) rounded up to 4.
 //
 // Control structure: ONE loop whose body visits a 64-sample chunk of the current line.  The chunk's records (aux) are
 // loaded into a VGPR once and read per sample with v_readlane; decoded samples are collected with v_writelane and
@@ -415,9 +441,20 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
     const wave::WaveModel m{reinterpret_cast<wave::PackedCtx*>(smem), reinterpret_cast<RunCtx*>(smem + wave::kCtxBytes)};
     uint32_t* ring = reinterpret_cast<uint32_t*>(smem + wave::kCtxBytes + wave::kRunBytes);
     const uint32_t width = d.width;
-    S* line = reinterpret_cast<S*>(smem + kFixedLds);
+    signed char* gradient_lut = reinterpret_cast<signed char*>(smem + kFixedLds); // 8-bit samples only
+    S* line = reinterpret_cast<S*>(smem + fixed_lds<S>());
+    CtxRecord* records = reinterpret_cast<CtxRecord*>(m.reg);
 
-    wave::init_model(t, m, lane);
+    {
+        const CtxRecord fresh = close_record(RegCtx{initial_a(t), 0, 0, 1});
+        for (int q = lane; q < 365; q += 64)
+            records[q] = fresh;
+        if (lane < 2)
+            m.run[lane] = RunCtx{lane, initial_a(t), 1, 0};
+        if (sizeof(S) == 1)
+            for (int q = lane; q < 511; q += 64)
+                gradient_lut[q] = (signed char)quantize(t, q - 255);
+    }
     for (uint32_t i = lane; i < width + 2; i += 64)
         line[i] = 0;
     DenseBits src;
@@ -435,6 +472,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
     uint32_t y = 0, i = 1;
     int ra = 0, rb = 0, rd = 0;
     const int vz = vector_zero();
+    const int v_zero = vz, v_one = vz | 1, v_maxval = vz | maxval, v_cmin = vz | -128, v_cmax = vz | 127; // VGPR constants
 
     for (;;)
     {
@@ -497,27 +535,33 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             const int sel = (int)((i - 1) & 63u);
             const uint32_t a = from_lane(v_aux, sel);
             const int rd_next = aux_rd<S>(a);
-            // Q3 = quantised (Rc - Ra); the quantiser is odd-symmetric (reference src/jpegls_algorithm.hpp:173-194)
-            const int d3 = rb - ra_v;
-            const int ad = d3 < 0 ? -d3 : d3;
-            int q3 = (ad > 0) + (ad >= t1) + (ad >= t2) + (ad >= t3);
-            q3 = d3 < 0 ? -q3 : q3;
+            // Q3 = quantised (Rc - Ra) (reference src/jpegls_algorithm.hpp:173-194): a table look-up for 8-bit samples
+            int q3;
+            if (sizeof(S) == 1)
+                q3 = (int)gradient_lut[(rb + 255) - ra_v];
+            else
+            {
+                const int d3 = rb - ra_v;
+                const int ad = d3 < 0 ? -d3 : d3;
+                q3 = (ad > 0) + (ad >= t1) + (ad >= t2) + (ad >= t3);
+                q3 = d3 < 0 ? -q3 : q3;
+            }
             const int qs_v = 9 * aux_pre<S>(a) + q3;
             const int s = qs_v >> 31;
-            const int idx = (qs_v ^ s) - s;
+            const int idx = qs_v < 0 ? -qs_v : qs_v;
             JLS_LOCKSTEP();
-            const wave::PackedCtx packed = m.reg[idx]; // idx 0 (run mode) reads a valid, unused slot
+            const CtxRecord packed = records[idx]; // idx 0 (run mode) reads a valid, unused slot
             if (uniform((uint32_t)qs_v) == 0)
             {
                 qs = 0;
                 event = kRun;
                 break;
             }
-            int a_acc = (int)packed.a;
-            int b = -(int)(packed.bcn & 0xFFu);
-            int c = (int)(signed char)((packed.bcn >> 8) & 0xFFu);
-            int n = (int)(packed.bcn >> 16);
-            int k_v = __clz(n) - __clz(a_acc);
+            const int a_acc = (int)(packed.an & 0xFFFFFFu);
+            const int n = (int)(packed.an >> 24);
+            const int b = (int)(short)(packed.bc & 0xFFFFu);
+            const int c = (int)packed.bc >> 16;
+            int k_v = __builtin_clz((unsigned)n) - __clz(a_acc); // N >= 1; A may be 0 (then k = 0)
             k_v = k_v < 0 ? 0 : k_v;
             k_v += ((n << k_v) < a_acc);
             const int k = (int)uniform((uint32_t)k_v);
@@ -529,34 +573,27 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
                 break;
             }
             // MED predictor = median of (Ra, Rb, Ra + Rb - Rc): src/jpegls_algorithm.hpp:143-161
-            const int grad = ra_v + rd - rb;
-            const int lo = ra_v < rd ? ra_v : rd, hi = ra_v < rd ? rd : ra_v;
-            int px = (grad < lo ? lo : (grad > hi ? hi : grad)) + ((c ^ s) - s);
-            px = px < 0 ? 0 : px;
-            px = px > maxval ? maxval : px;
+            const int px = med3(med3s(ra_v + (rd - rb), ra_v, rd) + ((c ^ s) - s), v_zero, v_maxval);
             const uint64_t after = w.cache << (u + 1);
             const int mm = (u << k) | (int)((after >> 1) >> (63 - k));
             w.cache = after << k;
             w.valid -= u + 1 + k;
             int e = (mm >> 1) ^ -(mm & 1);
-            e ^= k_v == 0 ? ((2 * b + n - 1) >> 31) : 0;
-            // A.12/A.13, src/regular_mode_context.hpp:45-93 (|B| cannot overflow in lossless mode)
-            a_acc += e < 0 ? -e : e;
-            a_seen |= (uint32_t)a_acc;
-            b += e;
+            e ^= ((k_v - 1) & (2 * b + n - 1)) >> 31; // k = 0 and 2B + N - 1 < 0: src/regular_mode_context.hpp:36-42
+            // A.12/A.13, src/regular_mode_context.hpp:45-93 (|B| cannot overflow in lossless mode).  With N' the new N
+            // and t = B + Errval (halved at a reset): delta = (t > 0) - (t + N' <= 0), B' = median(t - delta * N', 1 - N', 0),
+            // C' = median(C + delta, -128, 127).
+            const int a_new = a_acc + (e < 0 ? -e : e);
+            a_seen |= (uint32_t)a_new;
             const int sh = n == reset;
-            a_acc >>= sh;
-            b >>= sh;
-            n = (n >> sh) + 1;
-            const bool low = b + n <= 0, high = b > 0;
-            const int b_low = b + n > 1 - n ? b + n : 1 - n;
-            const int b_high = b - n < 0 ? b - n : 0;
-            const int c_low = c - 1 > -128 ? c - 1 : -128;
-            const int c_high = c + 1 < 127 ? c + 1 : 127;
-            b = low ? b_low : (high ? b_high : b);
-            c = low ? c_low : (high ? c_high : c);
+            const int n_new = (n >> sh) + 1;
+            const int tb = (b + e) >> sh;
+            const int minus_delta = 1 - med3(tb, v_zero, v_one) - med3(tb + n_new, v_zero, v_one);
+            const int b_new = med3(tb + minus_delta * n_new, 1 - n_new, v_zero);
+            const int c_new = med3(c - minus_delta, v_cmin, v_cmax);
             JLS_LOCKSTEP();
-            m.reg[idx] = wave::PackedCtx{(uint32_t)a_acc, (uint32_t)(-b) | (((uint32_t)c & 0xFFu) << 8) | ((uint32_t)n << 16)};
+            records[idx] = CtxRecord{(uint32_t)(a_new >> sh) | ((uint32_t)n_new << 24),
+                                     ((uint32_t)b_new & 0xFFFFu) | ((uint32_t)c_new << 16)};
             const int x = (px + ((e ^ s) - s)) & maxval;
             v_out = lane == sel ? (uint32_t)x : v_out;
             rb = rd;

@@ -55,9 +55,36 @@ JLS_DEV uint32_t to_lane(uint32_t old, uint32_t value, int l)
 }
 #endif
 
+// Median of three signed integers in one vector instruction (the compiler only forms v_med3_i32 for constant bounds).
+// med3s takes its last operand from a scalar register.
+#ifndef JLS_EMULATED
+JLS_DEV int med3(int a, int b, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+JLS_DEV int med3s(int a, int b, int c_scalar)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_scalar));
+    return r;
+}
+#else
+JLS_DEV int med3(int a, int b, int c)
+{
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    return c < lo ? lo : (c > hi ? hi : c);
+}
+JLS_DEV int med3s(int a, int b, int c)
+{
+    return med3(a, b, c);
+}
+#endif
+
 // Zero in a vector register that the compiler cannot see through.  OR-ing it into a wave-uniform value keeps that value
 // and everything computed from it on the vector ALU (the compiler would otherwise move uniform work to the scalar unit).
-#ifndef JLS_EMULATED_VECTOR_ZERO
+#ifndef JLS_EMULATED
 JLS_DEV int vector_zero()
 {
     int z;

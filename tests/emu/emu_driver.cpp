@@ -115,7 +115,7 @@ int emu_decode_scans_fast(const jls::ScanDesc* descs, jls::ScanResult* results, 
     const jls::ScanDesc& d = descs[0];
     const bool wide = d.bits_per_sample > 8;
     const size_t line_bytes = (((size_t)d.width + 2) * (wide ? 2 : 1) + 3) & ~size_t{3};
-    const size_t lds = jls::fast::kFixedLds + line_bytes;
+    const size_t lds = (wide ? jls::fast::fixed_lds<uint16_t>() : jls::fast::fixed_lds<uint8_t>()) + line_bytes;
     if (wide)
         emu::launch(jls::decode_scans_fast<uint16_t>, dim3(count), dim3(64), lds, descs, results);
     else

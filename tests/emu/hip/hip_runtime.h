@@ -196,7 +196,7 @@ inline int __builtin_amdgcn_readlane(int v, int lane)
     return __shfl(v, lane);
 }
 
-#define JLS_EMULATED_VECTOR_ZERO 1
+#define JLS_EMULATED 1
 #define JLS_TO_LANE(old, value, lane) (emu::lane_id() == (lane) ? (value) : (old))
 
 inline unsigned __builtin_amdgcn_readfirstlane(unsigned v)
