@@ -8,15 +8,18 @@
 //                        HBM-bound); run-mode segmentation of the line resolved as a carry chain over ballot masks
 //   B1 chain_offsets     per-line histograms of the 365 statistic chains (364 regular contexts + the run chain) ->
 //                        exclusive offsets (a stable counting sort by context, raster order kept inside a chain)
-//   B2 scatter_events    events move to their chain, lane-order ranks from ballots (deterministic, no atomics on order)
+//   B2 scatter_events    events move to their chain, lane-order ranks from ballots (deterministic, no atomics on order);
+//                        the slot of every sample is recorded (inv) so that codes can stay in chain order until D2
 //   C1 bias_chains       one LANE per chain: the {B,C,N} recurrence turns the chain's samples into Errval (the only
 //                        serial dependency of regular mode); the run chain carries RUNindex and the two run-interruption
 //                        contexts and codes its events directly.  Chains of different contexts never interact in
 //                        lossless mode, so 365 x scans lanes run concurrently.
 //   C2 code_events       one wavefront per chain: A is a segmented prefix sum of |Errval|, N a function of the event
-//                        index -> k and the Golomb words of 64 events per step, scattered back to raster order
-//   D1 sum/scan          code lengths -> bit offsets (two-level prefix sum per scan)
-//   D2 write_raw_bits    codes are concatenated MSB-first into the unstuffed bit stream (plain stores for owned words)
+//                        index -> k and the Golomb words of 64 events per step, stored in chain order (coalesced)
+//   D1 sum/scan          code lengths (gathered through inv) -> bit offsets (two-level prefix sum per scan)
+//   D2 write_raw_bits    codes are gathered in raster order and concatenated MSB-first into the unstuffed bit stream
+//                        (a line's samples of one chain are neighbours in chain order: the gathers hit whole cache
+//                        lines, where a scatter of 8-byte codes by chain wrote every line many times)
 //   D3 stuff_scan        JPEG-LS 0xFF bit stuffing + end-of-scan padding (src/scan_encoder.hpp:103-180), one wavefront
 //                        per scan streaming through LDS
 //
@@ -29,7 +32,10 @@
 namespace jls {
 namespace pipe {
 
-constexpr int kChains = 365;          // 0 = run chain, 1..364 = regular contexts
+constexpr int kChains = 366;          // 0 = run chain, 1..364 = regular contexts, 365 = slots of run-interruption samples
+constexpr int kRegularChains = 364;
+constexpr int kInterruptChain = 365;  // no recurrence of its own: the run chain codes these samples, in the same order
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint16_t kNoEvent = 0xFFFF; // key of a sample that produces no code of its own
 constexpr uint32_t kPackBlock = 4096; // samples per D1/D2 workgroup (256 threads x 16)
 constexpr uint32_t kStatusInvalid = 1u;
@@ -46,8 +52,9 @@ struct Work
     uint32_t* chain_base;  // [kChains] offset of the chain in sval/spos
     uint32_t* sval;        // [H*W + kChainSlack] events grouped by chain, raster order inside a chain; 16-byte aligned
     uint32_t* spos;        // [H*W + kChainSlack] raster index of the event | sign << 31; 16-byte aligned
-    uint8_t* len;          // [H*W] code length of the sample (0 = none)
-    uint64_t* code;        // [H*W] code bits, right aligned (re-uses the storage of key/val, dead after B2)
+    uint32_t* inv;         // [H*W] slot (index into sval/code/len) of the sample, or kNoSlot
+    uint8_t* len;          // [H*W + kChainSlack] code length per slot
+    uint64_t* code;        // [H*W + kChainSlack] code bits per slot, right aligned (re-uses key/val, dead after B2)
     uint32_t* blocksum;    // [ceil(H*W / kPackBlock)]
     uint64_t* blockbase;   // same count: exclusive bit offsets
     uint32_t* raw;         // unstuffed bit stream, 32-bit words in big-endian bit order; zeroed before D2
@@ -174,8 +181,13 @@ __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ 
             const bool eq = (a >> lane) & 1ull;
             if (!(s || q0))
                 atomicAdd(&s_hist[key_row[x] & 0x1FF], 1u); // regular sample, key already written by this lane
+            else if (s && eq)
+                key_row[x] = kNoEvent; // inside a run
             else if (s)
-                key_row[x] = kNoEvent; // inside a run, or the interruption sample of a run started earlier
+            { // the sample that ends a run started earlier: coded by the run chain, owns a slot of its own
+                key_row[x] = (uint16_t)kInterruptChain;
+                atomicAdd(&s_hist[kInterruptChain], 1u);
+            }
             else
             { // a run starts here (possibly of length 0)
                 uint32_t run = 0, eol = 0;
@@ -281,6 +293,8 @@ __global__ void __launch_bounds__(64) scatter_events(const ScanDesc* __restrict_
             w.sval[dest] = v;
             w.spos[dest] = (uint32_t)((size_t)y * width + x) | ((uint32_t)(key >> 9) << 31);
         }
+        if (x < width)
+            w.inv[(size_t)y * width + x] = has ? dest : kNoSlot;
     }
 }
 
@@ -320,6 +334,8 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
     if (tid >= scans * (uint32_t)kChains)
         return;
     const uint32_t chain = tid / scans;
+    if (chain == (uint32_t)kInterruptChain)
+        return;
     const ScanDesc d = descs[tid % scans];
     const Work w = works[tid % scans];
     const Traits t = make_traits(d);
@@ -388,9 +404,16 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
     }
     else
     { // ---- run mode: src/scan_encoder.hpp:53-73, src/scan_encoder_impl.hpp:249-275, src/scan_encoder_core.hpp:105-125
+        // Codes go to the slot of the sample they belong to: the run-length code to the run's own slot, the code of the
+        // interruption sample to the next slot of chain kInterruptChain (its events are these samples, in this order).
         RunCtx rc[2] = {RunCtx{0, initial_a(t), 1, 0}, RunCtx{1, initial_a(t), 1, 0}};
         int run_index = 0;
         const int mask = (1 << d.bits_per_sample) - 1;
+        uint64_t* run_code = w.code + w.chain_base[0];
+        uint8_t* run_len = w.len + w.chain_base[0];
+        uint64_t* int_code = w.code + w.chain_base[kInterruptChain];
+        uint8_t* int_len = w.len + w.chain_base[kInterruptChain];
+        uint32_t interruptions = 0;
         for (uint32_t e = 0; e < n; ++e)
         {
             const uint32_t v = sval[e];
@@ -418,8 +441,8 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
                     bits = (bits << 1) | 1ull;
                     ++len;
                 }
-                w.code[p] = bits;
-                w.len[p] = (uint8_t)len;
+                run_code[e] = bits;
+                run_len[e] = (uint8_t)len;
                 continue;
             }
             const int jb = run_j(run_index);
@@ -446,21 +469,22 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
                 --run_index;
             if (full == 0)
             { // both codes belong to the same sample: J+1 zero bits followed by the interruption code (<= LIMIT bits)
-                w.code[p] = (bits << c.len) | c.bits;
-                w.len[p] = (uint8_t)(len + c.len);
+                run_code[e] = (bits << c.len) | c.bits;
+                run_len[e] = (uint8_t)(len + c.len);
             }
             else
             {
-                w.code[p] = bits;
-                w.len[p] = (uint8_t)len;
-                w.code[p + full] = c.bits;
-                w.len[p + full] = (uint8_t)c.len;
+                run_code[e] = bits;
+                run_len[e] = (uint8_t)len;
+                int_code[interruptions] = c.bits;
+                int_len[interruptions] = (uint8_t)c.len;
+                ++interruptions;
             }
         }
     }
 }
 
-// C2: grid (364, scans), one wavefront per regular chain: 64 consecutive events of the chain per step.
+// C2: grid (kRegularChains, scans), one wavefront per regular chain: 64 consecutive events of the chain per step.
 //
 // Before event i of a chain, N_i depends on i only (it counts 1..RESET, then cycles RESET/2+1..RESET) and
 // A_i = A_seg + (sum of |Errval| since the last halving), where A_seg changes only at the events with N_i == RESET
@@ -477,9 +501,8 @@ __global__ void __launch_bounds__(64) code_events(const ScanDesc* __restrict__ d
     if (n == 0)
         return;
     const JLS_GLOBAL_AS uint32_t* serr = (const JLS_GLOBAL_AS uint32_t*)(w.sval + w.chain_base[chain]);
-    const JLS_GLOBAL_AS uint32_t* spos = (const JLS_GLOBAL_AS uint32_t*)(w.spos + w.chain_base[chain]);
-    JLS_GLOBAL_AS uint64_t* code_out = (JLS_GLOBAL_AS uint64_t*)w.code;
-    JLS_GLOBAL_AS uint8_t* len_out = (JLS_GLOBAL_AS uint8_t*)w.len;
+    JLS_GLOBAL_AS uint64_t* code_out = (JLS_GLOBAL_AS uint64_t*)(w.code + w.chain_base[chain]);
+    JLS_GLOBAL_AS uint8_t* len_out = (JLS_GLOBAL_AS uint8_t*)(w.len + w.chain_base[chain]);
     const uint32_t lane = threadIdx.x;
     const uint32_t reset = (uint32_t)t.reset;          // 0: N never matches (RESET = 256*m stored through uint8)
     const uint32_t half = reset >> 1;
@@ -491,7 +514,6 @@ __global__ void __launch_bounds__(64) code_events(const ScanDesc* __restrict__ d
         const uint32_t i = i0 + lane;
         const bool live = i < n;
         const uint32_t rec = live ? serr[i] : 0;
-        const uint32_t ps = live ? spos[i] : 0;
         const int err = (int)rec >> 1;
         const uint32_t mag = (uint32_t)(err < 0 ? -err : err);
         uint32_t incl = mag; // inclusive prefix sum of |Errval| over the lanes
@@ -534,9 +556,8 @@ __global__ void __launch_bounds__(64) code_events(const ScanDesc* __restrict__ d
             k = k > 15 ? 15 : k;
             const int corr = k == 0 ? -(int)(rec & 1u) : 0;
             const CodeWord c = golomb_word(t, k, map_error(corr ^ err), t.limit);
-            const uint32_t p = ps & 0x7FFFFFFFu;
-            code_out[p] = c.bits;
-            len_out[p] = (uint8_t)c.len;
+            code_out[i] = c.bits;
+            len_out[i] = (uint8_t)c.len;
         }
         // A before the first event of the next step: everything after the last halving of this step
         a_seg += (uint32_t)__shfl((int)incl, 63) - seg_base;
@@ -557,7 +578,10 @@ __global__ void __launch_bounds__(256) sum_code_lengths(const ScanDesc* __restri
     uint32_t sum = 0;
     for (int i = 0; i < 16; ++i)
         if (base + i < total)
-            sum += w.len[base + i];
+        {
+            const uint32_t slot = w.inv[base + i];
+            sum += slot != kNoSlot ? w.len[slot] : 0u;
+        }
     s_part[threadIdx.x] = sum;
     __syncthreads();
     for (int stride = 128; stride > 0; stride >>= 1)
@@ -607,10 +631,13 @@ __global__ void __launch_bounds__(256) write_raw_bits(const ScanDesc* __restrict
     const uint64_t total = (uint64_t)d.width * d.height;
     const uint64_t base = (uint64_t)blockIdx.x * kPackBlock + (uint64_t)threadIdx.x * 16;
     int lens[16];
+    uint32_t slots[16];
     uint32_t sum = 0;
     for (int i = 0; i < 16; ++i)
+        slots[i] = base + i < total ? w.inv[base + i] : kNoSlot;
+    for (int i = 0; i < 16; ++i)
     {
-        lens[i] = base + i < total ? w.len[base + i] : 0;
+        lens[i] = slots[i] != kNoSlot ? w.len[slots[i]] : 0;
         sum += (uint32_t)lens[i];
     }
     s_scan[threadIdx.x] = sum;
@@ -634,7 +661,7 @@ __global__ void __launch_bounds__(256) write_raw_bits(const ScanDesc* __restrict
         int left = lens[i];
         if (left == 0)
             continue;
-        const uint64_t v = w.code[base + i];
+        const uint64_t v = w.code[slots[i]];
         while (left > 0)
         {
             const int room = 64 - acc_bits;

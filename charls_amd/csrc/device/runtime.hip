@@ -262,11 +262,11 @@ size_t align_up(size_t v, size_t a)
     return (v + a - 1) / a * a;
 }
 
-// Bytes of work area one scan needs (17 B per sample + per-line histograms + the unstuffed stream).
+// Bytes of work area one scan needs (21 B per sample + per-line histograms + the unstuffed stream).
 struct PipeLayout
 {
     size_t samples, blocks, raw_bytes;
-    size_t off_key, off_val, off_hist, off_total, off_base, off_sval, off_spos, off_len, off_code, off_bsum, off_bbase,
+    size_t off_key, off_val, off_hist, off_total, off_base, off_sval, off_spos, off_inv, off_len, off_code, off_bsum, off_bbase,
         off_raw, off_bits, off_status, bytes;
     PipeLayout(const ScanDesc& d, size_t capacity_hint)
     {
@@ -282,7 +282,7 @@ struct PipeLayout
         };
         // key (2 B) + val (4 B) are dead once the events are scattered; the 8-byte codes written by stage C re-use them
         const size_t val_at = align_up(samples * 2, 256);
-        off_code = take(std::max(samples * 8, val_at + samples * 4));
+        off_code = take(std::max((samples + pipe::kChainSlack) * 8, val_at + samples * 4));
         off_key = off_code;
         off_val = off_code + val_at;
         off_hist = take(static_cast<size_t>(d.height) * pipe::kChains * 4);
@@ -290,7 +290,8 @@ struct PipeLayout
         off_base = take(pipe::kChains * 4);
         off_sval = take((samples + pipe::kChainSlack) * 4);
         off_spos = take((samples + pipe::kChainSlack) * 4);
-        off_len = take(samples);
+        off_inv = take(samples * 4);
+        off_len = take(samples + pipe::kChainSlack);
         off_bsum = take(blocks * 4);
         off_bbase = take(blocks * 8);
         off_raw = take(raw_bytes);
@@ -349,6 +350,7 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
             w.chain_base = reinterpret_cast<uint32_t*>(base + lay.off_base);
             w.sval = reinterpret_cast<uint32_t*>(base + lay.off_sval);
             w.spos = reinterpret_cast<uint32_t*>(base + lay.off_spos);
+            w.inv = reinterpret_cast<uint32_t*>(base + lay.off_inv);
             w.len = base + lay.off_len;
             w.code = reinterpret_cast<uint64_t*>(base + lay.off_code);
             w.blocksum = reinterpret_cast<uint32_t*>(base + lay.off_bsum);
@@ -357,8 +359,7 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
             w.raw_words = lay.raw_bytes / 4;
             w.total_bits = reinterpret_cast<uint64_t*>(base + lay.off_bits);
             w.status = reinterpret_cast<uint32_t*>(base + lay.off_status);
-            // len, raw, total_bits and status start at zero (contiguous at the end of the layout apart from code)
-            hip_check(hipMemsetAsync(w.len, 0, lay.samples, stream));
+            // raw, total_bits and status start at zero (contiguous at the end of the layout)
             hip_check(hipMemsetAsync(w.raw, 0, lay.off_status + 4 - lay.off_raw, stream));
         }
         hip_check(hipMemcpyAsync(d_works, works.data(), sizeof(pipe::Work) * n, hipMemcpyHostToDevice, stream));
@@ -377,7 +378,7 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         hipLaunchKernelGGL(pipe::scatter_events, dim3(rows_grid, n), dim3(64), 0, stream, descs, d_works);
         t.mark();
         hipLaunchKernelGGL((pipe::bias_chains<S>), dim3((n * pipe::kChains + 63) / 64), dim3(64), 0, stream, descs, d_works, n);
-        hipLaunchKernelGGL(pipe::code_events, dim3(pipe::kChains - 1, n), dim3(64), 0, stream, descs, d_works);
+        hipLaunchKernelGGL(pipe::code_events, dim3(pipe::kRegularChains, n), dim3(64), 0, stream, descs, d_works);
         t.mark();
         hipLaunchKernelGGL(pipe::sum_code_lengths, dim3(blocks, n), dim3(256), 0, stream, descs, d_works);
         hipLaunchKernelGGL(pipe::scan_block_sums, dim3(n), dim3(64), 0, stream, descs, d_works);

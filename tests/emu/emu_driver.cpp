@@ -11,6 +11,7 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 #include "../../charls_amd/csrc/device/scan_fast_decode.hip"
 
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 extern "C" {
@@ -63,19 +64,27 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
         allocs.push_back(q);
         return q;
     };
+    // work areas the product does not clear are filled with garbage here (the arena is reused from pass to pass)
+    auto galloc = [&](size_t bytes) {
+        void* q = std::malloc(bytes + 64);
+        std::memset(q, 0xA5, bytes + 64);
+        allocs.push_back(q);
+        return q;
+    };
     for (int i = 0; i < count; ++i)
     {
         pipe::Work& w = works[i];
         const size_t raw_bytes = ((size_t)descs[i].stream_capacity + 64 + 15) / 16 * 16;
-        w.code = (uint64_t*)zalloc(samples * 8 + 512);  // stage C re-uses the storage of key/val, as in runtime.hip
+        w.code = (uint64_t*)galloc((samples + pipe::kChainSlack) * 8 + 512);  // stage C re-uses the storage of key/val, as in runtime.hip
         w.key = (uint16_t*)w.code;
         w.val = (uint32_t*)((unsigned char*)w.code + ((samples * 2 + 255) / 256) * 256);
         w.hist = (uint32_t*)zalloc((size_t)p.height * pipe::kChains * 4);
         w.chain_total = (uint32_t*)zalloc(pipe::kChains * 4);
         w.chain_base = (uint32_t*)zalloc(pipe::kChains * 4);
-        w.sval = (uint32_t*)zalloc((samples + pipe::kChainSlack) * 4);
-        w.spos = (uint32_t*)zalloc((samples + pipe::kChainSlack) * 4);
-        w.len = (uint8_t*)zalloc(samples);
+        w.sval = (uint32_t*)galloc((samples + pipe::kChainSlack) * 4);
+        w.spos = (uint32_t*)galloc((samples + pipe::kChainSlack) * 4);
+        w.inv = (uint32_t*)galloc(samples * 4);
+        w.len = (uint8_t*)galloc(samples + pipe::kChainSlack);
         w.blocksum = (uint32_t*)zalloc(blocks * 4);
         w.blockbase = (uint64_t*)zalloc(blocks * 8);
         w.raw = (uint32_t*)zalloc(raw_bytes);
@@ -91,7 +100,7 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
     emu::launch(pipe::chain_offsets, dim3(count), dim3(384), 0, descs, wk);
     emu::launch(pipe::scatter_events, dim3(rows_grid, count), dim3(64), 0, descs, wk);
     emu::launch(pipe::bias_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
-    emu::launch(pipe::code_events, dim3(pipe::kChains - 1, count), dim3(64), 0, descs, wk);
+    emu::launch(pipe::code_events, dim3(pipe::kRegularChains, count), dim3(64), 0, descs, wk);
     emu::launch(pipe::sum_code_lengths, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
     emu::launch(pipe::scan_block_sums, dim3(count), dim3(64), 0, descs, wk);
     emu::launch(pipe::write_raw_bits, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
