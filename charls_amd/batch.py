@@ -128,7 +128,7 @@ def shard_range(total: int, rank: int, world: int):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def gather_streams(streams, sizes, dst=0, group=None, chunk_frames=128, sink=None):
+def gather_streams(streams, sizes, dst=0, group=None, chunk_frames=32, sink=None):
     """Variable-length gather of the encoded frames to rank `dst` (RCCL on GPU tensors, gloo on CPU tensors):
     an all-gather of the per-frame byte counts, then the payload in rounds of `chunk_frames` frames per rank, each round
     one padded `gather` trimmed to the round's maximum length into a receive buffer that is re-used (the payload of a
@@ -154,11 +154,12 @@ def gather_streams(streams, sizes, dst=0, group=None, chunk_frames=128, sink=Non
     for first in range(0, max_count, chunk_frames):
         n = min(chunk_frames, max_count - first)
         max_len = int(max((int(s[first:first + n].max()) if len(s) > first else 0) for s in all_sizes))
-        max_len = max(max_len, 1)
+        max_len = -(-max(max_len, 1) // 65536) * 65536  # few distinct buffer sizes -> re-used blocks (same on every rank)
         payload = torch.zeros((n, max_len), dtype=torch.uint8, device=dev)
         have = max(0, min(n, streams.shape[0] - first))
         if have:
-            payload[:have] = streams[first:first + have, :max_len]
+            cols = min(max_len, streams.shape[1])
+            payload[:have, :cols] = streams[first:first + have, :cols]
         if rank == dst:
             parts = [torch.empty_like(payload) for _ in range(world)]
             dist.gather(payload, parts, dst=dst, group=group)
