@@ -308,7 +308,7 @@ DeviceBuffer& pipeline_arena()
 }
 
 constexpr size_t kArenaBudget = size_t{96} << 30; // most HBM the pipeline uses for work areas per call
-constexpr size_t kArenaReserve = size_t{16} << 30; // HBM left to the caller (collective buffers, ...) when the device is nearly full
+constexpr size_t kArenaReserve = size_t{8} << 30; // HBM left to the caller (collective buffers, ...) when the device is nearly full
 
 // Work-area budget of this call: what is free now (plus what the arena already holds), capped by kArenaBudget.
 size_t arena_budget(size_t held)

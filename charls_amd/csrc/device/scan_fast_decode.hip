@@ -208,7 +208,7 @@ struct BitWindow
 };
 
 constexpr uint32_t kRingWords = kBitRingBits / 32;
-constexpr uint32_t kHandlerWords = 16;
+constexpr uint32_t kHandlerWords = 144; // 64 samples x 2 words + a run / long code (ring: 512 words, refill <= 258)
 constexpr uint32_t kUnlimitedWords = 0x40000000u;
 
 JLS_DEV void top_up(BitWindow& w, const uint32_t* ring) // requires valid <= 32
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
     src.init(d.stream, d.stream_capacity, ring, lane);
     BitWindow w{0, 0, 0, 0, false};
 
-    enum : int { kNone = 0, kRefill, kRun, kSlow, kRetry };
+    enum : int { kNone = 0, kChunkEnd, kRun, kSlow, kRetry };
     enum : int { kLineStart = 0, kInLine, kDrain };
     int phase = d.height == 0 ? kDrain : kLineStart;
     int corner = 0, first = 0;
@@ -517,21 +517,12 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
         // that crosses back per sample.  Wavefronts sharing a SIMD then overlap scalar and vector work.
         int ra_v = ra | vz;     // equal in all lanes, kept in a VGPR
         uint32_t a_seen = 0;    // OR of every updated A: the 2^24 overflow test is done once per chunk visit
-        while (i <= chunk_last)
+        // Single-exit loop (exits are taken at the bottom only: the compiler adds guard flags to multi-exit loops).  The
+        // producer margin (kHandlerWords) covers the 2 words a sample can consume times the 64 samples of a visit.
+        do
         {
             if (w.valid <= 32)
-            {
-                if (w.safe_words == 0)
-                {
-                    event = kRefill;
-                    break;
-                }
-                const uint32_t word = uniform(ring[(w.next_word & (kRingWords - 1)) ^ 1u]);
-                w.cache |= (uint64_t)word << (32 - w.valid);
-                w.valid += 32;
-                ++w.next_word;
-                --w.safe_words;
-            }
+                top_up(w, ring);
             const int sel = (int)((i - 1) & 63u);
             const uint32_t a = from_lane(v_aux, sel);
             const int rd_next = aux_rd<S>(a);
@@ -555,7 +546,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             {
                 qs = 0;
                 event = kRun;
-                break;
+                continue;
             }
             const int a_acc = (int)(packed.an & 0xFFFFFFu);
             const int n = (int)(packed.an >> 24);
@@ -566,11 +557,12 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             k_v += ((n << k_v) < a_acc);
             const int k = (int)uniform((uint32_t)k_v);
             const int u = w.cache == 0 ? 64 : __clzll((long long)w.cache);
-            if (u >= limit_m || u + 1 + k > w.valid || k >= 16)
+            // 8-bit samples: |Errval| <= 128 keeps A / N < 2^9, so k < 16 and A < 2^24 hold by construction there
+            if (u >= limit_m || u + 1 + k > w.valid || (sizeof(S) > 1 && k >= 16))
             {
                 qs = (int)uniform((uint32_t)qs_v);
                 event = kSlow;
-                break;
+                continue;
             }
             // MED predictor = median of (Ra, Rb, Ra + Rb - Rc): src/jpegls_algorithm.hpp:143-161
             const int px = med3(med3s(ra_v + (rd - rb), ra_v, rd) + ((c ^ s) - s), v_zero, v_maxval);
@@ -584,7 +576,8 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             // and t = B + Errval (halved at a reset): delta = (t > 0) - (t + N' <= 0), B' = median(t - delta * N', 1 - N', 0),
             // C' = median(C + delta, -128, 127).
             const int a_new = a_acc + (e < 0 ? -e : e);
-            a_seen |= (uint32_t)a_new;
+            if (sizeof(S) > 1)
+                a_seen |= (uint32_t)a_new;
             const int sh = n == reset;
             const int n_new = (n >> sh) + 1;
             const int tb = (b + e) >> sh;
@@ -600,7 +593,8 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             rd = rd_next;
             ra_v = x;
             ++i;
-        }
+            event = (int)((chunk_last - i) >> 31); // kChunkEnd (= 1) once i has passed the chunk, else kNone
+        } while (event == kNone);
         ra = (int)uniform((uint32_t)ra_v);
         if (uniform(a_seen) >= (1u << 24))
             event = kRetry;
