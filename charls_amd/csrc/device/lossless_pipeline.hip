@@ -356,27 +356,22 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
         // past the end of a chain are garbage that is processed into the chain's own padding.  Three register sets rotate
         // (loads run two groups ahead of the in-place store), so no register copies and no full vmcnt drains are needed.
         int b = 0, c = 0, nn = 1;
-        const int reset = t.reset, range = t.range, half_range = (t.range + 1) / 2, maxval = t.maxval;
+        const int reset = t.reset, maxval = t.maxval;
+        const int wrap = 32 - d.bits_per_sample; // RANGE = 2^bpp in lossless mode: modulo RANGE = sign extension
         auto step = [&](uint32_t v, uint32_t ps) -> uint32_t {
             const int s = (int)ps >> 31; // 0 or -1
-            int px = (int)(v >> 16) + ((c ^ s) - s);
-            px = px < 0 ? 0 : px;
-            px = px > maxval ? maxval : px;
+            const int px = med3((int)(v >> 16) + ((c ^ s) - s), 0, maxval);
             int err = (((int)(v & 0xFFFFu) - px) ^ s) - s;
-            err += (err >> 31) & range; // modulo RANGE, src/default_traits.hpp:123-139
-            err -= err >= half_range ? range : 0;
+            err = (int)((uint32_t)err << wrap) >> wrap; // src/default_traits.hpp:123-139
             const uint32_t out = ((uint32_t)err << 1) | ((uint32_t)(2 * b + nn - 1) >> 31);
-            b += err; // |B| < N + RANGE/2: cannot reach 2^24
+            // A.13 as in the decoder (scan_fast_decode.hip): with t = B + Errval (halved at a reset) and N' the new N,
+            // delta = (t > 0) - (t + N' <= 0), B' = median(t - delta * N', 1 - N', 0), C' = median(C + delta, -128, 127)
             const int sh = nn == reset;
-            b >>= sh;
+            const int tb = (b + err) >> sh; // |B| < N + RANGE/2: cannot reach 2^24
             nn = (nn >> sh) + 1;
-            const bool low = b + nn <= 0, high = b > 0;
-            const int b_low = b + nn > 1 - nn ? b + nn : 1 - nn;
-            const int b_high = b - nn < 0 ? b - nn : 0;
-            const int c_low = c - 1 > -128 ? c - 1 : -128;
-            const int c_high = c + 1 < 127 ? c + 1 : 127;
-            b = low ? b_low : (high ? b_high : b);
-            c = low ? c_low : (high ? c_high : c);
+            const int minus_delta = 1 - med3(tb, 0, 1) - med3(tb + nn, 0, 1);
+            b = med3(tb + __mul24(minus_delta, nn), 1 - nn, 0);
+            c = med3(c - minus_delta, -128, 127);
             return out;
         };
         typedef uint32_t u32x4 __attribute__((vector_size(16)));

@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(64) decode_scans_fast(const ScanDesc* __restri
             const int n_new = (n >> sh) + 1;
             const int tb = (b + e) >> sh;
             const int minus_delta = 1 - med3(tb, v_zero, v_one) - med3(tb + n_new, v_zero, v_one);
-            const int b_new = med3(tb + minus_delta * n_new, 1 - n_new, v_zero);
+            const int b_new = med3(tb + __mul24(minus_delta, n_new), 1 - n_new, v_zero);
             const int c_new = med3(c - minus_delta, v_cmin, v_cmax);
             JLS_LOCKSTEP();
             records[idx] = CtxRecord{(uint32_t)(a_new >> sh) | ((uint32_t)n_new << 24),

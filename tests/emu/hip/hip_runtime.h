@@ -197,6 +197,10 @@ inline int __builtin_amdgcn_readlane(int v, int lane)
 }
 
 #define JLS_EMULATED 1
+inline int __mul24(int a, int b)
+{
+    return a * b;
+}
 #define JLS_TO_LANE(old, value, lane) (emu::lane_id() == (lane) ? (value) : (old))
 
 inline unsigned __builtin_amdgcn_readfirstlane(unsigned v)
