@@ -167,9 +167,9 @@ def main():
         total_frames = frames_n * world * args.steps
         value = total_frames * pixels / 1e6 / elapsed
         jls_bytes = float(np.mean(enc.sizes.astype(np.float64)))
-        raw_bytes = pixels * (BITS + 7) // 8
+        raw_bytes = pixels * ((BITS + 7) // 8)
         # dominant kernel = largest HIP-event time per step (events recorded on the stream the kernels run on)
-        stage_names = ["analyze_rows", "chain_offsets+scatter_events", "code_chains", "sum/scan/write_raw_bits", "stuff_scan"]
+        stage_names = ["analyze_rows", "chain_offsets+scatter_events", "bias_chains+code_events", "sum/scan/write_raw_bits", "stuff_scan"]
         stages = np.mean([k[2:7] for k in enc_kernel_ms], axis=0) if enc_kernel_ms and len(enc_kernel_ms[0]) >= 7 else None
         dk = float(np.mean([k[1] for k in dec_kernel_ms])) if dec_kernel_ms else 0.0
         dom_name, dom_ms = "decode_scans_fast", dk
