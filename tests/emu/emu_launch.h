@@ -11,40 +11,45 @@ namespace emu {
 template <typename Kernel, typename... Args>
 void launch(Kernel kernel, dim3 grid, dim3 block, size_t dyn_shared_bytes, Args... args)
 {
+    // One set of OS threads per launch; the blocks of the grid run one after the other on it (a barrier between blocks).
     const int n = (int)(block.x * block.y * block.z);
     std::vector<unsigned char> dyn_store(dyn_shared_bytes + 64);
     unsigned char* dyn_aligned = dyn_store.data() + (64 - (reinterpret_cast<uintptr_t>(dyn_store.data()) & 63)) % 64;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx)
-            {
-                BlockState st;
-                st.nthreads = n;
-                st.dyn_shared = dyn_aligned;
-                pthread_barrier_init(&st.block_barrier, nullptr, n);
-                const int waves = (n + kWave - 1) / kWave;
-                for (int w = 0; w < waves; ++w)
-                {
-                    const int in_wave = (w == waves - 1) ? n - w * kWave : kWave;
-                    pthread_barrier_init(&st.wave_barrier[w], nullptr, in_wave);
-                }
-                g_block = &st;
-                std::vector<std::thread> threads;
-                threads.reserve(n);
-                for (int t = 0; t < n; ++t)
-                    threads.emplace_back([=]() {
-                        t_threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+    BlockState st;
+    st.nthreads = n;
+    st.dyn_shared = dyn_aligned;
+    pthread_barrier_init(&st.block_barrier, nullptr, n);
+    const int waves = (n + kWave - 1) / kWave;
+    for (int w = 0; w < waves; ++w)
+    {
+        const int in_wave = (w == waves - 1) ? n - w * kWave : kWave;
+        pthread_barrier_init(&st.wave_barrier[w], nullptr, in_wave);
+    }
+    pthread_barrier_t between;
+    pthread_barrier_init(&between, nullptr, n);
+    g_block = &st;
+    std::vector<std::thread> threads;
+    threads.reserve(n);
+    for (int t = 0; t < n; ++t)
+        threads.emplace_back([=, &between]() {
+            t_threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            t_blockDim = block;
+            t_gridDim = grid;
+            for (unsigned bz = 0; bz < grid.z; ++bz)
+                for (unsigned by = 0; by < grid.y; ++by)
+                    for (unsigned bx = 0; bx < grid.x; ++bx)
+                    {
                         t_blockIdx = dim3(bx, by, bz);
-                        t_blockDim = block;
-                        t_gridDim = grid;
                         kernel(args...);
-                    });
-                for (auto& th : threads)
-                    th.join();
-                pthread_barrier_destroy(&st.block_barrier);
-                for (int w = 0; w < waves; ++w)
-                    pthread_barrier_destroy(&st.wave_barrier[w]);
-            }
+                        pthread_barrier_wait(&between);
+                    }
+        });
+    for (auto& th : threads)
+        th.join();
+    pthread_barrier_destroy(&between);
+    pthread_barrier_destroy(&st.block_barrier);
+    for (int w = 0; w < waves; ++w)
+        pthread_barrier_destroy(&st.wave_barrier[w]);
 }
 
 } // namespace emu
