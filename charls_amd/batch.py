@@ -16,7 +16,7 @@ from . import capi
 class CodecParams(C.Structure):  # charls_amd_codec_params (include/charls_amd.h)
     _fields_ = [("frame_info", capi.FrameInfo), ("near_lossless", C.c_int32), ("interleave_mode", C.c_int32),
                 ("color_transformation", C.c_int32), ("preset_coding_parameters", capi.PcParameters),
-                ("encoding_options", C.c_uint32)]
+                ("encoding_options", C.c_uint32), ("restart_interval", C.c_uint32)]
 
 
 def _bind(lib):
@@ -61,9 +61,11 @@ def last_timings(lib=None):
 
 
 def encode_batch(frames, *, bits_per_sample=8, component_count=1, interleave_mode=0, near_lossless=0,
-                 color_transformation=0, preset=(0, 0, 0, 0, 0), encoding_options=0, streams=None, lib=None) -> EncodedBatch:
+                 color_transformation=0, preset=(0, 0, 0, 0, 0), encoding_options=0, restart_interval=0, streams=None,
+                 lib=None) -> EncodedBatch:
     """frames: contiguous torch tensor on the GPU, (F, H, W) / (F, C, H, W) for ILV_NONE or (F, H, W, C) otherwise,
-    dtype uint8 (<= 8 bit) or int16/uint16 (9..16 bit)."""
+    dtype uint8 (<= 8 bit) or int16/uint16 (9..16 bit).  restart_interval (lines, 0 = none) is this library's extension:
+    the intervals of a frame are coded in parallel and separated by RSTm markers."""
     import torch
     lib = lib or capi.load_product()
     l = _bind(lib)
@@ -79,7 +81,7 @@ def encode_batch(frames, *, bits_per_sample=8, component_count=1, interleave_mod
         streams = torch.empty((count, pitch), dtype=torch.uint8, device=frames.device)
     assert streams.is_contiguous() and streams.shape[0] == count
     p = CodecParams(capi.FrameInfo(width, height, bits_per_sample, component_count), near_lossless, interleave_mode,
-                    color_transformation, capi.PcParameters(*preset), encoding_options)
+                    color_transformation, capi.PcParameters(*preset), encoding_options, restart_interval)
     sizes = np.zeros(count, dtype=np.uint64)
     errcs = np.zeros(count, dtype=np.int32)
     stream = torch.cuda.current_stream(frames.device).cuda_stream

@@ -176,8 +176,9 @@ class CharLSLibrary:
     # -- jpegls_encoder::encode convenience (include/charls/jpegls_encoder.hpp:58-110) --------------------------
     def encode(self, image, *, width=None, height=None, bits_per_sample=8, component_count=1, near_lossless=0,
                interleave_mode=0, color_transformation=0, preset=None, encoding_options=0, stride=0,
-               destination_size=None) -> bytes:
-        """Encode `image` (ndarray or bytes, user layout of SURVEY 8a row a20) to a .jls byte string."""
+               destination_size=None, restart_interval=0) -> bytes:
+        """Encode `image` (ndarray or bytes, user layout of SURVEY 8a row a20) to a .jls byte string.
+        restart_interval != 0 uses charls_amd_jpegls_encoder_set_restart_interval (product library only)."""
         L = self.lib
         if isinstance(image, np.ndarray) and (width is None or height is None):
             if interleave_mode == 0 and component_count > 1:
@@ -201,6 +202,11 @@ class CharLSLibrary:
             if preset is not None:
                 pc = PcParameters(*preset)
                 self._check(L.charls_jpegls_encoder_set_preset_coding_parameters(enc, C.byref(pc)), "set_pc")
+            if restart_interval:
+                fn = L.charls_amd_jpegls_encoder_set_restart_interval
+                fn.argtypes = [C.c_void_p, C.c_uint32]
+                fn.restype = C.c_int32
+                self._check(fn(enc, restart_interval), "set_restart_interval")
             if destination_size is None:
                 n = C.c_size_t()
                 self._check(L.charls_jpegls_encoder_get_estimated_destination_size(enc, C.byref(n)), "estimate")

@@ -13,6 +13,7 @@
 #include "scan_wave_decode.hip"
 #include "lossless_pipeline.hip"
 #include "scan_fast_decode.hip"
+#include "restart_intervals.hip"
 
 namespace jls::dev {
 
@@ -145,6 +146,13 @@ bool wave_decode_eligible(const ScanDesc& d)
     return true;
 }
 
+// Scans whose restart intervals are decoded as scans of their own (restart_intervals.hip).
+bool interval_decode_candidate(const ScanDesc& d)
+{
+    return d.restart_interval != 0 && d.restart_interval < d.height && d.height <= 65535 && d.restart_interval <= 65535 &&
+           wave_decode_eligible(d) && std::getenv("CHARLS_AMD_SEQUENTIAL_INTERVALS") == nullptr;
+}
+
 size_t fast_decode_lds(const ScanDesc& d)
 {
     const size_t line_bytes = ((static_cast<size_t>(d.width) + 2) * (d.bits_per_sample > 8 ? 2 : 1) + 3) & ~size_t{3};
@@ -184,13 +192,85 @@ void launch_wave_decode(int nc, const ScanDesc* d_descs, ScanResult* d_results, 
 uint64_t decode_launch_key(const ScanDesc& d) noexcept
 {
     // width | components | interleave | wide | eligible : scans with equal keys can share a launch
-    return (static_cast<uint64_t>(d.width) << 16) | (static_cast<uint64_t>(d.components & 0xFF) << 8) |
-           (static_cast<uint64_t>(d.interleave_mode & 3) << 4) | (fast_decode_eligible(d) ? 4u : 0u) |
-           (d.bits_per_sample > 8 ? 2u : 0u) | (wave_decode_eligible(d) ? 1u : 0u);
+    const uint64_t base = (static_cast<uint64_t>(d.width) << 16) | (static_cast<uint64_t>(d.components & 0xFF) << 8) |
+                          (static_cast<uint64_t>(d.interleave_mode & 3) << 4) | (fast_decode_eligible(d) ? 4u : 0u) |
+                          (d.bits_per_sample > 8 ? 2u : 0u) | (wave_decode_eligible(d) ? 1u : 0u);
+    if (!interval_decode_candidate(d))
+        return base;
+    // interval-parallel decode also needs equal height and restart interval (both < 2^16 here, as is the width)
+    return (uint64_t{1} << 63) | (static_cast<uint64_t>(d.restart_interval) << 47) | (static_cast<uint64_t>(d.height) << 31) |
+           (static_cast<uint64_t>(d.width & 0xFFFF) << 15) | (static_cast<uint64_t>(d.components & 7) << 12) |
+           (static_cast<uint64_t>(d.interleave_mode & 3) << 10) | (base & 7u);
 }
+
+namespace {
+DeviceBuffer& interval_arena(int which)
+{
+    static thread_local DeviceBuffer buffers[6];
+    return buffers[which];
+}
+
+void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count,
+                         hipStream_t stream);
+
+// All `count` scans share proto's geometry and restart interval.
+void launch_decode_intervals(const ScanDesc& proto, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count,
+                             hipStream_t stream)
+{
+    const uint32_t lines = proto.restart_interval;
+    const uint32_t intervals = (proto.height + lines - 1) / lines;
+    const uint32_t max_marks = intervals - 1;
+    const size_t subs_n = static_cast<size_t>(count) * intervals;
+    auto* d_marks = static_cast<uint32_t*>(interval_arena(0).ensure(sizeof(uint32_t) * count * max_marks));
+    auto* d_counts = static_cast<uint32_t*>(interval_arena(1).ensure(sizeof(uint32_t) * count));
+    auto* d_subs = static_cast<ScanDesc*>(interval_arena(2).ensure(sizeof(ScanDesc) * subs_n));
+    auto* d_sub_results = static_cast<ScanResult*>(interval_arena(3).ensure(sizeof(ScanResult) * subs_n));
+    hipLaunchKernelGGL(interval::find_restart_markers, dim3(count), dim3(64), 0, stream, d_descs, d_marks, max_marks, d_counts);
+    hip_check(hipGetLastError());
+    std::vector<uint32_t> counts(count);
+    hip_check(hipMemcpyAsync(counts.data(), d_counts, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, stream));
+    hip_check(hipStreamSynchronize(stream));
+    bool regular = true;
+    for (uint32_t c : counts)
+        regular = regular && c == max_marks;
+    if (!regular)
+    { // a stream without the expected markers: the sequential decoder reports what the reference reports
+        launch_decode_plain(proto, d_descs, d_results, count, stream);
+        return;
+    }
+    hipLaunchKernelGGL(interval::build_decode_intervals, dim3(intervals, count), dim3(1), 0, stream, d_descs, d_marks, intervals,
+                       d_subs);
+    hip_check(hipGetLastError());
+    ScanDesc sub_proto = proto;
+    sub_proto.height = lines;
+    sub_proto.restart_interval = 0;
+    launch_decode_plain(sub_proto, d_subs, d_sub_results, static_cast<uint32_t>(subs_n), stream);
+    hipLaunchKernelGGL(interval::check_intervals, dim3((count + 63) / 64), dim3(64), 0, stream, d_descs, d_marks, intervals,
+                       d_sub_results, d_results, count);
+    hip_check(hipGetLastError());
+    std::vector<ScanResult> results(count);
+    hip_check(hipMemcpyAsync(results.data(), d_results, sizeof(ScanResult) * count, hipMemcpyDeviceToHost, stream));
+    hip_check(hipStreamSynchronize(stream));
+    for (uint32_t i = 0; i < count; ++i)
+        if ((results[i].flags & interval::kIntervalRetry) != 0)
+            launch_decode_plain(proto, d_descs + i, d_results + i, 1, stream);
+}
+} // namespace
 
 void launch_decode(const ScanDesc& proto, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count,
                    hipStream_t stream)
+{
+    if (count == 0)
+        return;
+    if (interval_decode_candidate(proto))
+        launch_decode_intervals(proto, d_descs, d_results, count, stream);
+    else
+        launch_decode_plain(proto, d_descs, d_results, count, stream);
+}
+
+namespace {
+void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count,
+                         hipStream_t stream)
 {
     if (count == 0)
         return;
@@ -226,6 +306,7 @@ void launch_decode(const ScanDesc& proto, const ScanDesc* d_descs, ScanResult* d
         if ((results[i].flags & fast::kFastRetry) != 0)
             exact(d_descs + i, d_results + i, 1);
 }
+} // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
 // Lossless pipeline orchestration.
@@ -411,10 +492,70 @@ bool pipeline_eligible(const ScanDesc& d) noexcept
     return true;
 }
 
+namespace {
+// Restart-interval encode (extension): every interval is coded as a scan of its own into a private buffer, then the
+// pieces are joined with RSTm markers (restart_intervals.hip).  All `count` scans share proto's geometry and interval.
+void launch_encode_intervals(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count,
+                             hipStream_t stream)
+{
+    const uint32_t lines = proto.restart_interval;
+    const uint32_t intervals = (proto.height + lines - 1) / lines;
+    const size_t subs_n = static_cast<size_t>(count) * intervals;
+    ScanDesc sub_proto = proto;
+    sub_proto.height = lines;
+    sub_proto.restart_interval = 0;
+    const size_t worst = worst_case_scan_bytes(proto.width, lines, proto.interleave_mode == 0 ? 1 : proto.components,
+                                               proto.bits_per_sample);
+    const bool needs_scratch = !pipeline_eligible(sub_proto);
+    const size_t scratch_samples = needs_scratch ? line_scratch_samples(proto.width, proto.interleave_mode, proto.components) : 0;
+    auto* d_subs = static_cast<ScanDesc*>(interval_arena(2).ensure(sizeof(ScanDesc) * subs_n));
+    auto* d_sub_results = static_cast<ScanResult*>(interval_arena(3).ensure(sizeof(ScanResult) * subs_n));
+    auto* d_offsets = static_cast<uint64_t*>(interval_arena(0).ensure(sizeof(uint64_t) * subs_n));
+    auto* d_scratch = needs_scratch
+                          ? static_cast<uint16_t*>(interval_arena(5).ensure(sizeof(uint16_t) * scratch_samples * subs_n))
+                          : nullptr;
+    // First attempt: twice the interval's share of the destination (a destination sized by
+    // charls_jpegls_encoder_get_estimated_destination_size leaves every interval more than it can use).  An interval
+    // that does not fit its private buffer makes the whole call repeat with worst-case buffers, so the verdict
+    // destination_too_small depends on the joined size only.
+    size_t capacity = std::min(worst, align_up(2 * (static_cast<size_t>(proto.stream_capacity) / intervals) + 4096, 256));
+    for (int attempt = 0; attempt < 2; ++attempt)
+    {
+        auto* d_buffers = static_cast<uint8_t*>(interval_arena(4).ensure(capacity * subs_n));
+        hipLaunchKernelGGL(interval::build_encode_intervals, dim3(intervals, count), dim3(1), 0, stream, d_descs, intervals,
+                           d_buffers, static_cast<uint64_t>(capacity), d_scratch, static_cast<uint64_t>(scratch_samples), d_subs);
+        hip_check(hipGetLastError());
+        sub_proto.stream_capacity = capacity;
+        launch_encode(sub_proto, d_subs, d_sub_results, static_cast<uint32_t>(subs_n), stream);
+        hipLaunchKernelGGL(interval::plan_join, dim3((count + 63) / 64), dim3(64), 0, stream, d_descs, intervals,
+                           d_sub_results, d_offsets, d_results, count);
+        hipLaunchKernelGGL(interval::join_intervals, dim3(intervals, count), dim3(256), 0, stream, d_descs, d_subs, intervals,
+                           d_sub_results, d_offsets, d_results);
+        hip_check(hipGetLastError());
+        if (capacity == worst)
+            break;
+        std::vector<ScanResult> results(count);
+        hip_check(hipMemcpyAsync(results.data(), d_results, sizeof(ScanResult) * count, hipMemcpyDeviceToHost, stream));
+        hip_check(hipStreamSynchronize(stream));
+        bool again = false;
+        for (const ScanResult& r : results)
+            again = again || (r.flags & interval::kIntervalRetry) != 0;
+        if (!again)
+            break;
+        capacity = worst;
+    }
+}
+} // namespace
+
 void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
 {
     if (count == 0)
         return;
+    if (proto.restart_interval != 0 && proto.restart_interval < proto.height)
+    {
+        launch_encode_intervals(proto, d_descs, d_results, count, stream);
+        return;
+    }
     if (!pipeline_eligible(proto))
     {
         if (encode_engine() == EncodeEngine::pipeline)

@@ -32,7 +32,7 @@ struct ScanDesc
     int32_t color_transformation;
     int32_t t1, t2, t3;
     int32_t reset;            // RESET after the reference's uint8_t cast (src/scan_codec.hpp:142)
-    uint32_t restart_interval; // decode only; 0 = none
+    uint32_t restart_interval; // lines per restart interval, 0 = none (encode: extension, see restart_intervals.hip)
     // memory (all device pointers)
     uint8_t* pixels;          // first row of the scan in the user's layout (source for encode, destination for decode)
     uint64_t pixel_stride;    // bytes between rows

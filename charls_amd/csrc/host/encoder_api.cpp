@@ -54,7 +54,10 @@ struct charls_jpegls_encoder
         size_t size = checked_mul(checked_mul(checked_mul(frame.width, frame.height),
                                               static_cast<size_t>(frame.component_count)),
                                   bytes_per_sample(frame.bits_per_sample));
-        const size_t extra = size / 16 + 1024 + kSpiffHeaderSize;
+        size_t extra = size / 16 + 1024 + kSpiffHeaderSize;
+        if (restart_interval != 0) // extension: DRI segment + two marker bytes per interval and scan
+            extra += 6 + 2 * static_cast<size_t>((frame.height + restart_interval - 1) / restart_interval) *
+                             static_cast<size_t>(frame.component_count);
         return size + extra < size ? SIZE_MAX : size + extra;
     }
 
@@ -143,10 +146,12 @@ struct charls_jpegls_encoder
                 writer.oversize_dimensions(frame.height, frame.width);
             if (!pc_is_default(user_pc, default_pc(bit_maxval, near)) || (has_option(4) && frame.bits_per_sample > 12))
                 writer.preset_coding_parameters(pc); // reference :409-418
+            if (restart_interval != 0)
+                writer.define_restart_interval(restart_interval); // extension: charls_amd_jpegls_encoder_set_restart_interval
         }
 
         engine.upload_pixels(static_cast<const uint8_t*>(source), min_size);
-        ScanSpec spec{frame.width, frame.height, 1, interleave, frame.bits_per_sample, near, transformation, pc, 0};
+        ScanSpec spec{frame.width, frame.height, 1, interleave, frame.bits_per_sample, near, transformation, pc, restart_interval};
         if (interleave == 0)
         {
             const size_t plane_bytes = stride * frame.height;
@@ -179,6 +184,7 @@ struct charls_jpegls_encoder
     int32_t interleave{};
     int32_t transformation{};
     uint32_t options{};
+    uint32_t restart_interval{}; // lines; 0 = none (extension)
     State state{State::initial};
     StreamWriter writer;
     charls_jpegls_pc_parameters user_pc{};
@@ -271,6 +277,17 @@ charls_jpegls_errc charls_jpegls_encoder_set_mapping_table_id(charls_jpegls_enco
     check_argument(component_index >= 0 && component_index <= kMaxComponents - 1);
     check_argument(table_id >= 0 && table_id <= 255);
     e->writer.set_mapping_table_id(static_cast<size_t>(component_index), table_id);
+    JLS_THUNK_END
+}
+
+// Extension (include/charls_amd.h part 2): restart interval in lines, 0 = none.  The reference's encoder has no such
+// setter; its decoder handles the resulting DRI/RSTm stream (src/jpeg_stream_reader.cpp:586-607, src/scan_decoder.hpp:335-349).
+charls_jpegls_errc charls_amd_jpegls_encoder_set_restart_interval(charls_jpegls_encoder* e, uint32_t lines)
+{
+    JLS_THUNK_BEGIN
+    check_pointer(e);
+    check_operation(e->encoded_components == 0 && e->state < charls_jpegls_encoder::State::completed);
+    e->restart_interval = lines;
     JLS_THUNK_END
 }
 

@@ -153,6 +153,22 @@ public:
         } while (done < size);
     }
 
+    // DRI segment as the reference's reader accepts it (src/jpeg_stream_reader.cpp:586-607): 16-bit interval when it
+    // fits, else 32-bit.  The reference's writer never emits it (restart-interval encoding is an extension here).
+    void define_restart_interval(uint32_t lines)
+    {
+        if (lines <= 65535)
+        {
+            segment(0xDD, 2);
+            put16(lines);
+        }
+        else
+        {
+            segment(0xDD, 4);
+            put32(lines);
+        }
+    }
+
     void start_of_scan(int32_t component_count, int32_t near, int32_t ilv)
     {
         segment(0xDA, 1 + static_cast<size_t>(component_count) * 2 + 3);

@@ -284,6 +284,7 @@ typedef struct charls_amd_codec_params
     charls_color_transformation color_transformation;
     charls_jpegls_pc_parameters preset_coding_parameters; /* all zero = defaults */
     charls_encoding_options encoding_options;
+    uint32_t restart_interval; /* lines per restart interval, 0 = none (encode: extension below; decode: from DRI) */
 } charls_amd_codec_params;
 
 CHARLS_AMD_API charls_jpegls_errc charls_amd_encode_batch_device(const charls_amd_codec_params* params,
@@ -298,6 +299,14 @@ CHARLS_AMD_API charls_jpegls_errc charls_amd_decode_batch_device(uint32_t frame_
                                                                  void* d_frames, size_t frame_pitch_bytes,
                                                                  uint32_t stride, charls_amd_codec_params* params_out,
                                                                  charls_jpegls_errc* errcs, void* hip_stream);
+
+/* Extension: restart intervals on the encoder of part 1.  `lines` rows per interval (0 = none, the default) are coded
+ * independently -- by different wavefronts at the same time -- and separated by RSTm markers; a DRI segment announces
+ * the interval.  The reference's encoder has no equivalent (its output never contains restart markers); its decoder
+ * reads these streams (reference src/jpeg_stream_reader.cpp:586-607, src/scan_decoder.hpp:335-349), and this library's
+ * decoder decodes the intervals in parallel.  Must be called before the first encode_* call of an image. */
+CHARLS_AMD_API charls_jpegls_errc charls_amd_jpegls_encoder_set_restart_interval(charls_jpegls_encoder* encoder,
+                                                                                 uint32_t lines);
 
 /* Engine selection for the lossless single-component encoder: 0 = automatic, 1 = force the one-wavefront-per-scan
  * kernel, 2 = force the parallel pipeline (returns invalid_argument when the scan is not eligible). Process-wide. */
