@@ -86,6 +86,10 @@ def main():
                          "the number of concurrent frames; 4096 = four wavefronts per SIMD = what LDS holds, and with "
                          "their bitstreams and decoded copies 210 GB of the 288 GB of HBM)")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 serial kernel, 2 pipeline")
+    ap.add_argument("--restart-interval", type=int, default=0,
+                    help="NOT the headline: code every N lines as a restart interval (this library's encoder extension; "
+                         "the reference's encoder cannot emit restart markers, so the streams are no longer the "
+                         "reference's bytes, only decodable by it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,7 +122,7 @@ def main():
 
     def step(timed: bool):
         t0 = time.perf_counter()
-        enc = batch.encode_batch(frames, bits_per_sample=BITS, streams=streams, lib=lib)
+        enc = batch.encode_batch(frames, bits_per_sample=BITS, streams=streams, restart_interval=args.restart_interval, lib=lib)
         t1 = time.perf_counter()
         _, errcs, dec_t = batch.decode_batch(enc.streams, enc.sizes, out, lib=lib)
         t2 = time.perf_counter()
@@ -155,7 +159,7 @@ def main():
     for f0 in range(0, frames_n, 128):  # chunked: torch.equal materialises a mask as large as its inputs
         assert torch.equal(out[f0:f0 + 128], frames[f0:f0 + 128]), "round trip is not lossless"
     bit_exact = None
-    if rank == 0:
+    if rank == 0 and args.restart_interval == 0:
         with open(os.path.join(ROOT, "tests", "golden", "cases.json")) as f:
             golden = {c["name"]: c for c in json.load(f)}["cfg2_full"]
         first = enc.streams[0, :int(enc.sizes[0])].cpu().numpy().tobytes()
@@ -170,7 +174,8 @@ def main():
         raw_bytes = pixels * ((BITS + 7) // 8)
         # dominant kernel = largest HIP-event time per step (events recorded on the stream the kernels run on)
         stage_names = ["analyze_rows", "chain_offsets+scatter_events", "bias_chains+code_events", "sum/scan/write_raw_bits", "stuff_scan"]
-        stages = np.mean([k[2:7] for k in enc_kernel_ms], axis=0) if enc_kernel_ms and len(enc_kernel_ms[0]) >= 7 else None
+        stages = (np.mean([k[2:7] for k in enc_kernel_ms], axis=0)
+                  if enc_kernel_ms and len(enc_kernel_ms[0]) >= 7 and args.restart_interval == 0 else None)
         dk = float(np.mean([k[1] for k in dec_kernel_ms])) if dec_kernel_ms else 0.0
         dom_name, dom_ms = "decode_scans_fast", dk
         if stages is not None and float(stages.max()) > dk:
@@ -187,7 +192,8 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         line = {
-            "metric": "MPixels/s encode+decode, 4096x4096 8-bit gray, bit-exact vs CharLS",
+            "metric": "MPixels/s encode+decode, 4096x4096 8-bit gray, bit-exact vs CharLS" if args.restart_interval == 0 else
+                      "MPixels/s encode+decode, 4096x4096 8-bit gray, restart-interval extension (CharLS-decodable, not CharLS's bytes)",
             "value": round(value, 2),
             "unit": "MPixels/s",
             "n_gpus": world,
@@ -202,7 +208,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 4096x4096 8-bit gray lossless, batch of independent frames",
                        "frames_per_gpu": frames_n, "jls_bytes_per_frame": int(jls_bytes),
                        "sharding": f"frames over {world} rank(s), RCCL gather of bitstreams to rank 0" if world > 1 else "1 GPU",
-                       "engine": args.engine},
+                       "engine": args.engine, "restart_interval": args.restart_interval},
             "bit_exact_vs_reference": bit_exact,
             "encode_mpix_s": round(frames_n * pixels / 1e6 / (np.mean(enc_ms) * 1e-3), 2),
             "decode_mpix_s": round(frames_n * pixels / 1e6 / (np.mean(dec_ms) * 1e-3), 2),

@@ -500,7 +500,6 @@ void launch_encode_intervals(const ScanDesc& proto, ScanDesc* d_descs, ScanResul
 {
     const uint32_t lines = proto.restart_interval;
     const uint32_t intervals = (proto.height + lines - 1) / lines;
-    const size_t subs_n = static_cast<size_t>(count) * intervals;
     ScanDesc sub_proto = proto;
     sub_proto.height = lines;
     sub_proto.restart_interval = 0;
@@ -508,41 +507,49 @@ void launch_encode_intervals(const ScanDesc& proto, ScanDesc* d_descs, ScanResul
                                                proto.bits_per_sample);
     const bool needs_scratch = !pipeline_eligible(sub_proto);
     const size_t scratch_samples = needs_scratch ? line_scratch_samples(proto.width, proto.interleave_mode, proto.components) : 0;
-    auto* d_subs = static_cast<ScanDesc*>(interval_arena(2).ensure(sizeof(ScanDesc) * subs_n));
-    auto* d_sub_results = static_cast<ScanResult*>(interval_arena(3).ensure(sizeof(ScanResult) * subs_n));
-    auto* d_offsets = static_cast<uint64_t*>(interval_arena(0).ensure(sizeof(uint64_t) * subs_n));
-    auto* d_scratch = needs_scratch
-                          ? static_cast<uint16_t*>(interval_arena(5).ensure(sizeof(uint16_t) * scratch_samples * subs_n))
-                          : nullptr;
     // First attempt: twice the interval's share of the destination (a destination sized by
     // charls_jpegls_encoder_get_estimated_destination_size leaves every interval more than it can use).  An interval
-    // that does not fit its private buffer makes the whole call repeat with worst-case buffers, so the verdict
+    // that does not fit its private buffer makes its group repeat with worst-case buffers, so the verdict
     // destination_too_small depends on the joined size only.
-    size_t capacity = std::min(worst, align_up(2 * (static_cast<size_t>(proto.stream_capacity) / intervals) + 4096, 256));
-    for (int attempt = 0; attempt < 2; ++attempt)
+    const size_t first_capacity = std::min(worst, align_up(2 * (static_cast<size_t>(proto.stream_capacity) / intervals) + 4096, 256));
+    constexpr size_t kBufferBudget = size_t{8} << 30; // private interval buffers in flight
+    for (uint32_t first = 0; first < count;)
     {
-        auto* d_buffers = static_cast<uint8_t*>(interval_arena(4).ensure(capacity * subs_n));
-        hipLaunchKernelGGL(interval::build_encode_intervals, dim3(intervals, count), dim3(1), 0, stream, d_descs, intervals,
-                           d_buffers, static_cast<uint64_t>(capacity), d_scratch, static_cast<uint64_t>(scratch_samples), d_subs);
-        hip_check(hipGetLastError());
-        sub_proto.stream_capacity = capacity;
-        launch_encode(sub_proto, d_subs, d_sub_results, static_cast<uint32_t>(subs_n), stream);
-        hipLaunchKernelGGL(interval::plan_join, dim3((count + 63) / 64), dim3(64), 0, stream, d_descs, intervals,
-                           d_sub_results, d_offsets, d_results, count);
-        hipLaunchKernelGGL(interval::join_intervals, dim3(intervals, count), dim3(256), 0, stream, d_descs, d_subs, intervals,
-                           d_sub_results, d_offsets, d_results);
-        hip_check(hipGetLastError());
-        if (capacity == worst)
-            break;
-        std::vector<ScanResult> results(count);
-        hip_check(hipMemcpyAsync(results.data(), d_results, sizeof(ScanResult) * count, hipMemcpyDeviceToHost, stream));
-        hip_check(hipStreamSynchronize(stream));
-        bool again = false;
-        for (const ScanResult& r : results)
-            again = again || (r.flags & interval::kIntervalRetry) != 0;
-        if (!again)
-            break;
-        capacity = worst;
+        size_t capacity = first_capacity;
+        uint32_t group = 0;
+        for (int attempt = 0; attempt < 2; ++attempt)
+        {
+            group = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count - first, kBufferBudget / (capacity * intervals))));
+            const size_t subs_n = static_cast<size_t>(group) * intervals;
+            auto* d_subs = static_cast<ScanDesc*>(interval_arena(2).ensure(sizeof(ScanDesc) * subs_n));
+            auto* d_sub_results = static_cast<ScanResult*>(interval_arena(3).ensure(sizeof(ScanResult) * subs_n));
+            auto* d_offsets = static_cast<uint64_t*>(interval_arena(0).ensure(sizeof(uint64_t) * subs_n));
+            auto* d_scratch = needs_scratch
+                                  ? static_cast<uint16_t*>(interval_arena(5).ensure(sizeof(uint16_t) * scratch_samples * subs_n))
+                                  : nullptr;
+            auto* d_buffers = static_cast<uint8_t*>(interval_arena(4).ensure(capacity * subs_n));
+            hipLaunchKernelGGL(interval::build_encode_intervals, dim3(intervals, group), dim3(1), 0, stream, d_descs + first,
+                               intervals, d_buffers, static_cast<uint64_t>(capacity), d_scratch,
+                               static_cast<uint64_t>(scratch_samples), d_subs);
+            hip_check(hipGetLastError());
+            sub_proto.stream_capacity = capacity;
+            launch_encode(sub_proto, d_subs, d_sub_results, static_cast<uint32_t>(subs_n), stream);
+            hipLaunchKernelGGL(interval::plan_join, dim3((group + 63) / 64), dim3(64), 0, stream, d_descs + first, intervals,
+                               d_sub_results, d_offsets, d_results + first, group);
+            hipLaunchKernelGGL(interval::join_intervals, dim3(intervals, group), dim3(256), 0, stream, d_descs + first, d_subs,
+                               intervals, d_sub_results, d_offsets, d_results + first);
+            hip_check(hipGetLastError());
+            std::vector<ScanResult> results(group);
+            hip_check(hipMemcpyAsync(results.data(), d_results + first, sizeof(ScanResult) * group, hipMemcpyDeviceToHost, stream));
+            hip_check(hipStreamSynchronize(stream)); // the private buffers are reused by the next group
+            bool again = false;
+            for (const ScanResult& r : results)
+                again = again || (r.flags & interval::kIntervalRetry) != 0;
+            if (!again || capacity == worst)
+                break;
+            capacity = worst;
+        }
+        first += group;
     }
 }
 } // namespace
