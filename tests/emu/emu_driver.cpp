@@ -9,6 +9,7 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 #include "../../charls_amd/csrc/device/scan_serial.hip"
 #include "../../charls_amd/csrc/device/lossless_pipeline.hip"
 #include "../../charls_amd/csrc/device/scan_fast_decode.hip"
+#include "../../charls_amd/csrc/device/restart_intervals.hip"
 
 #include <cstdlib>
 #include <cstring>
@@ -130,6 +131,35 @@ int emu_decode_scans_fast(const jls::ScanDesc* descs, jls::ScanResult* results, 
     else
         emu::launch(jls::decode_scans_fast<uint8_t>, dim3(count), dim3(64), lds, descs, results);
     return 0;
+}
+
+// restart_intervals.hip, decode side: marker search, interval descriptors, and (given the intervals' results) the check.
+void emu_find_restart_markers(const jls::ScanDesc* descs, uint32_t* marks, uint32_t max_marks, uint32_t* counts, int count)
+{
+    emu::launch(jls::interval::find_restart_markers, dim3(count), dim3(64), 0, descs, marks, max_marks, counts);
+}
+
+void emu_build_decode_intervals(const jls::ScanDesc* parents, const uint32_t* marks, uint32_t intervals, jls::ScanDesc* subs,
+                                int count)
+{
+    emu::launch(jls::interval::build_decode_intervals, dim3(intervals, count), dim3(1), 0, parents, marks, intervals, subs);
+}
+
+void emu_check_intervals(const jls::ScanDesc* parents, const uint32_t* marks, uint32_t intervals,
+                         const jls::ScanResult* sub_results, jls::ScanResult* results, int count)
+{
+    emu::launch(jls::interval::check_intervals, dim3((count + 63) / 64), dim3(64), 0, parents, marks, intervals, sub_results,
+                results, (uint32_t)count);
+}
+
+// encode side: the join of already coded intervals
+void emu_join_intervals(const jls::ScanDesc* parents, const jls::ScanDesc* subs, uint32_t intervals,
+                        const jls::ScanResult* sub_results, uint64_t* offsets, jls::ScanResult* results, int count)
+{
+    emu::launch(jls::interval::plan_join, dim3((count + 63) / 64), dim3(64), 0, parents, intervals, sub_results, offsets,
+                results, (uint32_t)count);
+    emu::launch(jls::interval::join_intervals, dim3(intervals, count), dim3(256), 0, parents, subs, intervals, sub_results,
+                (const uint64_t*)offsets, (const jls::ScanResult*)results);
 }
 
 size_t emu_sizeof_scan_desc() { return sizeof(jls::ScanDesc); }

@@ -69,6 +69,10 @@ inline int __popcll(unsigned long long x)
 {
     return __builtin_popcountll(x);
 }
+inline int __ffs(int x)
+{
+    return __builtin_ffs(x);
+}
 inline int __ffsll(unsigned long long x)
 {
     return __builtin_ffsll((long long)x);
