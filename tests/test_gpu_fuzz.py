@@ -1,0 +1,88 @@
+"""Decoder fuzzing against the oracle (reference fuzzing/libfuzzer-decoder/main.cpp:10-30): mutated
+streams must give the oracle's pixels or the oracle's error code, through the C ABI, for every decoder the dispatcher
+can pick (fast -> exact wave -> sequential, interval-parallel for DRI streams).  GPU only."""
+import numpy as np
+import pytest
+
+import common
+import jls_container
+import oracle_bind as ob
+from charls_amd import capi, synth
+from charls_amd.capi import JpegLSError
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = capi.load_product()
+    assert L.lib.charls_amd_device_status() == 0
+    return L
+
+
+def _bases(lib):
+    g8 = synth.frame_numpy(96, 40, seed=11, kind="mixed")
+    g16 = synth.frame_numpy(70, 24, seed=12, bits=16, kind="mixed")
+    rgb = np.stack([synth.frame_numpy(48, 20, seed=13 + c, kind="mixed") for c in range(3)], axis=-1)
+    flat = np.full((30, 64), 77, dtype=np.uint8)
+    flat[10:20, 5:50] = synth.frame_numpy(45, 10, seed=3, kind="mixed")
+    return {
+        "gray8": ob.encode(g8, width=96, height=40),
+        "gray16": ob.encode(g16, width=70, height=24, bits_per_sample=16),
+        "gray8_near3": ob.encode(g8, width=96, height=40, near_lossless=3),
+        "rgb_sample": ob.encode(rgb, width=48, height=20, component_count=3, interleave_mode=2),
+        "rgb_line_hp1": ob.encode(rgb, width=48, height=20, component_count=3, interleave_mode=1, color_transformation=1),
+        "runs": ob.encode(flat, width=64, height=30),
+        "gray8_dri": lib.encode(g8, restart_interval=8),
+        "ref_rm_7": common.refdata("test8_ilv_none_rm_7.jls"),
+    }
+
+
+def _mutate(rng, data: bytes, scan_start: int) -> bytes:
+    b = bytearray(data)
+    kind = rng.integers(0, 6)
+    lo = scan_start if rng.integers(0, 4) else 2  # mostly inside the entropy-coded part, sometimes the headers
+    if kind == 0:      # flip a few bits
+        for _ in range(int(rng.integers(1, 4))):
+            i = int(rng.integers(lo, len(b)))
+            b[i] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 1:    # overwrite a byte
+        b[int(rng.integers(lo, len(b)))] = int(rng.integers(0, 256))
+    elif kind == 2:    # truncate
+        del b[int(rng.integers(lo, len(b))):]
+    elif kind == 3:    # delete a short run
+        i = int(rng.integers(lo, len(b) - 1))
+        del b[i:i + int(rng.integers(1, 5))]
+    elif kind == 4:    # insert bytes (0xFF likes to make markers)
+        i = int(rng.integers(lo, len(b)))
+        b[i:i] = bytes(rng.choice([0x00, 0xFF, 0x7F, 0xD0, 0x80], size=int(rng.integers(1, 4))).astype(np.uint8))
+    else:              # swap two bytes
+        i, j = int(rng.integers(lo, len(b))), int(rng.integers(lo, len(b)))
+        b[i], b[j] = b[j], b[i]
+    return bytes(b)
+
+
+def _outcome(fn, data):
+    try:
+        out = fn(data)
+        return ("ok", np.asarray(out[1]).tobytes())
+    except (JpegLSError, ob.OracleError) as e:
+        return ("err", e.errc)
+
+
+@pytest.mark.parametrize("name", ["gray8", "gray16", "gray8_near3", "rgb_sample", "rgb_line_hp1", "runs", "gray8_dri", "ref_rm_7"])
+def test_mutated_streams_decode_like_the_oracle(lib, name):
+    base = _bases(lib)[name]
+    cont = jls_container.parse(base)
+    start = cont.scans[0].data_start
+    rng = np.random.default_rng(abs(hash(name)) % (1 << 32) if False else sum(name.encode()))
+    assert _outcome(lib.decode, base) == _outcome(ob.decode, base)
+    mismatches = []
+    for k in range(60):
+        data = _mutate(rng, base, start)
+        want = _outcome(ob.decode, data)
+        got = _outcome(lib.decode, data)
+        if got != want:
+            mismatches.append((k, want[0], want[1] if want[0] == "err" else len(want[1]), got[0],
+                               got[1] if got[0] == "err" else len(got[1])))
+    assert not mismatches, mismatches
