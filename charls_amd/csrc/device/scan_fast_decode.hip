@@ -12,7 +12,8 @@
 //     still hold the previous line), and kept in a vector register; the serial loop reads it with v_readlane and
 //     needs one gradient quantisation (Rc - Ra) and the context table per sample.  LDS per scan is the context
 //     table, the bit ring and ONE line: 9 KB for 4096 8-bit samples, i.e. four wavefronts per SIMD.
-//   * contexts are the packed 8-byte form of scan_wave_decode.hip; run mode is kept out of line.
+//   * context records are two words (A | N<<24, B | C<<16); the quantised gradient Rc - Ra of 8-bit samples comes from a
+//     511-entry LDS table; run mode and every unusual code are kept out of line.
 //
 // This kernel is not a restatement of the reference's bit reader; it decodes the same bit sequence.  Its result is used
 // only when the scan ends cleanly (all samples decoded inside the entropy-coded segment, zero padding, marker next).
@@ -425,7 +426,7 @@ JLS_DEV bool decode_regular_slow(const Traits& t, const wave::WaveModel& m, BitW
 // Dynamic LDS: fast::fixed_lds<S>() + (width + 2) * sizeof(S) rounded up to 4.
 //
 // Control structure: ONE loop whose body visits a 64-sample chunk of the current line.  The chunk's records (aux) are
-// loaded into a VGPR once and read per sample with v_readlane; decoded samples are collected with v_writelane and
+// computed into a VGPR once and read per sample with v_readlane; decoded samples are collected in a VGPR and
 // written back to the line in one LDS store, so the per-sample LDS traffic is the context record only.  The inner loop
 // handles nothing but plain regular-mode samples whose code fits the bit window; everything else leaves it with an event
 // code and is handled once, out of line: producer refill (the only call site of DenseBits::refill), run mode, long or

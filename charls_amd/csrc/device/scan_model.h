@@ -40,21 +40,6 @@ JLS_DEV uint32_t from_lane(uint32_t v, int l)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
 
-// `old` with lane `l` (wave-uniform l) replaced by the scalar `value`: v_writelane_b32 (this compiler has no builtin for
-// it).  gfx9 allows one SGPR on the constant bus, so the lane select travels in M0.
-#ifndef JLS_TO_LANE
-JLS_DEV uint32_t to_lane(uint32_t old, uint32_t value, int l)
-{
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(value), "s"(l) : "m0");
-    return old;
-}
-#else
-JLS_DEV uint32_t to_lane(uint32_t old, uint32_t value, int l)
-{
-    return JLS_TO_LANE(old, value, l);
-}
-#endif
-
 // Median of three signed integers in one vector instruction (the compiler only forms v_med3_i32 for constant bounds).
 // med3s takes its last operand from a scalar register.
 #ifndef JLS_EMULATED

@@ -205,7 +205,6 @@ inline int __mul24(int a, int b)
 {
     return a * b;
 }
-#define JLS_TO_LANE(old, value, lane) (emu::lane_id() == (lane) ? (value) : (old))
 
 inline unsigned __builtin_amdgcn_readfirstlane(unsigned v)
 {
