@@ -26,6 +26,7 @@ namespace interval {
 
 constexpr uint32_t kIntervalRetry = 8u; // ScanResult.flags: decode this scan sequentially
 constexpr uint32_t kTooManyMarkers = 0xFFFFFFFFu;
+constexpr uint32_t kUndecided = 4u | kIntervalRetry; // fast::kFastRetry or kIntervalRetry left in an interval's result
 
 // One wavefront per scan.  marks[scan * max_marks + j] = offset (from desc.stream) of the 0xFF of the j-th RSTm marker;
 // counts[scan] = number of RSTm markers before the first other marker (kTooManyMarkers when more than max_marks).
@@ -136,7 +137,7 @@ __global__ void check_intervals(const ScanDesc* __restrict__ parents, const uint
     uint64_t start = 0;
     for (uint32_t j = 0; j < intervals; ++j)
     {
-        ok = ok && sr[j].errc == kOk && sr[j].flags == 0;
+        ok = ok && sr[j].errc == kOk && (sr[j].flags & kUndecided) == 0;
         if (j + 1 < intervals)
         { // consumed exactly up to its marker, and the marker is the expected one
             ok = ok && sr[j].bytes == (uint64_t)mk[j] - start && d.stream[(uint64_t)mk[j] + 1] == 0xD0u + (j & 7u);

@@ -103,6 +103,7 @@ def test_interval_descriptors_check_and_join():
     assert check((5, 70, 2)) == (0, 0, 79 + 2)              # consumed = offset of the scan's terminating marker
     assert check((5, 69, 2)) == (0, 8, 0)                   # an interval that stopped short of its marker
     assert check((5, 70, 2), sub_flags=(0, 4, 0)) == (0, 8, 0)
+    assert check((5, 70, 2), sub_flags=(1, 1, 1)) == (0, 0, 81)  # 1 = "decoded by the exact wave decoder"
     assert check((5, 70, 2), sub_errc=(0, 0, 5)) == (0, 8, 0)
     buf[5 + 1] = 0xD3                                       # wrong marker number
     assert check((5, 70, 2)) == (0, 8, 0)

@@ -34,6 +34,8 @@ def _bases(lib):
         "rgb_line_hp1": ob.encode(rgb, width=48, height=20, component_count=3, interleave_mode=1, color_transformation=1),
         "runs": ob.encode(flat, width=64, height=30),
         "gray8_dri": lib.encode(g8, restart_interval=8),
+        "rgb_sample_near2_dri": lib.encode(rgb, component_count=3, interleave_mode=2, near_lossless=2, restart_interval=4),
+        "gray16_dri": lib.encode(g16, bits_per_sample=16, restart_interval=5),
         "ref_rm_7": common.refdata("test8_ilv_none_rm_7.jls"),
     }
 
@@ -41,7 +43,8 @@ def _bases(lib):
 def _mutate(rng, data: bytes, scan_start: int) -> bytes:
     b = bytearray(data)
     kind = rng.integers(0, 6)
-    lo = scan_start if rng.integers(0, 4) else 2  # mostly inside the entropy-coded part, sometimes the headers
+    lo = scan_start  # the entropy-coded part and what follows; header error codes are pinned by tests/test_host_facade.py
+    # against the reference itself (the oracle's container parser is minimal and reports fewer distinct codes)
     if kind == 0:      # flip a few bits
         for _ in range(int(rng.integers(1, 4))):
             i = int(rng.integers(lo, len(b)))
@@ -70,7 +73,8 @@ def _outcome(fn, data):
         return ("err", e.errc)
 
 
-@pytest.mark.parametrize("name", ["gray8", "gray16", "gray8_near3", "rgb_sample", "rgb_line_hp1", "runs", "gray8_dri", "ref_rm_7"])
+@pytest.mark.parametrize("name", ["gray8", "gray16", "gray8_near3", "rgb_sample", "rgb_line_hp1", "runs", "gray8_dri", "rgb_sample_near2_dri",
+                                  "gray16_dri", "ref_rm_7"])
 def test_mutated_streams_decode_like_the_oracle(lib, name):
     base = _bases(lib)[name]
     cont = jls_container.parse(base)

@@ -101,6 +101,40 @@ def test_restart_encode_is_the_reference_coding_of_every_interval(lib, name, bit
         assert lib.decode(jls)[1].tobytes() == got.tobytes()
 
 
+def _assemble_dri_stream(img, ri):
+    """A DRI stream put together on the CPU the way any encoder would: the oracle's coding of every interval as an image
+    of its own, RSTm between them.  Returns the stream and how many intervals end with 0xFF + a stuffed 7-bit byte."""
+    h, w = img.shape
+    full = ob.encode(img, width=w, height=h)
+    scan = jls_container.parse(full).scans[0]
+    sos = full.rfind(b"\xff\xda", 0, scan.data_start)
+    body, ff_endings, n = b"", 0, (h + ri - 1) // ri
+    for j in range(n):
+        sub = np.ascontiguousarray(img[j * ri:(j + 1) * ri])
+        s = ob.encode(sub, width=w, height=sub.shape[0])
+        sc = jls_container.parse(s).scans[0]
+        piece = s[sc.data_start:sc.data_end]
+        ff_endings += len(piece) >= 2 and piece[-2] == 0xFF
+        body += piece + (bytes([0xFF, 0xD0 + (j & 7)]) if j + 1 < n else b"")
+    return full[:sos] + b"\xff\xdd\x00\x04" + ri.to_bytes(2, "big") + full[sos:scan.data_start] + body + b"\xff\xd9", ff_endings
+
+
+def test_cpu_assembled_restart_streams_including_ff_terminated_intervals(lib):
+    rng = np.random.default_rng(1)
+    ff_total = 0
+    for trial in range(120):
+        w, h, ri = int(rng.integers(8, 80)), int(rng.integers(4, 40)), int(rng.integers(1, 4))
+        img = (rng.integers(0, 256, size=(h, w), dtype=np.uint8) if trial % 2 else
+               (rng.integers(0, 8, size=(h, w)) * 31).astype(np.uint8))
+        jls, ff = _assemble_dri_stream(img, ri)
+        ff_total += ff
+        assert ob.decode(jls)[1].tobytes() == img.tobytes()
+        assert lib.decode(jls)[1].tobytes() == img.tobytes(), (trial, w, h, ri)
+        # and our encoder writes exactly this file (short intervals of noise do not compress: roomy destination)
+        assert lib.encode(img, restart_interval=ri, destination_size=len(jls) + 64) == jls, (trial, w, h, ri)
+    assert ff_total > 0  # the sample contains intervals whose last data byte is 0xFF (followed by a stuffed byte)
+
+
 def test_sequential_and_interval_decoders_agree(lib, monkeypatch):
     img = synth.frame_numpy(320, 240, seed=77, kind="mixed")
     jls = lib.encode(img, restart_interval=16)

@@ -1,0 +1,53 @@
+"""Throughput of the other BASELINE.json configurations through the batch API (not bench lines: context for DESIGN.md).
+Run on the GPU box: python tools/measure_configs.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from charls_amd import batch, capi, synth  # noqa: E402
+
+lib = capi.load_product()
+dev = torch.device("cuda:0")
+
+
+def run(name, frames, *, bits, comps=1, ilv=0, near=0, xform=0, restart=0):
+    torch.cuda.synchronize()
+    kw = dict(bits_per_sample=bits, component_count=comps, interleave_mode=ilv, near_lossless=near,
+              color_transformation=xform, restart_interval=restart, lib=lib)
+    batch.encode_batch(frames[:2], **kw)  # warm-up (allocations)
+    t0 = time.perf_counter()
+    enc = batch.encode_batch(frames, **kw)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    out = torch.empty_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out, lib=lib)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    assert (enc.errcs == 0).all() and (errcs == 0).all()
+    diff = (out.to(torch.int32) - frames.to(torch.int32)).abs().max().item() if near else int(not torch.equal(out, frames))
+    assert diff <= near, diff
+    pix = frames[0].numel() // comps * frames.shape[0] / 1e6
+    ratio = frames[0].numel() * frames.element_size() / float(np.mean(enc.sizes))
+    print(f"{name}: {frames.shape[0]} frames, encode {pix / (t1 - t0):.0f} MPix/s, decode {pix / (t2 - t1):.0f} MPix/s, "
+          f"round trip {pix / (t2 - t0):.0f} MPix/s, compression {ratio:.2f}", flush=True)
+    del out, enc
+    torch.cuda.empty_cache()
+
+
+f = synth.frames_torch(512, 4096, 4096, seed0=2, bits=16, device=dev)
+run("config 2: 4096x4096 16-bit gray lossless", f, bits=16)
+del f
+torch.cuda.empty_cache()
+f = synth.frames_torch(256, 2048, 2048, seed0=2, bits=8, device=dev)
+run("config 3: 256 x 2048x2048 8-bit gray lossless (one GPU)", f, bits=8)
+del f
+torch.cuda.empty_cache()
+planes = synth.frames_torch(3 * 64, 1024, 1024, seed0=9, bits=8, device=dev).reshape(64, 3, 1024, 1024)
+rgb = planes.permute(0, 2, 3, 1).contiguous()
+run("config 4 (1024x1024 stand-in): RGB ILV_SAMPLE HP1 lossless", rgb, bits=8, comps=3, ilv=2, xform=1)
+run("config 4b (1024x1024 stand-in): RGB ILV_SAMPLE NEAR=2", rgb, bits=8, comps=3, ilv=2, near=2)
+run("config 4b with 16-line restart intervals (extension)", rgb, bits=8, comps=3, ilv=2, near=2, restart=16)
