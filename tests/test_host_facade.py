@@ -119,3 +119,30 @@ def test_no_cpu_fallback(lib):
         with pytest.raises(JpegLSError) as e:
             lib.decode(f.read())
     assert e.value.errc == 200
+
+
+def test_restart_interval_setter_is_additive_and_checked(lib):
+    """charls_amd_jpegls_encoder_set_restart_interval (include/charls_amd.h part 2): argument / state checks and its only
+    CPU-visible effect, the size estimate; with the default (0) nothing differs from the reference's ABI behaviour."""
+    L = lib.lib
+    fn = L.charls_amd_jpegls_encoder_set_restart_interval
+    fn.argtypes = [C.c_void_p, C.c_uint32]
+    fn.restype = C.c_int32
+    assert fn(None, 8) == 101  # invalid_argument (charls_jpegls_errc 101), as the reference reports a null handle
+    L.charls_jpegls_encoder_create.restype = C.c_void_p
+    enc = L.charls_jpegls_encoder_create()
+    try:
+        fi = capi.FrameInfo(640, 480, 8, 3)
+        assert L.charls_jpegls_encoder_set_frame_info(C.c_void_p(enc), C.byref(fi)) == 0
+        n0, n1, n2 = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        L.charls_jpegls_encoder_get_estimated_destination_size.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        assert L.charls_jpegls_encoder_get_estimated_destination_size(enc, C.byref(n0)) == 0
+        assert fn(enc, 16) == 0
+        assert L.charls_jpegls_encoder_get_estimated_destination_size(enc, C.byref(n1)) == 0
+        assert n1.value == n0.value + 6 + 2 * 30 * 3  # DRI segment + one marker per interval and component
+        assert fn(enc, 0) == 0
+        assert L.charls_jpegls_encoder_get_estimated_destination_size(enc, C.byref(n2)) == 0
+        assert n2.value == n0.value
+    finally:
+        L.charls_jpegls_encoder_destroy.argtypes = [C.c_void_p]
+        L.charls_jpegls_encoder_destroy(enc)
