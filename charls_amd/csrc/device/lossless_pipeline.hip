@@ -8,7 +8,7 @@
 //                        HBM-bound); run-mode segmentation of the line resolved as a carry chain over ballot masks
 //   B1 chain_offsets     per-line histograms of the 365 statistic chains (364 regular contexts + the run chain) ->
 //                        exclusive offsets (a stable counting sort by context, raster order kept inside a chain)
-//   B2 scatter_events    events move to their chain, lane-order ranks from ballots (deterministic, no atomics on order);
+//   B2 scatter_events    events move to their chain, stable ranks from a wave-level sort (deterministic, no atomics on order);
 //                        the slot of every sample is recorded (inv) so that codes can stay in chain order until D2
 //   C1 bias_chains       one LANE per chain: the {B,C,N} recurrence turns the chain's samples into Errval (the only
 //                        serial dependency of regular mode); the run chain carries RUNindex and the two run-interruption
@@ -259,7 +259,6 @@ __global__ void __launch_bounds__(64) scatter_events(const ScanDesc* __restrict_
     for (int c = lane; c < kChains; c += 64)
         s_cnt[c] = w.chain_base[c] + w.hist[(size_t)y * kChains + c];
     __syncthreads();
-    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (uint32_t k = 0; k < (width + 63) / 64; ++k)
     {
         const uint32_t x = k * 64 + lane;
@@ -271,23 +270,38 @@ __global__ void __launch_bounds__(64) scatter_events(const ScanDesc* __restrict_
             v = w.val[(size_t)y * width + x];
         }
         const bool has = key != kNoEvent;
-        const int chain = key & 0x1FF;
-        uint32_t dest = 0;
-        unsigned long long remaining = __ballot(has);
-        while (remaining) // one iteration per distinct chain present in the chunk
-        {
-            const int leader = __ffsll(remaining) - 1;
-            const int kc = __shfl(chain, leader);
-            const unsigned long long same = __ballot(has && chain == kc);
-            JLS_LOCKSTEP();
-            if (has && chain == kc)
-                dest = s_cnt[kc] + (uint32_t)__popcll(same & below);
-            JLS_LOCKSTEP();
-            if (lane == leader)
-                s_cnt[kc] += (uint32_t)__popcll(same);
-            JLS_LOCKSTEP();
-            remaining &= ~same;
-        }
+        // Stable rank of every event inside its chain: the 64 (chain, lane) keys are sorted with a bitonic network
+        // (21 compare-exchange steps instead of one ballot round per distinct chain of the chunk), a lane's rank is its
+        // distance from the start of its run of equal chains, and the slot number travels back with ds_permute.
+        uint32_t sorted = has ? ((uint32_t)(key & 0x1FF) << 6) | (uint32_t)lane : 0x7FFF0000u | (uint32_t)lane;
+#pragma unroll
+        for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1)
+            {
+                const uint32_t other = (uint32_t)__shfl_xor((int)sorted, stride);
+                const bool keep_min = ((lane & stride) == 0) == ((lane & size) == 0);
+                const uint32_t lo = sorted < other ? sorted : other, hi = sorted < other ? other : sorted;
+                sorted = keep_min ? lo : hi;
+            }
+        const bool live = sorted < 0x7FFF0000u;
+        const int chain = (int)(sorted >> 6) & 0x1FF;
+        const int before = __shfl_up(chain, 1);
+        const bool starts_run = live && (lane == 0 || chain != before);
+        const unsigned long long starts = __ballot(starts_run);
+        const unsigned long long lives = __ballot(live);
+        const int run_first = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane)))); // highest start at or below me
+        const unsigned long long above = lane == 63 ? 0ull : (starts >> (lane + 1)) << (lane + 1);
+        const int run_end = above ? __ffsll(above) - 1 : __popcll(lives);
+        uint32_t slot = 0;
+        JLS_LOCKSTEP();
+        if (live)
+            slot = s_cnt[chain] + (uint32_t)(lane - run_first);
+        JLS_LOCKSTEP();
+        if (starts_run)
+            s_cnt[chain] += (uint32_t)(run_end - run_first);
+        JLS_LOCKSTEP();
+        const uint32_t dest = (uint32_t)__builtin_amdgcn_ds_permute((int)(sorted & 63u) << 2, (int)slot);
         if (has)
         {
             w.sval[dest] = v;

@@ -103,6 +103,18 @@ inline unsigned long long wave_exchange(unsigned long long mine, int src_lane)
 }
 } // namespace emu
 
+// ds_permute_b32: lane (byte_address / 4) receives this lane's value ("push"); the kernels send to distinct lanes.
+inline int __builtin_amdgcn_ds_permute(int byte_address, int value)
+{
+    auto& slots = emu::g_block->xchg[emu::wave_id()];
+    emu::wave_sync();
+    slots[(byte_address >> 2) & (emu::kWave - 1)] = (unsigned long long)(unsigned)value;
+    emu::wave_sync();
+    const int v = (int)(unsigned)slots[emu::lane_id()];
+    emu::wave_sync();
+    return v;
+}
+
 template <typename T>
 inline T __shfl(T v, int src_lane, int = 64)
 {
