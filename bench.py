@@ -103,7 +103,12 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CHARLS_AMD_BENCH_FORCE_GATHER=1 runs the RCCL path (init, barrier, gather of bitstreams) with a single rank too
+    force_gather = os.environ.get("CHARLS_AMD_BENCH_FORCE_GATHER") == "1"
+    if world > 1 or force_gather:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"),
+                              RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     lib = capi.load_product()
@@ -126,7 +131,7 @@ def main():
         t1 = time.perf_counter()
         _, errcs, dec_t = batch.decode_batch(enc.streams, enc.sizes, out, lib=lib)
         t2 = time.perf_counter()
-        if world > 1:
+        if world > 1 or force_gather:
             batch.gather_streams(enc.streams, enc.sizes, dst=0, sink=lambda r, first, part, sz: None)
         if timed:
             enc_ms.append((t1 - t0) * 1e3)
@@ -139,7 +144,7 @@ def main():
         step(False)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_gather:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,7 +154,7 @@ def main():
         enc, errcs = step(True)
     barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if world > 1 or force_gather:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -225,7 +230,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if world > 1 or force_gather:
         dist.destroy_process_group()
 
 
