@@ -32,9 +32,12 @@
 namespace jls {
 namespace pipe {
 
-constexpr int kChains = 366;          // 0 = run chain, 1..364 = regular contexts, 365 = slots of run-interruption samples
-constexpr int kRegularChains = 364;
+constexpr int kChains = 367;          // 0 = run chain, 1..364 = regular contexts, 365 = slots of run-interruption samples,
+                                      // 366 = regular context 0
+constexpr int kRegularChains = 365;   // chains coded by code_events: 1..364 and kZeroContextChain
 constexpr int kInterruptChain = 365;  // no recurrence of its own: the run chain codes these samples, in the same order
+constexpr int kZeroContextChain = 366; // ILV_SAMPLE only: a component whose own gradients are all zero while the pixel
+                                       // as a whole is not in run mode is coded with regular context 0
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint16_t kNoEvent = 0xFFFF; // key of a sample that produces no code of its own
 constexpr uint32_t kPackBlock = 4096; // samples per D1/D2 workgroup (256 threads x 16)
@@ -82,6 +85,32 @@ JLS_DEV int load_sample(const ScanDesc& d, uint32_t y, uint32_t x, int mask)
 
 // ---------------------------------------------------------------------------------------------------------------
 // A: grid (8 * ceil(height / 8), scans), one wavefront per line (see xcd_band_row).  Dynamic LDS: chunks * (8 + 8 + 4) bytes + kChains * 4.
+// Samples per line as the stages after A see them: ILV_SAMPLE scans are coded pixel by pixel, component by component
+// (reference src/scan_encoder_impl.hpp:146-247), so their "line" is width * components samples long and the raster
+// index of a sample is (y * width + x) * components + c.
+JLS_DEV uint32_t line_samples(const ScanDesc& d)
+{
+    return d.interleave_mode == 2 ? d.width * (uint32_t)d.components : d.width;
+}
+
+// One pixel of an ILV_SAMPLE scan as the codec sees it: masked to the sample precision, colour transform applied
+// (src/copy_to_line_buffer.hpp:37-93, src/color_transform.hpp).
+template <typename S>
+JLS_DEV void load_pixel(const ScanDesc& d, uint32_t y, uint32_t x, int mask, int out[4])
+{
+    const S* px = reinterpret_cast<const S*>(d.pixels + (size_t)y * d.pixel_stride) + (size_t)x * d.components;
+    for (int c = 0; c < d.components; ++c)
+        out[c] = (int)px[c] & mask;
+    if (d.color_transformation != 0)
+    {
+        unsigned t[3];
+        hp_forward(d.color_transformation, sizeof(S) == 2, out[0], out[1], out[2], t);
+        out[0] = (int)t[0];
+        out[1] = (int)t[1];
+        out[2] = (int)t[2];
+    }
+}
+
 template <typename S>
 __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
@@ -213,6 +242,164 @@ __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// A for ILV_SAMPLE scans (2..4 components): same launch geometry and LDS as analyze_rows, one LANE per PIXEL.  A pixel is
+// in run mode when all its components are (src/scan_encoder_impl.hpp:171-199, 222-247); regular-mode pixels give one
+// event per component, in component order, all drawing on the ONE set of contexts.  The component-0 sample of the pixel
+// where a run starts carries the run event; the components of the pixel that ends a run are events of
+// kInterruptChain, except component 0 of a run of length 0, whose code is merged with the run-length code.
+template <typename S>
+__global__ void __launch_bounds__(64) analyze_pixels(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    JLS_DYNAMIC_LDS(smem);
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const Traits t = make_traits(d);
+    const uint32_t y = xcd_band_row(blockIdx.x, d.height);
+    if (y >= d.height)
+        return;
+    const int lane = threadIdx.x;
+    const uint32_t width = d.width;
+    const int nc = d.components;
+    const uint32_t chunks = (width + 63) / 64;
+    uint64_t* s_eq = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* s_q0 = s_eq + chunks;
+    uint32_t* s_next = reinterpret_cast<uint32_t*>(s_q0 + chunks);
+    uint32_t* s_hist = s_next + chunks;
+    const int mask = (1 << d.bits_per_sample) - 1;
+    for (int c = lane; c < kChains; c += 64)
+        s_hist[c] = 0;
+    int edge_a[4] = {0, 0, 0, 0}, edge_c[4] = {0, 0, 0, 0}; // cur[0] = prev[1]; prev[0] = first pixel of line y-2
+    if (y > 0)
+        load_pixel<S>(d, y - 1, 0, mask, edge_a);
+    if (y > 1)
+        load_pixel<S>(d, y - 2, 0, mask, edge_c);
+    uint16_t* key_row = w.key + (size_t)y * width * nc;
+    uint32_t* val_row = w.val + (size_t)y * width * nc;
+
+    // ---- pass 1: every component as if coded in regular mode; equality / zero-context masks per 64-pixel chunk
+    for (uint32_t k = 0; k < chunks; ++k)
+    {
+        const uint32_t x = k * 64 + lane;
+        bool eq = false, q0 = false;
+        if (x < width)
+        {
+            int v[4], ra[4], rb[4] = {0, 0, 0, 0}, rc[4] = {0, 0, 0, 0}, rd[4] = {0, 0, 0, 0};
+            load_pixel<S>(d, y, x, mask, v);
+            if (x > 0)
+                load_pixel<S>(d, y, x - 1, mask, ra);
+            else
+                for (int c = 0; c < 4; ++c)
+                    ra[c] = edge_a[c];
+            if (y > 0)
+            {
+                load_pixel<S>(d, y - 1, x, mask, rb);
+                if (x > 0)
+                    load_pixel<S>(d, y - 1, x - 1, mask, rc);
+                else
+                    for (int c = 0; c < 4; ++c)
+                        rc[c] = edge_c[c];
+                load_pixel<S>(d, y - 1, x + 1 < width ? x + 1 : width - 1, mask, rd);
+            }
+            eq = true;
+            q0 = true;
+            for (int c = 0; c < nc; ++c)
+            {
+                const int qs = context_id(t, ra[c], rb[c], rc[c], rd[c]);
+                const int sg = qs >> 31;
+                const int ctx = (qs ^ sg) - sg;
+                key_row[(size_t)x * nc + c] = (uint16_t)((ctx == 0 ? kZeroContextChain : ctx) | ((sg & 1) << 9));
+                val_row[(size_t)x * nc + c] = (uint32_t)v[c] | ((uint32_t)med_predict(ra[c], rb[c], rc[c]) << 16);
+                eq = eq && v[c] == ra[c];
+                q0 = q0 && qs == 0;
+            }
+        }
+        const unsigned long long m_eq = __ballot(eq);
+        const unsigned long long m_q0 = __ballot(q0);
+        if (lane == 0)
+        {
+            s_eq[k] = m_eq;
+            s_q0[k] = m_q0;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 2 (reverse): column of the first pixel at or after the NEXT chunk that differs from its left neighbour
+    if (lane == 0)
+    {
+        uint32_t carry = width;
+        for (uint32_t k = chunks; k-- > 0;)
+        {
+            s_next[k] = carry;
+            const uint32_t valid = width - k * 64 >= 64 ? 64 : width - k * 64;
+            const unsigned long long vm = valid == 64 ? ~0ull : ((1ull << valid) - 1ull);
+            const unsigned long long neq = ~s_eq[k] & vm;
+            if (neq)
+                carry = k * 64 + (uint32_t)__ffsll(neq) - 1;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 3: run-mode state before every pixel (the carry chain of analyze_rows)
+    unsigned long long carry = 0;
+    for (uint32_t k = 0; k < chunks; ++k)
+    {
+        const unsigned long long a = s_eq[k];
+        const unsigned long long b = s_eq[k] & s_q0[k];
+        const unsigned long long sum = a + b + carry;
+        const unsigned long long st = sum ^ a ^ b;
+        carry = (((a & b) | ((a | b) & st)) >> 63) & 1ull;
+        const uint32_t x = k * 64 + lane;
+        if (x < width)
+        {
+            const bool s = (st >> lane) & 1ull;
+            const bool q0 = (s_q0[k] >> lane) & 1ull;
+            const bool eq = (a >> lane) & 1ull;
+            uint16_t* keys = key_row + (size_t)x * nc;
+            if (!(s || q0))
+            {
+                for (int c = 0; c < nc; ++c)
+                    atomicAdd(&s_hist[keys[c] & 0x1FF], 1u);
+            }
+            else if (s && eq)
+            {
+                for (int c = 0; c < nc; ++c)
+                    keys[c] = kNoEvent;
+            }
+            else if (s)
+            { // the pixel that ends a run started earlier
+                for (int c = 0; c < nc; ++c)
+                    keys[c] = (uint16_t)kInterruptChain;
+                atomicAdd(&s_hist[kInterruptChain], (uint32_t)nc);
+            }
+            else
+            { // a run starts here (possibly of length 0: then this pixel also ends it)
+                uint32_t run = 0, eol = 0;
+                if (eq)
+                {
+                    const uint32_t valid = width - k * 64 >= 64 ? 64 : width - k * 64;
+                    const unsigned long long vm = valid == 64 ? ~0ull : ((1ull << valid) - 1ull);
+                    const unsigned long long neq = (~a & vm) >> lane;
+                    const uint32_t end = neq ? x + (uint32_t)__ffsll(neq) - 1 : s_next[k];
+                    run = end - x;
+                    eol = end == width ? 1u : 0u;
+                }
+                keys[0] = 0;
+                val_row[(size_t)x * nc] = run | (eol << 31);
+                atomicAdd(&s_hist[0], 1u);
+                for (int c = 1; c < nc; ++c)
+                    keys[c] = eq ? kNoEvent : (uint16_t)kInterruptChain;
+                if (!eq)
+                    atomicAdd(&s_hist[kInterruptChain], (uint32_t)(nc - 1));
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* hist_row = w.hist + (size_t)y * kChains;
+    for (int c = lane; c < kChains; c += 64)
+        hist_row[c] = s_hist[c];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // B1: one workgroup of 384 threads per scan.
 __global__ void __launch_bounds__(384) chain_offsets(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
@@ -255,7 +442,7 @@ __global__ void __launch_bounds__(64) scatter_events(const ScanDesc* __restrict_
     if (y >= d.height)
         return;
     const int lane = threadIdx.x;
-    const uint32_t width = d.width;
+    const uint32_t width = line_samples(d);
     for (int c = lane; c < kChains; c += 64)
         s_cnt[c] = w.chain_base[c] + w.hist[(size_t)y * kChains + c];
     __syncthreads();
@@ -429,8 +616,9 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
             const uint32_t p = spos[e] & 0x7FFFFFFFu;
             uint32_t run = v & 0x7FFFFFFFu;
             const bool eol = (v >> 31) != 0;
-            const uint32_t y = p / d.width;
-            const uint32_t x0 = p - y * d.width;
+            const uint32_t samples_per_line = line_samples(d);
+            const uint32_t y = p / samples_per_line;
+            const uint32_t x0 = (p - y * samples_per_line) / (d.interleave_mode == 2 ? (uint32_t)d.components : 1u);
             const uint32_t full = run;
             // run-length part: ones for every completed 2^J block, then either the end-of-line one or 0 + remainder
             uint64_t bits = 0;
@@ -459,6 +647,50 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
             len += jb + 1;
             // run interruption sample at x0 + full
             const uint32_t xi = x0 + full;
+            if (d.interleave_mode == 2)
+            { // every component against run context 0, in component order (src/scan_encoder_impl.hpp:222-247,
+              // src/scan_encoder_core.hpp:127-138); component 0 of a run of length 0 shares the run's slot
+                int xv[4], ra[4], rb[4] = {0, 0, 0, 0};
+                load_pixel<S>(d, y, xi, mask, xv);
+                if (xi > 0)
+                    load_pixel<S>(d, y, xi - 1, mask, ra);
+                else if (y > 0)
+                    load_pixel<S>(d, y - 1, 0, mask, ra);
+                else
+                    ra[0] = ra[1] = ra[2] = ra[3] = 0;
+                if (y > 0)
+                    load_pixel<S>(d, y - 1, xi, mask, rb);
+                for (int c = 0; c < d.components; ++c)
+                {
+                    const int sg = (rb[c] - ra[c]) < 0 ? -1 : 1;
+                    const int err = error_value(t, (xv[c] - rb[c]) * sg);
+                    RunCtx& ctx = rc[0];
+                    const int k = run_k(ctx);
+                    const int map = run_map(ctx, err, k);
+                    const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - map;
+                    const CodeWord cw = golomb_word(t, k, em, t.limit - jb - 1);
+                    run_update(ctx, err, em, t.reset);
+                    if (c == 0 && full == 0)
+                    {
+                        run_code[e] = (bits << cw.len) | cw.bits;
+                        run_len[e] = (uint8_t)(len + cw.len);
+                    }
+                    else
+                    {
+                        if (c == 0)
+                        {
+                            run_code[e] = bits;
+                            run_len[e] = (uint8_t)len;
+                        }
+                        int_code[interruptions] = cw.bits;
+                        int_len[interruptions] = (uint8_t)cw.len;
+                        ++interruptions;
+                    }
+                }
+                if (run_index > 0)
+                    --run_index;
+                continue;
+            }
             const int xv = load_sample<S>(d, y, xi, mask);
             const int ra = xi > 0 ? load_sample<S>(d, y, xi - 1, mask) : (y > 0 ? load_sample<S>(d, y - 1, 0, mask) : 0);
             const int rb = y > 0 ? load_sample<S>(d, y - 1, xi, mask) : 0;
@@ -505,7 +737,7 @@ __global__ void __launch_bounds__(64) code_events(const ScanDesc* __restrict__ d
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const Traits t = make_traits(d);
-    const uint32_t chain = blockIdx.x + 1;
+    const uint32_t chain = blockIdx.x < 364 ? blockIdx.x + 1 : (uint32_t)kZeroContextChain;
     const uint32_t n = w.chain_total[chain];
     if (n == 0)
         return;
@@ -582,7 +814,7 @@ __global__ void __launch_bounds__(256) sum_code_lengths(const ScanDesc* __restri
     __shared__ uint32_t s_part[256];
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
-    const uint64_t total = (uint64_t)d.width * d.height;
+    const uint64_t total = (uint64_t)line_samples(d) * d.height;
     const uint64_t base = (uint64_t)blockIdx.x * kPackBlock + (uint64_t)threadIdx.x * 16;
     uint32_t sum = 0;
     for (int i = 0; i < 16; ++i)
@@ -608,7 +840,7 @@ __global__ void __launch_bounds__(64) scan_block_sums(const ScanDesc* __restrict
 {
     const ScanDesc d = descs[blockIdx.x];
     const Work w = works[blockIdx.x];
-    const uint64_t total = (uint64_t)d.width * d.height;
+    const uint64_t total = (uint64_t)line_samples(d) * d.height;
     const uint32_t blocks = (uint32_t)((total + kPackBlock - 1) / kPackBlock);
     const int lane = threadIdx.x;
     uint64_t carry = 0;
@@ -637,7 +869,7 @@ __global__ void __launch_bounds__(256) write_raw_bits(const ScanDesc* __restrict
     __shared__ uint32_t s_scan[256];
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
-    const uint64_t total = (uint64_t)d.width * d.height;
+    const uint64_t total = (uint64_t)line_samples(d) * d.height;
     const uint64_t base = (uint64_t)blockIdx.x * kPackBlock + (uint64_t)threadIdx.x * 16;
     int lens[16];
     uint32_t slots[16];

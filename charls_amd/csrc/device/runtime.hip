@@ -351,9 +351,10 @@ struct PipeLayout
         off_raw, off_bits, off_status, bytes;
     PipeLayout(const ScanDesc& d, size_t capacity_hint)
     {
-        samples = static_cast<size_t>(d.width) * d.height;
+        const int32_t comps = d.interleave_mode == 2 ? d.components : 1;
+        samples = static_cast<size_t>(d.width) * d.height * static_cast<size_t>(comps);
         blocks = (samples + pipe::kPackBlock - 1) / pipe::kPackBlock;
-        const size_t worst = worst_case_scan_bytes(d.width, d.height, 1, d.bits_per_sample);
+        const size_t worst = worst_case_scan_bytes(d.width, d.height, comps, d.bits_per_sample);
         raw_bytes = align_up((capacity_hint < worst ? capacity_hint : worst) + 64, 16);
         size_t o = 0;
         auto take = [&](size_t n) {
@@ -453,7 +454,10 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         const uint32_t rows_grid = 8 * ((proto.height + 7) / 8);
         StageTimer t(stream);
         t.mark();
-        hipLaunchKernelGGL((pipe::analyze_rows<S>), dim3(rows_grid, n), dim3(64), lds_a, stream, descs, d_works);
+        if (proto.interleave_mode == 2)
+            hipLaunchKernelGGL((pipe::analyze_pixels<S>), dim3(rows_grid, n), dim3(64), lds_a, stream, descs, d_works);
+        else
+            hipLaunchKernelGGL((pipe::analyze_rows<S>), dim3(rows_grid, n), dim3(64), lds_a, stream, descs, d_works);
         t.mark();
         hipLaunchKernelGGL(pipe::chain_offsets, dim3(n), dim3(384), 0, stream, descs, d_works);
         hipLaunchKernelGGL(pipe::scatter_events, dim3(rows_grid, n), dim3(64), 0, stream, descs, d_works);
@@ -483,9 +487,15 @@ bool pipeline_eligible(const ScanDesc& d) noexcept
 {
     if (encode_engine() == EncodeEngine::serial)
         return false;
-    if (d.near_lossless != 0 || d.interleave_mode != 0 || d.components != 1 || d.color_transformation != 0)
-        return false;
-    if (static_cast<uint64_t>(d.width) * d.height >= (uint64_t{1} << 31) || d.width > 65536)
+    if (d.near_lossless != 0)
+        return false; // the template then holds reconstructed samples: nothing is known ahead of the chain
+    const bool planar = d.interleave_mode == 0 && d.components == 1 && d.color_transformation == 0;
+    const bool by_sample = d.interleave_mode == 2 && d.components >= 2 && d.components <= 4 &&
+                           (d.color_transformation == 0 || d.components == 3);
+    if (!planar && !by_sample)
+        return false; // ILV_LINE keeps one RUNindex per component: exact kernel
+    const uint64_t samples = static_cast<uint64_t>(d.width) * d.height * static_cast<uint64_t>(d.components);
+    if (samples >= (uint64_t{1} << 31) || d.width > 65536)
         return false;
     if (d.bits_per_sample > 8 && ((reinterpret_cast<uintptr_t>(d.pixels) | d.pixel_stride) & 1u) != 0)
         return false;

@@ -56,7 +56,7 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
 {
     using namespace jls;
     const ScanDesc& p = descs[0];
-    const size_t samples = (size_t)p.width * p.height;
+    const size_t samples = (size_t)p.width * p.height * (size_t)(p.interleave_mode == 2 ? p.components : 1);
     const size_t blocks = (samples + pipe::kPackBlock - 1) / pipe::kPackBlock;
     std::vector<pipe::Work> works(count);
     std::vector<void*> allocs;
@@ -97,7 +97,10 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
     const size_t lds_a = (size_t)chunks * 20 + pipe::kChains * 4;
     const pipe::Work* wk = works.data();
     const unsigned rows_grid = 8 * ((p.height + 7) / 8);
-    emu::launch(pipe::analyze_rows<S>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
+    if (p.interleave_mode == 2)
+        emu::launch(pipe::analyze_pixels<S>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
+    else
+        emu::launch(pipe::analyze_rows<S>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
     emu::launch(pipe::chain_offsets, dim3(count), dim3(384), 0, descs, wk);
     emu::launch(pipe::scatter_events, dim3(rows_grid, count), dim3(64), 0, descs, wk);
     emu::launch(pipe::bias_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);

@@ -130,3 +130,59 @@ def test_pipeline_reset_values_with_long_chains(bits, reset):
     (errc, flags, data), = _encode_planes(L, [img], w, h, bits, pc, capacity_slack=w * h * 4 + 1024)
     assert errc == 0
     assert data == want[cont.scans[0].data_start:cont.scans[0].data_end]
+
+
+def _encode_interleaved(L, img, width, height, comps, bits, xform, capacity):
+    keep = []
+    pix = np.frombuffer(np.ascontiguousarray(img).tobytes(), dtype=np.uint8).copy()
+    out = np.zeros(capacity, dtype=np.uint8)
+    pc = jls_container.validated_pc((0,) * 5, bits, 0)
+    d = emu_bind.make_desc(width, height, comps, 2, bits, 0, xform, pc, 0, pix, width * comps * (1 if bits <= 8 else 2), out, keep)
+    res = (emu_bind.ScanResult * 1)()
+    L.emu_encode_pipeline((emu_bind.ScanDesc * 1)(d), res, 1)
+    return res[0].errc, res[0].flags, out[:res[0].bytes].tobytes()
+
+
+@pytest.mark.parametrize("kind,bits,comps,xform,w,h", [("mixed", 8, 3, 0, 33, 9), ("zero", 8, 3, 0, 70, 6), ("mixed", 8, 3, 1, 40, 7),
+                                                       ("mixed", 8, 3, 2, 20, 5), ("mixed", 8, 3, 3, 21, 5), ("mixed", 16, 3, 1, 18, 5),
+                                                       ("hard", 12, 2, 0, 19, 6), ("mixed", 8, 4, 0, 17, 5), ("mixed", 8, 3, 0, 1, 9),
+                                                       ("runs", 8, 3, 0, 90, 8)])
+def test_pipeline_sample_interleaved_scans(kind, bits, comps, xform, w, h):
+    """ILV_SAMPLE lossless (2..4 components, HP1..3 for RGB): one set of contexts shared by the components, pixel-level
+    run mode, run-interruption codes of every component against run context 0."""
+    L = emu_bind.lib()
+    if kind == "runs":  # flat areas with isolated differing pixels and single differing components
+        rng = np.random.default_rng(4)
+        img = np.full((h, w, comps), 50, dtype=np.uint8)
+        for _ in range(25):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            img[y, x, int(rng.integers(0, comps))] = int(rng.integers(0, 256))
+        img[3, 10:30] = (9, 200, 77)
+    else:
+        planes = [synth.frame_numpy(w, h, seed=60 + c, bits=bits, kind=kind) for c in range(comps)]
+        img = np.stack(planes, axis=-1)
+    want = ob.encode(img, width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=2,
+                     color_transformation=xform)
+    cont = jls_container.parse(want)
+    errc, flags, data = _encode_interleaved(L, img, w, h, comps, bits, xform, w * h * comps * 4 + 1024)
+    assert errc == 0
+    assert data == want[cont.scans[0].data_start:cont.scans[0].data_end]
+
+
+def test_pipeline_sample_interleaved_random_small_images():
+    """Many tiny ILV_SAMPLE images with few grey levels: runs of every length, runs ended by a single component,
+    components with a zero context inside non-run pixels (regular context 0), all colour transforms."""
+    L = emu_bind.lib()
+    rng = np.random.default_rng(12)
+    for trial in range(40 if FULL else 14):
+        comps = int(rng.choice([2, 3, 3, 4]))
+        w, h = int(rng.integers(1, 12)), int(rng.integers(1, 6))
+        levels = int(rng.choice([2, 3, 256]))
+        img = (rng.integers(0, levels, size=(h, w, comps)) * (255 // (levels - 1) if levels < 256 else 1)).astype(np.uint8)
+        if trial % 3 == 0:
+            img[:, w // 2:] = img[:, w // 2:w // 2 + 1]  # long runs to the end of the line
+        xform = int(rng.integers(0, 4)) if comps == 3 else 0
+        want = ob.encode(img, width=w, height=h, component_count=comps, interleave_mode=2, color_transformation=xform)
+        cont = jls_container.parse(want)
+        errc, flags, data = _encode_interleaved(L, img, w, h, comps, 8, xform, w * h * comps * 4 + 1024)
+        assert errc == 0 and data == want[cont.scans[0].data_start:cont.scans[0].data_end], (trial, w, h, comps, xform)
