@@ -1,4 +1,5 @@
-// lossless_pipeline.hip -- parallel JPEG-LS encoder for lossless single-component scans (the BASELINE headline path).
+// lossless_pipeline.hip -- parallel JPEG-LS encoder for lossless scans: single-component (the BASELINE headline path) and
+// the component-interleaved modes ILV_LINE / ILV_SAMPLE with 2..4 components (see analyze_pixels, coded_lines).
 //
 // In lossless mode the causal template holds SOURCE samples, so everything except the adaptive statistics is a pure
 // function of the image (reference src/scan_encoder_impl.hpp:109-144).  The scan is therefore coded in
@@ -76,15 +77,36 @@ JLS_DEV uint32_t xcd_band_row(uint32_t block, uint32_t height)
     return (block >> 3) < band && y < height ? y : height;
 }
 
-template <typename S>
-JLS_DEV int load_sample(const ScanDesc& d, uint32_t y, uint32_t x, int mask)
+// ILV_LINE scans are coded line by line and, within a line of pixels, component by component: "coded line" L is
+// component L % components of pixel row L / components, with the contexts shared and ONE RUNindex per component
+// (reference src/scan_encoder_impl.hpp:109-144 with component_count lines per row).  The previous line of the same
+// component is coded line L - line_step.
+JLS_DEV uint32_t coded_lines(const ScanDesc& d)
 {
-    const S* row = reinterpret_cast<const S*>(d.pixels + (size_t)y * d.pixel_stride);
+    return d.interleave_mode == 1 ? d.height * (uint32_t)d.components : d.height;
+}
+JLS_DEV uint32_t line_step(const ScanDesc& d)
+{
+    return d.interleave_mode == 1 ? (uint32_t)d.components : 1u;
+}
+
+template <typename S>
+JLS_DEV void load_pixel(const ScanDesc& d, uint32_t y, uint32_t x, int mask, int out[4]);
+
+// Sample x of coded line `line` as the codec sees it.
+template <typename S>
+JLS_DEV int load_sample(const ScanDesc& d, uint32_t line, uint32_t x, int mask)
+{
+    if (d.interleave_mode == 1)
+    {
+        int px[4];
+        load_pixel<S>(d, line / (uint32_t)d.components, x, mask, px);
+        return px[line % (uint32_t)d.components];
+    }
+    const S* row = reinterpret_cast<const S*>(d.pixels + (size_t)line * d.pixel_stride);
     return (int)row[x] & mask;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// A: grid (8 * ceil(height / 8), scans), one wavefront per line (see xcd_band_row).  Dynamic LDS: chunks * (8 + 8 + 4) bytes + kChains * 4.
 // Samples per line as the stages after A see them: ILV_SAMPLE scans are coded pixel by pixel, component by component
 // (reference src/scan_encoder_impl.hpp:146-247), so their "line" is width * components samples long and the raster
 // index of a sample is (y * width + x) * components + c.
@@ -93,7 +115,7 @@ JLS_DEV uint32_t line_samples(const ScanDesc& d)
     return d.interleave_mode == 2 ? d.width * (uint32_t)d.components : d.width;
 }
 
-// One pixel of an ILV_SAMPLE scan as the codec sees it: masked to the sample precision, colour transform applied
+// One pixel of an interleaved scan as the codec sees it: masked to the sample precision, colour transform applied
 // (src/copy_to_line_buffer.hpp:37-93, src/color_transform.hpp).
 template <typename S>
 JLS_DEV void load_pixel(const ScanDesc& d, uint32_t y, uint32_t x, int mask, int out[4])
@@ -118,9 +140,10 @@ __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ 
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const Traits t = make_traits(d);
-    const uint32_t y = xcd_band_row(blockIdx.x, d.height);
-    if (y >= d.height)
+    const uint32_t y = xcd_band_row(blockIdx.x, coded_lines(d)); // coded line
+    if (y >= coded_lines(d))
         return;
+    const uint32_t step = line_step(d);
     const int lane = threadIdx.x;
     const uint32_t width = d.width;
     const uint32_t chunks = (width + 63) / 64;
@@ -134,8 +157,8 @@ __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ 
         s_hist[c] = 0;
 
     // edge samples of the line (src/scan_codec.hpp:189-195 and the two-line ping-pong of src/scan_encoder_impl.hpp:55-106)
-    const int edge_a = y > 0 ? load_sample<S>(d, y - 1, 0, mask) : 0;           // cur[0]  = prev[1]
-    const int edge_c = y > 1 ? load_sample<S>(d, y - 2, 0, mask) : 0;           // prev[0] = line y-2, first sample
+    const int edge_a = y >= step ? load_sample<S>(d, y - step, 0, mask) : 0;     // cur[0]  = prev[1]
+    const int edge_c = y >= 2 * step ? load_sample<S>(d, y - 2 * step, 0, mask) : 0; // prev[0] = two lines up, first sample
     uint16_t* key_row = w.key + (size_t)y * width;
     uint32_t* val_row = w.val + (size_t)y * width;
 
@@ -149,11 +172,11 @@ __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ 
             const int v = load_sample<S>(d, y, x, mask);
             const int ra = x > 0 ? load_sample<S>(d, y, x - 1, mask) : edge_a;
             int rb = 0, rc = 0, rd = 0;
-            if (y > 0)
+            if (y >= step)
             {
-                rb = load_sample<S>(d, y - 1, x, mask);
-                rc = x > 0 ? load_sample<S>(d, y - 1, x - 1, mask) : edge_c;
-                rd = load_sample<S>(d, y - 1, x + 1 < width ? x + 1 : width - 1, mask);
+                rb = load_sample<S>(d, y - step, x, mask);
+                rc = x > 0 ? load_sample<S>(d, y - step, x - 1, mask) : edge_c;
+                rd = load_sample<S>(d, y - step, x + 1 < width ? x + 1 : width - 1, mask);
             }
             else
                 rc = x > 0 ? 0 : edge_c;
@@ -410,7 +433,7 @@ __global__ void __launch_bounds__(384) chain_offsets(const ScanDesc* __restrict_
     uint32_t running = 0;
     if (c < kChains)
     {
-        for (uint32_t y = 0; y < d.height; ++y)
+        for (uint32_t y = 0; y < coded_lines(d); ++y)
         {
             const uint32_t n = w.hist[(size_t)y * kChains + c];
             w.hist[(size_t)y * kChains + c] = running;
@@ -438,8 +461,8 @@ __global__ void __launch_bounds__(64) scatter_events(const ScanDesc* __restrict_
     __shared__ uint32_t s_cnt[kChains];
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
-    const uint32_t y = xcd_band_row(blockIdx.x, d.height);
-    if (y >= d.height)
+    const uint32_t y = xcd_band_row(blockIdx.x, coded_lines(d));
+    if (y >= coded_lines(d))
         return;
     const int lane = threadIdx.x;
     const uint32_t width = line_samples(d);
@@ -603,7 +626,8 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
         // Codes go to the slot of the sample they belong to: the run-length code to the run's own slot, the code of the
         // interruption sample to the next slot of chain kInterruptChain (its events are these samples, in this order).
         RunCtx rc[2] = {RunCtx{0, initial_a(t), 1, 0}, RunCtx{1, initial_a(t), 1, 0}};
-        int run_index = 0;
+        int run_indices[4] = {0, 0, 0, 0}; // ILV_LINE: one RUNindex per component (src/scan_encoder_impl.hpp:126-137)
+        const uint32_t step = line_step(d);
         const int mask = (1 << d.bits_per_sample) - 1;
         uint64_t* run_code = w.code + w.chain_base[0];
         uint8_t* run_len = w.len + w.chain_base[0];
@@ -617,7 +641,8 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
             uint32_t run = v & 0x7FFFFFFFu;
             const bool eol = (v >> 31) != 0;
             const uint32_t samples_per_line = line_samples(d);
-            const uint32_t y = p / samples_per_line;
+            const uint32_t y = p / samples_per_line; // coded line
+            int& run_index = run_indices[d.interleave_mode == 1 ? y % step : 0];
             const uint32_t x0 = (p - y * samples_per_line) / (d.interleave_mode == 2 ? (uint32_t)d.components : 1u);
             const uint32_t full = run;
             // run-length part: ones for every completed 2^J block, then either the end-of-line one or 0 + remainder
@@ -692,8 +717,8 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
                 continue;
             }
             const int xv = load_sample<S>(d, y, xi, mask);
-            const int ra = xi > 0 ? load_sample<S>(d, y, xi - 1, mask) : (y > 0 ? load_sample<S>(d, y - 1, 0, mask) : 0);
-            const int rb = y > 0 ? load_sample<S>(d, y - 1, xi, mask) : 0;
+            const int ra = xi > 0 ? load_sample<S>(d, y, xi - 1, mask) : (y >= step ? load_sample<S>(d, y - step, 0, mask) : 0);
+            const int rb = y >= step ? load_sample<S>(d, y - step, xi, mask) : 0;
             const int which = ra == rb ? 1 : 0;
             int err;
             if (which)
@@ -814,7 +839,7 @@ __global__ void __launch_bounds__(256) sum_code_lengths(const ScanDesc* __restri
     __shared__ uint32_t s_part[256];
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
-    const uint64_t total = (uint64_t)line_samples(d) * d.height;
+    const uint64_t total = (uint64_t)line_samples(d) * coded_lines(d);
     const uint64_t base = (uint64_t)blockIdx.x * kPackBlock + (uint64_t)threadIdx.x * 16;
     uint32_t sum = 0;
     for (int i = 0; i < 16; ++i)
@@ -840,7 +865,7 @@ __global__ void __launch_bounds__(64) scan_block_sums(const ScanDesc* __restrict
 {
     const ScanDesc d = descs[blockIdx.x];
     const Work w = works[blockIdx.x];
-    const uint64_t total = (uint64_t)line_samples(d) * d.height;
+    const uint64_t total = (uint64_t)line_samples(d) * coded_lines(d);
     const uint32_t blocks = (uint32_t)((total + kPackBlock - 1) / kPackBlock);
     const int lane = threadIdx.x;
     uint64_t carry = 0;
@@ -869,7 +894,7 @@ __global__ void __launch_bounds__(256) write_raw_bits(const ScanDesc* __restrict
     __shared__ uint32_t s_scan[256];
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
-    const uint64_t total = (uint64_t)line_samples(d) * d.height;
+    const uint64_t total = (uint64_t)line_samples(d) * coded_lines(d);
     const uint64_t base = (uint64_t)blockIdx.x * kPackBlock + (uint64_t)threadIdx.x * 16;
     int lens[16];
     uint32_t slots[16];

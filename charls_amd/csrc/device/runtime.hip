@@ -346,12 +346,13 @@ size_t align_up(size_t v, size_t a)
 // Bytes of work area one scan needs (21 B per sample + per-line histograms + the unstuffed stream).
 struct PipeLayout
 {
-    size_t samples, blocks, raw_bytes;
+    size_t samples, lines, blocks, raw_bytes;
     size_t off_key, off_val, off_hist, off_total, off_base, off_sval, off_spos, off_inv, off_len, off_code, off_bsum, off_bbase,
         off_raw, off_bits, off_status, bytes;
     PipeLayout(const ScanDesc& d, size_t capacity_hint)
     {
-        const int32_t comps = d.interleave_mode == 2 ? d.components : 1;
+        const int32_t comps = d.interleave_mode != 0 ? d.components : 1;
+        lines = static_cast<size_t>(d.height) * (d.interleave_mode == 1 ? static_cast<size_t>(d.components) : 1);
         samples = static_cast<size_t>(d.width) * d.height * static_cast<size_t>(comps);
         blocks = (samples + pipe::kPackBlock - 1) / pipe::kPackBlock;
         const size_t worst = worst_case_scan_bytes(d.width, d.height, comps, d.bits_per_sample);
@@ -367,7 +368,7 @@ struct PipeLayout
         off_code = take(std::max((samples + pipe::kChainSlack) * 8, val_at + samples * 4));
         off_key = off_code;
         off_val = off_code + val_at;
-        off_hist = take(static_cast<size_t>(d.height) * pipe::kChains * 4);
+        off_hist = take(lines * pipe::kChains * 4);
         off_total = take(pipe::kChains * 4);
         off_base = take(pipe::kChains * 4);
         off_sval = take((samples + pipe::kChainSlack) * 4);
@@ -451,7 +452,7 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         const uint32_t chunks = (proto.width + 63) / 64;
         const size_t lds_a = static_cast<size_t>(chunks) * 20 + pipe::kChains * 4;
         const uint32_t blocks = static_cast<uint32_t>(lay.blocks);
-        const uint32_t rows_grid = 8 * ((proto.height + 7) / 8);
+        const uint32_t rows_grid = 8 * ((static_cast<uint32_t>(lay.lines) + 7) / 8); // analyze_pixels idles the surplus
         StageTimer t(stream);
         t.mark();
         if (proto.interleave_mode == 2)
@@ -490,10 +491,10 @@ bool pipeline_eligible(const ScanDesc& d) noexcept
     if (d.near_lossless != 0)
         return false; // the template then holds reconstructed samples: nothing is known ahead of the chain
     const bool planar = d.interleave_mode == 0 && d.components == 1 && d.color_transformation == 0;
-    const bool by_sample = d.interleave_mode == 2 && d.components >= 2 && d.components <= 4 &&
-                           (d.color_transformation == 0 || d.components == 3);
-    if (!planar && !by_sample)
-        return false; // ILV_LINE keeps one RUNindex per component: exact kernel
+    const bool interleaved = d.interleave_mode != 0 && d.components >= 2 && d.components <= 4 &&
+                             (d.color_transformation == 0 || d.components == 3);
+    if (!planar && !interleaved)
+        return false;
     const uint64_t samples = static_cast<uint64_t>(d.width) * d.height * static_cast<uint64_t>(d.components);
     if (samples >= (uint64_t{1} << 31) || d.width > 65536)
         return false;

@@ -56,7 +56,8 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
 {
     using namespace jls;
     const ScanDesc& p = descs[0];
-    const size_t samples = (size_t)p.width * p.height * (size_t)(p.interleave_mode == 2 ? p.components : 1);
+    const size_t samples = (size_t)p.width * p.height * (size_t)(p.interleave_mode != 0 ? p.components : 1);
+    const size_t lines = (size_t)p.height * (size_t)(p.interleave_mode == 1 ? p.components : 1);
     const size_t blocks = (samples + pipe::kPackBlock - 1) / pipe::kPackBlock;
     std::vector<pipe::Work> works(count);
     std::vector<void*> allocs;
@@ -79,7 +80,7 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
         w.code = (uint64_t*)galloc((samples + pipe::kChainSlack) * 8 + 512);  // stage C re-uses the storage of key/val, as in runtime.hip
         w.key = (uint16_t*)w.code;
         w.val = (uint32_t*)((unsigned char*)w.code + ((samples * 2 + 255) / 256) * 256);
-        w.hist = (uint32_t*)zalloc((size_t)p.height * pipe::kChains * 4);
+        w.hist = (uint32_t*)zalloc(lines * pipe::kChains * 4);
         w.chain_total = (uint32_t*)zalloc(pipe::kChains * 4);
         w.chain_base = (uint32_t*)zalloc(pipe::kChains * 4);
         w.sval = (uint32_t*)galloc((samples + pipe::kChainSlack) * 4);
@@ -96,7 +97,7 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
     const uint32_t chunks = (p.width + 63) / 64;
     const size_t lds_a = (size_t)chunks * 20 + pipe::kChains * 4;
     const pipe::Work* wk = works.data();
-    const unsigned rows_grid = 8 * ((p.height + 7) / 8);
+    const unsigned rows_grid = 8 * (((unsigned)lines + 7) / 8);
     if (p.interleave_mode == 2)
         emu::launch(pipe::analyze_pixels<S>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
     else

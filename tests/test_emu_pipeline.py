@@ -132,12 +132,12 @@ def test_pipeline_reset_values_with_long_chains(bits, reset):
     assert data == want[cont.scans[0].data_start:cont.scans[0].data_end]
 
 
-def _encode_interleaved(L, img, width, height, comps, bits, xform, capacity):
+def _encode_interleaved(L, img, width, height, comps, bits, xform, capacity, ilv=2):
     keep = []
     pix = np.frombuffer(np.ascontiguousarray(img).tobytes(), dtype=np.uint8).copy()
     out = np.zeros(capacity, dtype=np.uint8)
     pc = jls_container.validated_pc((0,) * 5, bits, 0)
-    d = emu_bind.make_desc(width, height, comps, 2, bits, 0, xform, pc, 0, pix, width * comps * (1 if bits <= 8 else 2), out, keep)
+    d = emu_bind.make_desc(width, height, comps, ilv, bits, 0, xform, pc, 0, pix, width * comps * (1 if bits <= 8 else 2), out, keep)
     res = (emu_bind.ScanResult * 1)()
     L.emu_encode_pipeline((emu_bind.ScanDesc * 1)(d), res, 1)
     return res[0].errc, res[0].flags, out[:res[0].bytes].tobytes()
@@ -185,4 +185,30 @@ def test_pipeline_sample_interleaved_random_small_images():
         want = ob.encode(img, width=w, height=h, component_count=comps, interleave_mode=2, color_transformation=xform)
         cont = jls_container.parse(want)
         errc, flags, data = _encode_interleaved(L, img, w, h, comps, 8, xform, w * h * comps * 4 + 1024)
+        assert errc == 0 and data == want[cont.scans[0].data_start:cont.scans[0].data_end], (trial, w, h, comps, xform)
+
+
+def test_pipeline_line_interleaved_scans():
+    """ILV_LINE lossless: the components of a pixel row are coded as lines of their own, sharing the contexts but each
+    with its own RUNindex."""
+    L = emu_bind.lib()
+    rng = np.random.default_rng(21)
+    cases = [("mixed", 8, 3, 0, 33, 7), ("mixed", 8, 3, 1, 20, 5), ("mixed", 16, 3, 3, 12, 4), ("hard", 12, 2, 0, 19, 5),
+             ("mixed", 8, 4, 0, 9, 4)]
+    for kind, bits, comps, xform, w, h in cases:
+        img = np.stack([synth.frame_numpy(w, h, seed=80 + c, bits=bits, kind=kind) for c in range(comps)], axis=-1)
+        want = ob.encode(img, width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=1,
+                         color_transformation=xform)
+        cont = jls_container.parse(want)
+        errc, flags, data = _encode_interleaved(L, img, w, h, comps, bits, xform, w * h * comps * 4 + 1024, ilv=1)
+        assert errc == 0 and data == want[cont.scans[0].data_start:cont.scans[0].data_end], (kind, bits, comps, xform)
+    for trial in range(24 if FULL else 10):  # few grey levels: runs in every component, RUNindex walks per component
+        comps = int(rng.choice([2, 3, 4]))
+        w, h = int(rng.integers(1, 40)), int(rng.integers(1, 6))
+        img = (rng.integers(0, 2, size=(h, w, comps)) * 200).astype(np.uint8)
+        img[:, w // 3:, 0] = img[:, w // 3:w // 3 + 1, 0]
+        xform = int(rng.integers(0, 4)) if comps == 3 else 0
+        want = ob.encode(img, width=w, height=h, component_count=comps, interleave_mode=1, color_transformation=xform)
+        cont = jls_container.parse(want)
+        errc, flags, data = _encode_interleaved(L, img, w, h, comps, 8, xform, w * h * comps * 4 + 1024, ilv=1)
         assert errc == 0 and data == want[cont.scans[0].data_start:cont.scans[0].data_end], (trial, w, h, comps, xform)
