@@ -93,11 +93,12 @@ JLS_DEV uint32_t line_step(const ScanDesc& d)
 template <typename S>
 JLS_DEV void load_pixel(const ScanDesc& d, uint32_t y, uint32_t x, int mask, int out[4]);
 
-// Sample x of coded line `line` as the codec sees it.
-template <typename S>
+// Sample x of coded line `line` as the codec sees it.  ILV is the scan's interleave mode as a compile-time constant: the
+// planar instantiation (the headline path) carries none of the interleaved code.
+template <typename S, int ILV>
 JLS_DEV int load_sample(const ScanDesc& d, uint32_t line, uint32_t x, int mask)
 {
-    if (d.interleave_mode == 1)
+    if (ILV == 1)
     {
         int px[4];
         load_pixel<S>(d, line / (uint32_t)d.components, x, mask, px);
@@ -133,17 +134,18 @@ JLS_DEV void load_pixel(const ScanDesc& d, uint32_t y, uint32_t x, int mask, int
     }
 }
 
-template <typename S>
+template <typename S, int ILV>
 __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
     JLS_DYNAMIC_LDS(smem);
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const Traits t = make_traits(d);
-    const uint32_t y = xcd_band_row(blockIdx.x, coded_lines(d)); // coded line
-    if (y >= coded_lines(d))
+    const uint32_t lines = ILV == 1 ? coded_lines(d) : d.height;
+    const uint32_t y = xcd_band_row(blockIdx.x, lines); // coded line
+    if (y >= lines)
         return;
-    const uint32_t step = line_step(d);
+    const uint32_t step = ILV == 1 ? line_step(d) : 1u;
     const int lane = threadIdx.x;
     const uint32_t width = d.width;
     const uint32_t chunks = (width + 63) / 64;
@@ -157,8 +159,8 @@ __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ 
         s_hist[c] = 0;
 
     // edge samples of the line (src/scan_codec.hpp:189-195 and the two-line ping-pong of src/scan_encoder_impl.hpp:55-106)
-    const int edge_a = y >= step ? load_sample<S>(d, y - step, 0, mask) : 0;     // cur[0]  = prev[1]
-    const int edge_c = y >= 2 * step ? load_sample<S>(d, y - 2 * step, 0, mask) : 0; // prev[0] = two lines up, first sample
+    const int edge_a = y >= step ? load_sample<S, ILV>(d, y - step, 0, mask) : 0;     // cur[0]  = prev[1]
+    const int edge_c = y >= 2 * step ? load_sample<S, ILV>(d, y - 2 * step, 0, mask) : 0; // prev[0] = two lines up, first sample
     uint16_t* key_row = w.key + (size_t)y * width;
     uint32_t* val_row = w.val + (size_t)y * width;
 
@@ -169,14 +171,14 @@ __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ 
         bool eq = false, q0 = false;
         if (x < width)
         {
-            const int v = load_sample<S>(d, y, x, mask);
-            const int ra = x > 0 ? load_sample<S>(d, y, x - 1, mask) : edge_a;
+            const int v = load_sample<S, ILV>(d, y, x, mask);
+            const int ra = x > 0 ? load_sample<S, ILV>(d, y, x - 1, mask) : edge_a;
             int rb = 0, rc = 0, rd = 0;
             if (y >= step)
             {
-                rb = load_sample<S>(d, y - step, x, mask);
-                rc = x > 0 ? load_sample<S>(d, y - step, x - 1, mask) : edge_c;
-                rd = load_sample<S>(d, y - step, x + 1 < width ? x + 1 : width - 1, mask);
+                rb = load_sample<S, ILV>(d, y - step, x, mask);
+                rc = x > 0 ? load_sample<S, ILV>(d, y - step, x - 1, mask) : edge_c;
+                rd = load_sample<S, ILV>(d, y - step, x + 1 < width ? x + 1 : width - 1, mask);
             }
             else
                 rc = x > 0 ? 0 : edge_c;
@@ -550,7 +552,7 @@ JLS_DEV CodeWord golomb_word(const Traits& t, int k, int m, int limit)
     return c;
 }
 
-template <typename S>
+template <typename S, int ILV>
 __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works,
                                                   uint32_t scans)
 {
@@ -626,8 +628,8 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
         // Codes go to the slot of the sample they belong to: the run-length code to the run's own slot, the code of the
         // interruption sample to the next slot of chain kInterruptChain (its events are these samples, in this order).
         RunCtx rc[2] = {RunCtx{0, initial_a(t), 1, 0}, RunCtx{1, initial_a(t), 1, 0}};
-        int run_indices[4] = {0, 0, 0, 0}; // ILV_LINE: one RUNindex per component (src/scan_encoder_impl.hpp:126-137)
-        const uint32_t step = line_step(d);
+        int run_indices[ILV == 1 ? 4 : 1] = {}; // ILV_LINE: one RUNindex per component (src/scan_encoder_impl.hpp:126-137)
+        const uint32_t step = ILV == 1 ? line_step(d) : 1u;
         const int mask = (1 << d.bits_per_sample) - 1;
         uint64_t* run_code = w.code + w.chain_base[0];
         uint8_t* run_len = w.len + w.chain_base[0];
@@ -640,10 +642,10 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
             const uint32_t p = spos[e] & 0x7FFFFFFFu;
             uint32_t run = v & 0x7FFFFFFFu;
             const bool eol = (v >> 31) != 0;
-            const uint32_t samples_per_line = line_samples(d);
+            const uint32_t samples_per_line = ILV == 2 ? line_samples(d) : d.width;
             const uint32_t y = p / samples_per_line; // coded line
-            int& run_index = run_indices[d.interleave_mode == 1 ? y % step : 0];
-            const uint32_t x0 = (p - y * samples_per_line) / (d.interleave_mode == 2 ? (uint32_t)d.components : 1u);
+            int& run_index = run_indices[ILV == 1 ? y % step : 0];
+            const uint32_t x0 = (p - y * samples_per_line) / (ILV == 2 ? (uint32_t)d.components : 1u);
             const uint32_t full = run;
             // run-length part: ones for every completed 2^J block, then either the end-of-line one or 0 + remainder
             uint64_t bits = 0;
@@ -672,7 +674,7 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
             len += jb + 1;
             // run interruption sample at x0 + full
             const uint32_t xi = x0 + full;
-            if (d.interleave_mode == 2)
+            if (ILV == 2)
             { // every component against run context 0, in component order (src/scan_encoder_impl.hpp:222-247,
               // src/scan_encoder_core.hpp:127-138); component 0 of a run of length 0 shares the run's slot
                 int xv[4], ra[4], rb[4] = {0, 0, 0, 0};
@@ -716,9 +718,9 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
                     --run_index;
                 continue;
             }
-            const int xv = load_sample<S>(d, y, xi, mask);
-            const int ra = xi > 0 ? load_sample<S>(d, y, xi - 1, mask) : (y >= step ? load_sample<S>(d, y - step, 0, mask) : 0);
-            const int rb = y >= step ? load_sample<S>(d, y - step, xi, mask) : 0;
+            const int xv = load_sample<S, ILV>(d, y, xi, mask);
+            const int ra = xi > 0 ? load_sample<S, ILV>(d, y, xi - 1, mask) : (y >= step ? load_sample<S, ILV>(d, y - step, 0, mask) : 0);
+            const int rb = y >= step ? load_sample<S, ILV>(d, y - step, xi, mask) : 0;
             const int which = ra == rb ? 1 : 0;
             int err;
             if (which)

@@ -457,13 +457,21 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         t.mark();
         if (proto.interleave_mode == 2)
             hipLaunchKernelGGL((pipe::analyze_pixels<S>), dim3(rows_grid, n), dim3(64), lds_a, stream, descs, d_works);
+        else if (proto.interleave_mode == 1)
+            hipLaunchKernelGGL((pipe::analyze_rows<S, 1>), dim3(rows_grid, n), dim3(64), lds_a, stream, descs, d_works);
         else
-            hipLaunchKernelGGL((pipe::analyze_rows<S>), dim3(rows_grid, n), dim3(64), lds_a, stream, descs, d_works);
+            hipLaunchKernelGGL((pipe::analyze_rows<S, 0>), dim3(rows_grid, n), dim3(64), lds_a, stream, descs, d_works);
         t.mark();
         hipLaunchKernelGGL(pipe::chain_offsets, dim3(n), dim3(384), 0, stream, descs, d_works);
         hipLaunchKernelGGL(pipe::scatter_events, dim3(rows_grid, n), dim3(64), 0, stream, descs, d_works);
         t.mark();
-        hipLaunchKernelGGL((pipe::bias_chains<S>), dim3((n * pipe::kChains + 63) / 64), dim3(64), 0, stream, descs, d_works, n);
+        const dim3 chains_grid((n * pipe::kChains + 63) / 64);
+        if (proto.interleave_mode == 2)
+            hipLaunchKernelGGL((pipe::bias_chains<S, 2>), chains_grid, dim3(64), 0, stream, descs, d_works, n);
+        else if (proto.interleave_mode == 1)
+            hipLaunchKernelGGL((pipe::bias_chains<S, 1>), chains_grid, dim3(64), 0, stream, descs, d_works, n);
+        else
+            hipLaunchKernelGGL((pipe::bias_chains<S, 0>), chains_grid, dim3(64), 0, stream, descs, d_works, n);
         hipLaunchKernelGGL(pipe::code_events, dim3(pipe::kRegularChains, n), dim3(64), 0, stream, descs, d_works);
         t.mark();
         hipLaunchKernelGGL(pipe::sum_code_lengths, dim3(blocks, n), dim3(256), 0, stream, descs, d_works);

@@ -100,11 +100,19 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
     const unsigned rows_grid = 8 * (((unsigned)lines + 7) / 8);
     if (p.interleave_mode == 2)
         emu::launch(pipe::analyze_pixels<S>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
+    else if (p.interleave_mode == 1)
+        emu::launch(pipe::analyze_rows<S, 1>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
     else
-        emu::launch(pipe::analyze_rows<S>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
+        emu::launch(pipe::analyze_rows<S, 0>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
     emu::launch(pipe::chain_offsets, dim3(count), dim3(384), 0, descs, wk);
     emu::launch(pipe::scatter_events, dim3(rows_grid, count), dim3(64), 0, descs, wk);
-    emu::launch(pipe::bias_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    const dim3 chains_grid((count * pipe::kChains + 63) / 64);
+    if (p.interleave_mode == 2)
+        emu::launch(pipe::bias_chains<S, 2>, chains_grid, dim3(64), 0, descs, wk, (uint32_t)count);
+    else if (p.interleave_mode == 1)
+        emu::launch(pipe::bias_chains<S, 1>, chains_grid, dim3(64), 0, descs, wk, (uint32_t)count);
+    else
+        emu::launch(pipe::bias_chains<S, 0>, chains_grid, dim3(64), 0, descs, wk, (uint32_t)count);
     emu::launch(pipe::code_events, dim3(pipe::kRegularChains, count), dim3(64), 0, descs, wk);
     emu::launch(pipe::sum_code_lengths, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
     emu::launch(pipe::scan_block_sums, dim3(count), dim3(64), 0, descs, wk);
