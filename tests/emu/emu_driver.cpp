@@ -174,5 +174,25 @@ void emu_join_intervals(const jls::ScanDesc* parents, const jls::ScanDesc* subs,
                 (const uint64_t*)offsets, (const jls::ScanResult*)results);
 }
 
+// The whole restart-interval encode of runtime.hip (launch_encode_intervals) for lossless scans, on the host: interval
+// descriptors, the pipeline on the intervals, the join.
+void emu_encode_with_restart_intervals(const jls::ScanDesc* parents, jls::ScanResult* results, int count, uint64_t capacity)
+{
+    using namespace jls;
+    const uint32_t lines = parents[0].restart_interval;
+    const uint32_t intervals = (parents[0].height + lines - 1) / lines;
+    const size_t subs_n = (size_t)count * intervals;
+    std::vector<ScanDesc> subs(subs_n);
+    std::vector<ScanResult> sub_results(subs_n);
+    std::vector<uint64_t> offsets(subs_n);
+    std::vector<uint8_t> buffers(capacity * subs_n + 64, 0xA5);
+    emu::launch(interval::build_encode_intervals, dim3(intervals, count), dim3(1), 0, parents, intervals, buffers.data(),
+                capacity, (uint16_t*)nullptr, (uint64_t)0, subs.data());
+    // the last interval of a scan may be shorter: the pipeline takes its geometry per scan, as in the product
+    for (size_t i = 0; i < subs_n; ++i)
+        emu_encode_pipeline(&subs[i], &sub_results[i], 1);
+    emu_join_intervals(parents, subs.data(), intervals, sub_results.data(), offsets.data(), results, count);
+}
+
 size_t emu_sizeof_scan_desc() { return sizeof(jls::ScanDesc); }
 }

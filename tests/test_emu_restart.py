@@ -132,3 +132,28 @@ def test_interval_descriptors_check_and_join():
     parent2.stream_capacity = 128
     L.emu_join_intervals(C.byref(parent2), subs2, C.c_uint32(3), sr, offsets.ctypes.data_as(C.c_void_p), res, 1)
     assert (res[0].errc, res[0].flags) == (0, 8)
+
+
+@pytest.mark.parametrize("comps,ilv,ri,w,h", [(1, 0, 3, 40, 8), (1, 0, 1, 17, 4), (3, 2, 2, 12, 5), (3, 1, 4, 9, 6)])
+def test_restart_interval_encode_end_to_end(comps, ilv, ri, w, h):
+    """launch_encode_intervals on the CPU: the joined scan equals the oracle's coding of every interval with FF D0+m between
+    them (for ILV_NONE / ILV_LINE / ILV_SAMPLE scans of the parallel pipeline)."""
+    import oracle_bind as ob
+    from charls_amd import synth
+    L = emu_bind.lib()
+    planes = [synth.frame_numpy(w, h, seed=90 + c, kind="mixed") for c in range(comps)]
+    img = planes[0] if comps == 1 else np.ascontiguousarray(np.stack(planes, axis=-1))
+    want, n = b"", (h + ri - 1) // ri
+    for j in range(n):
+        sub = np.ascontiguousarray(img[j * ri:(j + 1) * ri])
+        s = ob.encode(sub, width=w, height=sub.shape[0], component_count=comps, interleave_mode=ilv)
+        sc = jls_container.parse(s).scans[0]
+        want += s[sc.data_start:sc.data_end] + (bytes([0xFF, 0xD0 + (j & 7)]) if j + 1 < n else b"")
+    keep = []
+    pix = np.frombuffer(img.tobytes(), dtype=np.uint8).copy()
+    out = np.zeros(len(want) + 100, dtype=np.uint8)
+    d = emu_bind.make_desc(w, h, comps, ilv, 8, 0, 0, (255, 3, 7, 21, 64), ri, pix, w * comps, out, keep)
+    res = (emu_bind.ScanResult * 1)()
+    L.emu_encode_with_restart_intervals(C.byref(d), res, 1, C.c_uint64(w * ri * comps * 4 + 256))
+    assert (res[0].errc, res[0].flags, res[0].bytes) == (0, 0, len(want))
+    assert out[:len(want)].tobytes() == want
