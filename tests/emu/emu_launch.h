@@ -18,15 +18,15 @@ void launch(Kernel kernel, dim3 grid, dim3 block, size_t dyn_shared_bytes, Args.
     BlockState st;
     st.nthreads = n;
     st.dyn_shared = dyn_aligned;
-    pthread_barrier_init(&st.block_barrier, nullptr, n);
+    st.block_barrier.init(n);
     const int waves = (n + kWave - 1) / kWave;
     for (int w = 0; w < waves; ++w)
     {
         const int in_wave = (w == waves - 1) ? n - w * kWave : kWave;
-        pthread_barrier_init(&st.wave_barrier[w], nullptr, in_wave);
+        st.wave_barrier[w].init(in_wave);
     }
-    pthread_barrier_t between;
-    pthread_barrier_init(&between, nullptr, n);
+    SpinBarrier between;
+    between.init(n);
     g_block = &st;
     std::vector<std::thread> threads;
     threads.reserve(n);
@@ -41,15 +41,11 @@ void launch(Kernel kernel, dim3 grid, dim3 block, size_t dyn_shared_bytes, Args.
                     {
                         t_blockIdx = dim3(bx, by, bz);
                         kernel(args...);
-                        pthread_barrier_wait(&between);
+                        between.wait();
                     }
         });
     for (auto& th : threads)
         th.join();
-    pthread_barrier_destroy(&between);
-    pthread_barrier_destroy(&st.block_barrier);
-    for (int w = 0; w < waves; ++w)
-        pthread_barrier_destroy(&st.wave_barrier[w]);
 }
 
 } // namespace emu

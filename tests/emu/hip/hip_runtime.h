@@ -7,7 +7,9 @@
 // ballots, and the atomics the kernels use.  It is never part of the product and says nothing about performance.
 #pragma once
 #include <pthread.h>
+#include <sched.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
@@ -30,10 +32,38 @@ struct dim3
 
 namespace emu {
 constexpr int kWave = 64;
+
+// Sense-reversing barrier that yields instead of sleeping: the emulated lanes hit a barrier every few instructions and
+// there are many more of them than cores, so futex sleeps/wake-ups dominated the run time of the CPU test suite.
+struct SpinBarrier
+{
+    std::atomic<int> waiting{0};
+    std::atomic<int> generation{0};
+    int parties{0};
+    void init(int n)
+    {
+        parties = n;
+        waiting.store(0);
+        generation.store(0);
+    }
+    void wait()
+    {
+        const int gen = generation.load(std::memory_order_acquire);
+        if (waiting.fetch_add(1, std::memory_order_acq_rel) + 1 == parties)
+        {
+            waiting.store(0, std::memory_order_relaxed);
+            generation.fetch_add(1, std::memory_order_release);
+            return;
+        }
+        while (generation.load(std::memory_order_acquire) == gen)
+            sched_yield();
+    }
+};
+
 struct BlockState
 {
-    pthread_barrier_t block_barrier;
-    pthread_barrier_t wave_barrier[16];
+    SpinBarrier block_barrier;
+    SpinBarrier wave_barrier[16];
     unsigned long long xchg[16][kWave]; // per-wave exchange slots for shuffles / ballots
     int nthreads;
     unsigned char* dyn_shared;
@@ -50,7 +80,7 @@ static const int warpSize = 64;
 
 inline void __syncthreads()
 {
-    pthread_barrier_wait(&emu::g_block->block_barrier);
+    emu::g_block->block_barrier.wait();
 }
 
 inline int __clz(int x)
@@ -89,7 +119,7 @@ inline int wave_id()
 }
 inline void wave_sync()
 {
-    pthread_barrier_wait(&g_block->wave_barrier[wave_id()]);
+    g_block->wave_barrier[wave_id()].wait();
 }
 // All 64 lanes of the wave must call these convergently (the kernels are written that way).
 inline unsigned long long wave_exchange(unsigned long long mine, int src_lane)
