@@ -11,7 +11,7 @@ import jls_container
 
 import os
 
-FULL = os.environ.get("CHARLS_AMD_FULL_EMU") == "1"  # every golden case through every kernel (tens of minutes)
+FULL = os.environ.get("CHARLS_AMD_QUICK_EMU") != "1"  # every golden case through every kernel by default; CHARLS_AMD_QUICK_EMU=1 = subset
 CASES = [c for c in common.cases() if c["errc"] == 0 and "file" in c and c["width"] * c["height"] <= 128 * 128]
 # The thread-per-lane emulation of the wave-uniform kernels costs seconds per case: by default they run a subset that
 # covers every coding mode once; the one-lane kernel (cheap to emulate) always runs everything.
