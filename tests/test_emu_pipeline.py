@@ -212,3 +212,49 @@ def test_pipeline_line_interleaved_scans():
         cont = jls_container.parse(want)
         errc, flags, data = _encode_interleaved(L, img, w, h, comps, 8, xform, w * h * comps * 4 + 1024, ilv=1)
         assert errc == 0 and data == want[cont.scans[0].data_start:cont.scans[0].data_end], (trial, w, h, comps, xform)
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_pipeline_and_fast_decoder_random_parameters(chunk):
+    """Random lossless parameter sets (bits 2..16, custom thresholds / RESET, odd sizes, planar and interleaved) through the
+    emulated parallel encoder, and the single-component ones back through the emulated speed-path decoder."""
+    from test_oracle_vs_reference import _image
+    L = emu_bind.lib()
+    rng = np.random.default_rng(700 + chunk)
+    for it in range(25):
+        bits = int(rng.integers(2, 17))
+        comps = int(rng.choice([1, 1, 1, 2, 3, 4]))
+        ilv = 0 if comps == 1 else int(rng.integers(1, 3))
+        w, h = int(rng.choice([1, 2, 5, 17, 64, 65, 130])), int(rng.choice([1, 2, 3, 8, 21]))
+        maxval = (1 << bits) - 1
+        kind = str(rng.choice(["rand", "smooth", "gradient", "mixed", "zero", "hard"]))
+        preset = (0,) * 5
+        if rng.random() < 0.4:
+            t1 = int(rng.integers(1, maxval + 1))
+            t2 = int(rng.integers(t1, maxval + 1))
+            t3 = int(rng.integers(t2, maxval + 1))
+            preset = (0, t1, t2, t3, int(rng.integers(3, max(255, maxval) + 1)))
+        xform = int(rng.integers(0, 4)) if (comps == 3 and bits in (8, 16) and rng.random() < 0.5) else 0
+        img = _image(rng, w, h, bits, comps, ilv, kind, it)
+        want = ob.encode(img, width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=ilv,
+                         color_transformation=xform, preset=preset if any(preset) else None)
+        cont = jls_container.parse(want)
+        pc = jls_container.validated_pc(preset, bits, 0)
+        keep = []
+        pix = np.frombuffer(np.ascontiguousarray(img).tobytes(), dtype=np.uint8).copy()
+        out = np.zeros(w * h * comps * 5 + 1024, dtype=np.uint8)
+        bps = 1 if bits <= 8 else 2
+        d = emu_bind.make_desc(w, h, comps, ilv, bits, 0, xform, pc, 0, pix, w * comps * bps, out, keep)
+        res = (emu_bind.ScanResult * 1)()
+        L.emu_encode_pipeline((emu_bind.ScanDesc * 1)(d), res, 1)
+        scan = cont.scans[0]
+        tag = (chunk, it, bits, comps, ilv, w, h, kind, preset, xform)
+        assert res[0].errc == 0 and out[:res[0].bytes].tobytes() == want[scan.data_start:scan.data_end], tag
+        if comps == 1 and (pc[4] & 0xFF) != 0:
+            back = np.zeros(w * h * bps, dtype=np.uint8)
+            src = np.frombuffer(want[scan.data_start:] + bytes(64), dtype=np.uint8).copy()
+            dd = emu_bind.make_desc(w, h, 1, 0, bits, 0, 0, pc, 0, back, w * bps, src, keep)
+            dd.stream_capacity = len(want) - scan.data_start
+            r2 = (emu_bind.ScanResult * 1)()
+            L.emu_decode_scans_fast((emu_bind.ScanDesc * 1)(dd), r2, 1)
+            assert (r2[0].errc, r2[0].flags) == (0, 0) and back.tobytes() == np.ascontiguousarray(img).tobytes(), tag
