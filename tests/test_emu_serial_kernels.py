@@ -200,3 +200,55 @@ def test_emulated_fast_decoder_defers_on_corrupt_streams(name):
     res = (emu_bind.ScanResult * 1)()
     L.emu_decode_scans_fast((emu_bind.ScanDesc * 1)(d), res, 1)
     assert res[0].errc == 0 and res[0].flags == 4
+
+
+# ---- the decoder dispatch of runtime.hip (speed path, exact wave decoder on kFastRetry) on mutated streams -------------
+def _emulated_dispatch(L, jls, cont, scan):
+    """What launch_decode does for a single-component lossless scan: returns (errc, pixels or None)."""
+    pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+    bps = 1 if cont.bits <= 8 else 2
+    keep = []
+    pix = np.zeros(cont.width * cont.height * bps, dtype=np.uint8)
+    src = _stream_copy(jls, scan.data_start)
+    d = emu_bind.make_desc(cont.width, cont.height, 1, 0, cont.bits, 0, 0, pc, 0, pix, cont.width * bps, src, keep)
+    res = (emu_bind.ScanResult * 1)()
+    L.emu_decode_scans_fast((emu_bind.ScanDesc * 1)(d), res, 1)
+    if res[0].flags & 4:
+        L.emu_decode_scans_wave((emu_bind.ScanDesc * 1)(d), res, 1)
+    return res[0].errc, res[0].bytes, pix
+
+
+@pytest.mark.parametrize("bits,kind", [(8, "mixed"), (8, "zero"), (16, "mixed"), (12, "hard")])
+def test_emulated_dispatch_on_mutated_scan_data_matches_the_oracle(bits, kind):
+    import oracle_bind as ob
+    from charls_amd import synth
+    L = emu_bind.lib()
+    w, h = 48, 12
+    img = synth.frame_numpy(w, h, seed=bits, bits=bits, kind=kind)
+    base = ob.encode(img, width=w, height=h, bits_per_sample=bits)
+    cont = jls_container.parse(base)
+    scan = cont.scans[0]
+    rng = np.random.default_rng(bits * 7 + len(kind))
+    for k in range(40):
+        b = bytearray(base)
+        how = int(rng.integers(0, 4))
+        i = int(rng.integers(scan.data_start, len(b) - 2))
+        if how == 0:
+            b[i] ^= 1 << int(rng.integers(0, 8))
+        elif how == 1:
+            b[i] = int(rng.choice([0x00, 0xFF, 0x7F, 0x80]))
+        elif how == 2:
+            del b[i:i + int(rng.integers(1, 4))]
+        else:
+            b[i:i] = bytes([int(rng.choice([0x00, 0xFF, 0x55]))])
+        data = bytes(b)
+        try:
+            want = (0, ob.decode(data)[1].tobytes())
+        except ob.OracleError as e:
+            want = (e.errc, None)
+        c2 = jls_container.parse(data) if want[0] == 0 else cont
+        errc, used, pix = _emulated_dispatch(L, data, cont, scan)
+        if want[0] == 0:
+            assert errc == 0 and pix.tobytes() == want[1], (k, how, i)
+        else:
+            assert errc == want[0], (k, how, i, errc, want[0])
