@@ -35,6 +35,12 @@ def _bind(lib):
     l.charls_amd_last_timings.restype = C.c_int32
     l.charls_amd_set_encode_engine.argtypes = [C.c_int32]
     l.charls_amd_set_encode_engine.restype = C.c_int32
+    l.charls_amd_set_workspace_limit.argtypes = [C.c_uint64]
+    l.charls_amd_set_workspace_limit.restype = C.c_int32
+    l.charls_amd_release_work_areas.argtypes = []
+    l.charls_amd_release_work_areas.restype = C.c_int32
+    l.charls_amd_work_area_bytes.argtypes = []
+    l.charls_amd_work_area_bytes.restype = C.c_uint64
     l._batch_bound = True
     return l
 
@@ -112,6 +118,20 @@ def decode_batch(streams, sizes, out, *, lib=None):
     if rc != 0:
         raise capi.JpegLSError(rc, "charls_amd_decode_batch_device")
     return p, errcs, last_timings(lib)
+
+
+def set_workspace_limit(nbytes: int, lib=None):
+    """HBM the library may keep for its work areas (process-wide; 0 = a quarter of the device)."""
+    _bind(lib or capi.load_product()).charls_amd_set_workspace_limit(int(nbytes))
+
+
+def release_work_areas(lib=None):
+    """Frees the calling thread's work areas (they are re-allocated on demand)."""
+    _bind(lib or capi.load_product()).charls_amd_release_work_areas()
+
+
+def work_area_bytes(lib=None) -> int:
+    return int(_bind(lib or capi.load_product()).charls_amd_work_area_bytes())
 
 
 def set_encode_engine(engine: int, lib=None):

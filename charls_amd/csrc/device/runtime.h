@@ -122,6 +122,13 @@ void launch_advance_cursor(FrameCursorPod* cursors, const ScanResult* results, u
 void launch_place_epilogue(uint8_t* slots, uint64_t slot_pitch, FrameCursorPod* cursors, bool even_size, uint64_t* sizes,
                            uint32_t* errcs, uint32_t frames, hipStream_t stream);
 
+// HBM the library keeps for its own work areas (the lossless pipeline's per-scan work area, restart-interval buffers).
+// The limit is process-wide (0 = a quarter of the device's memory); the areas themselves belong to the calling thread,
+// grow on demand up to the limit and stay allocated between calls until released.
+void set_workspace_limit(uint64_t bytes) noexcept;
+void release_work_areas() noexcept;
+size_t work_area_bytes() noexcept;
+
 // Per-thread record of the last batch call's GPU time (charls_amd_last_timings).
 struct Timings
 {

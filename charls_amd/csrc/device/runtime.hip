@@ -13,6 +13,7 @@
 #include "scan_wave_decode.hip"
 #include "lossless_pipeline.hip"
 #include "scan_fast_decode.hip"
+#include "scan_group_decode.hip"
 #include "restart_intervals.hip"
 
 namespace jls::dev {
@@ -21,6 +22,7 @@ namespace {
 std::once_flag g_once;
 charls_jpegls_errc g_status = CHARLS_AMD_ERRC_DEVICE_UNAVAILABLE;
 std::atomic<int32_t> g_engine{0};
+std::atomic<uint64_t> g_workspace_limit{0}; // charls_amd_set_workspace_limit; 0 = a quarter of the device
 
 void probe() noexcept
 {
@@ -103,6 +105,11 @@ void set_encode_engine(EncodeEngine e) noexcept
     g_engine.store(static_cast<int32_t>(e));
 }
 
+void set_workspace_limit(uint64_t bytes) noexcept
+{
+    g_workspace_limit.store(bytes);
+}
+
 Timings& last_timings() noexcept
 {
     static thread_local Timings t{};
@@ -159,12 +166,61 @@ size_t fast_decode_lds(const ScanDesc& d)
     return (d.bits_per_sample > 8 ? fast::fixed_lds<uint16_t>() : fast::fixed_lds<uint8_t>()) + line_bytes;
 }
 
-// Lossless single-component scans take the speed path (scan_fast_decode.hip); it defers to the exact kernels whenever
-// the scan does not end cleanly.
+size_t group_region_bytes(const ScanDesc& d)
+{
+    return d.bits_per_sample > 8 ? grp::region_bytes<uint16_t>(d.width) : grp::region_bytes<uint8_t>(d.width);
+}
+
+// Lanes per scan of the speed path (scan_group_decode.hip): the most scans per wavefront whose lines fit the LDS of a
+// workgroup; 0 = the one-scan-per-wavefront kernel (scan_fast_decode.hip).  CHARLS_AMD_DECODE_GROUP overrides (0, 8, 16, 32).
+int decode_group_lanes(const ScanDesc& d)
+{
+    if (d.bits_per_sample > 8 && d.t3 > grp::kMaxTableT3)
+        return 0;
+    const char* env = std::getenv("CHARLS_AMD_DECODE_GROUP");
+    const int forced = env ? std::atoi(env) : -1;
+    const size_t region = group_region_bytes(d);
+    if (forced == 0)
+        return 0;
+    if ((forced == 8 || forced == 16 || forced == 32) && region * (64 / forced) <= kMaxDynamicLds)
+        return forced;
+    if (region * 4 <= kMaxDynamicLds)
+        return 16;
+    if (region * 2 <= kMaxDynamicLds)
+        return 32;
+    return 0;
+}
+
+// Lossless single-component scans take the speed path (scan_group_decode.hip / scan_fast_decode.hip); it defers to the
+// exact kernels whenever the scan does not end cleanly.
 bool fast_decode_eligible(const ScanDesc& d)
 {
     return wave_decode_eligible(d) && d.near_lossless == 0 && d.interleave_mode == 0 && d.components == 1 &&
-           fast_decode_lds(d) <= kMaxDynamicLds && std::getenv("CHARLS_AMD_EXACT_DECODER") == nullptr;
+           (fast_decode_lds(d) <= kMaxDynamicLds || decode_group_lanes(d) != 0) &&
+           std::getenv("CHARLS_AMD_EXACT_DECODER") == nullptr;
+}
+
+// Scans the speed path handed back (ScanResult.flags & kFastRetry) are gathered so that ONE launch of the exact decoder
+// takes all of them.
+__global__ void gather_retries(const ScanDesc* __restrict__ descs, const ScanResult* __restrict__ results, uint32_t count,
+                               ScanDesc* __restrict__ retry_descs, uint32_t* __restrict__ retry_index,
+                               uint32_t* __restrict__ retry_count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && (results[i].flags & fast::kFastRetry) != 0)
+    {
+        const uint32_t slot = atomicAdd(retry_count, 1u);
+        retry_index[slot] = i;
+        retry_descs[slot] = descs[i];
+    }
+}
+
+__global__ void scatter_retries(const ScanResult* __restrict__ retry_results, const uint32_t* __restrict__ retry_index,
+                                uint32_t retries, ScanResult* __restrict__ results)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < retries)
+        results[retry_index[s]] = retry_results[s];
 }
 
 template <typename S>
@@ -204,9 +260,10 @@ uint64_t decode_launch_key(const ScanDesc& d) noexcept
 }
 
 namespace {
+constexpr int kIntervalArenas = 8;
 DeviceBuffer& interval_arena(int which)
 {
-    static thread_local DeviceBuffer buffers[6];
+    static thread_local DeviceBuffer buffers[kIntervalArenas];
     return buffers[which];
 }
 
@@ -293,18 +350,56 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
         exact(d_descs, d_results, count);
         return;
     }
-    if (proto.bits_per_sample > 8)
-        hipLaunchKernelGGL((decode_scans_fast<uint16_t>), dim3(count), dim3(64), fast_decode_lds(proto), stream, d_descs, d_results);
+    const int group = decode_group_lanes(proto);
+    if (group == 0)
+    {
+        if (proto.bits_per_sample > 8)
+            hipLaunchKernelGGL((decode_scans_fast<uint16_t>), dim3(count), dim3(64), fast_decode_lds(proto), stream, d_descs, d_results);
+        else
+            hipLaunchKernelGGL((decode_scans_fast<uint8_t>), dim3(count), dim3(64), fast_decode_lds(proto), stream, d_descs, d_results);
+    }
     else
-        hipLaunchKernelGGL((decode_scans_fast<uint8_t>), dim3(count), dim3(64), fast_decode_lds(proto), stream, d_descs, d_results);
+    {
+        const uint32_t per_wave = 64u / static_cast<uint32_t>(group);
+        const dim3 grid((count + per_wave - 1) / per_wave);
+        const size_t lds = group_region_bytes(proto) * per_wave;
+#define JLS_LAUNCH_GROUP(S, G) hipLaunchKernelGGL((decode_scans_group<S, G>), grid, dim3(64), lds, stream, d_descs, d_results, count)
+        const bool wide = proto.bits_per_sample > 8;
+        if (group == 8)
+        {
+            if (wide) JLS_LAUNCH_GROUP(uint16_t, 8); else JLS_LAUNCH_GROUP(uint8_t, 8);
+        }
+        else if (group == 16)
+        {
+            if (wide) JLS_LAUNCH_GROUP(uint16_t, 16); else JLS_LAUNCH_GROUP(uint8_t, 16);
+        }
+        else
+        {
+            if (wide) JLS_LAUNCH_GROUP(uint16_t, 32); else JLS_LAUNCH_GROUP(uint8_t, 32);
+        }
+#undef JLS_LAUNCH_GROUP
+    }
     hip_check(hipGetLastError());
-    // scans that did not end cleanly are decided by the exact decoder (error codes and byte counts of the reference)
-    std::vector<ScanResult> results(count);
-    hip_check(hipMemcpyAsync(results.data(), d_results, sizeof(ScanResult) * count, hipMemcpyDeviceToHost, stream));
+    // scans that did not end cleanly are decided by the exact decoder (error codes and byte counts of the reference):
+    // they are gathered on the device and decoded by one launch
+    auto* d_retry_count = static_cast<uint32_t*>(interval_arena(4).ensure(sizeof(uint32_t)));
+    hip_check(hipMemsetAsync(d_retry_count, 0, sizeof(uint32_t), stream));
+    auto* d_retry_index = static_cast<uint32_t*>(interval_arena(5).ensure(sizeof(uint32_t) * count));
+    auto* d_retry_descs = static_cast<ScanDesc*>(interval_arena(6).ensure(sizeof(ScanDesc) * count));
+    hipLaunchKernelGGL(gather_retries, dim3((count + 255) / 256), dim3(256), 0, stream, d_descs,
+                       static_cast<const ScanResult*>(d_results), count, d_retry_descs, d_retry_index, d_retry_count);
+    hip_check(hipGetLastError());
+    uint32_t retries = 0;
+    hip_check(hipMemcpyAsync(&retries, d_retry_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     hip_check(hipStreamSynchronize(stream));
-    for (uint32_t i = 0; i < count; ++i)
-        if ((results[i].flags & fast::kFastRetry) != 0)
-            exact(d_descs + i, d_results + i, 1);
+    if (retries == 0)
+        return;
+    auto* d_retry_results = static_cast<ScanResult*>(interval_arena(7).ensure(sizeof(ScanResult) * retries));
+    exact(d_retry_descs, d_retry_results, retries);
+    hipLaunchKernelGGL(scatter_retries, dim3((retries + 255) / 256), dim3(256), 0, stream,
+                       static_cast<const ScanResult*>(d_retry_results), static_cast<const uint32_t*>(d_retry_index), retries,
+                       d_results);
+    hip_check(hipGetLastError());
 }
 } // namespace
 
@@ -390,21 +485,36 @@ DeviceBuffer& pipeline_arena()
     return arena;
 }
 
-constexpr size_t kArenaBudget = size_t{96} << 30; // most HBM the pipeline uses for work areas per call
 constexpr size_t kArenaReserve = size_t{8} << 30; // HBM left to the caller (collective buffers, ...) when the device is nearly full
 
-// Work-area budget of this call: what is free now (plus what the arena already holds), capped by kArenaBudget.
+// Work-area budget of this call: the workspace limit, capped by what is free now (plus what the arena already holds).
 size_t arena_budget(size_t held)
 {
     size_t free_bytes = 0, total_bytes = 0;
     if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess)
     {
         (void)hipGetLastError();
-        return kArenaBudget;
+        return size_t{1} << 30;
     }
+    const uint64_t configured = g_workspace_limit.load();
+    const size_t limit = configured != 0 ? static_cast<size_t>(configured) : total_bytes / 4;
     const size_t reachable = free_bytes + held;
-    const size_t usable = reachable > kArenaReserve ? reachable - kArenaReserve : 0;
-    return std::min(kArenaBudget, usable);
+    const size_t usable = reachable > kArenaReserve ? reachable - kArenaReserve : reachable / 2;
+    return std::min(limit, usable);
+}
+
+// ensure() that reports failure instead of raising (the arena is released, so the next attempt starts clean).
+void* try_ensure(DeviceBuffer& buffer, size_t bytes) noexcept
+{
+    try
+    {
+        return buffer.ensure(bytes);
+    }
+    catch (const error&)
+    {
+        (void)hipGetLastError();
+        return nullptr;
+    }
 }
 
 template <typename S>
@@ -412,8 +522,22 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
 {
     const PipeLayout lay(proto, proto.stream_capacity);
     const size_t budget = arena_budget(pipeline_arena().capacity());
-    const uint32_t per_pass = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, budget / (lay.bytes + sizeof(pipe::Work)))));
-    auto* arena = static_cast<uint8_t*>(pipeline_arena().ensure(lay.bytes * per_pass + per_pass * sizeof(pipe::Work)));
+    const size_t per_scan = lay.bytes + sizeof(pipe::Work);
+    uint32_t per_pass = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, budget / per_scan)));
+    uint8_t* arena = nullptr;
+    for (;;)
+    { // less HBM than the budget promised (fragmentation, another process): fewer scans per pass
+        arena = static_cast<uint8_t*>(try_ensure(pipeline_arena(), per_scan * per_pass));
+        if (arena != nullptr || per_pass == 1)
+            break;
+        per_pass = (per_pass + 1) / 2;
+    }
+    if (arena == nullptr)
+    { // not even one work area: the one-wavefront-per-scan kernel needs none
+        launch_encode_serial(d_descs, d_results, count, stream);
+        last_timings().count = 2;
+        return;
+    }
     auto* d_works = reinterpret_cast<pipe::Work*>(arena + lay.bytes * per_pass);
     std::vector<pipe::Work> works(per_pass);
     Timings& tm = last_timings();
@@ -601,6 +725,21 @@ void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_resul
     for (uint32_t i = 0; i < count; ++i)
         if (results[i].errc == kOk && (results[i].flags & 2u) != 0)
             launch_encode_serial(d_descs + i, d_results + i, 1, stream);
+}
+
+void release_work_areas() noexcept
+{
+    pipeline_arena().release();
+    for (int i = 0; i < kIntervalArenas; ++i)
+        interval_arena(i).release();
+}
+
+size_t work_area_bytes() noexcept
+{
+    size_t total = pipeline_arena().capacity();
+    for (int i = 0; i < kIntervalArenas; ++i)
+        total += interval_arena(i).capacity();
+    return total;
 }
 
 static_assert(sizeof(FrameCursorPod) == sizeof(FrameCursor), "cursor layout");

@@ -151,6 +151,23 @@ charls_jpegls_errc charls_amd_set_encode_engine(int32_t engine)
     return CHARLS_JPEGLS_ERRC_SUCCESS;
 }
 
+charls_jpegls_errc charls_amd_set_workspace_limit(uint64_t bytes)
+{
+    dev::set_workspace_limit(bytes);
+    return CHARLS_JPEGLS_ERRC_SUCCESS;
+}
+
+charls_jpegls_errc charls_amd_release_work_areas(void)
+{
+    dev::release_work_areas();
+    return CHARLS_JPEGLS_ERRC_SUCCESS;
+}
+
+uint64_t charls_amd_work_area_bytes(void)
+{
+    return dev::work_area_bytes();
+}
+
 int32_t charls_amd_last_timings(double* out, int32_t capacity)
 {
     const dev::Timings& t = dev::last_timings();

@@ -55,6 +55,8 @@ ScanResult ScanEngine::run(const ScanDesc& desc, bool decode)
         dev::launch_encode(desc, d_desc, d_result, 1, stream_);
     hip_check(hipMemcpyAsync(staged + sizeof desc, d_result, sizeof(ScanResult), hipMemcpyDeviceToHost, stream_));
     hip_check(hipStreamSynchronize(stream_));
+    if (dev::work_area_bytes() > (size_t{1} << 30))
+        dev::release_work_areas(); // a drop-in library must not sit on gigabytes of the caller's HBM between calls
     ScanResult r;
     std::memcpy(&r, staged + sizeof desc, sizeof r);
     return r;

@@ -312,6 +312,16 @@ CHARLS_AMD_API charls_jpegls_errc charls_amd_jpegls_encoder_set_restart_interval
  * kernel, 2 = force the parallel pipeline (returns invalid_argument when the scan is not eligible). Process-wide. */
 CHARLS_AMD_API charls_jpegls_errc charls_amd_set_encode_engine(int32_t engine);
 
+/* HBM kept by the library for its own work areas (the lossless encoder's per-scan work area of 21 B per sample, the
+ * private buffers of restart intervals).  They belong to the calling thread, grow on demand and stay allocated between
+ * calls.  The limit is process-wide: 0 (the default) = a quarter of the device's memory, and never more than what is
+ * free minus 8 GiB.  A batch larger than the limit allows is coded in several passes; when not even one work area can be
+ * allocated the encoder falls back to its one-wavefront-per-scan kernel, which needs none.  The host-pointer encoder /
+ * decoder of part 1 release work areas above 1 GiB before they return. */
+CHARLS_AMD_API charls_jpegls_errc charls_amd_set_workspace_limit(uint64_t bytes);
+CHARLS_AMD_API charls_jpegls_errc charls_amd_release_work_areas(void); /* the calling thread's */
+CHARLS_AMD_API uint64_t charls_amd_work_area_bytes(void);              /* the calling thread's, currently allocated */
+
 /* Milliseconds of GPU time (hipEvent) the last batch call on this thread spent in its kernels, by stage:
  * out[0] total, out[1] dominant kernel, out[2..7] stage breakdown. Returns the number of values. */
 CHARLS_AMD_API int32_t charls_amd_last_timings(double* out, int32_t capacity);

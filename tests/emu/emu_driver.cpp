@@ -9,6 +9,7 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 #include "../../charls_amd/csrc/device/scan_serial.hip"
 #include "../../charls_amd/csrc/device/lossless_pipeline.hip"
 #include "../../charls_amd/csrc/device/scan_fast_decode.hip"
+#include "../../charls_amd/csrc/device/scan_group_decode.hip"
 #include "../../charls_amd/csrc/device/restart_intervals.hip"
 
 #include <cstdlib>
@@ -142,6 +143,33 @@ int emu_decode_scans_fast(const jls::ScanDesc* descs, jls::ScanResult* results, 
         emu::launch(jls::decode_scans_fast<uint16_t>, dim3(count), dim3(64), lds, descs, results);
     else
         emu::launch(jls::decode_scans_fast<uint8_t>, dim3(count), dim3(64), lds, descs, results);
+    return 0;
+}
+
+// scan_group_decode.hip: `group` lanes per scan, 64 / group scans per workgroup (all scans share descs[0]'s geometry).
+int emu_decode_scans_group(const jls::ScanDesc* descs, jls::ScanResult* results, int count, int group)
+{
+    const jls::ScanDesc& d = descs[0];
+    const bool wide = d.bits_per_sample > 8;
+    const int per_wave = 64 / group;
+    const size_t lds = (size_t)per_wave * (wide ? jls::grp::region_bytes<uint16_t>(d.width) : jls::grp::region_bytes<uint8_t>(d.width));
+    const dim3 grid((count + per_wave - 1) / per_wave);
+#define EMU_GROUP(S, G) emu::launch(jls::decode_scans_group<S, G>, grid, dim3(64), lds, descs, results, (uint32_t)count)
+    if (group == 8)
+    {
+        if (wide) EMU_GROUP(uint16_t, 8); else EMU_GROUP(uint8_t, 8);
+    }
+    else if (group == 16)
+    {
+        if (wide) EMU_GROUP(uint16_t, 16); else EMU_GROUP(uint8_t, 16);
+    }
+    else if (group == 32)
+    {
+        if (wide) EMU_GROUP(uint16_t, 32); else EMU_GROUP(uint8_t, 32);
+    }
+    else
+        return -1;
+#undef EMU_GROUP
     return 0;
 }
 

@@ -1,0 +1,60 @@
+"""Decode throughput of the speed-path kernels over batch sizes (batch API, frames resident in HBM).
+Run on the GPU box: python tools/decode_sweep.py [--frames 4096] [--groups 0,16] [--sizes 64,256,1024,4096] [--bits 8]
+CHARLS_AMD_DECODE_GROUP: 0 = one scan per wavefront (scan_fast_decode.hip), 8/16/32 = lanes per scan (scan_group_decode.hip)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from charls_amd import batch, capi, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=4096)
+ap.add_argument("--width", type=int, default=4096)
+ap.add_argument("--height", type=int, default=4096)
+ap.add_argument("--bits", type=int, default=8)
+ap.add_argument("--groups", default="0,16")
+ap.add_argument("--sizes", default="64,256,1024,4096")
+ap.add_argument("--repeat", type=int, default=1)
+args = ap.parse_args()
+
+lib = capi.load_product()
+dev = torch.device("cuda:0")
+t0 = time.perf_counter()
+frames = synth.frames_torch(args.frames, args.width, args.height, seed0=2, bits=args.bits, device=dev)
+torch.cuda.synchronize()
+out = torch.empty_like(frames)
+batch.set_workspace_limit(64 << 30, lib)
+t1 = time.perf_counter()
+enc = batch.encode_batch(frames, bits_per_sample=args.bits, lib=lib)
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+assert (enc.errcs == 0).all()
+batch.release_work_areas(lib)
+mpix = args.width * args.height / 1e6
+print(f"synth {t1 - t0:.1f}s encode {t2 - t1:.2f}s = {mpix * args.frames / (t2 - t1):.0f} MPix/s", flush=True)
+rows = []
+for g in [int(x) for x in args.groups.split(",")]:
+    os.environ["CHARLS_AMD_DECODE_GROUP"] = str(g)
+    for n in [int(x) for x in args.sizes.split(",")]:
+        if n > args.frames:
+            continue
+        best = None
+        for it in range(args.repeat + 1):  # first pass warms allocations
+            out[:n].zero_()
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            params, errcs, gpu_ms = batch.decode_batch(enc.streams[:n], enc.sizes[:n], out[:n], lib=lib)
+            torch.cuda.synchronize()
+            b = time.perf_counter()
+            best = b - a if best is None or (it > 0 and b - a < best) or it == 1 else best
+        ok = bool((errcs == 0).all())
+        for f0 in range(0, n, 64):  # compare in pieces: torch.equal materialises a mask of the operands' size
+            ok = ok and torch.equal(out[f0:min(n, f0 + 64)], frames[f0:min(n, f0 + 64)])
+        rows.append({"group": g, "frames": n, "decode_s": round(best, 4), "mpix_s": round(mpix * n / best, 1),
+                     "kernel_ms": round(gpu_ms[0], 2), "ok": ok})
+        print(json.dumps(rows[-1]), flush=True)
