@@ -62,19 +62,27 @@ struct Record
     uint32_t ncb;
 };
 
-// 32 dense bits starting at bit p (MSB first).
+// The dense bit ring is LSB first: stream bit j is bit (j & 31) of word (j >> 5), so that the next 32 bits of the stream are
+// one funnel shift (v_alignbit_b32) of two neighbouring words, the unary prefix is a count of TRAILING zeros, and a
+// k-bit field of the stream (whose first bit is the most significant) is the bit-reversed low end of the window.
 JLS_DEV uint32_t peek32(const uint32_t* ring, uint32_t p)
 {
     const uint32_t wi = (p >> 5) & (kRingWords - 1);
-    const uint64_t both = ((uint64_t)ring[wi] << 32) | ring[wi + 1];
-    return (uint32_t)((both << (p & 31)) >> 32);
+    const uint64_t both = ((uint64_t)ring[wi + 1] << 32) | ring[wi];
+    return (uint32_t)(both >> (p & 31));
+}
+
+// Value of the first n bits of window w, first bit most significant (0 <= n <= 32).
+JLS_DEV uint32_t field(uint32_t w, int n)
+{
+    return (uint32_t)(((uint64_t)bit_reverse(w) << n) >> 32);
 }
 
 JLS_DEV uint32_t take_bits(const uint32_t* ring, uint32_t& p, int n) // 0 <= n <= 32
 {
     const uint32_t w = peek32(ring, p);
     p += (uint32_t)n;
-    return n == 0 ? 0u : w >> (32 - n);
+    return field(w, n);
 }
 
 // Producer of one scan's dense bit ring (all members replicated over the lanes of the group).
@@ -90,27 +98,21 @@ struct Producer
     bool ended;           // marker or end of source reached: `produced` is final
 };
 
-// OR `n` (1..8) bits, right aligned in v, at dense bit position p.
+// OR `n` (1..8) bits, right aligned in v with the first bit of the stream most significant, at dense bit position p.
 JLS_DEV void put_bits(uint32_t* ring, uint32_t p, uint32_t v, int n)
 {
     const uint32_t q = (p >> 5) & (kRingWords - 1);
     const int off = (int)(p & 31);
-    const int room = 32 - off;
-    if (n <= room)
+    const uint32_t rv = bit_reverse(v) >> (32 - n); // first bit of the stream at bit 0
+    atomicOr(&ring[q], rv << off);
+    if (q == 0)
+        atomicOr(&ring[kRingWords], rv << off);
+    if (off + n > 32)
     {
-        atomicOr(&ring[q], v << (room - n));
-        if (q == 0)
-            atomicOr(&ring[kRingWords], v << (room - n));
-    }
-    else
-    {
-        atomicOr(&ring[q], v >> (n - room));
-        if (q == 0)
-            atomicOr(&ring[kRingWords], v >> (n - room));
         const uint32_t q2 = (q + 1) & (kRingWords - 1);
-        atomicOr(&ring[q2], v << (32 - (n - room)));
+        atomicOr(&ring[q2], rv >> (32 - off));
         if (q2 == 0)
-            atomicOr(&ring[kRingWords], v << (32 - (n - room)));
+            atomicOr(&ring[kRingWords], rv >> (32 - off));
     }
 }
 
@@ -229,7 +231,7 @@ JLS_DEV int take_unary(const uint32_t* ring, uint32_t& p, int most)
     for (;;)
     {
         const uint32_t w = peek32(ring, p);
-        const int u = w == 0 ? 32 : __clz((int)w);
+        const int u = w == 0 ? 32 : __ffs((int)w) - 1;
         if (u < 32)
         {
             p += (uint32_t)(u + 1);
@@ -246,12 +248,20 @@ JLS_DEV int take_unary(const uint32_t* ring, uint32_t& p, int most)
 } // namespace grp
 
 // Dynamic LDS: (64 / G) * grp::region_bytes<S>(width).  `count` scans, 64 / G of them per workgroup of one wavefront.
+//
+// A lone wavefront issues one instruction every 4.3 - 5 cycles whatever its kind or dependences, and an LDS read returns
+// after 48 cycles, hidden by eleven independent instructions (profiles/r02_microbench_latency.txt).  A step of the loop
+// below therefore costs its instruction count, and the loop is written for that count: the window of the previous line
+// is one packed register that slides with v_alignbit, the two gradients that depend on the previous line only are
+// carried as T = 9 Q1 + Q2, sign handling is three multiply-adds with +-1, the RESET halving is a rarely taken block, and
+// what an event needs (run mode or an unusual code) is worked out after the loop from the state it leaves behind.
 template <typename S, int G>
 __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restrict__ descs, ScanResult* __restrict__ results,
                                                          uint32_t count)
 {
     using namespace grp;
     using L = Layout<S>;
+    static_assert(G == 8 || G == 16 || G == 32, "lanes per scan");
     constexpr int kScansPerWave = 64 / G;
     constexpr bool kWide = sizeof(S) > 1;
     JLS_DYNAMIC_LDS(smem);
@@ -299,31 +309,43 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
     }
     JLS_LOCKSTEP();
 
-    enum : int { kNone = 0, kRun, kSlow };
     enum : int { kLineStart = 0, kInLine, kDrain, kDone };
     int phase = !live ? kDone : (d.height == 0 ? kDrain : kLineStart);
     bool retry = false;
     uint32_t p = 0;     // consumed dense bits
     uint32_t y = 0, i = 1;
     int corner = 0, first = 0, run_index = 0;
-    int a = 0, b = 0, c = 0, dd = 0, dnn = 0; // Ra, Rb = prev[i], Rc = prev[i - 1], prev[i + 1], prev[i + 2]
-    int q1 = 0, q2 = 0;                       // quantised prev[i + 1] - prev[i] and prev[i] - prev[i - 1]
-    uint32_t a_seen = 0;                      // OR of every updated A (samples wider than 8 bits): 2^24 overflow test
+    // Window of the previous line around sample i: prev[i - 1], prev[i], prev[i + 1], prev[i + 2] = Rc, Rb, Rd and the
+    // sample after it.  8-bit samples: one byte each in w0; wider samples: two halves each in w0 (Rc, Rb) and w1.
+    uint32_t w0 = 0, w1 = 0;
+    int a = 0;           // Ra
+    int q1 = 0, t9 = 0;  // Q1 = quantised (Rd - Rb) and T = 9 Q1 + Q2 of sample i
+    uint32_t a_seen = 0; // OR of every updated A (samples wider than 8 bits): 2^24 overflow test
     const int maxval = t.maxval, reset = t.reset;
-    const int limit_m = t.limit - t.qbpp - 1;
+    const uint32_t limit_m = (uint32_t)(t.limit - t.qbpp - 1);
 
     auto quantised = [&](int diff) -> int {
         if (kWide)
-            diff = diff < -cap ? -cap : (diff > cap ? cap : diff);
+            diff = med3(diff, -cap, cap);
         return (int)lut[diff + cap];
     };
-    // (re)loads the window of the previous line for sample i; c (= prev[i - 1]) is the caller's
-    auto prime = [&]() {
-        b = (int)line[i];
-        dd = (int)line[i + 1];
-        dnn = (int)line[i + 2];
-        q2 = quantised(b - c);
-        q1 = quantised(dd - b);
+    auto rc_of = [&]() -> int { return kWide ? (int)(w0 & 0xFFFFu) : (int)(w0 & 0xFFu); };
+    auto rb_of = [&]() -> int { return kWide ? (int)(w0 >> 16) : (int)((w0 >> 8) & 0xFFu); };
+    auto rd_of = [&]() -> int { return kWide ? (int)(w1 & 0xFFFFu) : (int)((w0 >> 16) & 0xFFu); };
+    auto rd2_of = [&]() -> int { return kWide ? (int)(w1 >> 16) : (int)(w0 >> 24); };
+    // (re)loads the window of the previous line for sample i; rc = prev[i - 1] is the caller's (that slot of the line
+    // already holds the current line)
+    auto prime = [&](int rc) {
+        const uint32_t rb = line[i], rd = line[i + 1], rd2 = line[i + 2];
+        if (kWide)
+        {
+            w0 = (uint32_t)rc | (rb << 16);
+            w1 = rd | (rd2 << 16);
+        }
+        else
+            w0 = (uint32_t)rc | (rb << 8) | (rd << 16) | (rd2 << 24);
+        q1 = quantised((int)rd - (int)rb);
+        t9 = 9 * q1 + quantised((int)rb - rc);
     };
 
     for (;;)
@@ -350,90 +372,141 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 JLS_LOCKSTEP();
                 if (starting)
                 {
-                    c = corner;          // prev[0]
                     i = 1;
-                    prime();
-                    a = b;               // cur[0] = prev[1]
-                    first = b;
+                    prime(corner);       // Rc = prev[0]
+                    a = rb_of();         // cur[0] = prev[1]
+                    first = a;
                     phase = kInLine;
                 }
             }
         }
         // ---- step loop: one regular-mode sample per scan and step
-        int event = kNone;
-        for (int step = 0; step < kStepsPerCheck; ++step)
+        const bool in_line = phase == kInLine; // i <= width: the end of a line is handled as soon as it is reached
+        const LaneMask in_line_m = lanes_where(in_line);
+        LaneMask ok_m = ~0ull; // lanes whose last step decoded a sample
+        int qs = 0;
+        if (in_line_m != 0)
         {
-            const bool active = phase == kInLine && i <= width;
-            const uint32_t win = peek32(ring, p);
-            const int q1n = quantised(dnn - dd);
-            const int q3 = quantised(c - a);
-            const int qs = 81 * q1 + 9 * q2 + q3;
-            const int s = qs >> 31;
-            const int idx = (qs ^ s) - s;
-            const Record rec = records[idx]; // idx 0 (run mode) reads a valid, unused record
-            const int ctx_a = (int)rec.a;
-            const int n = (int)(rec.ncb & 0xFFu);
-            const int cc = (int)(signed char)(rec.ncb >> 8);
-            const int bb = (int)rec.ncb >> 16;
-            int k = __clz(n) - __clz(ctx_a); // N >= 1; A may be 0 (then k = 0)
-            k = k < 0 ? 0 : k;
-            k += ((n << k) < ctx_a);
-            const int u = win == 0 ? 32 : __clz((int)win);
-            const bool fits = u < limit_m && u + 1 + k <= 32 && (!kWide || k < 16);
-            const bool ok = active && qs != 0 && fits;
-            // Golomb code -> mapped error -> Errval (src/scan_decoder_core.hpp:38-69)
-            const uint32_t rest = (win << u) << 1;
-            const int mm = (u << k) | (int)(uint32_t)(((uint64_t)rest << k) >> 32);
-            int e = (mm >> 1) ^ -(mm & 1);
-            e ^= ((k - 1) & (2 * bb + n - 1)) >> 31; // k = 0 and 2B + N - 1 < 0: src/regular_mode_context.hpp:36-42
-            // MED predictor = median(Ra, Rb, Ra + Rb - Rc), src/jpegls_algorithm.hpp:143-161, plus the bias C
-            const int px = med3(med3(a + (b - c), a, b) + ((cc ^ s) - s), 0, maxval);
-            const int x = (px + ((e ^ s) - s)) & maxval;
-            // A.12 / A.13, src/regular_mode_context.hpp:45-93 (|B| cannot overflow in lossless mode).  With N' the new N
-            // and tb = B + Errval (halved at a reset): delta = (tb > 0) - (tb + N' <= 0),
-            // B' = median(tb - delta * N', 1 - N', 0), C' = median(C + delta, -128, 127).
-            const int a_new = ctx_a + (e < 0 ? -e : e);
-            const int sh = n == reset;
-            const int n_new = (n >> sh) + 1;
-            const int tb = (bb + e) >> sh;
-            const int minus_delta = 1 - med3(tb, 0, 1) - med3(tb + n_new, 0, 1);
-            const int b_new = med3(tb + minus_delta * n_new, 1 - n_new, 0);
-            const int c_new = med3(cc - minus_delta, -128, 127);
-            JLS_LOCKSTEP();
-            if (ok)
+            // no scan may step past the end of its line: the wavefront takes as many steps as the shortest rest allows
+            const uint32_t rest_of_line = width + 1 - i;
+            uint32_t steps = kStepsPerCheck;
+            while (lanes_where(in_line && rest_of_line < steps) != 0)
+                --steps;
+            // lanes outside their line never pass the `u < limit` test below
+            const uint32_t limit_v = opaque(in_line ? limit_m : 0u);
+            S* lp = line + i; // slot of sample i; lp[1..] still hold the previous line
+            uint32_t k_seen = 0, mm_seen = 0;
+            uint32_t ticker = 1u << (steps - 1); // `steps` steps, 1 <= steps <= kStepsPerCheck
+            do
             {
-                records[idx] = Record{(uint32_t)(a_new >> sh),
-                                      (uint32_t)n_new | (((uint32_t)c_new & 0xFFu) << 8) | ((uint32_t)b_new << 16)};
-                line[i] = (S)x;
+                // independent of the chain: the next sample of the previous line, the bit window, Q1 of the next sample
+                const uint32_t next_prev = lp[3];
+                const uint32_t win = peek32(ring, p);
+                const int q1n = quantised(rd2_of() - rd_of());
+                const int t9n = mad24(q1n, 9, q1);
+                // the chain: Ra -> Q3 -> context -> k -> code -> Errval -> sample
+                const int rc = rc_of(), rb = rb_of();
+                const int q3 = quantised(rc - a);
+                qs = mad24(t9, 9, q3);
+                const int sgn = (qs >> 31) | 1;
+                const int idx = __mul24(qs, sgn);
+                const Record rec = records[idx]; // idx 0 (run mode) reads a valid, unused record
+                const uint32_t u = lowest_one(win); // length of the unary prefix; 0xFFFFFFFF for an all-zero window
+                const int ctx_a = (int)rec.a;
+                const int n = (int)(rec.ncb & 0xFFu);
+                const int cc = (int)(signed char)(rec.ncb >> 8);
+                const int bb = (int)rec.ncb >> 16;
+                // k = min{k : N << k >= A} (N >= 1; A may be 0, then k = 0).  Scaling a float by 2^k adds k << 23 to its bit
+                // pattern and positive floats order like their bit patterns, so N * 2^k >= A <=> k << 23 >= bits(A) - bits(N):
+                // k = max(0, ceil((bits(A) - bits(N)) / 2^23)).  A < 2^24 and N <= 255 convert exactly.
+                const int k_raw = ((int)(float_bits((uint32_t)ctx_a) - float_bits((uint32_t)n)) + 0x7FFFFF) >> 23;
+                const int k = k_raw < 0 ? 0 : k_raw;
+                // A regular-mode sample whose code lies inside the 32-bit window.  8-bit samples: valid streams keep
+                // A / N < 2^9, so k <= 9, and u < LIMIT - qbpp - 1 <= 23 then bounds the code by 32 bits and |Errval| by
+                // 5888; k (and, for wider samples, the mapped error) are only accumulated here and examined after the
+                // loop: a stream that breaks those bounds is invalid and goes to the exact decoder as a whole.
+                ok_m = lanes_where(qs != 0) & lanes_where(u < limit_v);
+                if (kWide)
+                    ok_m &= lanes_where(u + (uint32_t)k < 32u);
+                const bool ok = lane_of(ok_m);
+                // Golomb code -> mapped error -> Errval (src/scan_decoder_core.hpp:38-69)
+                const uint32_t u1 = u + 1u; // the window beyond the prefix: u1 = 32 only with k = 0, where no field is read
+                const int mm = (int)((u << k) | field(win >> (u1 & 31u), k));
+                // Errval = unmap(mm), complemented when k = 0 and 2B + N - 1 < 0 (src/regular_mode_context.hpp:36-42):
+                // e = (mm >> 1) ^ -odd and |e| = (mm >> 1) + odd with odd = the low bit of mm, flipped by the correction
+                const int half = mm >> 1;
+                const int odd = (mm ^ (((k - 1) & (2 * bb + n - 1)) >> 31)) & 1;
+                const int e = half ^ -odd;
+                // MED predictor = median(Ra, Rb, Ra + Rb - Rc), src/jpegls_algorithm.hpp:143-161, plus the bias C
+                const int px = med3(mad24(cc, sgn, med3(a + (rb - rc), a, rb)), 0, maxval);
+                const int x = mad24(e, sgn, px) & maxval;
+                // A.12 / A.13, src/regular_mode_context.hpp:45-93 (|B| cannot overflow in lossless mode).  With N' the new
+                // N and tb = B + Errval (halved at a reset): delta = (tb > 0) - (tb + N' <= 0),
+                // B' = median(tb - delta * N', 1 - N', 0), C' = median(C + delta, -128, 127).
+                int a_new = ctx_a + half + odd;
                 if (kWide)
                     a_seen |= (uint32_t)a_new;
-                p += (uint32_t)(u + 1 + k);
-                a = x;
-                c = b;
-                b = dd;
-                dd = dnn;
-                dnn = (int)line[i + 3];
-                q2 = q1;
-                q1 = q1n;
-                ++i;
-            }
-            else if (active)
-                event = qs == 0 ? kRun : kSlow;
-            JLS_LOCKSTEP();
-            if (__any(event != kNone || (phase == kInLine && i > width)))
-                break;
+                int n_old = n;
+                int tb = bb + e;
+                const LaneMask halve_m = ok_m & lanes_where(n == reset);
+                if (halve_m != 0)
+                { // once per RESET samples of a context
+                    JLS_RARE_BLOCK();
+                    if (lane_of(halve_m))
+                    {
+                        a_new >>= 1;
+                        n_old >>= 1;
+                        tb >>= 1;
+                    }
+                }
+                const int n_new = n_old + 1;
+                const int minus_delta = 1 - med3(tb, 0, 1) - med3(tb + n_new, 0, 1);
+                const int b_new = med3(mad24(minus_delta, n_new, tb), -n_old, 0);
+                const int c_new = med3(cc - minus_delta, -128, 127);
+                JLS_LOCKSTEP();
+                if (ok)
+                {
+                    records[idx] = Record{(uint32_t)a_new, ((uint32_t)b_new << 16) | pack_bytes((uint32_t)c_new, (uint32_t)n_new)};
+                    lp[0] = (S)x;
+                    p += u1 + (uint32_t)k;
+                    a = x;
+                    if (kWide)
+                    {
+                        w0 = (w0 >> 16) | (w1 << 16);
+                        w1 = (w1 >> 16) | (next_prev << 16);
+                        mm_seen |= (uint32_t)mm;
+                    }
+                    else
+                        w0 = (w0 >> 8) | (next_prev << 24);
+                    k_seen |= (uint32_t)k;
+                    t9 = t9n;
+                    q1 = q1n;
+                    ++lp;
+                }
+                JLS_LOCKSTEP();
+                // one exit (the compiler unifies loop exits anyway): a one-hot counter that an event clears
+                ticker = tick(ticker, in_line_m, ok_m);
+            } while (ticker != 0);
+            i = (uint32_t)(lp - line);
+            // the reference raises invalid_data for k >= 16 and for |Errval| > 65535 (src/regular_mode_context.hpp:99-111,
+            // src/scan_decoder_core.hpp:38-69)
+            if (k_seen >= (kWide ? 16u : 10u) || (kWide && mm_seen > 131071u))
+                retry = true;
         }
+        // what stopped a scan that is still inside its line: Q = 0 is run mode, anything else an unusual code
+        const bool stopped = in_line && !lane_of(ok_m);
+        const bool in_run = stopped && qs == 0 && !retry;
+        const bool slow = stopped && qs != 0 && !retry;
 
         // ---- run mode: reference src/scan_decoder_impl.hpp:264-337, src/scan_decoder_core.hpp:72-100
-        if (__any(event == kRun))
+        if (__any(in_run))
         {
-            const bool in_run = event == kRun;
             const uint32_t remaining = width - (i - 1);
             uint32_t run = 0;
             bool counting = in_run;
             while (__any(counting))
             {
-                const uint32_t bit = peek32(ring, p) >> 31;
+                const uint32_t bit = peek32(ring, p) & 1u;
                 if (counting)
                 {
                     ++p;
@@ -506,7 +579,6 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 run_ctx[which] = ctx;
                 line[at] = (S)x;
                 a = x;
-                c = b_at; // becomes Rc of the next sample
                 if (run_index > 0)
                     --run_index;
                 i = at + 1;
@@ -515,20 +587,19 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 i = width + 1; // the run reached the end of the line
             JLS_LOCKSTEP();
             if (interrupted && i <= width)
-                prime();
+                prime(b_at); // prev[at] becomes Rc of the next sample
         }
 
         // ---- one regular-mode sample with every case the step loop leaves out (escape codes, long prefixes)
-        if (__any(event == kSlow))
+        if (__any(slow))
         {
-            const bool slow = event == kSlow;
-            const int qs = 81 * q1 + 9 * q2 + quantised(c - a);
+            const int rc = rc_of(), rb = rb_of();
             const int s = qs >> 31;
             const int idx = (qs ^ s) - s;
             const Record rec = records[idx];
             RegCtx ctx{(int)rec.a, (int)rec.ncb >> 16, (int)(signed char)(rec.ncb >> 8), (int)(rec.ncb & 0xFFu)};
             const int k = regular_k(ctx);
-            const int px = clamp_sample(t, med_predict(a, b, c) + ((ctx.c ^ s) - s));
+            const int px = clamp_sample(t, med_predict(a, rb, rc) + ((ctx.c ^ s) - s));
             int x = 0;
             bool good = slow && k < 16;
             if (good)
@@ -539,7 +610,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 else
                 {
                     int mm;
-                    if (u < limit_m)
+                    if ((uint32_t)u < limit_m)
                         mm = (u << k) | (int)take_bits(ring, p, k);
                     else
                         mm = (int)take_bits(ring, p, t.qbpp) + 1;
@@ -558,14 +629,13 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                                       (uint32_t)ctx.n | (((uint32_t)ctx.c & 0xFFu) << 8) | ((uint32_t)ctx.b << 16)};
                 line[i] = (S)x;
                 a = x;
-                c = b;
                 ++i;
             }
             else if (slow)
                 retry = true;
             JLS_LOCKSTEP();
             if (good && i <= width)
-                prime();
+                prime(rb); // prev[i - 1] of the next sample
         }
 
         if (kWide && a_seen >= (1u << 24))
@@ -624,7 +694,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
     if (!retry)
     {
         const uint32_t left = src.produced - p; // > 2^31 when the consumer ran past the producer
-        const bool clean = src.u_marker != ~0ull && left < 15u && (left == 0 || (peek32(ring, p) >> (32 - left)) == 0);
+        const bool clean = src.u_marker != ~0ull && left < 15u && (left == 0 || field(peek32(ring, p), (int)left) == 0);
         if (clean)
             r.bytes = src.u_marker - src.u_begin;
         else

@@ -83,6 +83,124 @@ JLS_DEV int vector_zero()
 }
 #endif
 
+// Bit tricks with the exact semantics of the gfx950 instructions (the C builtins are undefined for 0).
+#ifndef JLS_EMULATED
+JLS_DEV uint32_t bit_reverse(uint32_t v)
+{
+    return __builtin_bitreverse32(v);
+}
+JLS_DEV uint32_t lowest_one(uint32_t v) // v_ffbl_b32: index of the lowest set bit; 0xFFFFFFFF for v = 0
+{
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+JLS_DEV uint32_t leading_zeros(uint32_t v) // v_ffbh_u32: number of leading zero bits; 0xFFFFFFFF for v = 0
+{
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+#else
+JLS_DEV uint32_t bit_reverse(uint32_t v)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < 32; ++i)
+        r |= ((v >> i) & 1u) << (31 - i);
+    return r;
+}
+JLS_DEV uint32_t lowest_one(uint32_t v)
+{
+    return v == 0 ? 0xFFFFFFFFu : (uint32_t)__builtin_ctz(v);
+}
+JLS_DEV uint32_t leading_zeros(uint32_t v)
+{
+    return v == 0 ? 0xFFFFFFFFu : (uint32_t)__builtin_clz(v);
+}
+#endif
+
+// Lane predicates as 64-bit masks in scalar registers: combining them is scalar arithmetic, testing them a scalar branch
+// (the compiler keeps `bool`s that way too, but only the ballot of a single comparison stays free of a detour through a
+// vector register).  mad24 = a * b + c on the low 24 bits in one instruction; pack_bytes = s1.byte0 | s0.byte0 << 8; a
+// `rare` marker keeps the compiler from turning a seldom-taken block into unconditional selects.
+typedef unsigned long long LaneMask;
+#ifndef JLS_EMULATED
+JLS_DEV LaneMask lanes_where(bool p)
+{
+    return __builtin_amdgcn_ballot_w64(p);
+}
+JLS_DEV bool lane_of(LaneMask m)
+{
+    return __builtin_amdgcn_inverse_ballot_w64(m);
+}
+JLS_DEV int mad24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+JLS_DEV uint32_t pack_bytes(uint32_t s0, uint32_t s1)
+{
+    return __builtin_amdgcn_perm(s0, s1, 0x0C0C0400u);
+}
+#define JLS_RARE_BLOCK() asm volatile("; rarely taken")
+// One-hot loop counter: shifted right once per step, cleared when any lane of `busy` is missing from `ok` (then the
+// caller's `while (ticker != 0)` ends the loop).  Three scalar instructions; the compiler's own rendering of the same
+// condition takes nine, because it has to merge the loop's exits.
+JLS_DEV uint32_t tick(uint32_t ticker, LaneMask busy, LaneMask ok)
+{
+    LaneMask missing;
+    asm volatile("s_andn2_b64 %1, %2, %3\n\ts_cselect_b32 %0, 0, %0\n\ts_lshr_b32 %0, %0, 1"
+                 : "+s"(ticker), "=&s"(missing)
+                 : "s"(busy), "s"(ok)
+                 : "scc");
+    return ticker;
+}
+// Hides how a per-lane value was computed (the compiler would otherwise fold a select into the predicates that use it).
+JLS_DEV uint32_t opaque(uint32_t v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+JLS_DEV uint32_t float_bits(uint32_t v) // bit pattern of (float)v; exact below 2^24
+{
+    return __float_as_uint((float)v);
+}
+#else
+JLS_DEV LaneMask lanes_where(bool p)
+{
+    return __ballot(p);
+}
+JLS_DEV bool lane_of(LaneMask m)
+{
+    return ((m >> emu::lane_id()) & 1ull) != 0;
+}
+JLS_DEV int mad24(int a, int b, int c)
+{
+    return a * b + c;
+}
+JLS_DEV uint32_t pack_bytes(uint32_t s0, uint32_t s1)
+{
+    return (s1 & 0xFFu) | ((s0 & 0xFFu) << 8);
+}
+#define JLS_RARE_BLOCK() ((void)0)
+JLS_DEV uint32_t tick(uint32_t ticker, LaneMask busy, LaneMask ok)
+{
+    return (busy & ~ok) != 0 ? 0u : ticker >> 1;
+}
+JLS_DEV uint32_t opaque(uint32_t v)
+{
+    return v;
+}
+JLS_DEV uint32_t float_bits(uint32_t v)
+{
+    const float f = (float)v;
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+#endif
+
 // J[] run-length order table (reference src/scan_codec.hpp:18-19), 4 bits per entry packed into two 64-bit words.
 JLS_DEV int run_j(int run_index)
 {
