@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
     Record* records = reinterpret_cast<Record*>(region + L::kRecords);
     RunCtx* run_ctx = reinterpret_cast<RunCtx*>(region + L::kRun);
     uint32_t* ring = reinterpret_cast<uint32_t*>(region + L::kRing);
-    signed char* lut = reinterpret_cast<signed char*>(region + L::kLut);
+    unsigned char* lut = reinterpret_cast<unsigned char*>(region + L::kLut); // quantised gradient + 4
     S* line = reinterpret_cast<S*>(region + L::kLine);
     const int cap = kWide ? t.t3 : 255; // the table covers gradients -cap .. cap; beyond that the magnitude is 4
 
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
         if (sub < 2)
             run_ctx[sub] = RunCtx{sub, initial_a(t), 1, 0};
         for (int q = sub; q <= 2 * cap; q += G)
-            lut[q] = (signed char)quantize(t, q - cap);
+            lut[q] = (unsigned char)(quantize(t, q - cap) + 4);
         for (uint32_t q = sub; q < width + 6; q += G)
             line[q] = 0;
         for (uint32_t q = sub; q <= kRingWords; q += G)
@@ -319,11 +319,13 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
     // sample after it.  8-bit samples: one byte each in w0; wider samples: two halves each in w0 (Rc, Rb) and w1.
     uint32_t w0 = 0, w1 = 0;
     int a = 0;           // Ra
-    int q1 = 0, t9 = 0;  // Q1 = quantised (Rd - Rb) and T = 9 Q1 + Q2 of sample i
+    int q1 = 0, t9 = 0;  // Q1 + 4 = quantised (Rd - Rb) + 4 and T = 9 (Q1 + 4) + (Q2 + 4) of sample i
     uint32_t a_seen = 0; // OR of every updated A (samples wider than 8 bits): 2^24 overflow test
     const int maxval = t.maxval, reset = t.reset;
     const uint32_t limit_m = (uint32_t)(t.limit - t.qbpp - 1);
 
+    // quantised gradient + 4 (0..8): the three of a context then combine without sign extensions, and
+    // Q = 81 Q1 + 9 Q2 + Q3 = 9 (9 (Q1 + 4) + (Q2 + 4)) + (Q3 + 4) - 364
     auto quantised = [&](int diff) -> int {
         if (kWide)
             diff = med3(diff, -cap, cap);
@@ -392,106 +394,184 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             uint32_t steps = kStepsPerCheck;
             while (lanes_where(in_line && rest_of_line < steps) != 0)
                 --steps;
+            uint32_t ticker = 1u << (steps - 1); // one-hot step counter, 1 <= steps <= kStepsPerCheck
             // lanes outside their line never pass the `u < limit` test below
             const uint32_t limit_v = opaque(in_line ? limit_m : 0u);
-            S* lp = line + i; // slot of sample i; lp[1..] still hold the previous line
-            uint32_t k_seen = 0, mm_seen = 0;
-            uint32_t ticker = 1u << (steps - 1); // `steps` steps, 1 <= steps <= kStepsPerCheck
+            // The loop is rotated.  An iteration first does the bookkeeping the PREVIOUS step left behind -- Ra, bit position,
+            // window and line pointer advance, its A.12 / A.13 context update and the two stores -- and then decodes its own
+            // sample; the four LDS reads of the new step are issued before the update arithmetic and the context read
+            // before the prefix / predictor arithmetic, so the wavefront finds every LDS result waiting.  Nothing in the
+            // loop is predicated: when a lane cannot decode its sample the loop ends before that lane's next bookkeeping,
+            // and the lanes that did decode theirs get it after the loop.  The first iteration does the bookkeeping of a
+            // step that changes nothing (it rewrites cur[i - 1] and an unused context record); scans that are not inside
+            // a line (finished or waiting for their marker: their contexts and line are dead) run along on their own dead
+            // state without advancing.
+            const uint32_t p_kept = p;
+            S* lp = in_line ? line + i - 1 : line + width + 2; // slot of the previous step's sample
+            const uint32_t lp_step = in_line ? 1u : 0u;
+            Record* where = records + 365;      // the previous step's context record (an unused slot at first)
+            // what the previous step leaves for its context update: A + |Errval|, N, B + Errval (all three already halved
+            // when N had reached RESET) and the record's other word, for C
+            int u_a = 0, u_n = 1, u_tb = 0;
+            uint32_t t_ncb = 0, t_adv = 0, t_mm = 0;
+            int q1n = q1; // Q1 + 4 of the next sample
+            uint32_t t_next; // the sample of the previous line that slides into the window
+            if (kWide)
+            {
+                t_next = w1 >> 16;
+                w1 = (w0 >> 16) | (w1 << 16);
+                w0 <<= 16;
+            }
+            else
+            {
+                t_next = w0 >> 24;
+                w0 <<= 8;
+            }
+            uint32_t k_seen = 0, mm_seen = 0, a_seen_now = 0;
             do
             {
-                // independent of the chain: the next sample of the previous line, the bit window, Q1 of the next sample
-                const uint32_t next_prev = lp[3];
+                // -- bookkeeping of the previous step, part 1: registers (Ra was set when the sample was decoded)
+                p += t_adv;
+                if (kWide)
+                {
+                    w0 = (w0 >> 16) | (w1 << 16);
+                    w1 = (w1 >> 16) | (t_next << 16);
+                    mm_seen |= t_mm;
+                }
+                else
+                    w0 = (w0 >> 8) | (t_next << 24);
+                lp += lp_step; // now the slot of this step's sample; lp[1..] still hold the previous line
+                q1 = q1n;
+                // -- this step's LDS reads: next sample of the previous line, bit window, Q1 of the next sample, Q3
+                t_next = lp[3];
                 const uint32_t win = peek32(ring, p);
-                const int q1n = quantised(rd2_of() - rd_of());
-                const int t9n = mad24(q1n, 9, q1);
-                // the chain: Ra -> Q3 -> context -> k -> code -> Errval -> sample
+                q1n = quantised(rd2_of() - rd_of());
                 const int rc = rc_of(), rb = rb_of();
                 const int q3 = quantised(rc - a);
-                qs = mad24(t9, 9, q3);
+                // -- bookkeeping, part 2: A.12 / A.13, src/regular_mode_context.hpp:45-93 (|B| cannot overflow in lossless
+                // mode).  With N' the new N and tb = B + Errval (halved at a reset): delta = (tb > 0) - (tb + N' <= 0),
+                // B' = median(tb - delta * N', 1 - N', 0), C' = median(C + delta, -128, 127).
+                Record updated;
+                {
+                    const int cc = (int)(signed char)(t_ncb >> 8);
+                    const int n_new = u_n + 1;
+                    const int minus_delta = 1 - med3(u_tb, 0, 1) - med3(u_tb + n_new, 0, 1);
+                    const int b_new = med3(mad24(minus_delta, n_new, u_tb), -u_n, 0);
+                    const int c_new = med3(cc - minus_delta, -128, 127);
+                    updated = Record{(uint32_t)u_a, ((uint32_t)b_new << 16) | pack_bytes((uint32_t)c_new, (uint32_t)n_new)};
+                }
+                JLS_SCHEDULE_FENCE(); // the arithmetic above covers the latency of the four reads
+                // -- the chain: Ra -> Q3 -> context -> k -> code -> Errval -> sample
+                qs = mad24(t9, 9, q3) - 364;
+                t9 = mad24(q1n, 9, q1); // T of the next sample (a lane that cannot decode this one rebuilds its T and Q1)
                 const int sgn = (qs >> 31) | 1;
                 const int idx = __mul24(qs, sgn);
-                const Record rec = records[idx]; // idx 0 (run mode) reads a valid, unused record
+                JLS_LOCKSTEP();
+                *where = updated;      // bookkeeping, part 3: the stores
+                lp[-1] = (S)a;
+                JLS_LOCKSTEP();
+                where = records + idx; // idx 0 (run mode) reads a valid, unused record
+                const Record rec = *where;
                 const uint32_t u = lowest_one(win); // length of the unary prefix; 0xFFFFFFFF for an all-zero window
-                const int ctx_a = (int)rec.a;
+                const uint32_t u1 = u + 1u; // the window beyond the prefix: u1 = 32 only with k = 0, where no field is read
+                const uint32_t beyond = bit_reverse(win >> (u1 & 31u));
+                const int px0 = med3(a + (rb - rc), a, rb); // MED predictor = median(Ra, Rb, Ra + Rb - Rc), src/jpegls_algorithm.hpp:143-161
+                // A regular-mode sample whose code lies inside the 32-bit window.  8-bit samples: valid streams keep
+                // A / N < 2^9, so k <= 9, and u < LIMIT - qbpp - 1 <= 23 then bounds the code by 32 bits and |Errval| by
+                // 5888; k (and, for wider samples, the mapped error) are only accumulated here and examined after the
+                // loop: a stream that breaks those bounds is invalid and goes to the exact decoder as a whole.
+                ok_m = lanes_where(qs != 0) & lanes_where(u < limit_v);
+                JLS_SCHEDULE_FENCE(); // the arithmetic above covers the latency of the context read
+                t_ncb = rec.ncb;
                 const int n = (int)(rec.ncb & 0xFFu);
                 const int cc = (int)(signed char)(rec.ncb >> 8);
                 const int bb = (int)rec.ncb >> 16;
                 // k = min{k : N << k >= A} (N >= 1; A may be 0, then k = 0).  Scaling a float by 2^k adds k << 23 to its bit
                 // pattern and positive floats order like their bit patterns, so N * 2^k >= A <=> k << 23 >= bits(A) - bits(N):
                 // k = max(0, ceil((bits(A) - bits(N)) / 2^23)).  A < 2^24 and N <= 255 convert exactly.
-                const int k_raw = ((int)(float_bits((uint32_t)ctx_a) - float_bits((uint32_t)n)) + 0x7FFFFF) >> 23;
+                const int k_raw = ((int)(float_bits(rec.a) - float_bits((uint32_t)n)) + 0x7FFFFF) >> 23;
                 const int k = k_raw < 0 ? 0 : k_raw;
-                // A regular-mode sample whose code lies inside the 32-bit window.  8-bit samples: valid streams keep
-                // A / N < 2^9, so k <= 9, and u < LIMIT - qbpp - 1 <= 23 then bounds the code by 32 bits and |Errval| by
-                // 5888; k (and, for wider samples, the mapped error) are only accumulated here and examined after the
-                // loop: a stream that breaks those bounds is invalid and goes to the exact decoder as a whole.
-                ok_m = lanes_where(qs != 0) & lanes_where(u < limit_v);
                 if (kWide)
                     ok_m &= lanes_where(u + (uint32_t)k < 32u);
-                const bool ok = lane_of(ok_m);
                 // Golomb code -> mapped error -> Errval (src/scan_decoder_core.hpp:38-69)
-                const uint32_t u1 = u + 1u; // the window beyond the prefix: u1 = 32 only with k = 0, where no field is read
-                const int mm = (int)((u << k) | field(win >> (u1 & 31u), k));
+                const int mm = (int)((u << k) | (uint32_t)(((uint64_t)beyond << k) >> 32));
                 // Errval = unmap(mm), complemented when k = 0 and 2B + N - 1 < 0 (src/regular_mode_context.hpp:36-42):
                 // e = (mm >> 1) ^ -odd and |e| = (mm >> 1) + odd with odd = the low bit of mm, flipped by the correction
                 const int half = mm >> 1;
                 const int odd = (mm ^ (((k - 1) & (2 * bb + n - 1)) >> 31)) & 1;
                 const int e = half ^ -odd;
-                // MED predictor = median(Ra, Rb, Ra + Rb - Rc), src/jpegls_algorithm.hpp:143-161, plus the bias C
-                const int px = med3(mad24(cc, sgn, med3(a + (rb - rc), a, rb)), 0, maxval);
-                const int x = mad24(e, sgn, px) & maxval;
-                // A.12 / A.13, src/regular_mode_context.hpp:45-93 (|B| cannot overflow in lossless mode).  With N' the new
-                // N and tb = B + Errval (halved at a reset): delta = (tb > 0) - (tb + N' <= 0),
-                // B' = median(tb - delta * N', 1 - N', 0), C' = median(C + delta, -128, 127).
-                int a_new = ctx_a + half + odd;
+                const int px = med3(mad24(cc, sgn, px0), 0, maxval); // plus the bias C
+                a = mad24(e, sgn, px) & maxval; // every lane: a lane that could not decode reloads its Ra after the loop
+                t_adv = u1 + (uint32_t)k;
+                t_mm = (uint32_t)mm;
+                // first half of A.12 / A.13 for this step (the rest is the next iteration's): A += |Errval|, B += Errval, and
+                // the halving of A, B and N once N has reached RESET
+                u_a = (int)rec.a + half + odd;
                 if (kWide)
-                    a_seen |= (uint32_t)a_new;
-                int n_old = n;
-                int tb = bb + e;
-                const LaneMask halve_m = ok_m & lanes_where(n == reset);
+                    a_seen_now |= (uint32_t)u_a;
+                u_n = n;
+                u_tb = bb + e;
+                const LaneMask halve_m = lanes_where(n == reset);
                 if (halve_m != 0)
                 { // once per RESET samples of a context
                     JLS_RARE_BLOCK();
                     if (lane_of(halve_m))
                     {
-                        a_new >>= 1;
-                        n_old >>= 1;
-                        tb >>= 1;
+                        u_a >>= 1;
+                        u_n >>= 1;
+                        u_tb >>= 1;
                     }
                 }
-                const int n_new = n_old + 1;
-                const int minus_delta = 1 - med3(tb, 0, 1) - med3(tb + n_new, 0, 1);
-                const int b_new = med3(mad24(minus_delta, n_new, tb), -n_old, 0);
-                const int c_new = med3(cc - minus_delta, -128, 127);
-                JLS_LOCKSTEP();
-                if (ok)
-                {
-                    records[idx] = Record{(uint32_t)a_new, ((uint32_t)b_new << 16) | pack_bytes((uint32_t)c_new, (uint32_t)n_new)};
-                    lp[0] = (S)x;
-                    p += u1 + (uint32_t)k;
-                    a = x;
-                    if (kWide)
-                    {
-                        w0 = (w0 >> 16) | (w1 << 16);
-                        w1 = (w1 >> 16) | (next_prev << 16);
-                        mm_seen |= (uint32_t)mm;
-                    }
-                    else
-                        w0 = (w0 >> 8) | (next_prev << 24);
-                    k_seen |= (uint32_t)k;
-                    t9 = t9n;
-                    q1 = q1n;
-                    ++lp;
-                }
-                JLS_LOCKSTEP();
+                // (keeps the compiler from carrying these two as bytes and widening them again in every iteration)
+                t_next = opaque(t_next);
+                q1n = (int)opaque((uint32_t)q1n);
+                k_seen |= (uint32_t)k; // of every lane: a lane that cannot decode still looked at a real context
                 // one exit (the compiler unifies loop exits anyway): a one-hot counter that an event clears
                 ticker = tick(ticker, in_line_m, ok_m);
             } while (ticker != 0);
-            i = (uint32_t)(lp - line);
-            // the reference raises invalid_data for k >= 16 and for |Errval| > 65535 (src/regular_mode_context.hpp:99-111,
-            // src/scan_decoder_core.hpp:38-69)
-            if (k_seen >= (kWide ? 16u : 10u) || (kWide && mm_seen > 131071u))
-                retry = true;
+            // the bookkeeping owed to the lanes whose last step decoded a sample
+            bool owed_last;
+            int ra_stopped;
+            {
+                RegCtx ctx{u_a, u_tb, (int)(signed char)(t_ncb >> 8), u_n + 1};
+                const int minus_delta = 1 - med3(ctx.b, 0, 1) - med3(ctx.b + ctx.n, 0, 1);
+                ctx.b = med3(ctx.b + minus_delta * ctx.n, 1 - ctx.n, 0);
+                ctx.c = med3(ctx.c - minus_delta, -128, 127);
+                const bool owed = in_line && lane_of(ok_m);
+                owed_last = owed;
+                JLS_LOCKSTEP();
+                ra_stopped = (int)lp[-1]; // Ra of a lane whose last step did not decode: stored by that step
+                if (owed)
+                {
+                    *where = Record{(uint32_t)ctx.a, ((uint32_t)ctx.b << 16) | pack_bytes((uint32_t)ctx.c, (uint32_t)ctx.n)};
+                    lp[0] = (S)a;
+                    p += t_adv;
+                    if (kWide)
+                    {
+                        w0 = (w0 >> 16) | (w1 << 16);
+                        w1 = (w1 >> 16) | (t_next << 16);
+                        mm_seen |= t_mm;
+                    }
+                    else
+                        w0 = (w0 >> 8) | (t_next << 24);
+                    ++lp;
+                    q1 = q1n;
+                }
+                JLS_LOCKSTEP();
+            }
+            if (in_line)
+            {
+                if (!owed_last)
+                    a = ra_stopped;
+                i = (uint32_t)(lp - line);
+                a_seen |= a_seen_now;
+                // the reference raises invalid_data for k >= 16 and for |Errval| > 65535
+                // (src/regular_mode_context.hpp:99-111, src/scan_decoder_core.hpp:38-69)
+                if (k_seen >= (kWide ? 16u : 10u) || (kWide && mm_seen > 131071u))
+                    retry = true;
+            }
+            else
+                p = p_kept;
         }
         // what stopped a scan that is still inside its line: Q = 0 is run mode, anything else an unusual code
         const bool stopped = in_line && !lane_of(ok_m);

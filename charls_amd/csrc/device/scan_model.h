@@ -144,6 +144,9 @@ JLS_DEV uint32_t pack_bytes(uint32_t s0, uint32_t s1)
     return __builtin_amdgcn_perm(s0, s1, 0x0C0C0400u);
 }
 #define JLS_RARE_BLOCK() asm volatile("; rarely taken")
+// Nothing is scheduled across this point (used to keep the arithmetic that covers an LDS latency ahead of the first use
+// of the loaded values; the machine scheduler otherwise pulls single users up next to their loads).
+#define JLS_SCHEDULE_FENCE() __builtin_amdgcn_sched_barrier(0)
 // One-hot loop counter: shifted right once per step, cleared when any lane of `busy` is missing from `ok` (then the
 // caller's `while (ticker != 0)` ends the loop).  Three scalar instructions; the compiler's own rendering of the same
 // condition takes nine, because it has to merge the loop's exits.
@@ -184,6 +187,7 @@ JLS_DEV uint32_t pack_bytes(uint32_t s0, uint32_t s1)
     return (s1 & 0xFFu) | ((s0 & 0xFFu) << 8);
 }
 #define JLS_RARE_BLOCK() ((void)0)
+#define JLS_SCHEDULE_FENCE() ((void)0)
 JLS_DEV uint32_t tick(uint32_t ticker, LaneMask busy, LaneMask ok)
 {
     return (busy & ~ok) != 0 ? 0u : ticker >> 1;

@@ -74,7 +74,33 @@ PROBE(p_dpp_bcast_dep, , "v_mov_b32_dpp %0, %0 row_newbcast:3 row_mask:0xf bank_
 PROBE(p_dpp_shr_dep, , "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n")
 PROBE(p_saveexec, , "s_and_saveexec_b64 s[40:41], vcc\n s_or_b64 exec, exec, s[40:41]\n", "s40", "s41")
 PROBE(p_vadd_sadd_mix, , "v_add_u32 %0, %0, %1\n s_add_u32 %5, %5, 1\n")
+PROBE(p_branch_taken, , "s_branch 0\n")
+PROBE(p_cbranch_not_taken, , "s_cmp_eq_u32 %5, %5\n s_cbranch_scc0 0\n")
+PROBE(p_cbranch_taken, , "s_cmp_eq_u32 %5, %5\n s_cbranch_scc1 0\n")
+PROBE(p_branch_taken_far, , "s_branch 15\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n"
+      "v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n"
+      "v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %1\n")
+PROBE(p_waitcnt_idle, , "s_waitcnt lgkmcnt(0)\n")
+PROBE(p_snop, , "s_nop 0\n")
+PROBE(p_vperm, , "v_perm_b32 %0, %0, %1, %2\n")
+PROBE(p_vcvt, , "v_cvt_f32_u32 %0, %0\n")
+PROBE(p_vbfrev, , "v_bfrev_b32 %0, %0\n")
+PROBE(p_ds_write_b8, v0 = 64, "ds_write_b8 %0, %1\n")
+PROBE(p_ds_write2, v0 = 64, "ds_write2_b32 %0, %1, %2 offset1:1\n")
 PROBE(p_sdwa_dep, , "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n")
+
+// Does the LDS address VGPR + immediate offset wrap modulo 2^32 (a negative register with a larger positive offset)?
+__global__ void negative_lds_address(int* out)
+{
+    extern __shared__ int lds[];
+    for (int i = threadIdx.x; i < 4096; i += 64)
+        lds[i] = i * 3 + 1;
+    __syncthreads();
+    int addr = -8 - 4 * (int)threadIdx.x; // bytes
+    int v;
+    asm volatile("ds_read_b32 %0, %1 offset:1024\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    out[threadIdx.x] = v; // expected lds[(1024 - 8 - 4 t) / 4]
+}
 
 struct Probe
 {
@@ -122,6 +148,17 @@ int main(int argc, char** argv)
         {"s_and_saveexec + s_or exec (pair)", p_saveexec, 2},
         {"v_add + s_add alternating (pair)", p_vadd_sadd_mix, 2},
         {"v_add_sdwa dependent", p_sdwa_dep, 1},
+        {"s_branch to the next instruction", p_branch_taken, 1},
+        {"s_cmp + s_cbranch not taken (pair)", p_cbranch_not_taken, 2},
+        {"s_cmp + s_cbranch taken (pair)", p_cbranch_taken, 2},
+        {"s_branch over 15 instructions", p_branch_taken_far, 1},
+        {"s_waitcnt with nothing outstanding", p_waitcnt_idle, 1},
+        {"s_nop 0", p_snop, 1},
+        {"v_perm_b32 dependent", p_vperm, 1},
+        {"v_cvt_f32_u32 dependent", p_vcvt, 1},
+        {"v_bfrev_b32 dependent", p_vbfrev, 1},
+        {"ds_write_b8 back to back", p_ds_write_b8, 1},
+        {"ds_write2_b32 back to back", p_ds_write2, 1},
     };
     printf("wavefronts in the workgroup: %d\n", waves);
     printf("%-42s %10s %10s\n", "probe", "cyc/copy", "cyc/instr");
@@ -138,6 +175,18 @@ int main(int argc, char** argv)
         }
         const double per = (double)best / (16.0 * 64.0);
         printf("%-42s %10.2f %10.2f\n", p.name, per, per / p.ops);
+    }
+    {
+        int* d_v;
+        (void)hipMalloc(&d_v, 256);
+        hipLaunchKernelGGL(negative_lds_address, dim3(1), dim3(64), 16384, 0, d_v);
+        int h[64];
+        (void)hipMemcpy(h, d_v, 256, hipMemcpyDeviceToHost);
+        int good = 0;
+        for (int t = 0; t < 64; ++t)
+            good += h[t] == ((1024 - 8 - 4 * t) / 4) * 3 + 1;
+        printf("negative LDS address register + offset wraps correctly for %d of 64 lanes (lane 0 read %d, expected %d)\n", good,
+               h[0], ((1024 - 8) / 4) * 3 + 1);
     }
     return 0;
 }
