@@ -134,6 +134,7 @@ void launch_decode_serial(const ScanDesc* d_descs, ScanResult* d_results, uint32
 
 namespace {
 constexpr size_t kMaxDynamicLds = 64 * 1024;
+constexpr size_t kGroupDecodeLds = 160 * 1024; // a workgroup of the group decoder may take the whole LDS of a CU
 
 size_t wave_decode_lds(const ScanDesc& d)
 {
@@ -166,29 +167,47 @@ size_t fast_decode_lds(const ScanDesc& d)
     return (d.bits_per_sample > 8 ? fast::fixed_lds<uint16_t>() : fast::fixed_lds<uint8_t>()) + line_bytes;
 }
 
-size_t group_region_bytes(const ScanDesc& d)
+size_t group_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
 {
-    return d.bits_per_sample > 8 ? grp::region_bytes<uint16_t>(d.width) : grp::region_bytes<uint8_t>(d.width);
+    return d.bits_per_sample > 8 ? grp::workgroup_lds_bytes<uint16_t>(d.width, scans_per_wave)
+                                 : grp::workgroup_lds_bytes<uint8_t>(d.width, scans_per_wave);
 }
 
-// Lanes per scan of the speed path (scan_group_decode.hip): the most scans per wavefront whose lines fit the LDS of a
-// workgroup; 0 = the one-scan-per-wavefront kernel (scan_fast_decode.hip).  CHARLS_AMD_DECODE_GROUP overrides (0, 8, 16, 32).
-int decode_group_lanes(const ScanDesc& d)
+// Lanes per scan of the speed path (scan_group_decode.hip) for a launch of `count` scans; 0 = the one-scan-per-wavefront
+// kernel (scan_fast_decode.hip).  What a scan costs per sample does not depend on how many scans share its wavefront, but
+// wavefronts that share a CU slow each other down (four of them by a third: they queue at the LDS), so the scans are packed
+// as densely as it takes to give every CU at most one wavefront -- and no denser, because the lanes of a scan share its
+// bulk work (un-stuffing, row stores) and every event of one scan (run mode, end of line) stalls the others of its
+// wavefront: measured on 4096 frames of 4096 x 4096, 8 lanes per scan decode in 4.84 s, 16 in 5.48 s, 4 in 5.86 s.
+// CHARLS_AMD_DECODE_GROUP overrides (0, 4, 8, 16, 32).
+int decode_group_lanes(const ScanDesc& d, uint32_t count)
 {
     if (d.bits_per_sample > 8 && d.t3 > grp::kMaxTableT3)
         return 0;
     const char* env = std::getenv("CHARLS_AMD_DECODE_GROUP");
     const int forced = env ? std::atoi(env) : -1;
-    const size_t region = group_region_bytes(d);
     if (forced == 0)
         return 0;
-    if ((forced == 8 || forced == 16 || forced == 32) && region * (64 / forced) <= kMaxDynamicLds)
+    if ((forced == 4 || forced == 8 || forced == 16 || forced == 32) && group_lds_bytes(d, 64u / forced) <= kGroupDecodeLds)
         return forced;
-    if (region * 4 <= kMaxDynamicLds)
-        return 16;
-    if (region * 2 <= kMaxDynamicLds)
-        return 32;
-    return 0;
+    static const uint32_t cus = [] {
+        hipDeviceProp_t prop;
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess)
+            return 256u;
+        return static_cast<uint32_t>(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    }();
+    int best = 0;
+    for (int lanes = 32; lanes >= 8; lanes /= 2)
+    {
+        const uint32_t per_wave = 64u / static_cast<uint32_t>(lanes);
+        if (group_lds_bytes(d, per_wave) > kGroupDecodeLds)
+            break;
+        best = lanes;
+        if ((count + per_wave - 1) / per_wave <= cus)
+            break;
+    }
+    return best;
 }
 
 // Lossless single-component scans take the speed path (scan_group_decode.hip / scan_fast_decode.hip); it defers to the
@@ -196,7 +215,7 @@ int decode_group_lanes(const ScanDesc& d)
 bool fast_decode_eligible(const ScanDesc& d)
 {
     return wave_decode_eligible(d) && d.near_lossless == 0 && d.interleave_mode == 0 && d.components == 1 &&
-           (fast_decode_lds(d) <= kMaxDynamicLds || decode_group_lanes(d) != 0) &&
+           (fast_decode_lds(d) <= kMaxDynamicLds || decode_group_lanes(d, 1) != 0) &&
            std::getenv("CHARLS_AMD_EXACT_DECODER") == nullptr;
 }
 
@@ -350,7 +369,7 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
         exact(d_descs, d_results, count);
         return;
     }
-    const int group = decode_group_lanes(proto);
+    const int group = decode_group_lanes(proto, count);
     if (group == 0)
     {
         if (proto.bits_per_sample > 8)
@@ -362,10 +381,21 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
     {
         const uint32_t per_wave = 64u / static_cast<uint32_t>(group);
         const dim3 grid((count + per_wave - 1) / per_wave);
-        const size_t lds = group_region_bytes(proto) * per_wave;
-#define JLS_LAUNCH_GROUP(S, G) hipLaunchKernelGGL((decode_scans_group<S, G>), grid, dim3(64), lds, stream, d_descs, d_results, count)
+        const size_t lds = group_lds_bytes(proto, per_wave);
+#define JLS_LAUNCH_GROUP(S, G)                                                                                           \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        if (lds > kMaxDynamicLds) /* more than the default limit of dynamic LDS per workgroup */                          \
+            hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_scans_group<S, G>),                      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
+        hipLaunchKernelGGL((decode_scans_group<S, G>), grid, dim3(64), lds, stream, d_descs, d_results, count);          \
+    } while (0)
         const bool wide = proto.bits_per_sample > 8;
-        if (group == 8)
+        if (group == 4)
+        {
+            if (wide) JLS_LAUNCH_GROUP(uint16_t, 4); else JLS_LAUNCH_GROUP(uint8_t, 4);
+        }
+        else if (group == 8)
         {
             if (wide) JLS_LAUNCH_GROUP(uint16_t, 8); else JLS_LAUNCH_GROUP(uint8_t, 8);
         }

@@ -14,8 +14,9 @@
 //     of line, under the predicate of the groups that raised it;
 //   * the G lanes of a group share the bulk work of their scan: un-stuffing 16 coded bytes per lane into the dense
 //     bit ring (as in scan_fast_decode.hip), run fills, and the 16-byte row stores of every finished line;
-//   * LDS per scan: 365 context records (8 B), two run contexts, a 1 KB dense bit ring, the gradient table and ONE line
-//     of samples = 8.6 KB for 4096 8-bit samples, 34.5 KB per wavefront at G = 16: four wavefronts per CU, one per SIMD.
+//   * LDS per scan: 365 context records (8 B), two run contexts, a 1 KB dense bit ring and ONE line of samples = 8.1 KB
+//     for 4096 8-bit samples; with the gradient table the scans of a wavefront share, 33 KB per wavefront at G = 16: four
+//     wavefronts per CU, one per SIMD.
 //
 // Like scan_fast_decode.hip this is not a restatement of the reference's bit reader: a result is accepted only when the
 // scan ends cleanly (all samples decoded inside the entropy-coded segment, zero padding, marker next); everything else
@@ -31,27 +32,32 @@ namespace grp {
 
 constexpr uint32_t kRingWords = 256;               // dense bits resident per scan: 8192 (word kRingWords mirrors word 0)
 constexpr uint32_t kRingBits = kRingWords * 32;
-constexpr int kStepsPerCheck = 16;                 // regular-mode steps between two looks at the producer
+constexpr int kStepsPerCheck = 32;                 // regular-mode steps between two looks at the producer
 constexpr uint32_t kMarginBits = kStepsPerCheck * 32 + 320; // dense bits the step loop and one event handler may consume
 constexpr int kMaxTableT3 = 1023;                  // widest gradient table (2 * T3 + 1 entries) for samples wider than 8 bits
 
-// Per-scan LDS region.  The line starts one sample before a 16-byte boundary so that sample 1 (the first of the row) is
-// aligned for the 16-byte row stores.
+// LDS of a workgroup (one wavefront): the gradient table shared by its scans, then one region per scan.  A scan's line
+// starts one sample before a 16-byte boundary so that sample 1 (the first of the row) is aligned for the 16-byte row stores.
 template <typename S>
 struct Layout
 {
-    static constexpr uint32_t kRecords = 0;                       // 365 x 8 B (+ pad)
-    static constexpr uint32_t kRun = 2928;                        // 2 x RunCtx
-    static constexpr uint32_t kRing = kRun + 32;                  // kRingWords + 1 words
-    static constexpr uint32_t kLut = kRing + kRingWords * 4 + 16; // gradient table
-    static constexpr uint32_t kLutBytes = sizeof(S) == 1 ? 512 : 2 * kMaxTableT3 + 2;
-    static constexpr uint32_t kLine = kLut + kLutBytes + 16 - sizeof(S);
+    static constexpr uint32_t kLutBytes = sizeof(S) == 1 ? 512 : 2 * kMaxTableT3 + 2; // quantised gradient + 4 for -cap .. cap
+    static constexpr uint32_t kRecords = 0;                        // 365 x 8 B (+ an unused slot)
+    static constexpr uint32_t kRun = 2928;                         // 2 x RunCtx
+    static constexpr uint32_t kRing = kRun + 32;                   // kRingWords + 1 words
+    static constexpr uint32_t kLine = kRing + kRingWords * 4 + 16 + 16 - sizeof(S);
 };
 
 template <typename S>
 __host__ __device__ constexpr uint32_t region_bytes(uint32_t width)
 {
     return (Layout<S>::kLine + (width + 6) * (uint32_t)sizeof(S) + 15u) & ~15u;
+}
+
+template <typename S>
+__host__ __device__ constexpr uint32_t workgroup_lds_bytes(uint32_t width, uint32_t scans_per_wave)
+{
+    return Layout<S>::kLutBytes + scans_per_wave * region_bytes<S>(width);
 }
 
 // Regular-mode context record: word 0 = A, word 1 = N | (C & 0xFF) << 8 | B << 16.  N <= RESET <= 255, -128 <= C <= 127
@@ -70,6 +76,13 @@ JLS_DEV uint32_t peek32(const uint32_t* ring, uint32_t p)
     const uint32_t wi = (p >> 5) & (kRingWords - 1);
     const uint64_t both = ((uint64_t)ring[wi + 1] << 32) | ring[wi];
     return (uint32_t)(both >> (p & 31));
+}
+
+// The two ring words around bit p, the ring given by its LDS address held in one register (two address instructions).
+JLS_DEV uint64_t ring_words_at(uint32_t ring_address, uint32_t p)
+{
+    const uint32_t at = ring_address + (bit_field(p, 5, 8) << 2); // word (p >> 5) mod kRingWords
+    return ((uint64_t)lds_load<uint32_t>(at + 4) << 32) | lds_load<uint32_t>(at);
 }
 
 // Value of the first n bits of window w, first bit most significant (0 <= n <= 32).
@@ -261,7 +274,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
 {
     using namespace grp;
     using L = Layout<S>;
-    static_assert(G == 8 || G == 16 || G == 32, "lanes per scan");
+    static_assert(G == 4 || G == 8 || G == 16 || G == 32, "lanes per scan");
     constexpr int kScansPerWave = 64 / G;
     constexpr bool kWide = sizeof(S) > 1;
     JLS_DYNAMIC_LDS(smem);
@@ -274,13 +287,21 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
     const Traits t = make_traits(d);
     const uint32_t width = d.width;
 
-    unsigned char* region = smem + (size_t)sid * region_bytes<S>(width);
+    unsigned char* region = smem + L::kLutBytes + (size_t)sid * region_bytes<S>(width);
     Record* records = reinterpret_cast<Record*>(region + L::kRecords);
     RunCtx* run_ctx = reinterpret_cast<RunCtx*>(region + L::kRun);
     uint32_t* ring = reinterpret_cast<uint32_t*>(region + L::kRing);
-    unsigned char* lut = reinterpret_cast<unsigned char*>(region + L::kLut); // quantised gradient + 4
+    const uint32_t ring_address = opaque(lds_address(ring));
+    // The gradient table (quantised gradient + 4 for gradients -cap .. cap; beyond that the magnitude is 4) is shared by
+    // the scans of the wavefront: its index is then a difference plus a constant, with no per-scan base to add.  It is
+    // built from the thresholds of the workgroup's first scan; a scan with other thresholds (batches mix them only when
+    // the streams carry different LSE segments) is left to the exact decoder.
+    unsigned char* lut = smem;
+    const ScanDesc& d_first = descs[blockIdx.x * kScansPerWave];
+    const Traits t_first = make_traits(d_first);
     S* line = reinterpret_cast<S*>(region + L::kLine);
-    const int cap = kWide ? t.t3 : 255; // the table covers gradients -cap .. cap; beyond that the magnitude is 4
+    const int cap = kWide ? t_first.t3 : 255;
+    const bool own_table = t.t1 == t_first.t1 && t.t2 == t_first.t2 && t.t3 == t_first.t3 && t.bpp == t_first.bpp;
 
     {
         const Record fresh{(uint32_t)initial_a(t), 1u};
@@ -288,8 +309,8 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             records[q] = fresh;
         if (sub < 2)
             run_ctx[sub] = RunCtx{sub, initial_a(t), 1, 0};
-        for (int q = sub; q <= 2 * cap; q += G)
-            lut[q] = (unsigned char)(quantize(t, q - cap) + 4);
+        for (int q = lane; q <= 2 * cap; q += 64)
+            lut[q] = (unsigned char)(quantize(t_first, q - cap) + 4);
         for (uint32_t q = sub; q < width + 6; q += G)
             line[q] = 0;
         for (uint32_t q = sub; q <= kRingWords; q += G)
@@ -310,8 +331,9 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
     JLS_LOCKSTEP();
 
     enum : int { kLineStart = 0, kInLine, kDrain, kDone };
-    int phase = !live ? kDone : (d.height == 0 ? kDrain : kLineStart);
-    bool retry = false;
+    const bool usable = own_table && lds_address(smem) == 0; // (see lds_load)
+    int phase = !live || !usable ? kDone : (d.height == 0 ? kDrain : kLineStart);
+    bool retry = live && !usable;
     uint32_t p = 0;     // consumed dense bits
     uint32_t y = 0, i = 1;
     int corner = 0, first = 0, run_index = 0;
@@ -329,7 +351,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
     auto quantised = [&](int diff) -> int {
         if (kWide)
             diff = med3(diff, -cap, cap);
-        return (int)lut[diff + cap];
+        return (int)lds_load<unsigned char>((uint32_t)(diff + cap)); // the table is at LDS address 0
     };
     auto rc_of = [&]() -> int { return kWide ? (int)(w0 & 0xFFFFu) : (int)(w0 & 0xFFu); };
     auto rb_of = [&]() -> int { return kWide ? (int)(w0 >> 16) : (int)((w0 >> 8) & 0xFFu); };
@@ -386,7 +408,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
         const bool in_line = phase == kInLine; // i <= width: the end of a line is handled as soon as it is reached
         const LaneMask in_line_m = lanes_where(in_line);
         LaneMask ok_m = ~0ull; // lanes whose last step decoded a sample
-        int qs = 0;
+        int qsu = 364;         // Q + 364 of the last step
         if (in_line_m != 0)
         {
             // no scan may step past the end of its line: the wavefront takes as many steps as the shortest rest allows
@@ -412,7 +434,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             Record* where = records + 365;      // the previous step's context record (an unused slot at first)
             // what the previous step leaves for its context update: A + |Errval|, N, B + Errval (all three already halved
             // when N had reached RESET) and the record's other word, for C
-            int u_a = 0, u_n = 1, u_tb = 0;
+            int u_a = 0, u_n1 = 2, u_tb = 0; // u_n1 = N + 1
             uint32_t t_ncb = 0, t_adv = 0, t_mm = 0;
             int q1n = q1; // Q1 + 4 of the next sample
             uint32_t t_next; // the sample of the previous line that slides into the window
@@ -444,7 +466,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 q1 = q1n;
                 // -- this step's LDS reads: next sample of the previous line, bit window, Q1 of the next sample, Q3
                 t_next = lp[3];
-                const uint32_t win = peek32(ring, p);
+                const uint64_t ring_words = ring_words_at(ring_address, p);
                 q1n = quantised(rd2_of() - rd_of());
                 const int rc = rc_of(), rb = rb_of();
                 const int q3 = quantised(rc - a);
@@ -454,18 +476,19 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 Record updated;
                 {
                     const int cc = (int)(signed char)(t_ncb >> 8);
-                    const int n_new = u_n + 1;
+                    const int n_new = u_n1;
                     const int minus_delta = 1 - med3(u_tb, 0, 1) - med3(u_tb + n_new, 0, 1);
-                    const int b_new = med3(mad24(minus_delta, n_new, u_tb), -u_n, 0);
+                    const int b_new = med3(mad24(minus_delta, n_new, u_tb), 1 - n_new, 0);
                     const int c_new = med3(cc - minus_delta, -128, 127);
                     updated = Record{(uint32_t)u_a, ((uint32_t)b_new << 16) | pack_bytes((uint32_t)c_new, (uint32_t)n_new)};
                 }
                 JLS_SCHEDULE_FENCE(); // the arithmetic above covers the latency of the four reads
+                const uint32_t win = (uint32_t)(ring_words >> (p & 31)); // the next 32 bits of the stream
                 // -- the chain: Ra -> Q3 -> context -> k -> code -> Errval -> sample
-                qs = mad24(t9, 9, q3) - 364;
+                qsu = mad24(t9, 9, q3); // Q + 364 (the three gradients come with + 4 each)
                 t9 = mad24(q1n, 9, q1); // T of the next sample (a lane that cannot decode this one rebuilds its T and Q1)
-                const int sgn = (qs >> 31) | 1;
-                const int idx = __mul24(qs, sgn);
+                const int sgn = qsu < 364 ? -1 : 1;
+                const int idx = (int)abs_difference((uint32_t)qsu, 364u);
                 JLS_LOCKSTEP();
                 *where = updated;      // bookkeeping, part 3: the stores
                 lp[-1] = (S)a;
@@ -480,7 +503,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 // A / N < 2^9, so k <= 9, and u < LIMIT - qbpp - 1 <= 23 then bounds the code by 32 bits and |Errval| by
                 // 5888; k (and, for wider samples, the mapped error) are only accumulated here and examined after the
                 // loop: a stream that breaks those bounds is invalid and goes to the exact decoder as a whole.
-                ok_m = lanes_where(qs != 0) & lanes_where(u < limit_v);
+                ok_m = lanes_where(qsu != 364) & lanes_where(u < limit_v);
                 JLS_SCHEDULE_FENCE(); // the arithmetic above covers the latency of the context read
                 t_ncb = rec.ncb;
                 const int n = (int)(rec.ncb & 0xFFu);
@@ -509,16 +532,16 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 u_a = (int)rec.a + half + odd;
                 if (kWide)
                     a_seen_now |= (uint32_t)u_a;
-                u_n = n;
+                u_n1 = n + 1;
                 u_tb = bb + e;
                 const LaneMask halve_m = lanes_where(n == reset);
-                if (halve_m != 0)
+                if (__builtin_expect(halve_m != 0, 0))
                 { // once per RESET samples of a context
                     JLS_RARE_BLOCK();
                     if (lane_of(halve_m))
                     {
                         u_a >>= 1;
-                        u_n >>= 1;
+                        u_n1 = (n >> 1) + 1;
                         u_tb >>= 1;
                     }
                 }
@@ -533,7 +556,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             bool owed_last;
             int ra_stopped;
             {
-                RegCtx ctx{u_a, u_tb, (int)(signed char)(t_ncb >> 8), u_n + 1};
+                RegCtx ctx{u_a, u_tb, (int)(signed char)(t_ncb >> 8), u_n1};
                 const int minus_delta = 1 - med3(ctx.b, 0, 1) - med3(ctx.b + ctx.n, 0, 1);
                 ctx.b = med3(ctx.b + minus_delta * ctx.n, 1 - ctx.n, 0);
                 ctx.c = med3(ctx.c - minus_delta, -128, 127);
@@ -574,6 +597,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 p = p_kept;
         }
         // what stopped a scan that is still inside its line: Q = 0 is run mode, anything else an unusual code
+        const int qs = qsu - 364;
         const bool stopped = in_line && !lane_of(ok_m);
         const bool in_run = stopped && qs == 0 && !retry;
         const bool slow = stopped && qs != 0 && !retry;

@@ -143,6 +143,18 @@ JLS_DEV uint32_t pack_bytes(uint32_t s0, uint32_t s1)
 {
     return __builtin_amdgcn_perm(s0, s1, 0x0C0C0400u);
 }
+JLS_DEV uint32_t bit_field(uint32_t v, uint32_t offset, uint32_t width) // (v >> offset) & (2^width - 1), constants
+{
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "n"(offset), "n"(width));
+    return r;
+}
+JLS_DEV uint32_t abs_difference(uint32_t a, uint32_t b) // |a - b| of unsigned values in one instruction
+{
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 #define JLS_RARE_BLOCK() asm volatile("; rarely taken")
 // Nothing is scheduled across this point (used to keep the arithmetic that covers an LDS latency ahead of the first use
 // of the loaded values; the machine scheduler otherwise pulls single users up next to their loads).
@@ -169,6 +181,20 @@ JLS_DEV uint32_t float_bits(uint32_t v) // bit pattern of (float)v; exact below 
 {
     return __float_as_uint((float)v);
 }
+// LDS by absolute address (the dynamic LDS region of a kernel without static LDS starts at 0; kernels that use these
+// check lds_address(their region) == 0).  An index that is "difference + constant" then needs no base register: the
+// constant goes into the instruction's offset field, and the hardware adds register and offset modulo 2^32, so a
+// negative difference is fine (checked on gfx950: tools/microbench/latency.hip).
+#define JLS_LDS_AS __attribute__((address_space(3)))
+JLS_DEV uint32_t lds_address(const void* p)
+{
+    return (uint32_t)(uintptr_t)(const JLS_LDS_AS void*)p;
+}
+template <typename T>
+JLS_DEV T lds_load(uint32_t address)
+{
+    return *(const JLS_LDS_AS T*)(uintptr_t)address;
+}
 #else
 JLS_DEV LaneMask lanes_where(bool p)
 {
@@ -186,6 +212,14 @@ JLS_DEV uint32_t pack_bytes(uint32_t s0, uint32_t s1)
 {
     return (s1 & 0xFFu) | ((s0 & 0xFFu) << 8);
 }
+JLS_DEV uint32_t bit_field(uint32_t v, uint32_t offset, uint32_t width)
+{
+    return (v >> offset) & ((1u << width) - 1u);
+}
+JLS_DEV uint32_t abs_difference(uint32_t a, uint32_t b)
+{
+    return a > b ? a - b : b - a;
+}
 #define JLS_RARE_BLOCK() ((void)0)
 #define JLS_SCHEDULE_FENCE() ((void)0)
 JLS_DEV uint32_t tick(uint32_t ticker, LaneMask busy, LaneMask ok)
@@ -194,6 +228,17 @@ JLS_DEV uint32_t tick(uint32_t ticker, LaneMask busy, LaneMask ok)
 }
 JLS_DEV uint32_t opaque(uint32_t v)
 {
+    return v;
+}
+JLS_DEV uint32_t lds_address(const void* p)
+{
+    return (uint32_t)(static_cast<const unsigned char*>(p) - emu::g_block->dyn_shared);
+}
+template <typename T>
+JLS_DEV T lds_load(uint32_t address)
+{
+    T v;
+    std::memcpy(&v, emu::g_block->dyn_shared + address, sizeof(T));
     return v;
 }
 JLS_DEV uint32_t float_bits(uint32_t v)

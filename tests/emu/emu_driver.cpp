@@ -152,10 +152,14 @@ int emu_decode_scans_group(const jls::ScanDesc* descs, jls::ScanResult* results,
     const jls::ScanDesc& d = descs[0];
     const bool wide = d.bits_per_sample > 8;
     const int per_wave = 64 / group;
-    const size_t lds = (size_t)per_wave * (wide ? jls::grp::region_bytes<uint16_t>(d.width) : jls::grp::region_bytes<uint8_t>(d.width));
+    const size_t lds = wide ? jls::grp::workgroup_lds_bytes<uint16_t>(d.width, per_wave) : jls::grp::workgroup_lds_bytes<uint8_t>(d.width, per_wave);
     const dim3 grid((count + per_wave - 1) / per_wave);
 #define EMU_GROUP(S, G) emu::launch(jls::decode_scans_group<S, G>, grid, dim3(64), lds, descs, results, (uint32_t)count)
-    if (group == 8)
+    if (group == 4)
+    {
+        if (wide) EMU_GROUP(uint16_t, 4); else EMU_GROUP(uint8_t, 4);
+    }
+    else if (group == 8)
     {
         if (wide) EMU_GROUP(uint16_t, 8); else EMU_GROUP(uint8_t, 8);
     }

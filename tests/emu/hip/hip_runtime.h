@@ -248,6 +248,10 @@ inline int __mul24(int a, int b)
     return a * b;
 }
 
+inline unsigned __builtin_amdgcn_ubfe(unsigned v, unsigned offset, unsigned width)
+{
+    return width == 0 ? 0u : (v >> (offset & 31u)) & (width >= 32 ? ~0u : ((1u << width) - 1u));
+}
 inline unsigned __builtin_amdgcn_readfirstlane(unsigned v)
 {
     return __shfl(v, 0);

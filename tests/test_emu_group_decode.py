@@ -1,0 +1,213 @@
+"""Kernel-logic check on the CPU of scan_group_decode.hip (several scans per wavefront): the unmodified kernel source
+compiled for the host (tests/emu) against golden vectors, the oracle, corrupt and mutated streams.  Test infrastructure:
+it proves the kernel's logic, the product path is covered by tests/test_gpu_*.py on the GPU box."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+import emu_bind
+import jls_container
+import oracle_bind as ob
+from charls_amd import synth
+from test_emu_serial_kernels import FAST_CASES, _stream_copy
+
+GROUPS = [4, 8, 16, 32]  # lanes per scan: 16, 8, 4, 2 scans per wavefront
+
+
+def _group_eligible(bits, pc):
+    return (pc[4] & 0xFF) != 0 and (bits <= 8 or pc[3] <= 1023)
+
+
+def _launch(L, descs, group):
+    n = len(descs)
+    arr = (emu_bind.ScanDesc * n)(*descs)
+    res = (emu_bind.ScanResult * n)()
+    assert L.emu_decode_scans_group(arr, res, n, group) == 0
+    return res
+
+
+@pytest.mark.parametrize("c", FAST_CASES, ids=lambda c: c["name"])
+def test_group_decoder_matches_reference_pixels(c):
+    """All scans of a golden case in ONE launch (they share the geometry), lanes per scan varied over the cases."""
+    L = emu_bind.lib()
+    with open(f"{common.GOLDEN}/{c['file']}", "rb") as f:
+        jls = f.read()
+    cont = jls_container.parse(jls)
+    pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+    if not _group_eligible(cont.bits, pc):
+        pytest.skip("scan_fast_decode.hip / the exact decoder take this one")
+    bps = 1 if cont.bits <= 8 else 2
+    w, h = cont.width, cont.height
+    keep, outs, descs = [], [], []
+    for scan in cont.scans:
+        pix = np.zeros(w * bps * h, dtype=np.uint8)
+        outs.append(pix)
+        descs.append(emu_bind.make_desc(w, h, 1, 0, cont.bits, 0, 0, pc, 0, pix, w * bps, _stream_copy(jls, scan.data_start), keep))
+    group = GROUPS[len(c["name"]) % len(GROUPS)]
+    res = _launch(L, descs, group)
+    for r, scan in zip(res, cont.scans):
+        assert (r.errc, r.flags) == (0, 0), "a valid stream must not need the exact decoder"
+        assert r.bytes == scan.data_end - scan.data_start
+    assert common.sha(b"".join(o.tobytes() for o in outs)) == c["decoded_sha256"]
+
+
+@pytest.mark.parametrize("group", GROUPS)
+@pytest.mark.parametrize("w,h,bits,kind,count", [(64, 20, 8, "mixed", 7), (300, 5, 8, "noise", 5), (33, 9, 16, "mixed", 5),
+                                                 (41, 7, 12, "hard", 3), (1, 9, 8, "mixed", 3), (520, 3, 2, "noise", 9),
+                                                 (70, 6, 8, "zero", 4)])
+def test_group_decoder_batches_of_different_frames(group, w, h, bits, kind, count):
+    """`count` different frames of one geometry per launch (count is not a multiple of the scans per wavefront, so the last
+    wavefront has idle lane groups); runs, escapes, several refills of the bit ring and lines of a few samples."""
+    L = emu_bind.lib()
+    bps = 1 if bits <= 8 else 2
+    keep, outs, descs, imgs, ends = [], [], [], [], []
+    for f in range(count):
+        img = synth.frame_numpy(w, h, seed=11 * f + bits, bits=bits, kind=kind)
+        jls = ob.encode(img, width=w, height=h, bits_per_sample=bits)
+        cont = jls_container.parse(jls)
+        pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+        pix = np.zeros(w * h * bps, dtype=np.uint8)
+        scan = cont.scans[0]
+        descs.append(emu_bind.make_desc(w, h, 1, 0, bits, 0, 0, pc, 0, pix, w * bps, _stream_copy(jls, scan.data_start), keep))
+        outs.append(pix)
+        imgs.append(img)
+        ends.append(scan.data_end - scan.data_start)
+    res = _launch(L, descs, group)
+    for f in range(count):
+        assert (res[f].errc, res[f].flags, res[f].bytes) == (0, 0, ends[f]), f
+        assert outs[f].tobytes() == imgs[f].tobytes(), f
+
+
+def test_group_decoder_leaves_other_thresholds_to_the_exact_decoder():
+    """The gradient table is shared by the scans of a wavefront and built from the first one's thresholds: a scan with
+    other thresholds reports kFastRetry, its neighbours decode."""
+    L = emu_bind.lib()
+    w, h = 40, 12
+    keep, outs, descs, imgs = [], [], [], []
+    presets = [None, None, (255, 9, 20, 60, 64), None, None]
+    for f, preset in enumerate(presets):
+        img = synth.frame_numpy(w, h, seed=f + 3, bits=8, kind="mixed")
+        jls = ob.encode(img, width=w, height=h, preset=preset)
+        cont = jls_container.parse(jls)
+        pc = jls_container.validated_pc(cont.pc, 8, 0)
+        pix = np.zeros(w * h, dtype=np.uint8)
+        descs.append(emu_bind.make_desc(w, h, 1, 0, 8, 0, 0, pc, 0, pix, w, _stream_copy(jls, cont.scans[0].data_start), keep))
+        outs.append(pix)
+        imgs.append(img)
+    res = _launch(L, descs, 8)  # eight scans per wavefront: all five share one
+    for f in range(len(presets)):
+        if presets[f] is None:
+            assert (res[f].errc, res[f].flags) == (0, 0) and outs[f].tobytes() == imgs[f].tobytes(), f
+        else:
+            assert (res[f].errc, res[f].flags) == (0, 4), f
+
+
+@pytest.mark.parametrize("name", ["fuzzy-input-bad-run-mode-golomb-code.jls", "fuzzy_input_golomb_16.jls",
+                                  "fuzzy-input-no-valid-bits-at-the-end.jls", "no_start_byte_after_encoded_scan.jls"])
+def test_group_decoder_defers_on_corrupt_streams(name):
+    """The speed path never reports an error itself: anything unusual is handed to the exact decoder."""
+    L = emu_bind.lib()
+    jls = common.refdata(name)
+    cont = jls_container.parse(jls)
+    scan = cont.scans[0]
+    if scan.near != 0 or scan.ilv != 0:
+        pytest.skip("not a scan the speed path takes")
+    pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+    bps = 1 if cont.bits <= 8 else 2
+    keep = []
+    pix = np.zeros(cont.width * bps * cont.height, dtype=np.uint8)
+    d = emu_bind.make_desc(cont.width, cont.height, 1, 0, cont.bits, 0, 0, pc, 0, pix, cont.width * bps,
+                           _stream_copy(jls, scan.data_start), keep)
+    res = _launch(L, [d], 16)
+    assert (res[0].errc, res[0].flags) == (0, 4)
+
+
+@pytest.mark.parametrize("bits,kind", [(8, "mixed"), (8, "zero"), (16, "mixed"), (12, "hard")])
+def test_group_dispatch_on_mutated_scan_data_matches_the_oracle(bits, kind):
+    """What runtime.hip's launch_decode_plain does (group kernel, then ONE launch of the exact wave decoder for the scans
+    that reported kFastRetry) on a batch of mutated streams; every frame ends with the oracle's pixels or error code."""
+    L = emu_bind.lib()
+    w, h = 48, 12
+    img = synth.frame_numpy(w, h, seed=bits, bits=bits, kind=kind)
+    base = ob.encode(img, width=w, height=h, bits_per_sample=bits)
+    cont = jls_container.parse(base)
+    scan = cont.scans[0]
+    pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+    bps = 1 if bits <= 8 else 2
+    rng = np.random.default_rng(bits * 13 + len(kind))
+    keep, descs, outs, wants = [], [], [], []
+    for k in range(36):
+        b = bytearray(base)
+        how = int(rng.integers(0, 5))
+        i = int(rng.integers(scan.data_start, len(b) - 2))
+        if how == 0:
+            b[i] ^= 1 << int(rng.integers(0, 8))
+        elif how == 1:
+            b[i] = int(rng.choice([0x00, 0xFF, 0x7F, 0x80]))
+        elif how == 2:
+            del b[i:i + int(rng.integers(1, 4))]
+        elif how == 3:
+            b[i:i] = bytes([int(rng.choice([0x00, 0xFF, 0x55]))])
+        data = bytes(b)  # how == 4: untouched
+        try:
+            wants.append((0, ob.decode(data)[1].tobytes()))
+        except ob.OracleError as e:
+            wants.append((e.errc, None))
+        pix = np.zeros(w * h * bps, dtype=np.uint8)
+        outs.append(pix)
+        descs.append(emu_bind.make_desc(w, h, 1, 0, bits, 0, 0, pc, 0, pix, w * bps, _stream_copy(data, scan.data_start), keep))
+    res = _launch(L, descs, 16)
+    retry = [k for k in range(len(descs)) if res[k].flags & 4]
+    for k in retry:  # the product gathers them into one launch; the emulated exact decoder takes one geometry per call too
+        one = (emu_bind.ScanResult * 1)()
+        L.emu_decode_scans_wave((emu_bind.ScanDesc * 1)(descs[k]), one, 1)
+        res[k].errc, res[k].flags, res[k].bytes = one[0].errc, one[0].flags, one[0].bytes
+    for k, want in enumerate(wants):
+        if want[0] == 0:
+            assert res[k].errc == 0 and outs[k].tobytes() == want[1], k
+        else:
+            assert res[k].errc == want[0], (k, res[k].errc, want[0])
+
+
+@pytest.mark.parametrize("chunk", range(2))
+def test_group_decoder_random_parameters(chunk):
+    """Random lossless single-component parameter sets (bits 2..16, custom thresholds / RESET, odd sizes)."""
+    from test_oracle_vs_reference import _image
+    L = emu_bind.lib()
+    rng = np.random.default_rng(900 + chunk)
+    done = 0
+    for it in range(40):
+        bits = int(rng.integers(2, 17))
+        w, h = int(rng.choice([1, 2, 5, 17, 64, 65, 130])), int(rng.choice([1, 2, 3, 8, 21]))
+        maxval = (1 << bits) - 1
+        kind = str(rng.choice(["rand", "smooth", "gradient", "mixed", "zero", "hard"]))
+        preset = None
+        if rng.random() < 0.4:
+            t1 = int(rng.integers(1, maxval + 1))
+            t2 = int(rng.integers(t1, maxval + 1))
+            t3 = int(rng.integers(t2, maxval + 1))
+            preset = (0, t1, t2, t3, int(rng.integers(3, max(255, maxval) + 1)))
+        pc = jls_container.validated_pc(preset or (0,) * 5, bits, 0)
+        if not _group_eligible(bits, pc):
+            continue
+        count = int(rng.integers(1, 6))
+        bps = 1 if bits <= 8 else 2
+        keep, descs, outs, imgs = [], [], [], []
+        for f in range(count):
+            img = _image(rng, w, h, bits, 1, 0, kind, it + f)
+            jls = ob.encode(img, width=w, height=h, bits_per_sample=bits, preset=preset)
+            cont = jls_container.parse(jls)
+            pix = np.zeros(w * h * bps, dtype=np.uint8)
+            descs.append(emu_bind.make_desc(w, h, 1, 0, bits, 0, 0, pc, 0, pix, w * bps,
+                                            _stream_copy(jls, cont.scans[0].data_start), keep))
+            outs.append(pix)
+            imgs.append(np.ascontiguousarray(img))
+        group = int(rng.choice(GROUPS))
+        res = _launch(L, descs, group)
+        for f in range(count):
+            tag = (chunk, it, f, bits, w, h, kind, preset, group)
+            assert (res[f].errc, res[f].flags) == (0, 0) and outs[f].tobytes() == imgs[f].tobytes(), tag
+        done += 1
+    assert done >= 15

@@ -22,6 +22,42 @@ ap.add_argument("--sizes", default="64,256,1024,4096")
 ap.add_argument("--repeat", type=int, default=1)
 args = ap.parse_args()
 
+import glob
+import threading
+
+
+class ClockSampler:
+    """Samples the shader clock (sysfs pp_dpm_sclk, the line marked '*') while a decode runs."""
+
+    def __init__(self):
+        self.files = glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")
+        self.values = []
+        self.stop = False
+
+    def _run(self):
+        while not self.stop:
+            for f in self.files:
+                try:
+                    for line in open(f):
+                        if "*" in line:
+                            self.values.append(int(line.split(":")[1].strip().lower().split("mhz")[0]))
+                except Exception:
+                    pass
+            time.sleep(0.05)
+
+    def __enter__(self):
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        self.thread.join()
+
+    def mean(self):
+        return round(sum(self.values) / len(self.values)) if self.values else None
+
+
 lib = capi.load_product()
 dev = torch.device("cuda:0")
 t0 = time.perf_counter()
@@ -48,13 +84,14 @@ for g in [int(x) for x in args.groups.split(",")]:
             out[:n].zero_()
             torch.cuda.synchronize()
             a = time.perf_counter()
-            params, errcs, gpu_ms = batch.decode_batch(enc.streams[:n], enc.sizes[:n], out[:n], lib=lib)
-            torch.cuda.synchronize()
+            with ClockSampler() as clocks:
+                params, errcs, gpu_ms = batch.decode_batch(enc.streams[:n], enc.sizes[:n], out[:n], lib=lib)
+                torch.cuda.synchronize()
             b = time.perf_counter()
             best = b - a if best is None or (it > 0 and b - a < best) or it == 1 else best
         ok = bool((errcs == 0).all())
         for f0 in range(0, n, 64):  # compare in pieces: torch.equal materialises a mask of the operands' size
             ok = ok and torch.equal(out[f0:min(n, f0 + 64)], frames[f0:min(n, f0 + 64)])
         rows.append({"group": g, "frames": n, "decode_s": round(best, 4), "mpix_s": round(mpix * n / best, 1),
-                     "kernel_ms": round(gpu_ms[0], 2), "ok": ok})
+                     "kernel_ms": round(gpu_ms[0], 2), "sclk_mhz": clocks.mean(), "ok": ok})
         print(json.dumps(rows[-1]), flush=True)
