@@ -4,15 +4,20 @@
 Workload (BASELINE.json configs[1]): 4096x4096 8-bit grayscale frames, lossless.  One "step" = one pass of the hot
 path over one batch: encode `--frames` device-resident frames to .jls and decode them back (per GPU).  With N > 1
 ranks every rank owns its own frames (weak scaling, frames are the sharding unit) and the encoded
-bitstreams are gathered to rank 0 over RCCL inside the timed region.  Inputs are resident in HBM before the clock
-starts; `value` = frames * pixels of all ranks / (max-over-ranks time), in MPixels/s.
+bitstreams are sent to rank 0 over RCCL inside the timed region (exact byte counts, point to point).  Inputs are
+resident in HBM before the clock starts; `value` = frames * pixels of all ranks / (max-over-ranks time), in MPixels/s.
+
+`python bench.py --gpus N` starts the N ranks itself (one process per GPU through torch.distributed.run on 127.0.0.1)
+when it is not already running under a launcher, and fails when the box has fewer than N GPUs.
 
 Correctness is checked outside the timed region: every frame must round-trip bit-exactly and rank 0's first frame
 must hash to the committed golden produced by the reference (tests/golden/cases.json: cfg2_full).
 
 One JSON line is printed by rank 0 (see the driver contract): it carries `roofline` for the dominant kernel
 (HIP-event time of that kernel on its own stream, algorithmic bytes per launch) and `cpu_baseline` (the reference's
-CPU codec, or the oracle port when oracle/_ref did not travel, timed on this box's host cores).
+CPU codec, or the oracle port when oracle/_ref did not travel, timed on this box's host cores: one thread, and one
+handle per thread on all cores).  Extra keys outside `value`: `batch_sweep` (throughput against the number
+of frames in flight), `single_frame_ms` and `host_abi` (wall clock through the host-pointer C ABI, PCIe inclusive).
 """
 from __future__ import annotations
 
@@ -20,6 +25,7 @@ import argparse
 import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,23 +39,46 @@ import numpy as np  # noqa: E402
 WIDTH = HEIGHT = 4096
 BITS = 8
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+WORKSPACE_BYTES = 96 << 30  # HBM the encoder may keep for its work areas during the bench (charls_amd_set_workspace_limit)
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
-    """Reference CPU codec (single thread) on a bounded sample of the same workload: frames of cfg2 (seed 2)."""
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_description():
+    model, cores = "unknown", os.cpu_count() or 1
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, cores
+
+
+def _cpu_codec():
     from charls_amd import synth
     img = synth.frame_numpy(WIDTH, HEIGHT, seed=2, bits=BITS)
     ref_path = os.path.join(ROOT, "oracle", "_ref", "libcharls_ref.so")
-    kind = "reference" if os.path.exists(ref_path) else "port"
-    if kind == "reference":
+    if os.path.exists(ref_path):
         from charls_amd.capi import CharLSLibrary
         codec = CharLSLibrary(ref_path)
-        enc = lambda: codec.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS)  # noqa: E731
-        dec = lambda data: codec.decode(data)  # noqa: E731
-    else:
-        import oracle_bind as ob
-        enc = lambda: ob.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS)  # noqa: E731
-        dec = lambda data: ob.decode(data)  # noqa: E731
+        return ("reference", img, lambda: codec.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS),
+                lambda data: codec.decode(data),
+                "g++ -O3 -flto -DNDEBUG -std=c++17 (oracle/Makefile: the flags of the reference's Release shared build)")
+    import oracle_bind as ob
+    return ("port", img, lambda: ob.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS),
+            lambda data: ob.decode(data), "gcc -O2 -std=c99 (oracle/Makefile)")
+
+
+def cpu_baseline(seconds_budget: float = 10.0, all_cores_budget: float = 8.0):
+    """Reference CPU codec on a bounded sample of the same workload (frames of cfg2, seed 2): one thread, then one
+    handle per thread on every host core (independent frames, the fair comparison for batches)."""
+    from concurrent.futures import ThreadPoolExecutor
+    kind, img, enc, dec, flags = _cpu_codec()
     jls = enc()  # warm-up
     dec(jls)
     t_enc, t_dec, reps = [], [], 0
@@ -65,6 +94,32 @@ def cpu_baseline(seconds_budget: float = 12.0):
         reps += 1
     mpix = WIDTH * HEIGHT / 1e6
     best_enc, best_dec = min(t_enc), min(t_dec)
+    model, cores = cpu_description()
+
+    # all cores: every thread owns its codec handles (created per call, as cli/benchmark.cpp does) and codes its own copy
+    # of the frame; ctypes releases the GIL for the duration of the C calls
+    def worker(deadline):
+        n_enc = n_dec = 0
+        t_e = t_d = 0.0
+        while time.perf_counter() < deadline or n_enc == 0:
+            a = time.perf_counter()
+            data = enc()
+            b = time.perf_counter()
+            dec(data)
+            c = time.perf_counter()
+            t_e += b - a
+            t_d += c - b
+            n_enc += 1
+            n_dec += 1
+        return n_enc, t_e, n_dec, t_d
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        results = list(pool.map(worker, [t0 + all_cores_budget] * cores))
+    wall = time.perf_counter() - t0
+    frames_done = sum(r[0] for r in results)
+    enc_rate = sum(r[0] / r[1] for r in results) * mpix  # sum of the threads' own rates
+    dec_rate = sum(r[2] / r[3] for r in results) * mpix
     return {
         "value": round(mpix / (best_enc + best_dec), 2),
         "unit": "MPixels/s encode+decode",
@@ -73,7 +128,64 @@ def cpu_baseline(seconds_budget: float = 12.0):
         "sample": f"{reps} x one 4096x4096 8-bit frame (seed 2), C ABI in-memory, best of {reps}",
         "encode_mpix_s": round(mpix / best_enc, 2),
         "decode_mpix_s": round(mpix / best_dec, 2),
+        "single_frame_ms": {"encode": round(best_enc * 1e3, 1), "decode": round(best_dec * 1e3, 1)},
+        "cpu_model": model,
+        "host_cores": cores,
+        "compiler_flags": flags,
+        "all_cores": {"threads": cores, "value": round(frames_done * mpix / wall, 2), "unit": "MPixels/s encode+decode",
+                      "encode_mpix_s": round(enc_rate, 2), "decode_mpix_s": round(dec_rate, 2),
+                      "sample": f"{frames_done} frames in {wall:.1f} s, one handle per thread, independent frames"},
     }
+
+
+def relaunch_under_torchrun(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) and return their exit status."""
+    import torch
+    backend = os.environ.get("CHARLS_AMD_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            log(f"--gpus {args.gpus} but this box has {have} GPU(s): refusing to run fewer ranks than asked for")
+            return 2
+    port = os.environ.get("MASTER_PORT", "29533")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching " + " ".join(cmd))
+    return subprocess.call(cmd)
+
+
+def exchange_selftest(world, rank):
+    """--selftest-exchange: the launcher, the process group and the exact-size bitstream exchange on FABRICATED streams
+    (no codec, no GPU needed with CHARLS_AMD_BENCH_BACKEND=gloo).  Not a measurement."""
+    import torch
+    import torch.distributed as dist
+    from charls_amd import batch
+    rng = np.random.default_rng(1234 + rank)
+    count = 5 + rank  # ranks own different numbers of frames
+    sizes = rng.integers(1, 5000, size=count).astype(np.uint64)
+    pitch = 5120
+    streams = torch.zeros((count, pitch), dtype=torch.uint8)
+    for f in range(count):
+        streams[f, :int(sizes[f])] = torch.from_numpy(rng.integers(0, 256, size=int(sizes[f]), dtype=np.uint8))
+    digest = hashlib.sha256()
+    for f in range(count):
+        digest.update(streams[f, :int(sizes[f])].numpy().tobytes())
+    mine = torch.tensor(list(digest.digest()), dtype=torch.uint8)
+    all_digests = [torch.zeros(32, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(all_digests, mine)
+    received = {}
+    batch.gather_streams(streams, sizes, dst=0, sink=lambda r, first, frames, sz: received.setdefault(r, []).append((first, frames, sz)))
+    ok = True
+    if rank == 0:
+        for r in range(world):
+            h = hashlib.sha256()
+            for first, frames, sz in sorted(received.get(r, []), key=lambda x: x[0]):
+                for f in range(len(frames)):
+                    h.update(frames[f][:int(sz[f])].numpy().tobytes())
+            ok = ok and list(h.digest()) == all_digests[r].tolist()
+        print(json.dumps({"selftest": "exchange", "n_gpus": world, "backend": dist.get_backend(),
+                          "ranks_seen_by_backend": dist.get_world_size(), "ok": ok}), flush=True)
+    return 0 if ok else 1
 
 
 def main():
@@ -82,38 +194,63 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=int(os.environ.get("CHARLS_AMD_BENCH_FRAMES", "4096")),
-                    help="frames per GPU per step (decoding is one serial chain per frame: throughput comes from "
-                         "the number of concurrent frames; 4096 = four wavefronts per SIMD = what LDS holds, and with "
-                         "their bitstreams and decoded copies 210 GB of the 288 GB of HBM)")
+                    help="frames per GPU per step (decoding is one serial chain per frame: throughput comes from the "
+                         "number of frames in flight, see `batch_sweep` in the output; 4096 frames with their bitstreams and "
+                         "decoded copies are 210 GB of the 288 GB of HBM)")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 serial kernel, 2 pipeline")
     ap.add_argument("--restart-interval", type=int, default=0,
                     help="NOT the headline: code every N lines as a restart interval (this library's encoder extension; "
                          "the reference's encoder cannot emit restart markers, so the streams are no longer the "
                          "reference's bytes, only decodable by it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip batch_sweep / single_frame_ms / host_abi")
+    ap.add_argument("--selftest-exchange", action="store_true", help="launcher + exchange on fabricated streams (no codec)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
 
     import torch
     import torch.distributed as dist
-    from charls_amd import batch, capi, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # CHARLS_AMD_BENCH_FORCE_GATHER=1 runs the RCCL path (init, barrier, gather of bitstreams) with a single rank too
+    if world != args.gpus:
+        log(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the arguments disagree")
+        sys.exit(2)
+    backend = os.environ.get("CHARLS_AMD_BENCH_BACKEND", "nccl")
+    # CHARLS_AMD_BENCH_FORCE_GATHER=1 runs the RCCL path (init, barrier, exchange of bitstreams) with a single rank too
     force_gather = os.environ.get("CHARLS_AMD_BENCH_FORCE_GATHER") == "1"
-    if world > 1 or force_gather:
+    use_dist = world > 1 or force_gather
+    dev = None
+    if backend == "nccl":
+        if torch.cuda.device_count() <= local_rank:
+            log(f"rank {rank}: no GPU {local_rank} on this box ({torch.cuda.device_count()} visible)")
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    if use_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"),
                               RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        if rank == 0:
+            log(f"process group up: backend={dist.get_backend()} nranks={dist.get_world_size()}")
+    if args.selftest_exchange:
+        rc = exchange_selftest(world, rank)
+        if use_dist:
+            dist.destroy_process_group()
+        sys.exit(rc)
 
+    from charls_amd import batch, capi, synth
     lib = capi.load_product()
     assert lib.lib.charls_amd_device_status() == 0, "no usable GPU: the product has no CPU fallback"
     batch.set_encode_engine(args.engine, lib)
+    batch.set_workspace_limit(WORKSPACE_BYTES, lib)
 
     frames_n = args.frames
     seed0 = 2 + rank * 100003  # rank 0 frame 0 == golden cfg2_full
@@ -131,7 +268,7 @@ def main():
         t1 = time.perf_counter()
         _, errcs, dec_t = batch.decode_batch(enc.streams, enc.sizes, out, lib=lib)
         t2 = time.perf_counter()
-        if world > 1 or force_gather:
+        if use_dist:
             batch.gather_streams(enc.streams, enc.sizes, dst=0, sink=lambda r, first, part, sz: None)
         if timed:
             enc_ms.append((t1 - t0) * 1e3)
@@ -144,7 +281,7 @@ def main():
         step(False)
 
     def barrier():
-        if world > 1 or force_gather:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -154,7 +291,7 @@ def main():
         enc, errcs = step(True)
     barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1 or force_gather:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -173,8 +310,9 @@ def main():
 
     if rank == 0:
         pixels = WIDTH * HEIGHT
+        mpix = pixels / 1e6
         total_frames = frames_n * world * args.steps
-        value = total_frames * pixels / 1e6 / elapsed
+        value = total_frames * mpix / elapsed
         jls_bytes = float(np.mean(enc.sizes.astype(np.float64)))
         raw_bytes = pixels * ((BITS + 7) // 8)
         # dominant kernel = largest HIP-event time per step (events recorded on the stream the kernels run on)
@@ -182,15 +320,15 @@ def main():
         stages = (np.mean([k[2:7] for k in enc_kernel_ms], axis=0)
                   if enc_kernel_ms and len(enc_kernel_ms[0]) >= 7 and args.restart_interval == 0 else None)
         dk = float(np.mean([k[1] for k in dec_kernel_ms])) if dec_kernel_ms else 0.0
-        dom_name, dom_ms = "decode_scans_fast", dk
+        dom_name, dom_ms = "decode_scans_group", dk
         if stages is not None and float(stages.max()) > dk:
             dom_name, dom_ms = stage_names[int(stages.argmax())], float(stages.max())
         # algorithmic bytes: every pixel byte and every .jls byte touched once by a pass over the batch
         alg_bytes = frames_n * (raw_bytes + jls_bytes)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
-        try:  # HBM bytes per frame of the dominant kernel measured with rocprofv3 PMC (profiles/r01_traffic.json)
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        try:  # HBM bytes per frame of the dominant kernel measured with rocprofv3 PMC in its own run (profiles/README.md)
+            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
                 tj = json.load(f)
             if tj.get("kernel") == dom_name:
                 traffic = int(tj["hbm_bytes_per_frame"] * frames_n)
@@ -212,11 +350,13 @@ def main():
             "data": "synthetic (seeded gradient + noise frames, charls_amd/synth.py)",
             "config": {"workload": "BASELINE configs[1]: 4096x4096 8-bit gray lossless, batch of independent frames",
                        "frames_per_gpu": frames_n, "jls_bytes_per_frame": int(jls_bytes),
-                       "sharding": f"frames over {world} rank(s), RCCL gather of bitstreams to rank 0" if world > 1 else "1 GPU",
+                       "sharding": (f"frames over {world} rank(s), bitstreams sent to rank 0 over "
+                                    f"{dist.get_backend() if use_dist else 'nccl'} inside the timed region") if world > 1 else "1 GPU",
+                       "ranks_seen_by_backend": dist.get_world_size() if use_dist else 1,
                        "engine": args.engine, "restart_interval": args.restart_interval},
             "bit_exact_vs_reference": bit_exact,
-            "encode_mpix_s": round(frames_n * pixels / 1e6 / (np.mean(enc_ms) * 1e-3), 2),
-            "decode_mpix_s": round(frames_n * pixels / 1e6 / (np.mean(dec_ms) * 1e-3), 2),
+            "encode_mpix_s": round(frames_n * mpix / (np.mean(enc_ms) * 1e-3), 2),
+            "decode_mpix_s": round(frames_n * mpix / (np.mean(dec_ms) * 1e-3), 2),
             "encode_ms": round(float(np.mean(enc_ms)), 3),
             "decode_ms": round(float(np.mean(dec_ms)), 3),
             "encode_stage_ms": dict(zip(["analyze", "partition", "chains", "pack", "stuff"],
@@ -224,14 +364,74 @@ def main():
             if enc_kernel_ms and len(enc_kernel_ms[0]) >= 7 else None,
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "traffic_source": "rocprofv3 PMC run committed under profiles/ (not collected in this run)" if traffic else None,
                          "kernel_ms_per_launch": round(dom_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
+        if not args.no_extras and args.restart_interval == 0:
+            line.update(extras(lib, batch, torch, frames, streams, out, enc, dev, mpix, pitch))
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
 
-    if world > 1 or force_gather:
+    if use_dist:
         dist.destroy_process_group()
+
+
+def extras(lib, batch, torch, frames, streams, out, enc, dev, mpix, pitch):
+    """Context for `value` (never part of it): throughput against the number of frames in flight, one frame through the
+    host-pointer C ABI (the literal reading of BASELINE configs[1]), and a batch with the PCIe copies inside the clock."""
+    result = {}
+    # ---- throughput against the batch size (frames resident in HBM, as in the timed region)
+    sweep = []
+    for n in (1, 64, 256, 1024, 4096):
+        if n > frames.shape[0]:
+            continue
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        e = batch.encode_batch(frames[:n], bits_per_sample=BITS, streams=streams[:n], lib=lib)
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        batch.decode_batch(e.streams, e.sizes, out[:n], lib=lib)
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+        sweep.append({"frames": n, "encode_mpix_s": round(n * mpix / (b - a), 1), "decode_mpix_s": round(n * mpix / (c - b), 1)})
+    result["batch_sweep"] = sweep
+    # ---- one frame through the host-pointer C ABI (handle created inside the clock, as cli/benchmark.cpp does)
+    img = frames[0].cpu().numpy()
+    lib.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS)  # warm-up (allocations, module load)
+    a = time.perf_counter()
+    jls = lib.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS)
+    b = time.perf_counter()
+    _, px = lib.decode(jls)
+    c = time.perf_counter()
+    assert px.tobytes() == img.tobytes()
+    result["single_frame_ms"] = {"encode": round((b - a) * 1e3, 1), "decode": round((c - b) * 1e3, 1),
+                                 "path": "charls_jpegls_encoder_encode_from_buffer / charls_jpegls_decoder_decode_to_buffer, "
+                                         "host buffers in and out (PCIe inclusive), one 4096x4096 8-bit frame"}
+    # ---- a batch with the PCIe copies inside the clock: pinned host frames -> HBM -> encode -> .jls back to pinned host
+    # memory, and the way back for decode
+    n = min(256, frames.shape[0])
+    host_frames = torch.empty((n, HEIGHT, WIDTH), dtype=torch.uint8).pin_memory()
+    host_frames.copy_(frames[:n])
+    host_streams = torch.empty((n, pitch), dtype=torch.uint8).pin_memory()
+    host_out = torch.empty((n, HEIGHT, WIDTH), dtype=torch.uint8).pin_memory()
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    out[:n].copy_(host_frames, non_blocking=True)
+    e = batch.encode_batch(out[:n], bits_per_sample=BITS, streams=streams[:n], lib=lib)
+    longest = int(e.sizes.max())
+    host_streams[:, :longest].copy_(e.streams[:, :longest], non_blocking=True)
+    torch.cuda.synchronize()
+    b = time.perf_counter()
+    streams[:n, :longest].copy_(host_streams[:, :longest], non_blocking=True)
+    batch.decode_batch(streams[:n], e.sizes, out[:n], lib=lib)
+    host_out.copy_(out[:n], non_blocking=True)
+    torch.cuda.synchronize()
+    c = time.perf_counter()
+    assert torch.equal(host_out, host_frames)
+    result["host_abi"] = {"frames": n, "encode_mpix_s": round(n * mpix / (b - a), 1), "decode_mpix_s": round(n * mpix / (c - b), 1),
+                          "path": "pinned host buffers, H2D + batch call + D2H inside the clock (PCIe inclusive; never `value`)"}
+    return result
 
 
 if __name__ == "__main__":

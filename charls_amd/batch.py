@@ -151,13 +151,15 @@ def shard_range(total: int, rank: int, world: int):
 
 
 def gather_streams(streams, sizes, dst=0, group=None, chunk_frames=32, sink=None):
-    """Variable-length gather of the encoded frames to rank `dst` (RCCL on GPU tensors, gloo on CPU tensors):
-    an all-gather of the per-frame byte counts, then the payload in rounds of `chunk_frames` frames per rank, each round
-    one padded `gather` trimmed to the round's maximum length into a receive buffer that is re-used (the payload of a
-    big batch does not have to fit rank dst's HBM at once).  `sink(rank, first_frame, tensor, sizes)` is called on dst for
-    every received piece; without a sink the pieces are kept and returned.
-    Returns on dst: (list of per-rank lists of (first_frame, uint8 tensor (n, max_len)), per-rank size arrays);
-    elsewhere: (None, per-rank size arrays)."""
+    """Variable-length gather of the encoded frames to rank `dst` (RCCL on GPU tensors, gloo on CPU tensors): an all-gather
+    of the per-frame byte counts, then the payload point to point in rounds of `chunk_frames` frames per rank -- every
+    frame is ONE send of exactly its bytes (`streams[f, :sizes[f]]` is contiguous, nothing is packed, padded or copied on
+    the sending side), the sends / receives of a round are posted together (dist.batch_isend_irecv = one ncclGroup), and
+    rank dst receives into a buffer per source rank that is re-used from round to round (the payload of a big batch does
+    not have to fit rank dst's HBM at once).  `sink(rank, first_frame, tensor, sizes)` is called on dst for every received
+    piece (its own frames are handed over as views, they never move); without a sink the pieces are kept and returned.
+    Returns on dst: (list of per-rank lists of (first_frame, uint8 tensor (n, >= max size of the piece)), per-rank size
+    arrays); elsewhere: (None, per-rank size arrays)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -167,32 +169,37 @@ def gather_streams(streams, sizes, dst=0, group=None, chunk_frames=32, sink=None
     dist.all_gather(counts, torch.tensor([len(sizes)], dtype=torch.int64, device=dev), group=group)
     counts = [int(c.item()) for c in counts]
     max_count = max(counts)
-    mine = torch.zeros(max_count, dtype=torch.int64, device=dev)
+    mine = torch.zeros(max(max_count, 1), dtype=torch.int64, device=dev)
     mine[:len(sizes)] = torch.as_tensor(np.asarray(sizes, dtype=np.int64), device=dev)
-    all_sizes = [torch.zeros(max_count, dtype=torch.int64, device=dev) for _ in range(world)]
+    all_sizes = [torch.zeros(max(max_count, 1), dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_sizes, mine, group=group)
     all_sizes = [s[:c].cpu().numpy().astype(np.uint64) for s, c in zip(all_sizes, counts)]
     kept = [[] for _ in range(world)] if rank == dst else None
     for first in range(0, max_count, chunk_frames):
-        n = min(chunk_frames, max_count - first)
-        max_len = int(max((int(s[first:first + n].max()) if len(s) > first else 0) for s in all_sizes))
-        max_len = -(-max(max_len, 1) // 65536) * 65536  # few distinct buffer sizes -> re-used blocks (same on every rank)
-        payload = torch.zeros((n, max_len), dtype=torch.uint8, device=dev)
-        have = max(0, min(n, streams.shape[0] - first))
-        if have:
-            cols = min(max_len, streams.shape[1])
-            payload[:have, :cols] = streams[first:first + have, :cols]
-        if rank == dst:
-            parts = [torch.empty_like(payload) for _ in range(world)]
-            dist.gather(payload, parts, dst=dst, group=group)
-            for r, part in enumerate(parts):
-                m = max(0, min(n, counts[r] - first))
-                if m == 0:
-                    continue
-                if sink is not None:
-                    sink(r, first, part[:m], all_sizes[r][first:first + m])
-                else:
-                    kept[r].append((first, part[:m]))
-        else:
-            dist.gather(payload, None, dst=dst, group=group)
+        if rank != dst:
+            ops = [dist.P2POp(dist.isend, streams[f, :int(sizes[f])], dst, group)
+                   for f in range(first, min(first + chunk_frames, len(sizes))) if int(sizes[f]) > 0]
+            for req in (dist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
+            continue
+        ops, pieces = [], []
+        for r in range(world):
+            m = max(0, min(chunk_frames, counts[r] - first))
+            if m == 0:
+                continue
+            sz = all_sizes[r][first:first + m]
+            if r == rank:
+                pieces.append((r, streams[first:first + m], sz))
+                continue
+            longest = -(-max(int(sz.max()), 1) // 65536) * 65536  # few distinct buffer sizes -> re-used blocks
+            part = torch.empty((m, longest), dtype=torch.uint8, device=dev)
+            ops += [dist.P2POp(dist.irecv, part[f, :int(sz[f])], r, group) for f in range(m) if int(sz[f]) > 0]
+            pieces.append((r, part, sz))
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        for r, part, sz in pieces:
+            if sink is not None:
+                sink(r, first, part, sz)
+            else:
+                kept[r].append((first, part))
     return kept, all_sizes

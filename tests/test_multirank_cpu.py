@@ -79,3 +79,36 @@ def test_gather_streams_world_size_2(total_frames):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) == "ok"
+
+
+def _run_bench(args, extra_env, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(_free_port()), **extra_env)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` without a launcher: bench.py re-executes itself under torch.distributed.run with two ranks
+    (gloo here, RCCL on a GPU box), the ranks exchange fabricated bitstreams of different sizes through
+    batch.gather_streams and rank 0 reports the number of ranks the backend sees."""
+    import json
+    r = _run_bench(["--gpus", "2", "--selftest-exchange"], {"CHARLS_AMD_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert lines[0] == {"selftest": "exchange", "n_gpus": 2, "backend": "gloo", "ranks_seen_by_backend": 2, "ok": True}
+    assert "nranks=2" in r.stderr
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked_for():
+    """A box with fewer GPUs than --gpus is an error, not a silent single-rank run (there is no GPU here at all)."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--frames", "1"], {})
+    assert r.returncode == 2
+    assert "refusing" in r.stderr and not [x for x in r.stdout.splitlines() if x.startswith("{")]
