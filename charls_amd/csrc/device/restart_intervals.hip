@@ -116,9 +116,11 @@ __global__ void build_decode_intervals(const ScanDesc* __restrict__ parents, con
     const uint64_t start = j == 0 ? 0 : (uint64_t)mk[j - 1] + 2;
     const uint64_t end = j + 1 < intervals ? (uint64_t)mk[j] + 2 : d.stream_capacity; // its own RSTm terminates an interval
     d.pixels += (uint64_t)j * lines * d.pixel_stride;
-    d.height = j + 1 < intervals ? lines : d.height - j * lines;
+    // rows of this interval; a parent without rows (a frame that already failed) has only empty intervals
+    const uint64_t before = (uint64_t)j * lines;
+    d.height = d.height > before ? (uint32_t)(d.height - before < lines ? d.height - before : lines) : 0u;
     d.stream += start;
-    d.stream_capacity = end - start;
+    d.stream_capacity = end > start ? end - start : 0;
     d.restart_interval = 0;
     subs[(size_t)s * intervals + j] = d;
 }
@@ -165,9 +167,14 @@ __global__ void build_encode_intervals(const ScanDesc* __restrict__ parents, uin
     const uint32_t lines = d.restart_interval;
     const size_t at = (size_t)s * intervals + j;
     d.pixels += (uint64_t)j * lines * d.pixel_stride;
-    d.height = j + 1 < intervals ? lines : d.height - j * lines;
+    // rows of this interval.  A parent with height 0 is a frame that failed earlier (container_kernels.hip:
+    // place_scan_header empties its descriptor): all its intervals are empty scans with no room, which fail fast without
+    // touching pixels or work areas -- the geometry of the launch (`intervals`) comes from the other frames.
+    const uint64_t before = (uint64_t)j * lines;
+    const bool dead = d.height == 0 || d.stream_capacity == 0;
+    d.height = !dead && d.height > before ? (uint32_t)(d.height - before < lines ? d.height - before : lines) : 0u;
     d.stream = buffers + at * capacity;
-    d.stream_capacity = capacity;
+    d.stream_capacity = dead ? 0 : capacity;
     d.restart_interval = 0;
     if (scratch != nullptr)
         d.line_scratch = scratch + at * scratch_samples;
@@ -185,6 +192,13 @@ __global__ void plan_join(const ScanDesc* __restrict__ parents, uint32_t interva
     const ScanDesc d = parents[s];
     const ScanResult* sr = sub_results + (size_t)s * intervals;
     uint64_t* off = offsets + (size_t)s * intervals;
+    if (d.height == 0 || d.stream_capacity == 0)
+    { // a frame that failed before this scan: nothing to join, and no reason to repeat its group with larger buffers
+        for (uint32_t j = 0; j < intervals; ++j)
+            off[j] = 0;
+        results[s] = ScanResult{kDestinationTooSmall, 0, 0};
+        return;
+    }
     ScanResult r{kOk, 0, 0};
     uint64_t at = 0;
     for (uint32_t j = 0; j < intervals; ++j)

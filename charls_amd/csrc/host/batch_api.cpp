@@ -486,7 +486,7 @@ try
             }
             parse(i, [&](Frame& y) {
                 // continue the same reader on the freshly fetched window
-                y.reader.set_source(y.window.data(), y.window.size());
+                y.reader.continue_on_window(y.window.data(), y.window.size());
                 if (last)
                     y.reader.read_end_of_image();
                 else

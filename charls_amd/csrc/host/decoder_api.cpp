@@ -99,6 +99,9 @@ struct charls_jpegls_decoder
             component += reader.scan_component_count();
             if (component == reader.component_count())
                 break;
+            // (the reference's span::subspan only asserts here; a wrapped size would let later planes write past the buffer)
+            if (dst_left < stride * height)
+                raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
             dst += stride * height;
             dst_left -= stride * height;
             reader.read_next_start_of_scan();

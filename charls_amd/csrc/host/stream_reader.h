@@ -28,6 +28,17 @@ public:
         end_ = data + size;
     }
 
+    // Continue on another window of the same stream (the batch decoder re-fetches a few KB around every marker
+    // segment): mapping-table fragments point into the PREVIOUS window, so their data is let go of -- ids, entry sizes
+    // and lengths stay (read_end_of_image() only looks at the ids).
+    void continue_on_window(const uint8_t* data, size_t size) noexcept
+    {
+        for (Table& t : tables_)
+            for (auto& f : t.fragments)
+                f.first = nullptr;
+        set_source(data, size);
+    }
+
     void at_comment(charls_at_comment_handler h, void* ctx) noexcept
     {
         comment_handler_ = h;
@@ -83,6 +94,9 @@ public:
     {
         if (tables_[i].size() > cap)
             raise(CHARLS_JPEGLS_ERRC_DESTINATION_TOO_SMALL);
+        for (const auto& f : tables_[i].fragments)
+            if (f.first == nullptr) // the source window that held the table is gone (continue_on_window)
+                raise(CHARLS_JPEGLS_ERRC_INVALID_OPERATION);
         for (const auto& f : tables_[i].fragments)
         {
             std::memcpy(dst, f.first, f.second);

@@ -275,6 +275,9 @@ CHARLS_AMD_API charls_jpegls_errc charls_validate_spiff_header(const charls_spif
  * `hip_stream` is a hipStream_t (NULL = default stream); the calls return after the stream work has completed.
  * Every frame gets the bytes and the errc the part-1 encoder/decoder would give it with a destination buffer of
  * stream_pitch_bytes (encode) or a source buffer of sizes[f] bytes (decode).
+ * Slots need no alignment, but the decoders load whole 16-byte aligned groups: the device allocation that holds
+ * d_streams must be readable from the 16-byte boundary at or before its first slot to the one at or after the end of its
+ * last slot (any hipMalloc'ed buffer is; a slot that ends on the last byte of a sub-allocated pool may not be).
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct charls_amd_codec_params
 {

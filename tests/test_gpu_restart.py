@@ -219,3 +219,34 @@ def test_single_frame_latency_with_restart_intervals(lib, capsys):
         print(f"\n[restart] 4096x4096 single frame, host-pointer ABI: no DRI encode {t[0][0]:.3f}s decode {t[0][1]:.3f}s "
               f"({t[0][2]} B); DRI=64 encode {t[64][0]:.3f}s decode {t[64][1]:.3f}s ({t[64][2]} B)")
     assert t[64][1] < t[0][1] / 4
+
+
+@pytest.mark.parametrize("interval", [8, 16])
+def test_batch_restart_planar_rgb_with_a_slot_that_is_too_small(lib, interval):
+    """A frame that fails in its first plane (destination_too_small) stays a per-frame error in the later planes of an
+    ILV_NONE batch with restart intervals: its emptied descriptor must produce empty intervals, not an underflowed row
+    count (round-1 advisor finding); the other frames get the bytes of a batch without the bad frame."""
+    import torch
+    from charls_amd import batch
+    w, h, n = 64, 40, 4
+    imgs = [synth.frame_numpy(w, h, seed=70 + f, components=3, kind="noise" if f == 1 else "zero", interleaved=False)
+            for f in range(n)]
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    good = batch.encode_batch(frames, component_count=3, interleave_mode=0, restart_interval=interval, lib=lib)
+    assert (good.errcs == 0).all()
+    # every slot is too small for the noise frame (frame 1) but large enough for the all-zero frames
+    pitch = (int(max(good.sizes[f] for f in (0, 2, 3))) + 255) & ~255
+    assert pitch < int(good.sizes[1])
+    streams = torch.zeros((n, pitch), dtype=torch.uint8, device="cuda:0")
+    enc = batch.encode_batch(frames, component_count=3, interleave_mode=0, restart_interval=interval, streams=streams, lib=lib)
+    assert list(enc.errcs) == [0, 3, 0, 0] and int(enc.sizes[1]) == 0
+    for f in (0, 2, 3):
+        assert enc.streams[f, :int(enc.sizes[f])].cpu().numpy().tobytes() == \
+            good.streams[f, :int(good.sizes[f])].cpu().numpy().tobytes()
+    out = torch.zeros_like(frames)
+    sizes = enc.sizes.copy()
+    sizes[1] = 0
+    _, errcs, _ = batch.decode_batch(enc.streams, sizes, out, lib=lib)
+    assert [int(e) == 0 for e in errcs] == [True, False, True, True]
+    for f in (0, 2, 3):
+        assert torch.equal(out[f], frames[f])
