@@ -11,6 +11,10 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libcharls_amd.so")
+# The same objects linked under the reference's SONAME (src/CMakeLists.txt:65-67: libcharls.so.3), so that a program
+# linked with -lcharls against CharLS finds this library when charls_amd/lib precedes CharLS on its library path.
+OUT_ALIAS = os.path.join(OUT_DIR, "libcharls.so.3")
+VERSION_SCRIPT = os.path.join(CSRC, "charls_amd.version")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # translation units; the *.hip kernel sources are #included by runtime.hip so that launches and kernels share a TU
@@ -31,7 +35,7 @@ def _newest_source() -> float:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest_source():
+    if not force and os.path.exists(OUT) and os.path.exists(OUT_ALIAS) and os.path.getmtime(OUT) >= _newest_source():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
     obj_dir = os.path.join(OUT_DIR, "obj")
@@ -57,10 +61,36 @@ def build(force: bool = False, verbose: bool = False) -> str:
             sys.stderr.write(out.decode())
     if failed:
         raise RuntimeError("hipcc failed")
-    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT, "-Wl,-soname,libcharls_amd.so",
-            "-Wl,--no-undefined"]
-    subprocess.check_call(link)
+    for out, soname in ((OUT, "libcharls_amd.so"), (OUT_ALIAS, "libcharls.so.3")):
+        link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out, "-Wl,-soname," + soname,
+                "-Wl,--no-undefined", "-Wl,--version-script=" + VERSION_SCRIPT]
+        subprocess.check_call(link)
+    dev_link = os.path.join(OUT_DIR, "libcharls.so")  # what -lcharls resolves at link time
+    if os.path.lexists(dev_link):
+        os.remove(dev_link)
+    os.symlink("libcharls.so.3", dev_link)
     return OUT
+
+
+C_CALLER_SRC = os.path.join(ROOT, "tests", "c_caller", "roundtrip.c")
+C_CALLER_DIR = os.path.join(ROOT, "tests", "c_caller", "build")
+
+
+def build_c_callers(reference_include: str = "/root/reference/include") -> list[str]:
+    """tests/c_caller/roundtrip.c compiled with gcc as C99 against this repository's header and -- where the reference tree
+    is present -- against the reference's own <charls/charls.h>, both linked with -lcharls (SONAME libcharls.so.3 of
+    charls_amd/lib).  The link test of INTEGRATION.md; the binaries travel to the GPU box and run in smoke()."""
+    os.makedirs(C_CALLER_DIR, exist_ok=True)
+    outs = []
+    variants = [("roundtrip_own_header", ["-I" + os.path.join(ROOT, "include")])]
+    if os.path.isdir(os.path.join(reference_include, "charls")):
+        variants.append(("roundtrip_reference_headers", ["-DUSE_REFERENCE_HEADERS", "-I" + reference_include]))
+    for name, flags in variants:
+        out = os.path.join(C_CALLER_DIR, name)
+        subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", *flags, C_CALLER_SRC, "-o", out, "-L" + OUT_DIR,
+                               "-lcharls", "-Wl,-rpath,$ORIGIN/../../../charls_amd/lib"])
+        outs.append(out)
+    return outs
 
 
 if __name__ == "__main__":

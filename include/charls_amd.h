@@ -92,14 +92,45 @@ enum
     CHARLS_AMD_ERRC_DEVICE_FAILURE = 201
 };
 
-typedef int32_t charls_interleave_mode; /* 0 none, 1 line, 2 sample */
-typedef int32_t charls_color_transformation; /* 0 none, 1 HP1, 2 HP2, 3 HP3 */
-typedef uint32_t charls_encoding_options; /* 1 even size, 2 version comment, 4 pc parameters (JAI) */
-typedef int32_t charls_compressed_data_format; /* 0 unknown, 1 interchange, 2 abbreviated image, 3 abbreviated tables */
+/* The reference declares these as C enums (include/charls/public_types.h:90-187); an enum of these values is an int,
+ * so 32-bit integer types with the same constant names give a C caller the same source and the same ABI. */
+typedef int32_t charls_interleave_mode;
+enum { CHARLS_INTERLEAVE_MODE_NONE = 0, CHARLS_INTERLEAVE_MODE_LINE = 1, CHARLS_INTERLEAVE_MODE_SAMPLE = 2 };
+typedef int32_t charls_color_transformation;
+enum { CHARLS_COLOR_TRANSFORMATION_NONE = 0, CHARLS_COLOR_TRANSFORMATION_HP1 = 1, CHARLS_COLOR_TRANSFORMATION_HP2 = 2,
+       CHARLS_COLOR_TRANSFORMATION_HP3 = 3 };
+typedef uint32_t charls_encoding_options;
+enum { CHARLS_ENCODING_OPTIONS_NONE = 0, CHARLS_ENCODING_OPTIONS_EVEN_DESTINATION_SIZE = 1,
+       CHARLS_ENCODING_OPTIONS_INCLUDE_VERSION_NUMBER = 2, CHARLS_ENCODING_OPTIONS_INCLUDE_PC_PARAMETERS_JAI = 4 };
+typedef int32_t charls_compressed_data_format;
+enum { CHARLS_COMPRESSED_DATA_FORMAT_UNKNOWN = 0, CHARLS_COMPRESSED_DATA_FORMAT_INTERCHANGE = 1,
+       CHARLS_COMPRESSED_DATA_FORMAT_ABBREVIATED_IMAGE_DATA = 2, CHARLS_COMPRESSED_DATA_FORMAT_ABBREVIATED_TABLE_SPECIFICATION = 3 };
 typedef int32_t charls_spiff_profile_id;
+enum { CHARLS_SPIFF_PROFILE_ID_NONE = 0, CHARLS_SPIFF_PROFILE_ID_CONTINUOUS_TONE_BASE = 1,
+       CHARLS_SPIFF_PROFILE_ID_CONTINUOUS_TONE_PROGRESSIVE = 2, CHARLS_SPIFF_PROFILE_ID_BI_LEVEL_FACSIMILE = 3,
+       CHARLS_SPIFF_PROFILE_ID_CONTINUOUS_TONE_FACSIMILE = 4 };
 typedef int32_t charls_spiff_color_space;
+enum { CHARLS_SPIFF_COLOR_SPACE_BI_LEVEL_BLACK = 0, CHARLS_SPIFF_COLOR_SPACE_YCBCR_ITU_BT_709_VIDEO = 1,
+       CHARLS_SPIFF_COLOR_SPACE_NONE = 2, CHARLS_SPIFF_COLOR_SPACE_YCBCR_ITU_BT_601_1_RGB = 3,
+       CHARLS_SPIFF_COLOR_SPACE_YCBCR_ITU_BT_601_1_VIDEO = 4, CHARLS_SPIFF_COLOR_SPACE_GRAYSCALE = 8,
+       CHARLS_SPIFF_COLOR_SPACE_PHOTO_YCC = 9, CHARLS_SPIFF_COLOR_SPACE_RGB = 10, CHARLS_SPIFF_COLOR_SPACE_CMY = 11,
+       CHARLS_SPIFF_COLOR_SPACE_CMYK = 12, CHARLS_SPIFF_COLOR_SPACE_YCCK = 13, CHARLS_SPIFF_COLOR_SPACE_CIE_LAB = 14,
+       CHARLS_SPIFF_COLOR_SPACE_BI_LEVEL_WHITE = 15 };
 typedef int32_t charls_spiff_compression_type;
+enum { CHARLS_SPIFF_COMPRESSION_TYPE_UNCOMPRESSED = 0, CHARLS_SPIFF_COMPRESSION_TYPE_MODIFIED_HUFFMAN = 1,
+       CHARLS_SPIFF_COMPRESSION_TYPE_MODIFIED_READ = 2, CHARLS_SPIFF_COMPRESSION_TYPE_MODIFIED_MODIFIED_READ = 3,
+       CHARLS_SPIFF_COMPRESSION_TYPE_JBIG = 4, CHARLS_SPIFF_COMPRESSION_TYPE_JPEG = 5, CHARLS_SPIFF_COMPRESSION_TYPE_JPEG_LS = 6 };
 typedef int32_t charls_spiff_resolution_units;
+enum { CHARLS_SPIFF_RESOLUTION_UNITS_ASPECT_RATIO = 0, CHARLS_SPIFF_RESOLUTION_UNITS_DOTS_PER_INCH = 1,
+       CHARLS_SPIFF_RESOLUTION_UNITS_DOTS_PER_CENTIMETER = 2 };
+enum { CHARLS_SPIFF_ENTRY_TAG_TRANSFER_CHARACTERISTICS = 2, CHARLS_SPIFF_ENTRY_TAG_COMPONENT_REGISTRATION = 3,
+       CHARLS_SPIFF_ENTRY_TAG_IMAGE_ORIENTATION = 4, CHARLS_SPIFF_ENTRY_TAG_THUMBNAIL = 5, CHARLS_SPIFF_ENTRY_TAG_IMAGE_TITLE = 6,
+       CHARLS_SPIFF_ENTRY_TAG_IMAGE_DESCRIPTION = 7, CHARLS_SPIFF_ENTRY_TAG_TIME_STAMP = 8,
+       CHARLS_SPIFF_ENTRY_TAG_VERSION_IDENTIFIER = 9, CHARLS_SPIFF_ENTRY_TAG_CREATOR_IDENTIFICATION = 10,
+       CHARLS_SPIFF_ENTRY_TAG_PROTECTION_INDICATOR = 11, CHARLS_SPIFF_ENTRY_TAG_COPYRIGHT_INFORMATION = 12,
+       CHARLS_SPIFF_ENTRY_TAG_CONTACT_INFORMATION = 13, CHARLS_SPIFF_ENTRY_TAG_TILE_INDEX = 14,
+       CHARLS_SPIFF_ENTRY_TAG_SCAN_INDEX = 15, CHARLS_SPIFF_ENTRY_TAG_SET_REFERENCE = 16 };
+enum { CHARLS_MAPPING_TABLE_MISSING = -1 };
 
 typedef struct charls_spiff_header
 {
