@@ -1,4 +1,6 @@
 """Batch API on device-resident frames (charls_amd.h part 2): every frame bit-exact, round-trip properties at scale."""
+import os
+
 import numpy as np
 import pytest
 
@@ -133,3 +135,40 @@ def test_serial_and_pipeline_encoders_agree(torch):
     for f in range(3):
         n = int(a.sizes[f])
         assert torch.equal(a.streams[f, :n], b.streams[f, :n])
+
+
+@pytest.mark.slow
+def test_config4_all_256_frames_and_their_exchange(torch):
+    """BASELINE configs[3] as stated: 256 independent 2048x2048 8-bit frames (seeds 100 + f).  The first four are pinned by
+    hashes of the reference's output, all of them round-trip, their lengths differ, and the whole payload goes through the
+    bitstream exchange of the multi-GPU path (RCCL with one rank here: process group, size all-gather, own-rank hand-over)."""
+    import torch.distributed as dist
+    cases = {c["name"]: c for c in common.cases()}
+    n = 256
+    frames = synth.frames_torch(n, 2048, 2048, seed0=100, device="cuda:0")
+    enc = batch.encode_batch(frames)
+    assert (enc.errcs == 0).all()
+    for f in range(4):
+        c = cases[f"cfg4_frame{f}"]
+        data = enc.streams[f, :int(enc.sizes[f])].cpu().numpy().tobytes()
+        assert (len(data), common.sha(data)) == (c["jls_size"], c["jls_sha256"])
+    assert len(set(int(s) for s in enc.sizes)) > 32  # variable lengths: what the exchange has to cope with
+    out = torch.empty_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+    assert (errcs == 0).all() and torch.equal(out, frames)
+    # the exchange, with the real payload
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        got = {}
+        _, sizes = batch.gather_streams(enc.streams, enc.sizes, dst=0, chunk_frames=32,
+                                        sink=lambda r, first, part, sz: got.setdefault(first, (part, sz)))
+        assert sorted(got) == list(range(0, n, 32)) and (sizes[0] == enc.sizes).all()
+        for first, (part, sz) in got.items():
+            for k in (0, len(sz) - 1):
+                f = first + k
+                assert torch.equal(part[k, :int(sz[k])], enc.streams[f, :int(enc.sizes[f])])
+    finally:
+        dist.destroy_process_group()
