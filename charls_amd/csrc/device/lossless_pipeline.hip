@@ -43,7 +43,7 @@ constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint16_t kNoEvent = 0xFFFF; // key of a sample that produces no code of its own
 constexpr uint32_t kPackBlock = 4096; // samples per D1/D2 workgroup (256 threads x 16)
 constexpr uint32_t kStatusInvalid = 1u;
-constexpr uint32_t kChainPad = 12;    // chains start on multiples of 12 records (three 16-byte groups), see bias_chains
+constexpr uint32_t kChainPad = 16;    // chains start on multiples of 16 records (four 16-byte groups = one cache line), see bias_chains
 constexpr uint32_t kChainSlack = kChains * kChainPad + 64; // spare records of sval/spos: padding + read-ahead
 
 // Per-scan work areas (device pointers), parallel to the ScanDesc array.
@@ -84,6 +84,10 @@ JLS_DEV uint32_t xcd_band_row(uint32_t block, uint32_t height)
 JLS_DEV uint32_t coded_lines(const ScanDesc& d)
 {
     return d.interleave_mode == 1 ? d.height * (uint32_t)d.components : d.height;
+}
+JLS_DEV bool sign_fits_record(const ScanDesc& d) // x : 16 | Px : 15 | sign of the context : 1
+{
+    return d.bits_per_sample <= 15;
 }
 JLS_DEV uint32_t line_step(const ScanDesc& d)
 {
@@ -516,8 +520,12 @@ __global__ void __launch_bounds__(64) scatter_events(const ScanDesc* __restrict_
         const uint32_t dest = (uint32_t)__builtin_amdgcn_ds_permute((int)(sorted & 63u) << 2, (int)slot);
         if (has)
         {
-            w.sval[dest] = v;
-            w.spos[dest] = (uint32_t)((size_t)y * width + x) | ((uint32_t)(key >> 9) << 31);
+            // Samples of up to 15 bits leave bit 31 of the (x, Px) record free for the sign of the context: the regular
+            // chains then read ONE array (bias_chains), and only the run chain (chain 0) needs the position.
+            const bool packed = sign_fits_record(d) && (key & 0x1FF) != 0;
+            w.sval[dest] = packed ? v | ((uint32_t)(key >> 9) << 31) : v;
+            if (!packed)
+                w.spos[dest] = (uint32_t)((size_t)y * width + x) | ((uint32_t)(key >> 9) << 31);
         }
         if (x < width)
             w.inv[(size_t)y * width + x] = has ? dest : kNoSlot;
@@ -552,24 +560,189 @@ JLS_DEV CodeWord golomb_word(const Traits& t, int k, int m, int limit)
     return c;
 }
 
+// The regular-mode chain of one lane (see bias_chains): `lines` cache lines of 16 records, in place.  kPacked: the sign of
+// the context sits in bit 31 of the record (samples of up to 15 bits), otherwise in bit 31 of the parallel array `pin`.
+// All lanes of the wavefront call this together (lanes without a regular chain with lines = 0).
+//
+// Memory: a lane reads its chain a whole cache line (64 bytes) per request, and the lanes of a wavefront belong to
+// different frames, hundreds of MB apart: such a request takes about 1600 cycles alone and several times that while
+// all chains of a pass are streaming (tools/microbench/stream_probe.hip), against about 1800 cycles of arithmetic per
+// line.  So lines are requested TWO lines ahead, into three register buffers that rotate by code position (the loop body
+// handles three lines, no copies), and a line's results are stored after the wait for the next line (the compiler's
+// wait-count bookkeeping is conservative across the loop's back edge and waits for everything outstanding, so each wait
+// is placed where everything outstanding was issued at least a line of arithmetic ago).
+typedef uint32_t u32x4 __attribute__((vector_size(16)));
+
+template <bool kPacked>
+JLS_DEV void walk_regular_chain(const JLS_GLOBAL_AS u32x4* vin, const JLS_GLOBAL_AS u32x4* pin, JLS_GLOBAL_AS u32x4* vout,
+                                uint32_t lines, int reset, int bits, int maxval)
+{
+    struct Line
+    {
+        u32x4 v[4];
+        u32x4 q[kPacked ? 1 : 4];
+    };
+    int b = 0, c = 0;
+    // one event; n_before = N before it (wave-uniform), halve = N has reached RESET (wave-uniform, rare)
+    auto event = [&](uint32_t v, uint32_t ps, int n_before, bool halve) -> uint32_t {
+        const int sgn = ((int)(kPacked ? v : ps) >> 31) | 1;
+        const int px_raw = kPacked ? (int)((v >> 16) & 0x7FFFu) : (int)(v >> 16);
+        const int px = med3(mad24(c, sgn, px_raw), 0, maxval);                      // src/scan_encoder_core.hpp:57-67
+        const int err = sign_extend(__mul24((int)(v & 0xFFFFu) - px, sgn), bits); // src/default_traits.hpp:123-139
+        const uint32_t out = ((uint32_t)err << 1) | ((uint32_t)(2 * b + n_before - 1) >> 31);
+        // A.13 as in the decoder: with t = B + Errval (halved at a reset) and N' the new N,
+        // delta = (t > 0) - (t + N' <= 0), B' = median(t - delta * N', 1 - N', 0), C' = median(C + delta, -128, 127)
+        int tb = b + err; // |B| < N + RANGE/2: cannot reach 2^24
+        int n_new = n_before + 1;
+        if (halve)
+        {
+            tb >>= 1;
+            n_new = (n_before >> 1) + 1;
+        }
+        const int minus_delta = 1 - med3(tb, 0, 1) - med3(tb + n_new, 0, 1);
+        b = med3(mad24(minus_delta, n_new, tb), 1 - n_new, 0);
+        c = med3(c - minus_delta, -128, 127);
+        return out;
+    };
+    int nn = 1; // wave-uniform
+    auto four = [&](const u32x4& v, const u32x4& q) -> u32x4 {
+        u32x4 o;
+        if (reset == 0 || nn + 3 < reset)
+        { // no RESET among these four
+            o[0] = event(v[0], q[0], nn, false);
+            o[1] = event(v[1], q[1], nn + 1, false);
+            o[2] = event(v[2], q[2], nn + 2, false);
+            o[3] = event(v[3], q[3], nn + 3, false);
+            nn += 4;
+        }
+        else
+        {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const bool halve = nn == reset;
+                o[j] = event(v[j], q[j], nn, halve);
+                nn = (halve ? nn >> 1 : nn) + 1;
+            }
+        }
+        return o;
+    };
+    // Unconditional: a lane past the end of its chain reads on into the next chain / the spare records behind the last one
+    // (kChainSlack) and ignores what it gets.  Requests that depend on a condition would force every wait to be a wait for
+    // everything outstanding -- it could no longer count on younger requests being there.
+    auto request = [&](Line& x, uint32_t line) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            x.v[j] = vin[line * 4 + j];
+            if (!kPacked)
+                x.q[j] = pin[line * 4 + j];
+        }
+    };
+    auto process = [&](const Line& x, u32x4 (&o)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = four(x.v[j], x.q[kPacked ? 0 : j]);
+    };
+    auto store = [&](const u32x4 (&o)[4], uint32_t line) {
+        if (line < lines)
+        {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                vout[line * 4 + j] = o[j];
+        }
+    };
+    auto arrived = [&](const Line& x) {
+#ifndef JLS_EMULATED
+        if (kPacked)
+            asm volatile("" ::"v"(x.v[0]), "v"(x.v[1]), "v"(x.v[2]), "v"(x.v[3]));
+        else
+            asm volatile("" ::"v"(x.v[0]), "v"(x.v[1]), "v"(x.v[2]), "v"(x.v[3]), "v"(x.q[0]), "v"(x.q[1]), "v"(x.q[2]), "v"(x.q[3]));
+#endif
+    };
+    Line la, lb, lc;
+    if (kPacked)
+        la.q[0] = lb.q[0] = lc.q[0] = u32x4{0, 0, 0, 0};
+    u32x4 oa[4], ob[4], oc[4];
+    request(la, 0);
+    request(lb, 1);
+    arrived(la);
+    request(lc, 2);
+    for (uint32_t line = 0; __any(line < lines); line += 3)
+    {
+        process(la, oa);        // line
+        arrived(lb);            // line + 1 is here (requested two lines of arithmetic ago)
+        store(oa, line);
+        request(la, line + 3);
+        process(lb, ob);        // line + 1
+        arrived(lc);            // line + 2
+        store(ob, line + 1);
+        request(lb, line + 4);
+        process(lc, oc);        // line + 2
+        arrived(la);            // line + 3
+        store(oc, line + 2);
+        request(lc, line + 5);
+    }
+}
+
+// C0: what the run chain needs of the IMAGE, worked out for all run events at once.  In lossless mode the interruption
+// sample of a run, its Ra and its Rb are source samples, so the type of the interruption (Ra == Rb or not) and its error
+// value are pure functions of the image (src/scan_encoder_core.hpp:105-125); only RUNindex, the two run-interruption
+// contexts and the code words are serial.  This kernel replaces the raster position in spos[e] of every run event of
+// chain 0 by {Errval : 17 bits | RItype << 17 | (coded line mod components) << 18}, so that the lane that walks the run
+// chain in bias_chains touches no pixel and does no division: three dependent global loads per event were what the whole
+// stage waited for (55 000 run events of a 4096 x 4096 test frame at about 3 us each).  Planar and line-interleaved scans;
+// sample-interleaved scans (several components per interruption) keep the position.  grid (64, scans) x 256 threads.
+template <typename S, int ILV>
+__global__ void __launch_bounds__(256) prepare_run_events(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    static_assert(ILV == 0 || ILV == 1, "one sample per interruption");
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const Traits t = make_traits(d);
+    const uint32_t n = w.chain_total[0];
+    const uint32_t* sval = w.sval + w.chain_base[0];
+    uint32_t* spos = w.spos + w.chain_base[0];
+    const uint32_t step = ILV == 1 ? line_step(d) : 1u;
+    const int mask = (1 << d.bits_per_sample) - 1;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n; e += gridDim.x * 256u)
+    {
+        const uint32_t v = sval[e];
+        const uint32_t p = spos[e] & 0x7FFFFFFFu;
+        const uint32_t y = p / d.width; // coded line
+        uint32_t packed = (y % step) << 18;
+        if ((v >> 31) == 0)
+        { // not an end-of-line run: the interruption sample follows the run
+            const uint32_t xi = p - y * d.width + (v & 0x7FFFFFFFu);
+            const int xv = load_sample<S, ILV>(d, y, xi, mask);
+            const int ra = xi > 0 ? load_sample<S, ILV>(d, y, xi - 1, mask) : (y >= step ? load_sample<S, ILV>(d, y - step, 0, mask) : 0);
+            const int rb = y >= step ? load_sample<S, ILV>(d, y - step, xi, mask) : 0;
+            const int which = ra == rb ? 1 : 0;
+            const int err = which ? error_value(t, xv - ra) : error_value(t, (xv - rb) * ((rb - ra) < 0 ? -1 : 1));
+            packed |= ((uint32_t)err & 0x1FFFFu) | ((uint32_t)which << 17);
+        }
+        spos[e] = packed;
+    }
+}
+
 template <typename S, int ILV>
 __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works,
                                                   uint32_t scans)
 {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= scans * (uint32_t)kChains)
-        return;
-    const uint32_t chain = tid / scans;
-    if (chain == (uint32_t)kInterruptChain)
-        return;
-    const ScanDesc d = descs[tid % scans];
-    const Work w = works[tid % scans];
+    // (no early exits: the regular-mode part below uses wavefront-wide votes, so every lane walks through it -- lanes
+    // without a regular chain with zero cache lines to do)
+    const bool exists = tid < scans * (uint32_t)kChains;
+    const uint32_t chain = exists ? tid / scans : 1u;
+    const uint32_t frame = exists ? tid % scans : 0u;
+    const ScanDesc d = descs[frame];
+    const Work w = works[frame];
     const Traits t = make_traits(d);
+    const bool regular = exists && chain != 0 && chain != (uint32_t)kInterruptChain;
     const uint32_t n = w.chain_total[chain];
     JLS_GLOBAL_AS uint32_t* sval = (JLS_GLOBAL_AS uint32_t*)(w.sval + w.chain_base[chain]);
     const JLS_GLOBAL_AS uint32_t* spos = (const JLS_GLOBAL_AS uint32_t*)(w.spos + w.chain_base[chain]);
 
-    if (chain != 0)
     { // ---- regular mode, serial half: src/scan_encoder_core.hpp:57-67, src/regular_mode_context.hpp:45-93
         // Of {A,B,C,N} only B and C feed back into the VALUE that is coded (through the bias-corrected prediction); N is
         // a function of the event index alone and A is a (periodically halved) running sum of |Errval| that only picks
@@ -577,53 +750,67 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
         // into Errval plus the sign of 2B+N-1 (the k=0 error-correction condition, src/regular_mode_context.hpp:36-42),
         // in place.  A, k and the code words are then computed 64 events at a time by code_events.
         //
-        // Memory: every chain starts on a multiple of kChainPad (= 12) records and the buffers carry kChainSlack spare
+        // Memory: every chain starts on a multiple of kChainPad (= 16) records and the buffers carry kChainSlack spare
         // records, so a lane streams its chain with aligned 16-byte loads/stores (4 records) and no bounds logic: records
-        // past the end of a chain are garbage that is processed into the chain's own padding.  Three register sets rotate
-        // (loads run two groups ahead of the in-place store), so no register copies and no full vmcnt drains are needed.
-        int b = 0, c = 0, nn = 1;
-        const int reset = t.reset, maxval = t.maxval;
-        const int wrap = 32 - d.bits_per_sample; // RANGE = 2^bpp in lossless mode: modulo RANGE = sign extension
-        auto step = [&](uint32_t v, uint32_t ps) -> uint32_t {
-            const int s = (int)ps >> 31; // 0 or -1
-            const int px = med3((int)(v >> 16) + ((c ^ s) - s), 0, maxval);
-            int err = (((int)(v & 0xFFFFu) - px) ^ s) - s;
-            err = (int)((uint32_t)err << wrap) >> wrap; // src/default_traits.hpp:123-139
-            const uint32_t out = ((uint32_t)err << 1) | ((uint32_t)(2 * b + nn - 1) >> 31);
-            // A.13 as in the decoder (scan_fast_decode.hip): with t = B + Errval (halved at a reset) and N' the new N,
-            // delta = (t > 0) - (t + N' <= 0), B' = median(t - delta * N', 1 - N', 0), C' = median(C + delta, -128, 127)
-            const int sh = nn == reset;
-            const int tb = (b + err) >> sh; // |B| < N + RANGE/2: cannot reach 2^24
-            nn = (nn >> sh) + 1;
-            const int minus_delta = 1 - med3(tb, 0, 1) - med3(tb + nn, 0, 1);
-            b = med3(tb + __mul24(minus_delta, nn), 1 - nn, 0);
-            c = med3(c - minus_delta, -128, 127);
-            return out;
-        };
-        typedef uint32_t u32x4 __attribute__((vector_size(16)));
+        // past the end of a chain are garbage that is processed into the chain's own padding.
+        //
+        // What a chain costs is what its lane issues per event (a lone wavefront issues an instruction every 4.3 - 5 cycles,
+        // profiles/r02_microbench_latency.txt), and the pass waits for the longest chain.  The lanes of a wavefront walk
+        // different frames in step, so N -- a function of the event index alone -- is the same in all of them: it lives in
+        // scalar registers (no vector work for N, 1 - N or the RESET test), a group of four events without a RESET is
+        // straight-line code, and a chain is read and written a whole cache line (16 records) per lane at a time, the
+        // next line of both arrays in flight while the current one is processed.
+        const int maxval = t.maxval;
+        const int bpp = d.bits_per_sample; // RANGE = 2^bpp in lossless mode: modulo RANGE = sign extension of bpp bits
+        const bool uniform_parameters = __all(t.reset == (int)uniform((uint32_t)t.reset) && bpp == (int)uniform((uint32_t)bpp)) != 0;
         const JLS_GLOBAL_AS u32x4* vin = (const JLS_GLOBAL_AS u32x4*)sval;
         const JLS_GLOBAL_AS u32x4* pin = (const JLS_GLOBAL_AS u32x4*)spos;
         JLS_GLOBAL_AS u32x4* vout = (JLS_GLOBAL_AS u32x4*)sval;
-        auto phase = [&](uint32_t g, const u32x4& v, const u32x4& q, u32x4& v_next, u32x4& q_next) {
-            v_next = vin[g + 2];
-            q_next = pin[g + 2];
-            u32x4 o;
-            o[0] = step(v[0], q[0]);
-            o[1] = step(v[1], q[1]);
-            o[2] = step(v[2], q[2]);
-            o[3] = step(v[3], q[3]);
-            vout[g] = o;
-        };
-        const uint32_t groups = (n + kChainPad - 1) / kChainPad * 3; // a multiple of three, into the padding
-        u32x4 va = vin[0], qa = pin[0], vb = vin[1], qb = pin[1], vc, qc;
-        for (uint32_t g = 0; g < groups; g += 3)
+        int b = 0, c = 0;
+        if (uniform_parameters)
         {
-            phase(g, va, qa, vc, qc);
-            phase(g + 1, vb, qb, va, qa);
-            phase(g + 2, vc, qc, vb, qb);
+            const int reset = (int)uniform((uint32_t)t.reset);
+            const int bits = (int)uniform((uint32_t)bpp);
+            const uint32_t lines = regular ? (n + kChainPad - 1) / kChainPad : 0u; // cache lines of this lane's chain (the last one runs into its padding)
+            if (bits <= 15)
+                walk_regular_chain<true>(vin, pin, vout, lines, reset, bits, maxval);
+            else
+                walk_regular_chain<false>(vin, pin, vout, lines, reset, bits, maxval);
+        }
+        else
+        { // frames with different RESET / precision in one wavefront (no caller of this library makes such batches): per lane
+            int nn = 1;
+            const int reset = t.reset;
+            const int wrap = 32 - bpp;
+            const bool packed = sign_fits_record(d);
+            auto step = [&](uint32_t v, uint32_t ps) -> uint32_t {
+                const int s = (int)(packed ? v : ps) >> 31; // 0 or -1
+                const int px = med3((int)((v >> 16) & (packed ? 0x7FFFu : 0xFFFFu)) + ((c ^ s) - s), 0, maxval);
+                int err = (((int)(v & 0xFFFFu) - px) ^ s) - s;
+                err = (int)((uint32_t)err << wrap) >> wrap;
+                const uint32_t out = ((uint32_t)err << 1) | ((uint32_t)(2 * b + nn - 1) >> 31);
+                const int sh = nn == reset;
+                const int tb = (b + err) >> sh;
+                nn = (nn >> sh) + 1;
+                const int minus_delta = 1 - med3(tb, 0, 1) - med3(tb + nn, 0, 1);
+                b = med3(tb + __mul24(minus_delta, nn), 1 - nn, 0);
+                c = med3(c - minus_delta, -128, 127);
+                return out;
+            };
+            const uint32_t groups = regular ? (n + kChainPad - 1) / kChainPad * 4 : 0u;
+            for (uint32_t g = 0; g < groups; ++g)
+            {
+                const u32x4 v = vin[g], q = pin[g];
+                u32x4 o;
+                o[0] = step(v[0], q[0]);
+                o[1] = step(v[1], q[1]);
+                o[2] = step(v[2], q[2]);
+                o[3] = step(v[3], q[3]);
+                vout[g] = o;
+            }
         }
     }
-    else
+    if (exists && chain == 0)
     { // ---- run mode: src/scan_encoder.hpp:53-73, src/scan_encoder_impl.hpp:249-275, src/scan_encoder_core.hpp:105-125
         // Codes go to the slot of the sample they belong to: the run-length code to the run's own slot, the code of the
         // interruption sample to the next slot of chain kInterruptChain (its events are these samples, in this order).
@@ -639,13 +826,17 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
         for (uint32_t e = 0; e < n; ++e)
         {
             const uint32_t v = sval[e];
-            const uint32_t p = spos[e] & 0x7FFFFFFFu;
+            const uint32_t p = spos[e] & (ILV == 2 ? 0x7FFFFFFFu : 0xFFFFFFFFu); // ILV != 2: prepare_run_events' record
             uint32_t run = v & 0x7FFFFFFFu;
             const bool eol = (v >> 31) != 0;
-            const uint32_t samples_per_line = ILV == 2 ? line_samples(d) : d.width;
-            const uint32_t y = p / samples_per_line; // coded line
-            int& run_index = run_indices[ILV == 1 ? y % step : 0];
-            const uint32_t x0 = (p - y * samples_per_line) / (ILV == 2 ? (uint32_t)d.components : 1u);
+            uint32_t y = 0, x0 = 0;
+            if (ILV == 2)
+            {
+                const uint32_t samples_per_line = line_samples(d);
+                y = p / samples_per_line; // coded line
+                x0 = (p - y * samples_per_line) / (uint32_t)d.components;
+            }
+            int& run_index = run_indices[ILV == 1 ? (p >> 18) & 3u : 0];
             const uint32_t full = run;
             // run-length part: ones for every completed 2^J block, then either the end-of-line one or 0 + remainder
             uint64_t bits = 0;
@@ -718,15 +909,9 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
                     --run_index;
                 continue;
             }
-            const int xv = load_sample<S, ILV>(d, y, xi, mask);
-            const int ra = xi > 0 ? load_sample<S, ILV>(d, y, xi - 1, mask) : (y >= step ? load_sample<S, ILV>(d, y - step, 0, mask) : 0);
-            const int rb = y >= step ? load_sample<S, ILV>(d, y - step, xi, mask) : 0;
-            const int which = ra == rb ? 1 : 0;
-            int err;
-            if (which)
-                err = error_value(t, xv - ra);
-            else
-                err = error_value(t, (xv - rb) * ((rb - ra) < 0 ? -1 : 1));
+            // type and error value of the interruption come from prepare_run_events
+            const int which = (int)((p >> 17) & 1u);
+            const int err = (int)(p << 15) >> 15;
             RunCtx& ctx = rc[which];
             const int k = run_k(ctx);
             const int map = run_map(ctx, err, k);

@@ -623,9 +623,15 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         if (proto.interleave_mode == 2)
             hipLaunchKernelGGL((pipe::bias_chains<S, 2>), chains_grid, dim3(64), 0, stream, descs, d_works, n);
         else if (proto.interleave_mode == 1)
+        {
+            hipLaunchKernelGGL((pipe::prepare_run_events<S, 1>), dim3(64, n), dim3(256), 0, stream, descs, d_works);
             hipLaunchKernelGGL((pipe::bias_chains<S, 1>), chains_grid, dim3(64), 0, stream, descs, d_works, n);
+        }
         else
+        {
+            hipLaunchKernelGGL((pipe::prepare_run_events<S, 0>), dim3(64, n), dim3(256), 0, stream, descs, d_works);
             hipLaunchKernelGGL((pipe::bias_chains<S, 0>), chains_grid, dim3(64), 0, stream, descs, d_works, n);
+        }
         hipLaunchKernelGGL(pipe::code_events, dim3(pipe::kRegularChains, n), dim3(64), 0, stream, descs, d_works);
         t.mark();
         hipLaunchKernelGGL(pipe::sum_code_lengths, dim3(blocks, n), dim3(256), 0, stream, descs, d_works);

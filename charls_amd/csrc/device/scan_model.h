@@ -149,6 +149,10 @@ JLS_DEV uint32_t bit_field(uint32_t v, uint32_t offset, uint32_t width) // (v >>
     asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "n"(offset), "n"(width));
     return r;
 }
+JLS_DEV int sign_extend(int v, int bits) // the low `bits` bits of v as a signed number (v_bfe_i32, one instruction)
+{
+    return __builtin_amdgcn_sbfe(v, 0, bits);
+}
 JLS_DEV uint32_t abs_difference(uint32_t a, uint32_t b) // |a - b| of unsigned values in one instruction
 {
     uint32_t r;
@@ -215,6 +219,11 @@ JLS_DEV uint32_t pack_bytes(uint32_t s0, uint32_t s1)
 JLS_DEV uint32_t bit_field(uint32_t v, uint32_t offset, uint32_t width)
 {
     return (v >> offset) & ((1u << width) - 1u);
+}
+JLS_DEV int sign_extend(int v, int bits)
+{
+    const int sh = 32 - bits;
+    return (int)((uint32_t)v << sh) >> sh;
 }
 JLS_DEV uint32_t abs_difference(uint32_t a, uint32_t b)
 {

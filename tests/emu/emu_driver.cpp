@@ -111,9 +111,15 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
     if (p.interleave_mode == 2)
         emu::launch(pipe::bias_chains<S, 2>, chains_grid, dim3(64), 0, descs, wk, (uint32_t)count);
     else if (p.interleave_mode == 1)
+    {
+        emu::launch(pipe::prepare_run_events<S, 1>, dim3(2, count), dim3(256), 0, descs, wk);
         emu::launch(pipe::bias_chains<S, 1>, chains_grid, dim3(64), 0, descs, wk, (uint32_t)count);
+    }
     else
+    {
+        emu::launch(pipe::prepare_run_events<S, 0>, dim3(2, count), dim3(256), 0, descs, wk);
         emu::launch(pipe::bias_chains<S, 0>, chains_grid, dim3(64), 0, descs, wk, (uint32_t)count);
+    }
     emu::launch(pipe::code_events, dim3(pipe::kRegularChains, count), dim3(64), 0, descs, wk);
     emu::launch(pipe::sum_code_lengths, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
     emu::launch(pipe::scan_block_sums, dim3(count), dim3(64), 0, descs, wk);
