@@ -566,11 +566,9 @@ JLS_DEV CodeWord golomb_word(const Traits& t, int k, int m, int limit)
 //
 // Memory: a lane reads its chain a whole cache line (64 bytes) per request, and the lanes of a wavefront belong to
 // different frames, hundreds of MB apart: such a request takes about 1600 cycles alone and several times that while
-// all chains of a pass are streaming (tools/microbench/stream_probe.hip), against about 1800 cycles of arithmetic per
-// line.  So lines are requested TWO lines ahead, into three register buffers that rotate by code position (the loop body
-// handles three lines, no copies), and a line's results are stored after the wait for the next line (the compiler's
-// wait-count bookkeeping is conservative across the loop's back edge and waits for everything outstanding, so each wait
-// is placed where everything outstanding was issued at least a line of arithmetic ago).
+// all chains of a pass -- or the wide stages of another pass -- are streaming (tools/microbench/stream_probe.hip), against
+// about 1800 cycles of arithmetic per line.  So lines are requested several lines ahead, into register buffers that
+// rotate by code position (no copies), and a line's results are stored after the wait for the next line.
 typedef uint32_t u32x4 __attribute__((vector_size(16)));
 
 template <bool kPacked>
@@ -660,28 +658,29 @@ JLS_DEV void walk_regular_chain(const JLS_GLOBAL_AS u32x4* vin, const JLS_GLOBAL
             asm volatile("" ::"v"(x.v[0]), "v"(x.v[1]), "v"(x.v[2]), "v"(x.v[3]), "v"(x.q[0]), "v"(x.q[1]), "v"(x.q[2]), "v"(x.q[3]));
 #endif
     };
-    Line la, lb, lc;
-    if (kPacked)
-        la.q[0] = lb.q[0] = lc.q[0] = u32x4{0, 0, 0, 0};
-    u32x4 oa[4], ob[4], oc[4];
-    request(la, 0);
-    request(lb, 1);
-    arrived(la);
-    request(lc, 2);
-    for (uint32_t line = 0; __any(line < lines); line += 3)
+    // kBuffers - 1 lines are in flight while one is processed; the loop body handles kBuffers lines so that every buffer
+    // keeps its registers.
+    constexpr int kBuffers = kPacked ? 5 : 3;
+    Line buffer[kBuffers];
+    u32x4 out[kBuffers][4];
+#pragma unroll
+    for (int k = 0; k < kBuffers; ++k)
     {
-        process(la, oa);        // line
-        arrived(lb);            // line + 1 is here (requested two lines of arithmetic ago)
-        store(oa, line);
-        request(la, line + 3);
-        process(lb, ob);        // line + 1
-        arrived(lc);            // line + 2
-        store(ob, line + 1);
-        request(lb, line + 4);
-        process(lc, oc);        // line + 2
-        arrived(la);            // line + 3
-        store(oc, line + 2);
-        request(lc, line + 5);
+        if (kPacked)
+            buffer[k].q[0] = u32x4{0, 0, 0, 0};
+        request(buffer[k], (uint32_t)k);
+    }
+    arrived(buffer[0]);
+    for (uint32_t line = 0; __any(line < lines); line += kBuffers)
+    {
+#pragma unroll
+        for (int k = 0; k < kBuffers; ++k)
+        {
+            process(buffer[k], out[k]);                 // line + k
+            arrived(buffer[(k + 1) % kBuffers]);        // line + k + 1 is here (requested kBuffers - 1 lines of arithmetic ago)
+            store(out[k], line + (uint32_t)k);
+            request(buffer[k], line + (uint32_t)(k + kBuffers));
+        }
     }
 }
 

@@ -443,6 +443,14 @@ struct StageTimer
     int n = 0;
     hipStream_t s;
     explicit StageTimer(hipStream_t stream) : s(stream) {}
+    StageTimer(const StageTimer&) = delete;
+    StageTimer& operator=(const StageTimer&) = delete;
+    StageTimer(StageTimer&& o) noexcept : n(o.n), s(o.s)
+    {
+        for (int i = 0; i < n; ++i)
+            ev[i] = o.ev[i];
+        o.n = 0;
+    }
     ~StageTimer()
     {
         for (int i = 0; i < n; ++i)
@@ -547,20 +555,56 @@ void* try_ensure(DeviceBuffer& buffer, size_t bytes) noexcept
     }
 }
 
+// Side streams of the pipeline (per thread, created once): passes of a batch that does not fit the work area at once are
+// dealt round-robin to up to kMaxPipelineLanes lanes, each with its own slice of the arena and its own HIP stream.
+constexpr int kMaxPipelineLanes = 3;
+struct PipelineLanes
+{
+    hipStream_t streams[kMaxPipelineLanes]{};
+    bool created = false;
+    ~PipelineLanes()
+    {
+        if (created)
+            for (hipStream_t s : streams)
+                (void)hipStreamDestroy(s);
+    }
+    void ensure()
+    {
+        if (created)
+            return;
+        for (hipStream_t& s : streams)
+            hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        created = true;
+    }
+};
+PipelineLanes& pipeline_lanes()
+{
+    static thread_local PipelineLanes lanes;
+    return lanes;
+}
+
+// Why lanes: the chain stage (bias_chains) is as long as the longest context chain of a frame whatever the number of
+// frames in the pass -- 58 ms for ONE 4096 x 4096 test frame, about 95 ms in a pass of 228 -- and keeps only a few hundred
+// wavefronts busy, while the other stages are bandwidth-shaped and fill the chip.  Passes that follow each other on ONE
+// stream pay that latency in full, once per pass; independent passes on different streams could run one pass's chain
+// stage under the other passes' wide stages (the arena is shared out between the lanes: smaller passes, more of them).
+// Measured (4096 frames, profiles/r02_encode_lanes.txt): 5.04 / 4.73 / 4.85 s with 1 / 2 / 3 lanes on one box, 5.09 /
+// 5.15 / 5.08 s on another -- the chain and stuffing stages, which live on memory latency, slow down under the other
+// lanes' traffic by about what the overlap wins.  One lane is the default; CHARLS_AMD_ENCODE_LANES = 2 or 3 selects more.
 template <typename S>
 void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
 {
     const PipeLayout lay(proto, proto.stream_capacity);
     const size_t budget = arena_budget(pipeline_arena().capacity());
     const size_t per_scan = lay.bytes + sizeof(pipe::Work);
-    uint32_t per_pass = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, budget / per_scan)));
+    uint32_t resident = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, budget / per_scan))); // scans in the arena
     uint8_t* arena = nullptr;
     for (;;)
-    { // less HBM than the budget promised (fragmentation, another process): fewer scans per pass
-        arena = static_cast<uint8_t*>(try_ensure(pipeline_arena(), per_scan * per_pass));
-        if (arena != nullptr || per_pass == 1)
+    { // less HBM than the budget promised (fragmentation, another process): fewer scans at a time
+        arena = static_cast<uint8_t*>(try_ensure(pipeline_arena(), per_scan * resident));
+        if (arena != nullptr || resident == 1)
             break;
-        per_pass = (per_pass + 1) / 2;
+        resident = (resident + 1) / 2;
     }
     if (arena == nullptr)
     { // not even one work area: the one-wavefront-per-scan kernel needs none
@@ -568,18 +612,46 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         last_timings().count = 2;
         return;
     }
-    auto* d_works = reinterpret_cast<pipe::Work*>(arena + lay.bytes * per_pass);
-    std::vector<pipe::Work> works(per_pass);
-    Timings& tm = last_timings();
-    double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    for (uint32_t first = 0; first < count; first += per_pass)
+    int lanes = 1;
+    if (count > resident)
+    { // several passes: overlap them
+        const char* env = std::getenv("CHARLS_AMD_ENCODE_LANES");
+        lanes = env ? std::atoi(env) : 1;
+        lanes = std::max(1, std::min({lanes, kMaxPipelineLanes, static_cast<int>(resident)}));
+    }
+    const uint32_t per_pass = resident / static_cast<uint32_t>(lanes); // scans of one pass = one lane's slice of the arena
+    const size_t lane_bytes = per_scan * per_pass;
+    const uint32_t passes = (count + per_pass - 1) / per_pass;
+    hipStream_t lane_stream[kMaxPipelineLanes] = {stream, stream, stream};
+    hipEvent_t fork{}, join[kMaxPipelineLanes]{};
+    if (lanes > 1)
     {
+        pipeline_lanes().ensure();
+        hip_check(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        hip_check(hipEventRecord(fork, stream)); // everything the caller queued (descriptors, scan headers) comes first
+        for (int l = 0; l < lanes; ++l)
+        {
+            lane_stream[l] = pipeline_lanes().streams[l];
+            hip_check(hipStreamWaitEvent(lane_stream[l], fork, 0));
+        }
+    }
+    std::vector<std::vector<pipe::Work>> works(passes); // one host copy per pass: the uploads are asynchronous
+    std::vector<StageTimer> timers;
+    timers.reserve(passes);
+
+    for (uint32_t pass = 0; pass < passes; ++pass)
+    {
+        const uint32_t first = pass * per_pass;
         const uint32_t n = std::min(per_pass, count - first);
+        const int lane = static_cast<int>(pass % static_cast<uint32_t>(lanes));
+        hipStream_t s = lane_stream[lane];
+        uint8_t* slice = arena + lane_bytes * static_cast<size_t>(lane);
+        auto* d_works = reinterpret_cast<pipe::Work*>(slice + lay.bytes * per_pass);
+        works[pass].resize(n);
         for (uint32_t i = 0; i < n; ++i)
         {
-            uint8_t* base = arena + lay.bytes * i;
-            pipe::Work& w = works[i];
+            uint8_t* base = slice + lay.bytes * i;
+            pipe::Work& w = works[pass][i];
             w.key = reinterpret_cast<uint16_t*>(base + lay.off_key);
             w.val = reinterpret_cast<uint32_t*>(base + lay.off_val);
             w.hist = reinterpret_cast<uint32_t*>(base + lay.off_hist);
@@ -597,57 +669,77 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
             w.total_bits = reinterpret_cast<uint64_t*>(base + lay.off_bits);
             w.status = reinterpret_cast<uint32_t*>(base + lay.off_status);
             // raw, total_bits and status start at zero (contiguous at the end of the layout)
-            hip_check(hipMemsetAsync(w.raw, 0, lay.off_status + 4 - lay.off_raw, stream));
+            hip_check(hipMemsetAsync(w.raw, 0, lay.off_status + 4 - lay.off_raw, s));
         }
-        hip_check(hipMemcpyAsync(d_works, works.data(), sizeof(pipe::Work) * n, hipMemcpyHostToDevice, stream));
-        hip_check(hipStreamSynchronize(stream)); // `works` is reused by the next pass
+        hip_check(hipMemcpyAsync(d_works, works[pass].data(), sizeof(pipe::Work) * n, hipMemcpyHostToDevice, s));
 
         const ScanDesc* descs = d_descs + first;
         const uint32_t chunks = (proto.width + 63) / 64;
         const size_t lds_a = static_cast<size_t>(chunks) * 20 + pipe::kChains * 4;
         const uint32_t blocks = static_cast<uint32_t>(lay.blocks);
         const uint32_t rows_grid = 8 * ((static_cast<uint32_t>(lay.lines) + 7) / 8); // analyze_pixels idles the surplus
-        StageTimer t(stream);
+        timers.emplace_back(s);
+        StageTimer& t = timers.back();
         t.mark();
         if (proto.interleave_mode == 2)
-            hipLaunchKernelGGL((pipe::analyze_pixels<S>), dim3(rows_grid, n), dim3(64), lds_a, stream, descs, d_works);
+            hipLaunchKernelGGL((pipe::analyze_pixels<S>), dim3(rows_grid, n), dim3(64), lds_a, s, descs, d_works);
         else if (proto.interleave_mode == 1)
-            hipLaunchKernelGGL((pipe::analyze_rows<S, 1>), dim3(rows_grid, n), dim3(64), lds_a, stream, descs, d_works);
+            hipLaunchKernelGGL((pipe::analyze_rows<S, 1>), dim3(rows_grid, n), dim3(64), lds_a, s, descs, d_works);
         else
-            hipLaunchKernelGGL((pipe::analyze_rows<S, 0>), dim3(rows_grid, n), dim3(64), lds_a, stream, descs, d_works);
+            hipLaunchKernelGGL((pipe::analyze_rows<S, 0>), dim3(rows_grid, n), dim3(64), lds_a, s, descs, d_works);
         t.mark();
-        hipLaunchKernelGGL(pipe::chain_offsets, dim3(n), dim3(384), 0, stream, descs, d_works);
-        hipLaunchKernelGGL(pipe::scatter_events, dim3(rows_grid, n), dim3(64), 0, stream, descs, d_works);
+        hipLaunchKernelGGL(pipe::chain_offsets, dim3(n), dim3(384), 0, s, descs, d_works);
+        hipLaunchKernelGGL(pipe::scatter_events, dim3(rows_grid, n), dim3(64), 0, s, descs, d_works);
         t.mark();
         const dim3 chains_grid((n * pipe::kChains + 63) / 64);
         if (proto.interleave_mode == 2)
-            hipLaunchKernelGGL((pipe::bias_chains<S, 2>), chains_grid, dim3(64), 0, stream, descs, d_works, n);
+            hipLaunchKernelGGL((pipe::bias_chains<S, 2>), chains_grid, dim3(64), 0, s, descs, d_works, n);
         else if (proto.interleave_mode == 1)
         {
-            hipLaunchKernelGGL((pipe::prepare_run_events<S, 1>), dim3(64, n), dim3(256), 0, stream, descs, d_works);
-            hipLaunchKernelGGL((pipe::bias_chains<S, 1>), chains_grid, dim3(64), 0, stream, descs, d_works, n);
+            hipLaunchKernelGGL((pipe::prepare_run_events<S, 1>), dim3(64, n), dim3(256), 0, s, descs, d_works);
+            hipLaunchKernelGGL((pipe::bias_chains<S, 1>), chains_grid, dim3(64), 0, s, descs, d_works, n);
         }
         else
         {
-            hipLaunchKernelGGL((pipe::prepare_run_events<S, 0>), dim3(64, n), dim3(256), 0, stream, descs, d_works);
-            hipLaunchKernelGGL((pipe::bias_chains<S, 0>), chains_grid, dim3(64), 0, stream, descs, d_works, n);
+            hipLaunchKernelGGL((pipe::prepare_run_events<S, 0>), dim3(64, n), dim3(256), 0, s, descs, d_works);
+            hipLaunchKernelGGL((pipe::bias_chains<S, 0>), chains_grid, dim3(64), 0, s, descs, d_works, n);
         }
-        hipLaunchKernelGGL(pipe::code_events, dim3(pipe::kRegularChains, n), dim3(64), 0, stream, descs, d_works);
+        hipLaunchKernelGGL(pipe::code_events, dim3(pipe::kRegularChains, n), dim3(64), 0, s, descs, d_works);
         t.mark();
-        hipLaunchKernelGGL(pipe::sum_code_lengths, dim3(blocks, n), dim3(256), 0, stream, descs, d_works);
-        hipLaunchKernelGGL(pipe::scan_block_sums, dim3(n), dim3(64), 0, stream, descs, d_works);
-        hipLaunchKernelGGL(pipe::write_raw_bits, dim3(blocks, n), dim3(256), 0, stream, descs, d_works);
+        hipLaunchKernelGGL(pipe::sum_code_lengths, dim3(blocks, n), dim3(256), 0, s, descs, d_works);
+        hipLaunchKernelGGL(pipe::scan_block_sums, dim3(n), dim3(64), 0, s, descs, d_works);
+        hipLaunchKernelGGL(pipe::write_raw_bits, dim3(blocks, n), dim3(256), 0, s, descs, d_works);
         t.mark();
-        hipLaunchKernelGGL(pipe::stuff_scan, dim3(n), dim3(64), 0, stream, descs, d_works, d_results + first);
+        hipLaunchKernelGGL(pipe::stuff_scan, dim3(n), dim3(64), 0, s, descs, d_works, d_results + first);
         t.mark();
         hip_check(hipGetLastError());
+    }
+    if (lanes > 1)
+    { // the caller's stream continues when every lane is through
+        for (int l = 0; l < lanes; ++l)
+        {
+            hip_check(hipEventCreateWithFlags(&join[l], hipEventDisableTiming));
+            hip_check(hipEventRecord(join[l], lane_stream[l]));
+            hip_check(hipStreamWaitEvent(stream, join[l], 0));
+        }
+    }
+    hip_check(hipStreamSynchronize(stream)); // the host copies of the work descriptors and the timers go out of scope
+    // values[2..6]: analyze, partition, chains, pack, stuff (ms), summed over the passes -- with several lanes the passes
+    // overlap, so the sum exceeds the wall time (values[0], taken by the batch API around the whole call)
+    Timings& tm = last_timings();
+    double stage_ms[5] = {0, 0, 0, 0, 0};
+    for (StageTimer& t : timers)
         for (int i = 0; i < 5; ++i)
             stage_ms[i] += t.between(i, i + 1);
-    }
-    // values[2..6]: analyze, partition, chains, pack, stuff (ms); filled in by the batch API with totals in [0],[1]
     for (int i = 0; i < 5; ++i)
         tm.values[2 + i] = stage_ms[i];
     tm.count = 7;
+    if (lanes > 1)
+    {
+        (void)hipEventDestroy(fork);
+        for (int l = 0; l < lanes; ++l)
+            (void)hipEventDestroy(join[l]);
+    }
 }
 
 } // namespace
