@@ -14,6 +14,7 @@
 #include "lossless_pipeline.hip"
 #include "scan_fast_decode.hip"
 #include "scan_group_decode.hip"
+#include "scan_group_pixels.hip"
 #include "restart_intervals.hip"
 
 namespace jls::dev {
@@ -210,6 +211,39 @@ int decode_group_lanes(const ScanDesc& d, uint32_t count)
     return best;
 }
 
+size_t pixel_group_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
+{
+    return d.bits_per_sample > 8 ? grp::pixel_workgroup_lds_bytes<uint16_t>(d.width, static_cast<uint32_t>(d.components), scans_per_wave)
+                                 : grp::pixel_workgroup_lds_bytes<uint8_t>(d.width, static_cast<uint32_t>(d.components), scans_per_wave);
+}
+
+// Lanes per scan of the speed path of sample-interleaved scans (scan_group_pixels.hip), lossless or near-lossless; 0 = the
+// exact decoder.  Packing as in decode_group_lanes.
+int pixel_group_lanes(const ScanDesc& d, uint32_t count)
+{
+    if (d.interleave_mode != 2 || d.components < 2 || d.components > 4 || !wave_decode_eligible(d))
+        return 0;
+    if ((d.bits_per_sample > 8 && d.t3 > grp::kMaxTableT3) || std::getenv("CHARLS_AMD_EXACT_DECODER") != nullptr)
+        return 0;
+    const char* env = std::getenv("CHARLS_AMD_DECODE_GROUP");
+    const int forced = env ? std::atoi(env) : -1;
+    if (forced == 0)
+        return 0;
+    if ((forced == 8 || forced == 16 || forced == 32) && pixel_group_lds_bytes(d, 64u / forced) <= kGroupDecodeLds)
+        return forced;
+    int best = 0;
+    for (int lanes = 32; lanes >= 8; lanes /= 2)
+    {
+        const uint32_t per_wave = 64u / static_cast<uint32_t>(lanes);
+        if (pixel_group_lds_bytes(d, per_wave) > kGroupDecodeLds)
+            break;
+        best = lanes;
+        if ((count + per_wave - 1) / per_wave <= 256u)
+            break;
+    }
+    return best;
+}
+
 // Lossless single-component scans take the speed path (scan_group_decode.hip / scan_fast_decode.hip); it defers to the
 // exact kernels whenever the scan does not end cleanly.
 bool fast_decode_eligible(const ScanDesc& d)
@@ -268,7 +302,8 @@ uint64_t decode_launch_key(const ScanDesc& d) noexcept
 {
     // width | components | interleave | wide | eligible : scans with equal keys can share a launch
     const uint64_t base = (static_cast<uint64_t>(d.width) << 16) | (static_cast<uint64_t>(d.components & 0xFF) << 8) |
-                          (static_cast<uint64_t>(d.interleave_mode & 3) << 4) | (fast_decode_eligible(d) ? 4u : 0u) |
+                          (static_cast<uint64_t>(d.interleave_mode & 3) << 4) |
+                          (fast_decode_eligible(d) || pixel_group_lanes(d, 1) != 0 ? 4u : 0u) |
                           (d.bits_per_sample > 8 ? 2u : 0u) | (wave_decode_eligible(d) ? 1u : 0u);
     if (!interval_decode_candidate(d))
         return base;
@@ -364,11 +399,50 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
             launch_wave_decode<uint8_t>(nc, descs, results, n, lds, stream);
         hip_check(hipGetLastError());
     };
-    if (!fast_decode_eligible(proto))
+    const int pixel_lanes = pixel_group_lanes(proto, count);
+    if (pixel_lanes != 0)
+    { // sample-interleaved scans, lossless or near-lossless
+        const uint32_t per_wave = 64u / static_cast<uint32_t>(pixel_lanes);
+        const dim3 grid((count + per_wave - 1) / per_wave);
+        const size_t lds = pixel_group_lds_bytes(proto, per_wave);
+#define JLS_LAUNCH_PIXELS(S, G, N)                                                                                       \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        if (lds > kMaxDynamicLds)                                                                                        \
+            hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_pixels_group<S, G, N>),                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
+        hipLaunchKernelGGL((decode_pixels_group<S, G, N>), grid, dim3(64), lds, stream, d_descs, d_results, count);      \
+    } while (0)
+#define JLS_LAUNCH_PIXELS_N(S, G)                                                                                        \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        if (proto.components == 2) JLS_LAUNCH_PIXELS(S, G, 2);                                                           \
+        else if (proto.components == 3) JLS_LAUNCH_PIXELS(S, G, 3);                                                      \
+        else JLS_LAUNCH_PIXELS(S, G, 4);                                                                                 \
+    } while (0)
+        const bool wide = proto.bits_per_sample > 8;
+        if (pixel_lanes == 8)
+        {
+            if (wide) JLS_LAUNCH_PIXELS_N(uint16_t, 8); else JLS_LAUNCH_PIXELS_N(uint8_t, 8);
+        }
+        else if (pixel_lanes == 16)
+        {
+            if (wide) JLS_LAUNCH_PIXELS_N(uint16_t, 16); else JLS_LAUNCH_PIXELS_N(uint8_t, 16);
+        }
+        else
+        {
+            if (wide) JLS_LAUNCH_PIXELS_N(uint16_t, 32); else JLS_LAUNCH_PIXELS_N(uint8_t, 32);
+        }
+#undef JLS_LAUNCH_PIXELS_N
+#undef JLS_LAUNCH_PIXELS
+    }
+    else if (!fast_decode_eligible(proto))
     {
         exact(d_descs, d_results, count);
         return;
     }
+    else
+    {
     const int group = decode_group_lanes(proto, count);
     if (group == 0)
     {
@@ -408,6 +482,7 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
             if (wide) JLS_LAUNCH_GROUP(uint16_t, 32); else JLS_LAUNCH_GROUP(uint8_t, 32);
         }
 #undef JLS_LAUNCH_GROUP
+    }
     }
     hip_check(hipGetLastError());
     // scans that did not end cleanly are decided by the exact decoder (error codes and byte counts of the reference):

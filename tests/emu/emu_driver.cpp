@@ -10,6 +10,7 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 #include "../../charls_amd/csrc/device/lossless_pipeline.hip"
 #include "../../charls_amd/csrc/device/scan_fast_decode.hip"
 #include "../../charls_amd/csrc/device/scan_group_decode.hip"
+#include "../../charls_amd/csrc/device/scan_group_pixels.hip"
 #include "../../charls_amd/csrc/device/restart_intervals.hip"
 
 #include <cstdlib>
@@ -180,6 +181,38 @@ int emu_decode_scans_group(const jls::ScanDesc* descs, jls::ScanResult* results,
     else
         return -1;
 #undef EMU_GROUP
+    return 0;
+}
+
+// scan_group_pixels.hip: sample-interleaved scans, `group` lanes per scan.
+int emu_decode_pixels_group(const jls::ScanDesc* descs, jls::ScanResult* results, int count, int group)
+{
+    const jls::ScanDesc& d = descs[0];
+    const bool wide = d.bits_per_sample > 8;
+    const int per_wave = 64 / group;
+    const int nc = d.components;
+    const size_t lds = wide ? jls::grp::pixel_workgroup_lds_bytes<uint16_t>(d.width, nc, per_wave)
+                            : jls::grp::pixel_workgroup_lds_bytes<uint8_t>(d.width, nc, per_wave);
+    const dim3 grid((count + per_wave - 1) / per_wave);
+#define EMU_PIXELS(S, G, N) emu::launch(jls::decode_pixels_group<S, G, N>, grid, dim3(64), lds, descs, results, (uint32_t)count)
+#define EMU_PIXELS_G(S, N)                                       \
+    do                                                           \
+    {                                                            \
+        if (group == 8) EMU_PIXELS(S, 8, N);                     \
+        else if (group == 16) EMU_PIXELS(S, 16, N);              \
+        else if (group == 32) EMU_PIXELS(S, 32, N);              \
+        else return -1;                                          \
+    } while (0)
+    if (!wide)
+    {
+        if (nc == 2) EMU_PIXELS_G(uint8_t, 2); else if (nc == 3) EMU_PIXELS_G(uint8_t, 3); else if (nc == 4) EMU_PIXELS_G(uint8_t, 4); else return -1;
+    }
+    else
+    {
+        if (nc == 2) EMU_PIXELS_G(uint16_t, 2); else if (nc == 3) EMU_PIXELS_G(uint16_t, 3); else if (nc == 4) EMU_PIXELS_G(uint16_t, 4); else return -1;
+    }
+#undef EMU_PIXELS_G
+#undef EMU_PIXELS
     return 0;
 }
 

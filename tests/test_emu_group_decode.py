@@ -211,3 +211,111 @@ def test_group_decoder_random_parameters(chunk):
             assert (res[f].errc, res[f].flags) == (0, 0) and outs[f].tobytes() == imgs[f].tobytes(), tag
         done += 1
     assert done >= 15
+
+
+# ---- scan_group_pixels.hip: sample-interleaved scans (2..4 components per pixel), lossless and near-lossless ----------
+PIXEL_CASES = [c for c in common.cases() if c["errc"] == 0 and "file" in c and c["interleave_mode"] == 2 and
+               c["width"] * c["height"] <= 128 * 128]
+
+
+def _launch_pixels(L, descs, group):
+    n = len(descs)
+    arr = (emu_bind.ScanDesc * n)(*descs)
+    res = (emu_bind.ScanResult * n)()
+    assert L.emu_decode_pixels_group(arr, res, n, group) == 0
+    return res
+
+
+@pytest.mark.parametrize("c", PIXEL_CASES, ids=lambda c: c["name"])
+def test_pixel_group_decoder_matches_reference_pixels(c):
+    L = emu_bind.lib()
+    with open(f"{common.GOLDEN}/{c['file']}", "rb") as f:
+        jls = f.read()
+    cont = jls_container.parse(jls)
+    scan = cont.scans[0]
+    pc = jls_container.validated_pc(cont.pc, cont.bits, scan.near)
+    if not _group_eligible(cont.bits, pc):
+        pytest.skip("the exact decoder takes this one")
+    bps = 1 if cont.bits <= 8 else 2
+    w, h, nc = cont.width, cont.height, scan.components
+    keep = []
+    pix = np.zeros(w * h * nc * bps, dtype=np.uint8)
+    d = emu_bind.make_desc(w, h, nc, 2, cont.bits, scan.near, cont.transform, pc, 0, pix, w * nc * bps,
+                           _stream_copy(jls, scan.data_start), keep)
+    group = [8, 16, 32][len(c["name"]) % 3]
+    res = _launch_pixels(L, [d], group)
+    assert (res[0].errc, res[0].flags) == (0, 0), "a valid stream must not need the exact decoder"
+    assert res[0].bytes == scan.data_end - scan.data_start
+    assert common.sha(pix.tobytes()) == c["decoded_sha256"]
+
+
+@pytest.mark.parametrize("group", [8, 16, 32])
+@pytest.mark.parametrize("w,h,bits,comps,near,xform,kind,count",
+                         [(40, 12, 8, 3, 0, 1, "mixed", 5), (37, 9, 8, 3, 2, 0, "gradient", 3), (33, 7, 16, 3, 0, 3, "mixed", 3),
+                          (33, 7, 8, 4, 1, 0, "mixed", 5), (300, 4, 8, 3, 0, 2, "noise", 3), (1, 5, 8, 2, 0, 0, "mixed", 2),
+                          (64, 6, 8, 3, 0, 0, "zero", 3), (20, 6, 12, 3, 3, 0, "hard", 2)])
+def test_pixel_group_decoder_batches(group, w, h, bits, comps, near, xform, kind, count):
+    """`count` different frames per launch; what they decode to is what the oracle decodes (near-lossless: the reconstructed
+    samples, bit for bit)."""
+    L = emu_bind.lib()
+    bps = 1 if bits <= 8 else 2
+    keep, descs, outs, wants, ends = [], [], [], [], []
+    for f in range(count):
+        img = synth.frame_numpy(w, h, seed=17 * f + bits + comps, bits=bits, components=comps, kind=kind, interleaved=True)
+        jls = ob.encode(img, width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=2,
+                        near_lossless=near, color_transformation=xform)
+        wants.append(ob.decode(jls)[1].tobytes())
+        cont = jls_container.parse(jls)
+        pc = jls_container.validated_pc(cont.pc, cont.bits, near)
+        pix = np.zeros(w * h * comps * bps, dtype=np.uint8)
+        descs.append(emu_bind.make_desc(w, h, comps, 2, bits, near, xform, pc, 0, pix, w * comps * bps,
+                                        _stream_copy(jls, cont.scans[0].data_start), keep))
+        outs.append(pix)
+        ends.append(cont.scans[0].data_end - cont.scans[0].data_start)
+    res = _launch_pixels(L, descs, group)
+    for f in range(count):
+        assert (res[f].errc, res[f].flags, res[f].bytes) == (0, 0, ends[f]), f
+        assert outs[f].tobytes() == wants[f], f
+
+
+def test_pixel_group_dispatch_on_mutated_scan_data_matches_the_oracle():
+    """Group kernel, then the exact wave decoder for the scans that reported kFastRetry, on mutated RGB streams."""
+    L = emu_bind.lib()
+    w, h = 40, 10
+    for near, xform in ((0, 1), (2, 0)):
+        img = synth.frame_numpy(w, h, seed=3 + near, components=3, kind="mixed", interleaved=True)
+        base = ob.encode(img, width=w, height=h, component_count=3, interleave_mode=2, near_lossless=near, color_transformation=xform)
+        cont = jls_container.parse(base)
+        scan = cont.scans[0]
+        pc = jls_container.validated_pc(cont.pc, cont.bits, near)
+        rng = np.random.default_rng(50 + near)
+        keep, descs, outs, wants = [], [], [], []
+        for k in range(24):
+            b = bytearray(base)
+            how = int(rng.integers(0, 4))
+            i = int(rng.integers(scan.data_start, len(b) - 2))
+            if how == 0:
+                b[i] ^= 1 << int(rng.integers(0, 8))
+            elif how == 1:
+                b[i] = int(rng.choice([0x00, 0xFF, 0x7F, 0x80]))
+            elif how == 2:
+                del b[i:i + int(rng.integers(1, 4))]
+            data = bytes(b)
+            try:
+                wants.append((0, ob.decode(data)[1].tobytes()))
+            except ob.OracleError as e:
+                wants.append((e.errc, None))
+            pix = np.zeros(w * h * 3, dtype=np.uint8)
+            outs.append(pix)
+            descs.append(emu_bind.make_desc(w, h, 3, 2, 8, near, xform, pc, 0, pix, w * 3, _stream_copy(data, scan.data_start), keep))
+        res = _launch_pixels(L, descs, 16)
+        for k in range(len(descs)):
+            if res[k].flags & 4:
+                one = (emu_bind.ScanResult * 1)()
+                L.emu_decode_scans_wave((emu_bind.ScanDesc * 1)(descs[k]), one, 1)
+                res[k].errc, res[k].flags, res[k].bytes = one[0].errc, one[0].flags, one[0].bytes
+        for k, want in enumerate(wants):
+            if want[0] == 0:
+                assert res[k].errc == 0 and outs[k].tobytes() == want[1], (near, k)
+            else:
+                assert res[k].errc == want[0], (near, k, res[k].errc, want[0])

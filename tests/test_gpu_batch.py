@@ -172,3 +172,29 @@ def test_config4_all_256_frames_and_their_exchange(torch):
                 assert torch.equal(part[k, :int(sz[k])], enc.streams[f, :int(enc.sizes[f])])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", ["cfg5a_full", "cfg5b_full"])
+def test_config5_full_size_equals_reference_hash(torch, name):
+    """BASELINE configs[4] at its real size, 4096x4096 RGB sample-interleaved: 5a = HP1 lossless, 5b = NEAR 2 (the literal
+    combination HP1 + NEAR 2 is rejected by the reference, see test_gpu_parity).  The stream must hash to the reference's
+    (tests/golden/cases.json), the decoder must restore the pixels (5a) or stay within NEAR and equal the oracle's
+    reconstruction checksum (5b)."""
+    cases = {c["name"]: c for c in common.cases()}
+    c = cases[name]
+    planes = [synth.frames_torch(1, 4096, 4096, seed0=c["seed"] + 7919 * k, device="cuda:0")[0] for k in range(3)]
+    rgb = torch.stack(planes, dim=2).unsqueeze(0).contiguous()  # (1, H, W, 3): synth.frame_numpy's interleaved layout
+    assert common.sha(rgb.cpu().numpy().tobytes()) == c["input_sha256"]
+    enc = batch.encode_batch(rgb, component_count=3, interleave_mode=2, near_lossless=c["near_lossless"],
+                             color_transformation=c["color_transformation"])
+    assert enc.errcs[0] == 0 and int(enc.sizes[0]) == c["jls_size"]
+    assert common.sha(enc.streams[0, :int(enc.sizes[0])].cpu().numpy().tobytes()) == c["jls_sha256"]
+    out = torch.empty_like(rgb)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+    assert errcs[0] == 0
+    if c["near_lossless"] == 0:
+        assert torch.equal(out, rgb)
+    else:
+        assert (out.int() - rgb.int()).abs().max().item() <= c["near_lossless"]
+    assert common.sha(out.cpu().numpy().tobytes()) == c["decoded_sha256"]

@@ -38,16 +38,43 @@ def run(name, frames, *, bits, comps=1, ilv=0, near=0, xform=0, restart=0):
     torch.cuda.empty_cache()
 
 
-f = synth.frames_torch(512, 4096, 4096, seed0=2, bits=16, device=dev)
-run("config 2: 4096x4096 16-bit gray lossless", f, bits=16)
-del f
-torch.cuda.empty_cache()
-f = synth.frames_torch(256, 2048, 2048, seed0=2, bits=8, device=dev)
-run("config 3: 256 x 2048x2048 8-bit gray lossless (one GPU)", f, bits=8)
-del f
-torch.cuda.empty_cache()
-planes = synth.frames_torch(3 * 64, 1024, 1024, seed0=9, bits=8, device=dev).reshape(64, 3, 1024, 1024)
-rgb = planes.permute(0, 2, 3, 1).contiguous()
-run("config 4 (1024x1024 stand-in): RGB ILV_SAMPLE HP1 lossless", rgb, bits=8, comps=3, ilv=2, xform=1)
-run("config 4b (1024x1024 stand-in): RGB ILV_SAMPLE NEAR=2", rgb, bits=8, comps=3, ilv=2, near=2)
-run("config 4b with 16-line restart intervals (extension)", rgb, bits=8, comps=3, ilv=2, near=2, restart=16)
+import argparse  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--only", default="2,3,5a,5b", help="which configurations to measure")
+ap.add_argument("--frames16", type=int, default=1024)
+ap.add_argument("--rgb-frames", type=int, default=256)
+args = ap.parse_args()
+only = set(args.only.split(","))
+
+
+def rgb_frames(count, size, seed0):
+    """(count, size, size, 3) uint8: synth.frame_numpy's interleaved layout (plane k of frame f uses seed seed0 + f + 7919 k)."""
+    out = torch.empty((count, size, size, 3), dtype=torch.uint8, device=dev)
+    for k in range(3):
+        out[..., k] = synth.frames_torch(count, size, size, seed0=seed0 + 7919 * k, bits=8, device=dev)
+    return out
+
+
+if "2" in only:
+    f = synth.frames_torch(args.frames16, 4096, 4096, seed0=4, bits=16, device=dev)
+    run("config 2: 4096x4096 16-bit gray lossless", f, bits=16)
+    del f
+    torch.cuda.empty_cache()
+    batch.release_work_areas(lib)
+if "3" in only:
+    f = synth.frames_torch(256, 2048, 2048, seed0=100, bits=8, device=dev)
+    run("config 3: 256 x 2048x2048 8-bit gray lossless (one GPU)", f, bits=8)
+    del f
+    torch.cuda.empty_cache()
+    batch.release_work_areas(lib)
+if "5a" in only:
+    rgb = rgb_frames(args.rgb_frames, 4096, 5)
+    run("config 4 as 5a: 4096x4096 RGB ILV_SAMPLE HP1 lossless", rgb, bits=8, comps=3, ilv=2, xform=1)
+    del rgb
+    torch.cuda.empty_cache()
+    batch.release_work_areas(lib)
+if "5b" in only:
+    rgb = rgb_frames(args.rgb_frames, 4096, 5)
+    run("config 4 as 5b: 4096x4096 RGB ILV_SAMPLE NEAR=2", rgb, bits=8, comps=3, ilv=2, near=2)
+    run("config 4 as 5b with 16-line restart intervals (extension)", rgb, bits=8, comps=3, ilv=2, near=2, restart=16)
