@@ -15,6 +15,7 @@
 #include "scan_fast_decode.hip"
 #include "scan_group_decode.hip"
 #include "scan_group_pixels.hip"
+#include "scan_group_encode.hip"
 #include "restart_intervals.hip"
 
 namespace jls::dev {
@@ -900,6 +901,80 @@ void launch_encode_intervals(const ScanDesc& proto, ScanDesc* d_descs, ScanResul
 }
 } // namespace
 
+namespace {
+size_t group_encode_region_bytes(const ScanDesc& d)
+{
+    const uint32_t nc = d.interleave_mode == 2 ? static_cast<uint32_t>(d.components) : 1u;
+    return d.bits_per_sample > 8 ? grp::encode_region_bytes<uint16_t>(d.width, nc) : grp::encode_region_bytes<uint8_t>(d.width, nc);
+}
+
+// Lanes per scan of the group encoder (scan_group_encode.hip) for scans the parallel pipeline cannot take -- near-lossless
+// single-component and sample-interleaved scans; 0 = the one-lane kernel (line-interleaved scans, lines that do not fit LDS).
+int group_encode_lanes(const ScanDesc& d, uint32_t count)
+{
+    const bool shape = (d.interleave_mode == 2 && d.components >= 2 && d.components <= 4) || (d.interleave_mode == 0 && d.components == 1);
+    if (!shape || encode_engine() == EncodeEngine::serial)
+        return 0;
+    const size_t region = group_encode_region_bytes(d);
+    int best = 0;
+    for (int lanes = 64; lanes >= 8; lanes /= 2)
+    {
+        const uint32_t per_wave = 64u / static_cast<uint32_t>(lanes);
+        if (region * per_wave > kGroupDecodeLds)
+            break;
+        best = lanes;
+        if ((count + per_wave - 1) / per_wave <= 256u)
+            break;
+    }
+    return best;
+}
+
+void launch_encode_group(const ScanDesc& proto, int lanes, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count,
+                         hipStream_t stream)
+{
+    const uint32_t per_wave = 64u / static_cast<uint32_t>(lanes);
+    const dim3 grid((count + per_wave - 1) / per_wave);
+    const size_t lds = group_encode_region_bytes(proto) * per_wave;
+    const int nc = proto.interleave_mode == 2 ? proto.components : 1;
+#define JLS_LAUNCH_ENCODE(S, G, N)                                                                                       \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        if (lds > kMaxDynamicLds)                                                                                        \
+            hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_pixels_group<S, G, N>),                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
+        hipLaunchKernelGGL((encode_pixels_group<S, G, N>), grid, dim3(64), lds, stream, d_descs, d_results, count);      \
+    } while (0)
+#define JLS_LAUNCH_ENCODE_N(S, G)                                                                                        \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        if (nc == 1) JLS_LAUNCH_ENCODE(S, G, 1);                                                                         \
+        else if (nc == 2) JLS_LAUNCH_ENCODE(S, G, 2);                                                                    \
+        else if (nc == 3) JLS_LAUNCH_ENCODE(S, G, 3);                                                                    \
+        else JLS_LAUNCH_ENCODE(S, G, 4);                                                                                 \
+    } while (0)
+    const bool wide = proto.bits_per_sample > 8;
+    if (lanes == 8)
+    {
+        if (wide) JLS_LAUNCH_ENCODE_N(uint16_t, 8); else JLS_LAUNCH_ENCODE_N(uint8_t, 8);
+    }
+    else if (lanes == 16)
+    {
+        if (wide) JLS_LAUNCH_ENCODE_N(uint16_t, 16); else JLS_LAUNCH_ENCODE_N(uint8_t, 16);
+    }
+    else if (lanes == 32)
+    {
+        if (wide) JLS_LAUNCH_ENCODE_N(uint16_t, 32); else JLS_LAUNCH_ENCODE_N(uint8_t, 32);
+    }
+    else
+    {
+        if (wide) JLS_LAUNCH_ENCODE_N(uint16_t, 64); else JLS_LAUNCH_ENCODE_N(uint8_t, 64);
+    }
+#undef JLS_LAUNCH_ENCODE_N
+#undef JLS_LAUNCH_ENCODE
+    hip_check(hipGetLastError());
+}
+} // namespace
+
 void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
 {
     if (count == 0)
@@ -913,7 +988,11 @@ void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_resul
     {
         if (encode_engine() == EncodeEngine::pipeline)
             raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT);
-        launch_encode_serial(d_descs, d_results, count, stream);
+        const int lanes = group_encode_lanes(proto, count);
+        if (lanes != 0)
+            launch_encode_group(proto, lanes, d_descs, d_results, count, stream);
+        else
+            launch_encode_serial(d_descs, d_results, count, stream);
         return;
     }
     if (proto.bits_per_sample > 8)

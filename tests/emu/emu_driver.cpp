@@ -11,6 +11,7 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 #include "../../charls_amd/csrc/device/scan_fast_decode.hip"
 #include "../../charls_amd/csrc/device/scan_group_decode.hip"
 #include "../../charls_amd/csrc/device/scan_group_pixels.hip"
+#include "../../charls_amd/csrc/device/scan_group_encode.hip"
 #include "../../charls_amd/csrc/device/restart_intervals.hip"
 
 #include <cstdlib>
@@ -213,6 +214,38 @@ int emu_decode_pixels_group(const jls::ScanDesc* descs, jls::ScanResult* results
     }
 #undef EMU_PIXELS_G
 #undef EMU_PIXELS
+    return 0;
+}
+
+// scan_group_encode.hip: the encoder for near-lossless (and any other) single-component or sample-interleaved scans.
+int emu_encode_pixels_group(const jls::ScanDesc* descs, jls::ScanResult* results, int count, int group)
+{
+    const jls::ScanDesc& d = descs[0];
+    const bool wide = d.bits_per_sample > 8;
+    const int per_wave = 64 / group;
+    const int nc = d.interleave_mode == 2 ? d.components : 1;
+    const size_t lds = (size_t)per_wave * (wide ? jls::grp::encode_region_bytes<uint16_t>(d.width, nc) : jls::grp::encode_region_bytes<uint8_t>(d.width, nc));
+    const dim3 grid((count + per_wave - 1) / per_wave);
+#define EMU_ENC(S, G, N) emu::launch(jls::encode_pixels_group<S, G, N>, grid, dim3(64), lds, descs, results, (uint32_t)count)
+#define EMU_ENC_G(S, N)                                        \
+    do                                                         \
+    {                                                          \
+        if (group == 8) EMU_ENC(S, 8, N);                      \
+        else if (group == 16) EMU_ENC(S, 16, N);               \
+        else if (group == 32) EMU_ENC(S, 32, N);               \
+        else if (group == 64) EMU_ENC(S, 64, N);               \
+        else return -1;                                        \
+    } while (0)
+    if (!wide)
+    {
+        if (nc == 1) EMU_ENC_G(uint8_t, 1); else if (nc == 2) EMU_ENC_G(uint8_t, 2); else if (nc == 3) EMU_ENC_G(uint8_t, 3); else EMU_ENC_G(uint8_t, 4);
+    }
+    else
+    {
+        if (nc == 1) EMU_ENC_G(uint16_t, 1); else if (nc == 2) EMU_ENC_G(uint16_t, 2); else if (nc == 3) EMU_ENC_G(uint16_t, 3); else EMU_ENC_G(uint16_t, 4);
+    }
+#undef EMU_ENC_G
+#undef EMU_ENC
     return 0;
 }
 

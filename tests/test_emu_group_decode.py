@@ -319,3 +319,72 @@ def test_pixel_group_dispatch_on_mutated_scan_data_matches_the_oracle():
                 assert res[k].errc == 0 and outs[k].tobytes() == want[1], (near, k)
             else:
                 assert res[k].errc == want[0], (near, k, res[k].errc, want[0])
+
+
+# ---- scan_group_encode.hip: the encoder for near-lossless single-component and sample-interleaved scans --------------
+def _encode_group(L, descs, group):
+    n = len(descs)
+    arr = (emu_bind.ScanDesc * n)(*descs)
+    res = (emu_bind.ScanResult * n)()
+    assert L.emu_encode_pixels_group(arr, res, n, group) == 0
+    return res
+
+
+@pytest.mark.parametrize("group", [8, 16, 32, 64])
+@pytest.mark.parametrize("w,h,bits,comps,near,xform,kind,count",
+                         [(40, 12, 8, 3, 2, 0, "mixed", 3), (64, 20, 8, 1, 3, 0, "mixed", 5), (37, 9, 16, 1, 5, 0, "gradient", 3),
+                          (33, 7, 16, 3, 0, 3, "mixed", 2), (33, 7, 8, 4, 1, 0, "mixed", 3), (700, 4, 8, 1, 1, 0, "noise", 3),
+                          (300, 4, 8, 3, 2, 0, "noise", 2), (64, 6, 8, 3, 2, 0, "zero", 2), (1, 5, 8, 1, 2, 0, "mixed", 2),
+                          (20, 6, 12, 3, 2, 0, "hard", 2), (48, 9, 8, 2, 0, 0, "mixed", 3)])
+def test_group_encoder_matches_reference_scan_bytes(group, w, h, bits, comps, near, xform, kind, count):
+    """`count` different frames per launch: every scan's bytes equal the reference's (the oracle's) entropy-coded segment."""
+    L = emu_bind.lib()
+    ilv = 2 if comps > 1 else 0
+    bps = 1 if bits <= 8 else 2
+    keep, descs, outs, wants = [], [], [], []
+    for f in range(count):
+        img = synth.frame_numpy(w, h, seed=19 * f + bits + near, bits=bits, components=comps, kind=kind, interleaved=True)
+        jls = ob.encode(img, width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=ilv,
+                        near_lossless=near, color_transformation=xform)
+        cont = jls_container.parse(jls)
+        scan = cont.scans[0]
+        wants.append(jls[scan.data_start:scan.data_end])
+        pc = jls_container.validated_pc(cont.pc, cont.bits, near)
+        pix = np.frombuffer(np.ascontiguousarray(img).tobytes(), dtype=np.uint8).copy()
+        out = np.zeros(len(wants[-1]) + 64, dtype=np.uint8)
+        outs.append(out)
+        descs.append(emu_bind.make_desc(w, h, comps, ilv, bits, near, xform, pc, 0, pix, w * bps * comps, out, keep))
+    res = _encode_group(L, descs, group)
+    for f in range(count):
+        assert res[f].errc == 0 and outs[f][:res[f].bytes].tobytes() == wants[f], f
+
+
+@pytest.mark.parametrize("comps,near", [(1, 2), (3, 2), (1, 0)])
+def test_group_encoder_destination_too_small_boundary(comps, near):
+    """The verdict destination_too_small depends on the reference's 32-bit flush history (src/scan_encoder.hpp:117-120): for
+    every capacity around the size of the output the group encoder must agree with the kernel that restates that history
+    lane by lane (encode_scans_serial, itself pinned to the reference by tests/test_oracle_vs_reference.py)."""
+    L = emu_bind.lib()
+    w, h = 41, 9
+    ilv = 2 if comps > 1 else 0
+    img = synth.frame_numpy(w, h, seed=5, components=comps, kind="mixed", interleaved=True)
+    jls = ob.encode(img, width=w, height=h, component_count=comps, interleave_mode=ilv, near_lossless=near)
+    cont = jls_container.parse(jls)
+    scan = cont.scans[0]
+    size = scan.data_end - scan.data_start
+    pc = jls_container.validated_pc(cont.pc, 8, near)
+    pix = np.frombuffer(np.ascontiguousarray(img).tobytes(), dtype=np.uint8).copy()
+    for cap in list(range(size - 6, size + 7)) + [0, 1, 3, 4, size // 2]:
+        got = []
+        for kernel in ("group", "serial"):
+            keep = []
+            out = np.zeros(size + 64, dtype=np.uint8)
+            d = emu_bind.make_desc(w, h, comps, ilv, 8, near, 0, pc, 0, pix, w * comps, out, keep)
+            d.stream_capacity = cap
+            res = (emu_bind.ScanResult * 1)()
+            if kernel == "group":
+                assert L.emu_encode_pixels_group((emu_bind.ScanDesc * 1)(d), res, 1, 16) == 0
+            else:
+                L.emu_encode_scans_serial((emu_bind.ScanDesc * 1)(d), res, 1)
+            got.append((res[0].errc, res[0].bytes if res[0].errc == 0 else 0, out[:res[0].bytes].tobytes() if res[0].errc == 0 else b""))
+        assert got[0] == got[1], cap

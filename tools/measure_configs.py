@@ -18,7 +18,8 @@ def run(name, frames, *, bits, comps=1, ilv=0, near=0, xform=0, restart=0):
     torch.cuda.synchronize()
     kw = dict(bits_per_sample=bits, component_count=comps, interleave_mode=ilv, near_lossless=near,
               color_transformation=xform, restart_interval=restart, lib=lib)
-    batch.encode_batch(frames[:2], **kw)  # warm-up (allocations)
+    batch.encode_batch(frames, **kw)  # warm-up with the whole batch: the work arena is sized by the call that needs it
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     enc = batch.encode_batch(frames, **kw)
     torch.cuda.synchronize()
