@@ -396,7 +396,9 @@ def extras(lib, batch, torch, frames, streams, out, enc, dev, mpix, pitch):
         c = time.perf_counter()
         sweep.append({"frames": n, "encode_mpix_s": round(n * mpix / (b - a), 1), "decode_mpix_s": round(n * mpix / (c - b), 1)})
     result["batch_sweep"] = sweep
-    # ---- one frame through the host-pointer C ABI (handle created inside the clock, as cli/benchmark.cpp does)
+    # ---- one frame through the host-pointer C ABI (handle created inside the clock, as cli/benchmark.cpp does); the
+    # batch-sized work areas go first: giving ~90 GB back to the driver takes seconds and is not part of coding a frame
+    batch.release_work_areas(lib)
     img = frames[0].cpu().numpy()
     lib.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS)  # warm-up (allocations, module load)
     a = time.perf_counter()

@@ -4,15 +4,16 @@
 # into the files committed under profiles/.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/final
+out=gpurun_out/${1:-final}
 rm -rf $out && mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/pytest_gpu.log
 tail -c 600 $out/bench.json
-timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/stats.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python bench.py --no-cpu-baseline --no-extras > $out/bench_under_rocprof.json 2> $out/stats.log
 rm -f $out/stats/*/bench_kernel_trace.csv $out/stats/bench_kernel_trace.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_$c.log 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc_$c.log 2>&1
 done
-timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_inst -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_inst.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_inst -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc_inst.log 2>&1
 find $out -name "*kernel_trace.csv" -size +8M -delete
 du -sh $out; find $out -type f | head -30

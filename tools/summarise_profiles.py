@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "final")
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "final")
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 PMC_FRAMES = 64
@@ -79,12 +79,12 @@ def main():
     with open(os.path.join(DST, f"{TAG}_pmc_instructions_frames{PMC_FRAMES}.txt"), "w") as f:
         f.write(f"# rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE\n")
         f.write(f"# python bench.py --frames {PMC_FRAMES} --steps 1 --warmup 0 --no-cpu-baseline; sums over all launches of a kernel; "
-                "per-sample figures divide by 64 frames x 4096 x 4096 samples (wave-level instruction counts)\n")
+                "per-sample figures divide by 64 frames x 4096 x 4096 samples (wave-level instruction counts; a wavefront of decode_scans_group carries several scans, so its per-sample figure is per wavefront-step divided by the scans it advances)\n")
         samples = PMC_FRAMES * 4096 * 4096
         for k in sorted(inst):
             c = inst[k]
             f.write(f"{k} launches={li[k]} " + " ".join(f"{n}={v:.4g}" for n, v in sorted(c.items())) + "\n")
-            if c.get("SQ_INSTS_VALU") and ("decode_scans_fast" in k or "bias_chains" in k or "code_events" in k):
+            if c.get("SQ_INSTS_VALU") and ("decode_scans" in k or "bias_chains" in k or "code_events" in k):
                 f.write(f"    per sample: VALU {c['SQ_INSTS_VALU']/samples:.1f}  SALU {c['SQ_INSTS_SALU']/samples:.1f}  "
                         f"LDS {c['SQ_INSTS_LDS']/samples:.2f}  wave-cycles(x4) {4*c['SQ_WAVE_CYCLES']/samples:.0f}\n")
     print("profiles written for", TAG, "value", bench["value"])
