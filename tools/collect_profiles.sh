@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/${1:-final}
 rm -rf $out && mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/pytest_gpu.log
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error|FAILED" | tail -8 > $out/pytest_gpu.log
 tail -c 600 $out/bench.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python bench.py --no-cpu-baseline --no-extras > $out/bench_under_rocprof.json 2> $out/stats.log
 rm -f $out/stats/*/bench_kernel_trace.csv $out/stats/bench_kernel_trace.csv
