@@ -30,7 +30,7 @@
 namespace jls {
 namespace grp {
 
-constexpr uint32_t kRingWords = 256;               // dense bits resident per scan: 8192 (word kRingWords mirrors word 0)
+constexpr uint32_t kRingWords = 256;               // dense bits resident per scan: 8192 (words kRingWords, kRingWords + 1 mirror words 0, 1)
 constexpr uint32_t kRingBits = kRingWords * 32;
 constexpr int kStepsPerCheck = 32;                 // regular-mode steps between two looks at the producer
 constexpr uint32_t kMarginBits = kStepsPerCheck * 32 + 320; // dense bits the step loop and one event handler may consume
@@ -44,7 +44,7 @@ struct Layout
     static constexpr uint32_t kLutBytes = sizeof(S) == 1 ? 512 : 2 * kMaxTableT3 + 2; // quantised gradient + 4 for -cap .. cap
     static constexpr uint32_t kRecords = 0;                        // 365 x 8 B (+ an unused slot)
     static constexpr uint32_t kRun = 2928;                         // 2 x RunCtx
-    static constexpr uint32_t kRing = kRun + 32;                   // kRingWords + 1 words
+    static constexpr uint32_t kRing = kRun + 32;                   // kRingWords + 2 words
     static constexpr uint32_t kLine = kRing + kRingWords * 4 + 16 + 16 - sizeof(S);
 };
 
@@ -118,14 +118,14 @@ JLS_DEV void put_bits(uint32_t* ring, uint32_t p, uint32_t v, int n)
     const int off = (int)(p & 31);
     const uint32_t rv = bit_reverse(v) >> (32 - n); // first bit of the stream at bit 0
     atomicOr(&ring[q], rv << off);
-    if (q == 0)
-        atomicOr(&ring[kRingWords], rv << off);
+    if (q < 2)
+        atomicOr(&ring[kRingWords + q], rv << off);
     if (off + n > 32)
     {
         const uint32_t q2 = (q + 1) & (kRingWords - 1);
         atomicOr(&ring[q2], rv >> (32 - off));
-        if (q2 == 0)
-            atomicOr(&ring[kRingWords], rv >> (32 - off));
+        if (q2 < 2)
+            atomicOr(&ring[kRingWords + q2], rv >> (32 - off));
     }
 }
 
@@ -144,8 +144,8 @@ JLS_DEV void refill(Producer& s, uint32_t* ring, bool want, int lane, int sub)
         {
             const uint32_t q = (first + j) & (kRingWords - 1);
             ring[q] = 0;
-            if (q == 0)
-                ring[kRingWords] = 0;
+            if (q < 2)
+                ring[kRingWords + q] = 0;
         }
     }
     JLS_LOCKSTEP();
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             lut[q] = (unsigned char)(quantize(t_first, q - cap) + 4);
         for (uint32_t q = sub; q < width + 6; q += G)
             line[q] = 0;
-        for (uint32_t q = sub; q <= kRingWords; q += G)
+        for (uint32_t q = sub; q <= kRingWords + 1; q += G)
             ring[q] = 0;
     }
     Producer src;

@@ -5,21 +5,26 @@
 // of its own with all its state replicated over the group's lanes, control flow convergent for the wavefront, the lanes
 // of a group sharing the bulk work (un-stuffing, run fills, colour transform and row stores) -- with the pixel as the
 // unit of a step:
-//   * the context of every component of the pixel comes first (two table look-ups per component: the gradient towards
-//     the next sample of the previous line is the next pixel's gradient towards the previous one);
 //   * the pixel is in run mode only when ALL its components have context 0 (src/scan_decoder_impl.hpp:196-204);
 //     otherwise its components are decoded one after the other in regular mode on the ONE set of contexts, a component
 //     with context 0 on context record 0 with positive sign;
 //   * the components of a run-interruption pixel are decoded against run context 0 with the sign of Rb - Ra
 //     (src/scan_decoder_impl.hpp:300-337, src/scan_decoder_core.hpp:72-100).
-// The arithmetic is the general one (NEAR >= 0, RANGE not a power of two: src/default_traits.hpp), written with the
-// shared inlines of scan_model.h rather than for instruction count: what this kernel buys is scans per wavefront and
-// state in LDS / registers.  The exact one-scan-per-wavefront decoder (scan_wave_decode.hip) decodes such a scan at about
-// 0.5 MPix/s whatever the batch.
 //
-// LDS per scan: 365 context records, two run contexts, the dense bit ring and one line PER COMPONENT (planar, the
-// interleaving and the inverse colour transform happen when a finished line goes to the user's row).  As in
-// scan_group_decode.hip a result is accepted only when the scan ends cleanly; everything else reports kFastRetry.
+// LDS per scan: 365 context records, two run contexts, the dense bit ring and TWO lines of pixels (the previous and the
+// current one, samples interleaved as in the user's row): nothing of a pixel's neighbourhood lives in registers, so a scan
+// is described by its pixel index and its bit position alone, and whatever cannot decode a pixel leaves no state behind.
+//
+// Two step forms:
+//   * the pixel loop for lossless scans of 8-bit samples, written like the step loop of scan_group_decode.hip for the
+//     number of instructions it issues (a lone wavefront issues one instruction every 4.3 - 5 cycles whatever it is):
+//     the codes of ALL components of a pixel are cut from one 64-bit window of the bit ring, a component that meets the
+//     context of an earlier component of its pixel takes that component's updated record from registers, the context
+//     records and samples of a pixel are stored together once every component has decoded, and the contexts of the NEXT
+//     pixel are worked out while this one decodes (they do not depend on it but for one gradient per component);
+//   * the general step (NEAR >= 0, samples wider than 8 bits, escape codes, long prefixes) with the shared inlines of
+//     scan_model.h; it also decodes the pixels the loop above stops at.
+// As in scan_group_decode.hip a result is accepted only when the scan ends cleanly; everything else reports kFastRetry.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,24 +34,45 @@
 namespace jls {
 namespace grp {
 
-constexpr int kPixelStepsPerCheck = 8; // pixels between two looks at the producer
+constexpr int kPixelStepsPerCheck = 16; // pixels between two looks at the producer
+
+// Bytes of one line of pixels: pixel 0 is the left edge, 1 .. width the row, width + 1 the right edge, two more are read
+// ahead; a multiple of 16 so that both lines place pixel 1 on a 16-byte boundary.
+template <typename S>
+__host__ __device__ constexpr uint32_t pixel_line_bytes(uint32_t width, uint32_t components)
+{
+    return ((width + 4) * components * (uint32_t)sizeof(S) + 15u) & ~15u;
+}
 
 template <typename S>
-__host__ __device__ constexpr uint32_t pixel_line_samples(uint32_t width)
+__host__ __device__ constexpr uint32_t pixel_lines_offset(uint32_t components)
 {
-    return (width + 6 + 15) & ~15u; // per component; multiples of 16 samples keep every component's sample 1 aligned alike
+    // first line: pixel 1 on a 16-byte boundary behind the ring (Layout::kRing + ring + its two mirror words)
+    const uint32_t after_ring = Layout<S>::kRing + kRingWords * 4 + 16;
+    return ((after_ring + components * (uint32_t)sizeof(S) + 15u) & ~15u) - components * (uint32_t)sizeof(S);
 }
 
 template <typename S>
 __host__ __device__ constexpr uint32_t pixel_region_bytes(uint32_t width, uint32_t components)
 {
-    return (Layout<S>::kLine + components * pixel_line_samples<S>(width) * (uint32_t)sizeof(S) + 15u) & ~15u;
+    return (pixel_lines_offset<S>(components) + 2 * pixel_line_bytes<S>(width, components) + 15u) & ~15u;
 }
 
 template <typename S>
 __host__ __device__ constexpr uint32_t pixel_workgroup_lds_bytes(uint32_t width, uint32_t components, uint32_t scans_per_wave)
 {
     return Layout<S>::kLutBytes + scans_per_wave * pixel_region_bytes<S>(width, components);
+}
+
+// The three ring words around bit p (see ring_words_at).
+struct RingWords3
+{
+    uint32_t w0, w1, w2;
+};
+JLS_DEV RingWords3 ring_words3_at(uint32_t ring_address, uint32_t p)
+{
+    const uint32_t at = ring_address + (bit_field(p, 5, 8) << 2);
+    return RingWords3{lds_load<uint32_t>(at), lds_load<uint32_t>(at + 4), lds_load<uint32_t>(at + 8)};
 }
 
 } // namespace grp
@@ -71,13 +97,15 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
     const ScanDesc d = descs[live ? scan : count - 1];
     const Traits t = make_traits(d);
     const uint32_t width = d.width;
-    const uint32_t line_samples = pixel_line_samples<S>(width);
+    const uint32_t line_bytes = pixel_line_bytes<S>(width, NC);
 
     unsigned char* region = smem + L::kLutBytes + (size_t)sid * pixel_region_bytes<S>(width, NC);
     Record* records = reinterpret_cast<Record*>(region + L::kRecords);
     RunCtx* run_ctx = reinterpret_cast<RunCtx*>(region + L::kRun);
     uint32_t* ring = reinterpret_cast<uint32_t*>(region + L::kRing);
-    S* lines = reinterpret_cast<S*>(region + L::kLine); // component c: lines + c * line_samples, sample i at [i]
+    // sample c of pixel j of a line: [j * NC + c]
+    S* line_a = reinterpret_cast<S*>(region + pixel_lines_offset<S>(NC));
+    S* line_b = reinterpret_cast<S*>(region + pixel_lines_offset<S>(NC) + line_bytes);
     // gradient table shared by the scans of the wavefront (see scan_group_decode.hip); NEAR is part of it
     unsigned char* lut = smem;
     const ScanDesc& d_first = descs[blockIdx.x * kScansPerWave];
@@ -93,9 +121,9 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
             run_ctx[sub] = RunCtx{sub, initial_a(t), 1, 0};
         for (int q = lane; q <= 2 * cap; q += 64)
             lut[q] = (unsigned char)(quantize(t_first, q - cap) + 4);
-        for (uint32_t q = sub; q < NC * line_samples; q += G)
-            lines[q] = 0;
-        for (uint32_t q = sub; q <= kRingWords; q += G)
+        for (uint32_t q = sub; q < 2 * line_bytes / (uint32_t)sizeof(S); q += G)
+            line_a[q] = 0;
+        for (uint32_t q = sub; q <= kRingWords + 1; q += G)
             ring[q] = 0;
     }
     Producer src;
@@ -113,26 +141,25 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
     JLS_LOCKSTEP();
 
     enum : int { kLineStart = 0, kInLine, kDrain, kDone };
-    int phase = !live || !own_table ? kDone : (d.height == 0 ? kDrain : kLineStart);
-    bool retry = live && !own_table;
+    const bool usable = own_table && lds_address(smem) == 0; // (see lds_load)
+    int phase = !live || !usable ? kDone : (d.height == 0 ? kDrain : kLineStart);
+    bool retry = live && !usable;
     uint32_t p = 0; // consumed dense bits
     uint32_t y = 0, i = 1;
     int run_index = 0;
-    int a[NC], rc[NC], corner[NC], first[NC]; // Ra, Rc = prev[i - 1], prev[0] of this line, cur[0] of this line, per component
-    int q_prev[NC];                           // quantised prev[i] - prev[i - 1] per component (the last pixel's Q1)
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-        a[c] = rc[c] = corner[c] = first[c] = q_prev[c] = 0;
+    S* prev = line_a; // the two lines swap after every row
+    S* cur = line_b;
     const uint32_t margin_bits = (uint32_t)(kPixelStepsPerCheck + 1) * NC * (uint32_t)t.limit + 320u;
+    // the pixel loop takes lossless scans of 8-bit samples; a wavefront with any other scan runs on the general step
+    const bool quick = !kWide && __all(!live || !usable || t.near == 0);
 
-    auto quantised = [&](int diff) -> int { // quantised gradient, -4 .. 4
+    auto quantised = [&](int diff) -> int { // quantised gradient + 4: 0 .. 8
         if (kWide)
             diff = diff < -cap ? -cap : (diff > cap ? cap : diff);
-        return (int)lut[diff + cap] - 4;
+        return (int)lut[diff + cap];
     };
-    auto line_of = [&](int c) -> S* { return lines + (uint32_t)c * line_samples; };
 
-    // Errval of one regular-mode sample of context q (sign s, index idx); false = leave the scan to the exact decoder
+    // Errval of one regular-mode sample of context index idx; false = leave the scan to the exact decoder
     auto decode_regular = [&](int idx, int& errval, RegCtx& ctx, int& c_before) -> bool {
         const Record rec = records[idx];
         ctx = RegCtx{(int)rec.a, (int)rec.ncb >> 16, (int)(signed char)(rec.ncb >> 8), (int)(rec.ncb & 0xFFu)};
@@ -159,6 +186,54 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
         return true;
     };
 
+    // One pixel in the general form for the lanes in `todo`: returns whether the pixel is in run mode (then nothing has
+    // been decoded); otherwise its components are decoded and stored, or `retry` is raised.
+    auto general_pixel = [&](bool todo) -> bool {
+        const uint32_t at = todo ? i : 1u;
+        int ra[NC], rb[NC], rc[NC], qs[NC];
+        bool all_zero = true;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+        {
+            ra[c] = (int)cur[(at - 1) * NC + c];
+            rc[c] = (int)prev[(at - 1) * NC + c];
+            rb[c] = (int)prev[at * NC + c];
+            const int rd = (int)prev[(at + 1) * NC + c];
+            qs[c] = 81 * (quantised(rd - rb[c]) - 4) + 9 * (quantised(rb[c] - rc[c]) - 4) + (quantised(rc[c] - ra[c]) - 4);
+            all_zero = all_zero && qs[c] == 0;
+        }
+        const bool regular = todo && !all_zero;
+        int x[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+        {
+            const int s = qs[c] >> 31;
+            const int idx = (qs[c] ^ s) - s;
+            int e = 0, c_before = 0;
+            RegCtx ctx{0, 0, 0, 1};
+            bool good = regular && !retry;
+            if (good)
+                good = decode_regular(idx, e, ctx, c_before);
+            const int px = clamp_sample(t, med_predict(ra[c], rb[c], rc[c]) + ((c_before ^ s) - s));
+            x[c] = reconstruct(t, px, (e ^ s) - s);
+            JLS_LOCKSTEP();
+            if (good)
+                records[idx] = Record{(uint32_t)ctx.a, (uint32_t)ctx.n | (((uint32_t)ctx.c & 0xFFu) << 8) | ((uint32_t)ctx.b << 16)};
+            else if (regular)
+                retry = true;
+            JLS_LOCKSTEP();
+        }
+        if (regular && !retry)
+        {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                cur[i * NC + c] = (S)x[c];
+            ++i;
+        }
+        JLS_LOCKSTEP();
+        return todo && all_zero;
+    };
+
     for (;;)
     {
         // ---- producer
@@ -173,83 +248,217 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                 continue;
             }
         }
-        // ---- first pixel of a line (src/scan_codec.hpp:189-195 per component)
+        // ---- first pixel of a line (src/scan_codec.hpp:189-195 per component): cur[0] = prev[1]; prev[0] is what was
+        // cur[0] of the line above, i.e. that line's prev[1]
         {
             const bool starting = phase == kLineStart;
             if (__any(starting))
             {
                 if (starting && sub < NC)
-                    line_of(sub)[width + 1] = line_of(sub)[width];
+                    cur[sub] = prev[NC + sub];
                 JLS_LOCKSTEP();
                 if (starting)
                 {
                     i = 1;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-                    {
-                        const int rb = (int)line_of(c)[1];
-                        rc[c] = corner[c];            // prev[0]
-                        a[c] = rb;                    // cur[0] = prev[1]
-                        first[c] = rb;
-                        q_prev[c] = quantised(rb - rc[c]);
-                    }
                     phase = kInLine;
                 }
             }
         }
         // ---- pixels
         bool in_run = false;
-        for (int step = 0; step < kPixelStepsPerCheck; ++step)
+        bool stepped = false; // the pixel loop ran: the lanes it stopped at take ONE general step
+        if constexpr (!kWide)
         {
-            const bool active = phase == kInLine && i <= width && !retry;
-            int rb[NC], qs[NC], q1[NC];
-            bool all_zero = true;
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
+            const bool active = quick && phase == kInLine && !retry; // i <= width: the end of a line is handled at once
+            const LaneMask active_m = lanes_where(active);
+            if (active_m != 0)
             {
-                rb[c] = (int)line_of(c)[active ? i : 0];
-                const int rd = (int)line_of(c)[active ? i + 1 : 0];
-                q1[c] = quantised(rd - rb[c]);
-                qs[c] = 81 * q1[c] + 9 * q_prev[c] + quantised(rc[c] - a[c]);
-                all_zero = all_zero && qs[c] == 0;
-            }
-            in_run = active && all_zero;
-            const bool regular = active && !all_zero;
-            int x[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-            {
-                const int s = qs[c] >> 31;
-                const int idx = (qs[c] ^ s) - s;
-                int e = 0, c_before = 0;
-                RegCtx ctx{0, 0, 0, 1};
-                bool good = regular && !retry;
-                if (good)
-                    good = decode_regular(idx, e, ctx, c_before);
-                const int px = clamp_sample(t, med_predict(a[c], rb[c], rc[c]) + ((c_before ^ s) - s));
-                x[c] = reconstruct(t, px, (e ^ s) - s);
-                JLS_LOCKSTEP();
-                if (good)
-                    records[idx] = Record{(uint32_t)ctx.a, (uint32_t)ctx.n | (((uint32_t)ctx.c & 0xFFu) << 8) | ((uint32_t)ctx.b << 16)};
-                else if (regular)
-                    retry = true;
-                JLS_LOCKSTEP();
-            }
-            if (regular && !retry)
-            {
+                stepped = true;
+                const uint32_t rest_of_line = width + 1 - i;
+                uint32_t steps = kPixelStepsPerCheck;
+                while (lanes_where(active && rest_of_line < steps) != 0)
+                    --steps;
+                uint32_t ticker = 1u << (steps - 1);
+                const uint32_t limit_v = opaque(active ? (uint32_t)(t.limit - t.qbpp - 1) : 0u);
+                const int maxval = t.maxval, reset = t.reset;
+                const uint32_t ring_address = opaque(lds_address(ring));
+                const uint32_t records_address = opaque(lds_address(records));
+                // scans outside a line stay on pixel 1 of their (dead) lines and store nothing
+                const S* pp = prev + (active ? i : 1u) * NC; // pixel i of the previous line
+                S* cp = cur + (active ? i : 1u) * NC;
+                const uint32_t advance = active ? (uint32_t)NC : 0u;
+                // what a pixel brings into its iteration: per component Q + 364 (the three gradients come with + 4 each),
+                // Q1 + 4 (the next pixel's Q2 + 4), Ra, Rb, Rc, and its context record as read before the pixel
+                int qsu[NC], q1[NC], ra[NC], rb[NC], rc[NC];
+                Record rec[NC];
+                auto index_of = [&](int q) -> uint32_t { return abs_difference((uint32_t)q, 364u); };
+                auto gradient = [&](int diff) -> int { return (int)lds_load<unsigned char>((uint32_t)(diff + 255)); }; // the table is at LDS address 0
+                auto record_at = [&](uint32_t idx) -> Record {
+                    const uint32_t at = records_address + (idx << 3);
+                    return Record{lds_load<uint32_t>(at), lds_load<uint32_t>(at + 4)};
+                };
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
                 {
-                    line_of(c)[i] = (S)x[c];
-                    a[c] = x[c];
-                    rc[c] = rb[c];
-                    q_prev[c] = q1[c];
+                    ra[c] = (int)cp[c - NC];
+                    rc[c] = (int)pp[c - NC];
+                    rb[c] = (int)pp[c];
+                    const int rd = (int)pp[c + NC];
+                    q1[c] = gradient(rd - rb[c]);
+                    qsu[c] = mad24(mad24(q1[c], 9, gradient(rb[c] - rc[c])), 9, gradient(rc[c] - ra[c]));
+                    rec[c] = record_at(index_of(qsu[c]));
                 }
-                ++i;
+                RingWords3 words = ring_words3_at(ring_address, p);
+                uint32_t k_seen = 0, mm_seen = 0;
+                LaneMask ok_m;
+                do
+                {
+                    // the next pixel's Rb and Rd: reads that depend on nothing of this pixel go first
+                    const S* const pn = pp + advance;
+                    int rb_next[NC], rd_next[NC], q1_next[NC], q3_next[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                    {
+                        rb_next[c] = (int)pn[c];
+                        rd_next[c] = (int)pn[c + NC];
+                    }
+                    // the next 64 bits of the stream: bit j of the pair is stream bit p + j (v_alignbit shifts by p mod 32)
+                    const uint32_t lo = funnel_shift(words.w1, words.w0, p);
+                    const uint32_t hi = funnel_shift(words.w2, words.w1, p);
+                    const uint64_t window = ((uint64_t)hi << 32) | lo;
+                    // a pixel in run mode: every component has context 0
+                    LaneMask run_m = lanes_where(qsu[0] == 364);
+#pragma unroll
+                    for (int c = 1; c < NC; ++c)
+                        run_m &= lanes_where(qsu[c] == 364);
+                    ok_m = ~run_m;
+                    uint32_t taken = 0; // bits of this pixel's earlier components: at most 32 for the window to hold the next code
+                    uint32_t k_pixel = 0, mm_pixel = 0;
+                    int x[NC];
+                    uint32_t idx[NC];
+                    Record updated[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                    {
+                        idx[c] = index_of(qsu[c]);
+                        // the record as the earlier components of this pixel left it
+                        Record r = rec[c];
+#pragma unroll
+                        for (int e = 0; e < c; ++e)
+                        {
+                            const bool same = idx[c] == idx[e];
+                            r.a = same ? updated[e].a : r.a;
+                            r.ncb = same ? updated[e].ncb : r.ncb;
+                        }
+                        const uint32_t win = (uint32_t)(window >> taken);
+                        const uint32_t u = lowest_one(win); // length of the unary prefix; 0xFFFFFFFF for an all-zero window
+                        const uint32_t u1 = u + 1u;
+                        const uint32_t beyond = bit_reverse(win >> (u1 & 31u));
+                        ok_m &= lanes_where(u < limit_v);
+                        const int n = (int)(r.ncb & 0xFFu);
+                        const int cc = (int)(signed char)(r.ncb >> 8);
+                        const int bb = (int)r.ncb >> 16;
+                        // k = min{k : N << k >= A} from the exponents of A and N (see scan_group_decode.hip)
+                        const int k_raw = ((int)(float_bits(r.a) - float_bits((uint32_t)n)) + 0x7FFFFF) >> 23;
+                        const int k = k_raw < 0 ? 0 : k_raw;
+                        const int mm = (int)((u << k) | (uint32_t)(((uint64_t)beyond << k) >> 32));
+                        const int half = mm >> 1;
+                        const int odd = (mm ^ (((k - 1) & (2 * bb + n - 1)) >> 31)) & 1;
+                        const int e = half ^ -odd;
+                        const int sgn = qsu[c] < 364 ? -1 : 1;
+                        const int px0 = med3(ra[c] + (rb[c] - rc[c]), ra[c], rb[c]);
+                        const int px = med3(mad24(cc, sgn, px0), 0, maxval);
+                        x[c] = mad24(e, sgn, px) & maxval;
+                        q3_next[c] = gradient(rb[c] - x[c]); // the next pixel's Rc - Ra
+                        if (c == 0)
+                        {
+#pragma unroll
+                            for (int f = 0; f < NC; ++f)
+                                q1_next[f] = gradient(rd_next[f] - rb_next[f]);
+                        }
+                        taken += u1 + (uint32_t)k;
+                        if (c + 1 < NC)
+                            ok_m &= lanes_where(taken <= 32u);
+                        k_pixel |= (uint32_t)k;
+                        mm_pixel |= (uint32_t)mm;
+                        // A.12 / A.13, src/regular_mode_context.hpp:45-93, in the median form of scan_group_decode.hip
+                        int u_a = (int)r.a + half + odd;
+                        int u_n1 = n + 1;
+                        int u_tb = bb + e;
+                        const LaneMask halve_m = lanes_where(n == reset);
+                        if (__builtin_expect(halve_m != 0, 0))
+                        {
+                            JLS_RARE_BLOCK();
+                            if (lane_of(halve_m))
+                            {
+                                u_a >>= 1;
+                                u_n1 = (n >> 1) + 1;
+                                u_tb >>= 1;
+                            }
+                        }
+                        const int minus_delta = 1 - med3(u_tb, 0, 1) - med3(u_tb + u_n1, 0, 1);
+                        const int b_new = med3(mad24(minus_delta, u_n1, u_tb), 1 - u_n1, 0);
+                        const int c_new = med3(cc - minus_delta, -128, 127);
+                        updated[c] = Record{(uint32_t)u_a, ((uint32_t)b_new << 16) | pack_bytes((uint32_t)c_new, (uint32_t)u_n1)};
+                    }
+                    // the next pixel's contexts (Rc = this pixel's Rb, Ra = this pixel's samples)
+                    uint32_t at_next[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                    {
+                        qsu[c] = mad24(mad24(q1_next[c], 9, q1[c]), 9, q3_next[c]);
+                        q1[c] = q1_next[c];
+                        rc[c] = rb[c];
+                        rb[c] = rb_next[c];
+                        ra[c] = x[c];
+                        at_next[c] = records_address + (index_of(qsu[c]) << 3);
+                    }
+                    // the pixel is complete: its records and samples go to LDS together (a lane that could not decode one of
+                    // its components stores nothing and keeps its position; the loop ends for everybody)
+                    JLS_LOCKSTEP();
+                    if (lane_of(ok_m))
+                    {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                        {
+                            const uint32_t at = records_address + (idx[c] << 3);
+                            lds_store<uint32_t>(at, updated[c].a); // in component order: the last of equal contexts stays
+                            lds_store<uint32_t>(at + 4, updated[c].ncb);
+                            cp[c] = (S)x[c];
+                        }
+                        p += taken;
+                        ++i;
+                        k_seen |= k_pixel;
+                        mm_seen |= mm_pixel;
+                    }
+                    JLS_LOCKSTEP_STORES();
+                    pp = pn;
+                    cp += advance;
+                    // the records and the bit window of the next pixel: read behind the stores
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        rec[c] = Record{lds_load<uint32_t>(at_next[c]), lds_load<uint32_t>(at_next[c] + 4)};
+                    words = ring_words3_at(ring_address, p);
+                    ticker = tick(ticker, active_m, ok_m);
+                } while (ticker != 0);
+                // the reference raises invalid_data for k >= 16; valid streams of 8-bit samples keep k <= 9 and the mapped
+                // error below RANGE (anything else is left to the exact decoder as a whole)
+                if (active && (k_seen >= 10u || (mm_seen >> t.qbpp) != 0u))
+                    retry = true;
+                // one general step for the lanes the loop stopped at
+                const bool stopped = active && !lane_of(ok_m) && !retry;
+                in_run = general_pixel(stopped);
             }
-            JLS_LOCKSTEP();
-            if (__any(in_run || retry || (phase == kInLine && i > width)))
-                break;
+        }
+        if (!stepped && __any(phase == kInLine))
+        {
+            for (int step = 0; step < kPixelStepsPerCheck; ++step)
+            {
+                const bool todo = phase == kInLine && i <= width && !retry;
+                in_run = general_pixel(todo);
+                if (__any(in_run || retry || (phase == kInLine && i > width)))
+                    break;
+            }
         }
 
         // ---- run mode of a pixel: src/scan_decoder_impl.hpp:264-337
@@ -289,6 +498,10 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                     run = 0;
                 }
             }
+            int a[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                a[c] = (int)cur[((in_run ? i : 1u) - 1) * NC + c];
             JLS_LOCKSTEP();
             {
                 uint32_t r = (uint32_t)sub;
@@ -298,18 +511,18 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                     {
 #pragma unroll
                         for (int c = 0; c < NC; ++c)
-                            line_of(c)[i + r] = (S)a[c];
+                            cur[(i + r) * NC + c] = (S)a[c];
                     }
                     r += G;
                 }
             }
             const uint32_t at = i + run;
             JLS_LOCKSTEP();
-            int x[NC], rb_at[NC];
+            int x[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c)
             { // every component against run context 0, in component order (src/scan_decoder_impl.hpp:300-337)
-                rb_at[c] = (int)line_of(c)[interrupted ? at : 0]; // prev[at]: not overwritten yet
+                const int rb_at = (int)prev[(interrupted ? at : 1u) * NC + c];
                 RunCtx ctx = run_ctx[0];
                 x[c] = 0;
                 if (interrupted)
@@ -331,7 +544,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                             em = (int)take_bits(ring, p, t.qbpp) + 1;
                         const int e = run_error_value(ctx, em + ctx.ritype, k);
                         run_update(ctx, e, em, t.reset);
-                        x[c] = reconstruct(t, rb_at[c], e * ((rb_at[c] - a[c]) < 0 ? -1 : 1));
+                        x[c] = reconstruct(t, rb_at, e * ((rb_at - a[c]) < 0 ? -1 : 1));
                     }
                 }
                 JLS_LOCKSTEP();
@@ -343,11 +556,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
             {
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
-                {
-                    line_of(c)[at] = (S)x[c];
-                    a[c] = x[c];
-                    rc[c] = rb_at[c];
-                }
+                    cur[at * NC + c] = (S)x[c];
                 if (run_index > 0)
                     --run_index;
                 i = at + 1;
@@ -355,51 +564,63 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
             else if (in_run && !retry)
                 i = width + 1; // the run reached the end of the line
             JLS_LOCKSTEP();
-            if (interrupted && i <= width)
-            {
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    q_prev[c] = quantised((int)line_of(c)[i] - rc[c]);
-            }
         }
 
         if (retry)
             phase = kDone;
 
-        // ---- finished line -> user's row: interleave, inverse colour transform (src/copy_from_line_buffer.hpp:19-191)
+        // ---- finished line -> user's row (inverse colour transform: src/copy_from_line_buffer.hpp:19-191); the line
+        // becomes the previous one
         {
             const bool ending = phase == kInLine && i > width;
             if (__any(ending))
             {
                 uint8_t* row = d.pixels + (size_t)y * d.pixel_stride;
-                uint32_t xx = (uint32_t)sub;
-                while (__any(ending && xx < width))
+                const S* samples = cur + NC; // pixel 1
+                const bool transformed = NC == 3 && d.color_transformation != 0;
+                const uint32_t row_bytes = width * NC * (uint32_t)sizeof(S);
+                const bool aligned = ((reinterpret_cast<uintptr_t>(d.pixels) | d.pixel_stride) & 15u) == 0;
+                const uint32_t wide_bytes = aligned && !transformed ? row_bytes & ~15u : 0u;
+                uint32_t off = (uint32_t)sub * 16u;
+                while (__any(ending && off < wide_bytes))
                 {
-                    if (ending && xx < width)
-                    {
-                        unsigned v[4];
-#pragma unroll
-                        for (int c = 0; c < NC; ++c)
-                            v[c] = line_of(c)[1 + xx];
-                        if (NC == 3 && d.color_transformation != 0)
-                            hp_inverse(d.color_transformation, kWide, (int)v[0], (int)v[1], (int)v[2], v);
-#pragma unroll
-                        for (int c = 0; c < NC; ++c)
-                        {
-                            uint8_t* q = row + ((size_t)xx * NC + c) * sizeof(S);
-                            q[0] = (uint8_t)v[c];
-                            if (kWide)
-                                q[1] = (uint8_t)(v[c] >> 8);
-                        }
-                    }
-                    xx += G;
+                    if (ending && off < wide_bytes)
+                        *reinterpret_cast<uint4*>(row + off) =
+                            *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(samples) + off);
+                    off += G * 16u;
                 }
+                if (__any(ending && transformed))
+                {
+                    uint32_t xx = (uint32_t)sub;
+                    while (__any(ending && transformed && xx < width))
+                    {
+                        if (ending && transformed && xx < width)
+                        {
+                            unsigned v[3];
+                            hp_inverse(d.color_transformation, kWide, (int)samples[xx * NC], (int)samples[xx * NC + 1],
+                                       (int)samples[xx * NC + (NC > 2 ? 2 : 0)], v);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                reinterpret_cast<S*>(row)[xx * NC + (c < NC ? c : 0)] = (S)v[c];
+                        }
+                        xx += G;
+                    }
+                }
+                uint32_t ss = wide_bytes / (uint32_t)sizeof(S) + (uint32_t)sub;
+                while (__any(ending && !transformed && ss < width * NC))
+                {
+                    if (ending && !transformed && ss < width * NC)
+                        reinterpret_cast<S*>(row)[ss] = samples[ss];
+                    ss += G;
+                }
+                if (ending && sub < NC)
+                    cur[(width + 1) * NC + sub] = cur[width * NC + sub]; // the right edge of the next line's previous line
                 JLS_LOCKSTEP();
                 if (ending)
                 {
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-                        corner[c] = first[c];
+                    S* const was_prev = prev;
+                    prev = cur;
+                    cur = was_prev;
                     ++y;
                     phase = y == d.height ? kDrain : kLineStart;
                 }

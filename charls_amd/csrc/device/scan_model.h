@@ -14,6 +14,14 @@ namespace jls {
 // stops the compiler from reordering across it (no instruction is emitted).  The CPU test harness maps it to a real
 // barrier between the lane threads.
 #define JLS_LOCKSTEP() __builtin_amdgcn_wave_barrier()
+// Behind a sequence of stores that every lane of a group issues identically (the later of two stores to one address
+// must stay): lockstep execution orders them without the compiler's help, so nothing is needed on the GPU, not even a
+// scheduling boundary; the lane threads of the CPU test harness have to meet before any of them reads the result.
+#ifdef JLS_EMULATED
+#define JLS_LOCKSTEP_STORES() __builtin_amdgcn_wave_barrier()
+#else
+#define JLS_LOCKSTEP_STORES() ((void)0)
+#endif
 
 // Pointers that are loaded from a descriptor in memory are "generic" to the compiler, which then emits flat_* memory
 // instructions; those tick both wait counters and force conservative s_waitcnt 0.  Declaring them global lets the
@@ -199,6 +207,16 @@ JLS_DEV T lds_load(uint32_t address)
 {
     return *(const JLS_LDS_AS T*)(uintptr_t)address;
 }
+template <typename T>
+JLS_DEV void lds_store(uint32_t address, T v)
+{
+    *(JLS_LDS_AS T*)(uintptr_t)address = v;
+}
+// Bits [shift mod 32, shift mod 32 + 32) of the 64-bit value hi:lo (v_alignbit_b32 takes the low five bits of the shift).
+JLS_DEV uint32_t funnel_shift(uint32_t hi, uint32_t lo, uint32_t shift)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, shift);
+}
 #else
 JLS_DEV LaneMask lanes_where(bool p)
 {
@@ -249,6 +267,15 @@ JLS_DEV T lds_load(uint32_t address)
     T v;
     std::memcpy(&v, emu::g_block->dyn_shared + address, sizeof(T));
     return v;
+}
+template <typename T>
+JLS_DEV void lds_store(uint32_t address, T v)
+{
+    std::memcpy(emu::g_block->dyn_shared + address, &v, sizeof(T));
+}
+JLS_DEV uint32_t funnel_shift(uint32_t hi, uint32_t lo, uint32_t shift)
+{
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (shift & 31u));
 }
 JLS_DEV uint32_t float_bits(uint32_t v)
 {

@@ -253,7 +253,8 @@ def test_pixel_group_decoder_matches_reference_pixels(c):
 @pytest.mark.parametrize("w,h,bits,comps,near,xform,kind,count",
                          [(40, 12, 8, 3, 0, 1, "mixed", 5), (37, 9, 8, 3, 2, 0, "gradient", 3), (33, 7, 16, 3, 0, 3, "mixed", 3),
                           (33, 7, 8, 4, 1, 0, "mixed", 5), (300, 4, 8, 3, 0, 2, "noise", 3), (1, 5, 8, 2, 0, 0, "mixed", 2),
-                          (64, 6, 8, 3, 0, 0, "zero", 3), (20, 6, 12, 3, 3, 0, "hard", 2)])
+                          (64, 6, 8, 3, 0, 0, "zero", 3), (20, 6, 12, 3, 3, 0, "hard", 2), (90, 8, 8, 4, 0, 0, "hard", 3),
+                          (130, 6, 5, 3, 0, 0, "mixed", 3), (257, 5, 8, 2, 0, 0, "noise", 4), (75, 10, 8, 3, 0, 3, "gradient", 5)])
 def test_pixel_group_decoder_batches(group, w, h, bits, comps, near, xform, kind, count):
     """`count` different frames per launch; what they decode to is what the oracle decodes (near-lossless: the reconstructed
     samples, bit for bit)."""
