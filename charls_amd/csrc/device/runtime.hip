@@ -902,10 +902,11 @@ void launch_encode_intervals(const ScanDesc& proto, ScanDesc* d_descs, ScanResul
 } // namespace
 
 namespace {
-size_t group_encode_region_bytes(const ScanDesc& d)
+size_t group_encode_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
 {
     const uint32_t nc = d.interleave_mode == 2 ? static_cast<uint32_t>(d.components) : 1u;
-    return d.bits_per_sample > 8 ? grp::encode_region_bytes<uint16_t>(d.width, nc) : grp::encode_region_bytes<uint8_t>(d.width, nc);
+    return d.bits_per_sample > 8 ? grp::encode_workgroup_lds_bytes<uint16_t>(d.width, nc, scans_per_wave)
+                                 : grp::encode_workgroup_lds_bytes<uint8_t>(d.width, nc, scans_per_wave);
 }
 
 // Lanes per scan of the group encoder (scan_group_encode.hip) for scans the parallel pipeline cannot take -- near-lossless
@@ -915,12 +916,11 @@ int group_encode_lanes(const ScanDesc& d, uint32_t count)
     const bool shape = (d.interleave_mode == 2 && d.components >= 2 && d.components <= 4) || (d.interleave_mode == 0 && d.components == 1);
     if (!shape || encode_engine() == EncodeEngine::serial)
         return 0;
-    const size_t region = group_encode_region_bytes(d);
     int best = 0;
     for (int lanes = 64; lanes >= 8; lanes /= 2)
     {
         const uint32_t per_wave = 64u / static_cast<uint32_t>(lanes);
-        if (region * per_wave > kGroupDecodeLds)
+        if (group_encode_lds_bytes(d, per_wave) > kGroupDecodeLds)
             break;
         best = lanes;
         if ((count + per_wave - 1) / per_wave <= 256u)
@@ -934,7 +934,7 @@ void launch_encode_group(const ScanDesc& proto, int lanes, const ScanDesc* d_des
 {
     const uint32_t per_wave = 64u / static_cast<uint32_t>(lanes);
     const dim3 grid((count + per_wave - 1) / per_wave);
-    const size_t lds = group_encode_region_bytes(proto) * per_wave;
+    const size_t lds = group_encode_lds_bytes(proto, per_wave);
     const int nc = proto.interleave_mode == 2 ? proto.components : 1;
 #define JLS_LAUNCH_ENCODE(S, G, N)                                                                                       \
     do                                                                                                                   \

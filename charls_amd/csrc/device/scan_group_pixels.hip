@@ -16,7 +16,7 @@
 // is described by its pixel index and its bit position alone, and whatever cannot decode a pixel leaves no state behind.
 //
 // Two step forms:
-//   * the pixel loop for lossless scans of 8-bit samples, written like the step loop of scan_group_decode.hip for the
+//   * the pixel loop for scans of 8-bit samples (lossless or near-lossless), written like the step loop of scan_group_decode.hip for the
 //     number of instructions it issues (a lone wavefront issues one instruction every 4.3 - 5 cycles whatever it is):
 //     the codes of ALL components of a pixel are cut from one 64-bit window of the bit ring, a component that meets the
 //     context of an earlier component of its pixel takes that component's updated record from registers, the context
@@ -27,6 +27,8 @@
 // As in scan_group_decode.hip a result is accepted only when the scan ends cleanly; everything else reports kFastRetry.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "scan_group_decode.hip"
 #include "scan_model.h"
@@ -150,8 +152,8 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
     S* prev = line_a; // the two lines swap after every row
     S* cur = line_b;
     const uint32_t margin_bits = (uint32_t)(kPixelStepsPerCheck + 1) * NC * (uint32_t)t.limit + 320u;
-    // the pixel loop takes lossless scans of 8-bit samples; a wavefront with any other scan runs on the general step
-    const bool quick = !kWide && __all(!live || !usable || t.near == 0);
+    // the pixel loop takes scans of 8-bit samples (the scans of a wavefront share NEAR: it is part of their gradient table)
+    const bool quick = !kWide;
 
     auto quantised = [&](int diff) -> int { // quantised gradient + 4: 0 .. 8
         if (kWide)
@@ -160,7 +162,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
     };
 
     // Errval of one regular-mode sample of context index idx; false = leave the scan to the exact decoder
-    auto decode_regular = [&](int idx, int& errval, RegCtx& ctx, int& c_before) -> bool {
+    auto decode_regular = [&](int idx, int& errval, RegCtx& ctx, int& c_before) __attribute__((always_inline)) -> bool {
         const Record rec = records[idx];
         ctx = RegCtx{(int)rec.a, (int)rec.ncb >> 16, (int)(signed char)(rec.ncb >> 8), (int)(rec.ncb & 0xFFu)};
         c_before = ctx.c; // the prediction is corrected with C as it was BEFORE this sample's update
@@ -188,7 +190,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
 
     // One pixel in the general form for the lanes in `todo`: returns whether the pixel is in run mode (then nothing has
     // been decoded); otherwise its components are decoded and stored, or `retry` is raised.
-    auto general_pixel = [&](bool todo) -> bool {
+    auto general_pixel = [&](bool todo) __attribute__((always_inline)) -> bool {
         const uint32_t at = todo ? i : 1u;
         int ra[NC], rb[NC], rc[NC], qs[NC];
         bool all_zero = true;
@@ -271,8 +273,11 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
         {
             const bool active = quick && phase == kInLine && !retry; // i <= width: the end of a line is handled at once
             const LaneMask active_m = lanes_where(active);
-            if (active_m != 0)
-            {
+            // the loop in two renderings: lossless, and near-lossless (de-quantised error, reconstruction with the range
+            // fix of src/default_traits.hpp:118-141, no k = 0 correction)
+            auto pixel_loop = [&](auto near_tag) __attribute__((always_inline)) {
+                constexpr bool kNearLoop = decltype(near_tag)::value;
+                const int near = t.near, step_size = 2 * t.near + 1, range_span = t.range * (2 * t.near + 1);
                 stepped = true;
                 const uint32_t rest_of_line = width + 1 - i;
                 uint32_t steps = kPixelStepsPerCheck;
@@ -363,12 +368,19 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                         const int k = k_raw < 0 ? 0 : k_raw;
                         const int mm = (int)((u << k) | (uint32_t)(((uint64_t)beyond << k) >> 32));
                         const int half = mm >> 1;
-                        const int odd = (mm ^ (((k - 1) & (2 * bb + n - 1)) >> 31)) & 1;
+                        const int odd = kNearLoop ? (mm & 1) : ((mm ^ (((k - 1) & (2 * bb + n - 1)) >> 31)) & 1);
                         const int e = half ^ -odd;
                         const int sgn = qsu[c] < 364 ? -1 : 1;
                         const int px0 = med3(ra[c] + (rb[c] - rc[c]), ra[c], rb[c]);
                         const int px = med3(mad24(cc, sgn, px0), 0, maxval);
-                        x[c] = mad24(e, sgn, px) & maxval;
+                        if (kNearLoop)
+                        {
+                            int v = mad24(e * sgn, step_size, px);
+                            v += v < -near ? range_span : (v > maxval + near ? -range_span : 0);
+                            x[c] = med3(v, 0, maxval);
+                        }
+                        else
+                            x[c] = mad24(e, sgn, px) & maxval;
                         q3_next[c] = gradient(rb[c] - x[c]); // the next pixel's Rc - Ra
                         if (c == 0)
                         {
@@ -384,7 +396,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                         // A.12 / A.13, src/regular_mode_context.hpp:45-93, in the median form of scan_group_decode.hip
                         int u_a = (int)r.a + half + odd;
                         int u_n1 = n + 1;
-                        int u_tb = bb + e;
+                        int u_tb = kNearLoop ? mad24(e, step_size, bb) : bb + e;
                         const LaneMask halve_m = lanes_where(n == reset);
                         if (__builtin_expect(halve_m != 0, 0))
                         {
@@ -448,6 +460,13 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                 // one general step for the lanes the loop stopped at
                 const bool stopped = active && !lane_of(ok_m) && !retry;
                 in_run = general_pixel(stopped);
+            };
+            if (active_m != 0)
+            {
+                if (t_first.near == 0)
+                    pixel_loop(std::false_type{});
+                else
+                    pixel_loop(std::true_type{});
             }
         }
         if (!stepped && __any(phase == kInLine))

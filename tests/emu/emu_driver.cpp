@@ -224,7 +224,7 @@ int emu_encode_pixels_group(const jls::ScanDesc* descs, jls::ScanResult* results
     const bool wide = d.bits_per_sample > 8;
     const int per_wave = 64 / group;
     const int nc = d.interleave_mode == 2 ? d.components : 1;
-    const size_t lds = (size_t)per_wave * (wide ? jls::grp::encode_region_bytes<uint16_t>(d.width, nc) : jls::grp::encode_region_bytes<uint8_t>(d.width, nc));
+    const size_t lds = wide ? jls::grp::encode_workgroup_lds_bytes<uint16_t>(d.width, nc, per_wave) : jls::grp::encode_workgroup_lds_bytes<uint8_t>(d.width, nc, per_wave);
     const dim3 grid((count + per_wave - 1) / per_wave);
 #define EMU_ENC(S, G, N) emu::launch(jls::encode_pixels_group<S, G, N>, grid, dim3(64), lds, descs, results, (uint32_t)count)
 #define EMU_ENC_G(S, N)                                        \

@@ -243,6 +243,7 @@ inline int __builtin_amdgcn_readlane(int v, int lane)
 }
 
 #define JLS_EMULATED 1
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline int __mul24(int a, int b)
 {
     return a * b;

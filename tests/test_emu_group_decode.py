@@ -254,7 +254,8 @@ def test_pixel_group_decoder_matches_reference_pixels(c):
                          [(40, 12, 8, 3, 0, 1, "mixed", 5), (37, 9, 8, 3, 2, 0, "gradient", 3), (33, 7, 16, 3, 0, 3, "mixed", 3),
                           (33, 7, 8, 4, 1, 0, "mixed", 5), (300, 4, 8, 3, 0, 2, "noise", 3), (1, 5, 8, 2, 0, 0, "mixed", 2),
                           (64, 6, 8, 3, 0, 0, "zero", 3), (20, 6, 12, 3, 3, 0, "hard", 2), (90, 8, 8, 4, 0, 0, "hard", 3),
-                          (130, 6, 5, 3, 0, 0, "mixed", 3), (257, 5, 8, 2, 0, 0, "noise", 4), (75, 10, 8, 3, 0, 3, "gradient", 5)])
+                          (130, 6, 5, 3, 0, 0, "mixed", 3), (257, 5, 8, 2, 0, 0, "noise", 4), (75, 10, 8, 3, 0, 3, "gradient", 5), (200, 6, 8, 3, 3, 0, "noise", 3),
+                          (90, 8, 7, 2, 1, 0, "mixed", 3), (64, 10, 8, 3, 5, 0, "hard", 2), (50, 8, 8, 3, 100, 0, "mixed", 2)])
 def test_pixel_group_decoder_batches(group, w, h, bits, comps, near, xform, kind, count):
     """`count` different frames per launch; what they decode to is what the oracle decodes (near-lossless: the reconstructed
     samples, bit for bit)."""
@@ -336,7 +337,9 @@ def _encode_group(L, descs, group):
                          [(40, 12, 8, 3, 2, 0, "mixed", 3), (64, 20, 8, 1, 3, 0, "mixed", 5), (37, 9, 16, 1, 5, 0, "gradient", 3),
                           (33, 7, 16, 3, 0, 3, "mixed", 2), (33, 7, 8, 4, 1, 0, "mixed", 3), (700, 4, 8, 1, 1, 0, "noise", 3),
                           (300, 4, 8, 3, 2, 0, "noise", 2), (64, 6, 8, 3, 2, 0, "zero", 2), (1, 5, 8, 1, 2, 0, "mixed", 2),
-                          (20, 6, 12, 3, 2, 0, "hard", 2), (48, 9, 8, 2, 0, 0, "mixed", 3)])
+                          (20, 6, 12, 3, 2, 0, "hard", 2), (48, 9, 8, 2, 0, 0, "mixed", 3), (90, 8, 8, 3, 0, 1, "hard", 2),
+                          (130, 6, 5, 3, 1, 0, "mixed", 3), (50, 8, 8, 3, 100, 0, "mixed", 2), (257, 5, 8, 1, 0, 0, "noise", 3),
+                          (75, 10, 7, 1, 2, 0, "gradient", 3), (300, 5, 8, 4, 3, 0, "noise", 2)])
 def test_group_encoder_matches_reference_scan_bytes(group, w, h, bits, comps, near, xform, kind, count):
     """`count` different frames per launch: every scan's bytes equal the reference's (the oracle's) entropy-coded segment."""
     L = emu_bind.lib()
