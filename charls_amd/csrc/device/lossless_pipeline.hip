@@ -448,6 +448,11 @@ __global__ void __launch_bounds__(384) chain_offsets(const ScanDesc* __restrict_
         w.chain_total[c] = running;
     }
     s_total[c] = c < kChains ? running : 0;
+    if (c == 383)
+    { // the two result words of the later stages start at zero (stage C2 / D1 write them)
+        *w.total_bits = 0;
+        *w.status = 0;
+    }
     __syncthreads();
     if (c == 0)
     { // 365 values: a serial scan is cheaper than its synchronisation

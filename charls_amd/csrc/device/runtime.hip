@@ -532,10 +532,11 @@ struct StageTimer
         for (int i = 0; i < n; ++i)
             (void)hipEventDestroy(ev[i]);
     }
-    void mark()
+    void mark() { mark_on(s); }
+    void mark_on(hipStream_t stream)
     {
         hip_check(hipEventCreate(&ev[n]));
-        hip_check(hipEventRecord(ev[n], s));
+        hip_check(hipEventRecord(ev[n], stream));
         ++n;
     }
     double between(int a, int b)
@@ -587,8 +588,8 @@ struct PipeLayout
         off_bsum = take(blocks * 4);
         off_bbase = take(blocks * 8);
         off_raw = take(raw_bytes);
-        off_bits = take(8);
-        off_status = take(4);
+        off_bits = take(16);  // total_bits and status in two copies: the stuffing of one pass runs under the next pass
+        off_status = take(8);
         bytes = o;
     }
 };
@@ -672,7 +673,7 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
 {
     const PipeLayout lay(proto, proto.stream_capacity);
     const size_t budget = arena_budget(pipeline_arena().capacity());
-    const size_t per_scan = lay.bytes + sizeof(pipe::Work);
+    const size_t per_scan = lay.bytes + 2 * sizeof(pipe::Work); // (two copies of the descriptors, see overlap_stuffing)
     uint32_t resident = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, budget / per_scan))); // scans in the arena
     uint8_t* arena = nullptr;
     for (;;)
@@ -714,6 +715,25 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
     std::vector<std::vector<pipe::Work>> works(passes); // one host copy per pass: the uploads are asynchronous
     std::vector<StageTimer> timers;
     timers.reserve(passes);
+    // The last stage (stuff_scan: one wavefront per scan walking 7 MB, 29 ms for a pass of 228 frames that leaves three
+    // quarters of the SIMDs idle) needs nothing of the arena but the raw bits, the two result words and the descriptors,
+    // and the next pass touches none of them before ITS pack stage: it runs on a side stream under the next pass's
+    // analyze / partition / chain stages (descriptors, total_bits and status alternate between two copies).
+    const bool overlap_stuffing = lanes == 1 && passes > 1;
+    hipStream_t stuff_stream = stream;
+    std::vector<hipEvent_t> packed, stuffed;
+    if (overlap_stuffing)
+    {
+        pipeline_lanes().ensure();
+        stuff_stream = pipeline_lanes().streams[0];
+        packed.resize(passes);
+        stuffed.resize(passes);
+        for (uint32_t pass = 0; pass < passes; ++pass)
+        {
+            hip_check(hipEventCreateWithFlags(&packed[pass], hipEventDisableTiming));
+            hip_check(hipEventCreateWithFlags(&stuffed[pass], hipEventDisableTiming));
+        }
+    }
 
     for (uint32_t pass = 0; pass < passes; ++pass)
     {
@@ -722,7 +742,8 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         const int lane = static_cast<int>(pass % static_cast<uint32_t>(lanes));
         hipStream_t s = lane_stream[lane];
         uint8_t* slice = arena + lane_bytes * static_cast<size_t>(lane);
-        auto* d_works = reinterpret_cast<pipe::Work*>(slice + lay.bytes * per_pass);
+        const size_t copy = pass & 1u;
+        auto* d_works = reinterpret_cast<pipe::Work*>(slice + lay.bytes * per_pass) + copy * per_pass;
         works[pass].resize(n);
         for (uint32_t i = 0; i < n; ++i)
         {
@@ -742,10 +763,8 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
             w.blockbase = reinterpret_cast<uint64_t*>(base + lay.off_bbase);
             w.raw = reinterpret_cast<uint32_t*>(base + lay.off_raw);
             w.raw_words = lay.raw_bytes / 4;
-            w.total_bits = reinterpret_cast<uint64_t*>(base + lay.off_bits);
-            w.status = reinterpret_cast<uint32_t*>(base + lay.off_status);
-            // raw, total_bits and status start at zero (contiguous at the end of the layout)
-            hip_check(hipMemsetAsync(w.raw, 0, lay.off_status + 4 - lay.off_raw, s));
+            w.total_bits = reinterpret_cast<uint64_t*>(base + lay.off_bits) + copy; // (zeroed by chain_offsets)
+            w.status = reinterpret_cast<uint32_t*>(base + lay.off_status) + copy;
         }
         hip_check(hipMemcpyAsync(d_works, works[pass].data(), sizeof(pipe::Work) * n, hipMemcpyHostToDevice, s));
 
@@ -784,12 +803,26 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         t.mark();
         hipLaunchKernelGGL(pipe::sum_code_lengths, dim3(blocks, n), dim3(256), 0, s, descs, d_works);
         hipLaunchKernelGGL(pipe::scan_block_sums, dim3(n), dim3(64), 0, s, descs, d_works);
+        if (overlap_stuffing && pass > 0)
+            hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
+        for (uint32_t i = 0; i < n; ++i)
+            hip_check(hipMemsetAsync(works[pass][i].raw, 0, lay.raw_bytes, s)); // write_raw_bits ORs its words in
         hipLaunchKernelGGL(pipe::write_raw_bits, dim3(blocks, n), dim3(256), 0, s, descs, d_works);
         t.mark();
-        hipLaunchKernelGGL(pipe::stuff_scan, dim3(n), dim3(64), 0, s, descs, d_works, d_results + first);
-        t.mark();
+        if (overlap_stuffing)
+        {
+            hip_check(hipEventRecord(packed[pass], s));
+            hip_check(hipStreamWaitEvent(stuff_stream, packed[pass], 0));
+        }
+        t.mark_on(stuff_stream);
+        hipLaunchKernelGGL(pipe::stuff_scan, dim3(n), dim3(64), 0, stuff_stream, descs, d_works, d_results + first);
+        t.mark_on(stuff_stream);
+        if (overlap_stuffing)
+            hip_check(hipEventRecord(stuffed[pass], stuff_stream));
         hip_check(hipGetLastError());
     }
+    if (overlap_stuffing)
+        hip_check(hipStreamWaitEvent(stream, stuffed[passes - 1], 0));
     if (lanes > 1)
     { // the caller's stream continues when every lane is through
         for (int l = 0; l < lanes; ++l)
@@ -805,8 +838,11 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
     Timings& tm = last_timings();
     double stage_ms[5] = {0, 0, 0, 0, 0};
     for (StageTimer& t : timers)
-        for (int i = 0; i < 5; ++i)
+    {
+        for (int i = 0; i < 4; ++i)
             stage_ms[i] += t.between(i, i + 1);
+        stage_ms[4] += t.between(5, 6); // on the stuffing stream: overlapped with the next pass when it is a side stream
+    }
     for (int i = 0; i < 5; ++i)
         tm.values[2 + i] = stage_ms[i];
     tm.count = 7;
@@ -816,6 +852,10 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         for (int l = 0; l < lanes; ++l)
             (void)hipEventDestroy(join[l]);
     }
+    for (hipEvent_t e : packed)
+        (void)hipEventDestroy(e);
+    for (hipEvent_t e : stuffed)
+        (void)hipEventDestroy(e);
 }
 
 } // namespace
