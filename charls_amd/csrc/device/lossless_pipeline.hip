@@ -59,8 +59,7 @@ struct Work
     uint32_t* inv;         // [H*W] slot (index into sval/code/len) of the sample, or kNoSlot
     uint8_t* len;          // [H*W + kChainSlack] code length per slot
     uint64_t* code;        // [H*W + kChainSlack] code bits per slot, right aligned (re-uses key/val, dead after B2)
-    uint32_t* blocksum;    // [ceil(H*W / kPackBlock)]
-    uint64_t* blockbase;   // same count: exclusive bit offsets
+    uint64_t* blockbase;   // [ceil(H*W / kPackBlock)] look-back states of write_raw_bits
     uint32_t* raw;         // unstuffed bit stream, 32-bit words in big-endian bit order; zeroed before D2
     uint64_t raw_words;    // capacity of raw
     uint64_t* total_bits;  // [1]
@@ -1024,65 +1023,21 @@ __global__ void __launch_bounds__(64) code_events(const ScanDesc* __restrict__ d
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// D1a: grid (blocks, scans), 256 threads: bits of each 4096-sample block.
-__global__ void __launch_bounds__(256) sum_code_lengths(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
-{
-    __shared__ uint32_t s_part[256];
-    const ScanDesc d = descs[blockIdx.y];
-    const Work w = works[blockIdx.y];
-    const uint64_t total = (uint64_t)line_samples(d) * coded_lines(d);
-    const uint64_t base = (uint64_t)blockIdx.x * kPackBlock + (uint64_t)threadIdx.x * 16;
-    uint32_t sum = 0;
-    for (int i = 0; i < 16; ++i)
-        if (base + i < total)
-        {
-            const uint32_t slot = w.inv[base + i];
-            sum += slot != kNoSlot ? w.len[slot] : 0u;
-        }
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int stride = 128; stride > 0; stride >>= 1)
-    {
-        if ((int)threadIdx.x < stride)
-            s_part[threadIdx.x] += s_part[threadIdx.x + stride];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        w.blocksum[blockIdx.x] = s_part[0];
-}
+// D: grid (blocks, scans), 256 threads x 16 samples: concatenate the codes into the raw bit stream.  Where a block's
+// bits start is the sum of the code lengths of all blocks before it; the blocks of a scan find that out among themselves
+// while they run (a chained scan with look-back: every block publishes the bits of its own samples as soon as it has
+// added them up, then the bits of everything up to and including itself once it knows its start; a block reads back
+// over its predecessors until it meets one that already knows), so the code lengths and the slot map are read ONCE --
+// a separate pass that summed the lengths per block read both a second time (197 MB of 2.1 GB per 4096 x 4096 frame).
+// Workgroups start in the order of their index, x fastest: a block only ever waits for blocks that were started before it.
+// blockbase[b]: bits 62..63 = state (0 nothing, 1 own bits, 2 bits up to and including b), bits 0..61 the value; zero
+// before the launch.
+constexpr uint64_t kBlockOwn = 1ull << 62, kBlockUpTo = 2ull << 62, kBlockValue = (1ull << 62) - 1ull;
 
-// D1b: one wavefront per scan: exclusive scan of the block sums.
-__global__ void __launch_bounds__(64) scan_block_sums(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
-{
-    const ScanDesc d = descs[blockIdx.x];
-    const Work w = works[blockIdx.x];
-    const uint64_t total = (uint64_t)line_samples(d) * coded_lines(d);
-    const uint32_t blocks = (uint32_t)((total + kPackBlock - 1) / kPackBlock);
-    const int lane = threadIdx.x;
-    uint64_t carry = 0;
-    for (uint32_t b0 = 0; b0 < blocks; b0 += 64)
-    {
-        const uint32_t b = b0 + lane;
-        const uint64_t v = b < blocks ? w.blocksum[b] : 0;
-        uint64_t inc = v;
-        for (int delta = 1; delta < 64; delta <<= 1)
-        {
-            const uint64_t up = __shfl_up(inc, delta);
-            if (lane >= delta)
-                inc += up;
-        }
-        if (b < blocks)
-            w.blockbase[b] = carry + inc - v;
-        carry += __shfl(inc, 63);
-    }
-    if (lane == 0)
-        *w.total_bits = carry;
-}
-
-// D2: grid (blocks, scans), 256 threads x 16 samples: concatenate the codes into the raw bit stream.
 __global__ void __launch_bounds__(256) write_raw_bits(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
     __shared__ uint32_t s_scan[256];
+    __shared__ uint64_t s_start;
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const uint64_t total = (uint64_t)line_samples(d) * coded_lines(d);
@@ -1106,7 +1061,46 @@ __global__ void __launch_bounds__(256) write_raw_bits(const ScanDesc* __restrict
         s_scan[threadIdx.x] += add;
         __syncthreads();
     }
-    uint64_t bitpos = w.blockbase[blockIdx.x] + s_scan[threadIdx.x] - sum;
+    // ---- where this block starts: the first wavefront looks back, 64 predecessors at a time
+    if (threadIdx.x < 64)
+    {
+        const int lane = threadIdx.x;
+        const uint64_t own = s_scan[255];
+        const uint32_t b = blockIdx.x;
+        if (lane == 0)
+            store_relaxed(&w.blockbase[b], (b == 0 ? kBlockUpTo : kBlockOwn) | own);
+        uint64_t start = 0;
+        uint32_t reach = b; // blocks [reach, b) are accounted for in `start`
+        while (reach > 0)
+        {
+            const bool mine = (uint32_t)lane < reach;
+            const uint32_t j = mine ? reach - 1 - (uint32_t)lane : 0;
+            uint64_t state = 0;
+            do
+            { // every predecessor in the window has published something
+                state = mine ? load_relaxed(&w.blockbase[j]) : kBlockOwn;
+            } while (__any((state >> 62) == 0));
+            const unsigned long long knows = __ballot(mine && (state >> 62) == 2);
+            const int last = knows ? (int)__ffsll(knows) - 1 : 63; // the nearest predecessor that knows its total
+            uint64_t part = mine && lane <= last ? state & kBlockValue : 0;
+            for (int delta = 32; delta > 0; delta >>= 1)
+                part += __shfl_xor(part, delta);
+            start += part;
+            if (knows)
+                break;
+            reach = reach > 64 ? reach - 64 : 0;
+        }
+        if (lane == 0)
+        {
+            if (b != 0)
+                store_relaxed(&w.blockbase[b], kBlockUpTo | (start + own));
+            s_start = start;
+            if ((uint64_t)(b + 1) * kPackBlock >= total)
+                *w.total_bits = start + own; // the last block of the scan
+        }
+    }
+    __syncthreads();
+    uint64_t bitpos = s_start + s_scan[threadIdx.x] - sum;
     if (sum == 0)
         return;
     uint64_t word = bitpos >> 5;

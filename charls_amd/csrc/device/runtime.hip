@@ -557,7 +557,7 @@ size_t align_up(size_t v, size_t a)
 struct PipeLayout
 {
     size_t samples, lines, blocks, raw_bytes;
-    size_t off_key, off_val, off_hist, off_total, off_base, off_sval, off_spos, off_inv, off_len, off_code, off_bsum, off_bbase,
+    size_t off_key, off_val, off_hist, off_total, off_base, off_sval, off_spos, off_inv, off_len, off_code, off_bbase,
         off_raw, off_bits, off_status, bytes;
     PipeLayout(const ScanDesc& d, size_t capacity_hint)
     {
@@ -585,7 +585,6 @@ struct PipeLayout
         off_spos = take((samples + pipe::kChainSlack) * 4);
         off_inv = take(samples * 4);
         off_len = take(samples + pipe::kChainSlack);
-        off_bsum = take(blocks * 4);
         off_bbase = take(blocks * 8);
         off_raw = take(raw_bytes);
         off_bits = take(16);  // total_bits and status in two copies: the stuffing of one pass runs under the next pass
@@ -759,7 +758,6 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
             w.inv = reinterpret_cast<uint32_t*>(base + lay.off_inv);
             w.len = base + lay.off_len;
             w.code = reinterpret_cast<uint64_t*>(base + lay.off_code);
-            w.blocksum = reinterpret_cast<uint32_t*>(base + lay.off_bsum);
             w.blockbase = reinterpret_cast<uint64_t*>(base + lay.off_bbase);
             w.raw = reinterpret_cast<uint32_t*>(base + lay.off_raw);
             w.raw_words = lay.raw_bytes / 4;
@@ -801,12 +799,10 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         }
         hipLaunchKernelGGL(pipe::code_events, dim3(pipe::kRegularChains, n), dim3(64), 0, s, descs, d_works);
         t.mark();
-        hipLaunchKernelGGL(pipe::sum_code_lengths, dim3(blocks, n), dim3(256), 0, s, descs, d_works);
-        hipLaunchKernelGGL(pipe::scan_block_sums, dim3(n), dim3(64), 0, s, descs, d_works);
         if (overlap_stuffing && pass > 0)
             hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
         for (uint32_t i = 0; i < n; ++i)
-            hip_check(hipMemsetAsync(works[pass][i].raw, 0, lay.raw_bytes, s)); // write_raw_bits ORs its words in
+            hip_check(hipMemsetAsync(works[pass][i].blockbase, 0, lay.off_raw + lay.raw_bytes - lay.off_bbase, s)); // look-back states; write_raw_bits ORs its words into raw
         hipLaunchKernelGGL(pipe::write_raw_bits, dim3(blocks, n), dim3(256), 0, s, descs, d_works);
         t.mark();
         if (overlap_stuffing)

@@ -212,6 +212,15 @@ JLS_DEV void lds_store(uint32_t address, T v)
 {
     *(JLS_LDS_AS T*)(uintptr_t)address = v;
 }
+// A 64-bit word other workgroups poll / publish (device scope, no ordering: the word carries everything).
+JLS_DEV uint64_t load_relaxed(const uint64_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+JLS_DEV void store_relaxed(uint64_t* p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // Bits [shift mod 32, shift mod 32 + 32) of the 64-bit value hi:lo (v_alignbit_b32 takes the low five bits of the shift).
 JLS_DEV uint32_t funnel_shift(uint32_t hi, uint32_t lo, uint32_t shift)
 {
@@ -276,6 +285,14 @@ JLS_DEV void lds_store(uint32_t address, T v)
 JLS_DEV uint32_t funnel_shift(uint32_t hi, uint32_t lo, uint32_t shift)
 {
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (shift & 31u));
+}
+JLS_DEV uint64_t load_relaxed(const uint64_t* p)
+{
+    return __atomic_load_n(p, __ATOMIC_RELAXED);
+}
+JLS_DEV void store_relaxed(uint64_t* p, uint64_t v)
+{
+    __atomic_store_n(p, v, __ATOMIC_RELAXED);
 }
 JLS_DEV uint32_t float_bits(uint32_t v)
 {

@@ -90,7 +90,6 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
         w.spos = (uint32_t*)galloc((samples + pipe::kChainSlack) * 4);
         w.inv = (uint32_t*)galloc(samples * 4);
         w.len = (uint8_t*)galloc(samples + pipe::kChainSlack);
-        w.blocksum = (uint32_t*)zalloc(blocks * 4);
         w.blockbase = (uint64_t*)zalloc(blocks * 8);
         w.raw = (uint32_t*)zalloc(raw_bytes);
         w.raw_words = raw_bytes / 4;
@@ -123,8 +122,6 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
         emu::launch(pipe::bias_chains<S, 0>, chains_grid, dim3(64), 0, descs, wk, (uint32_t)count);
     }
     emu::launch(pipe::code_events, dim3(pipe::kRegularChains, count), dim3(64), 0, descs, wk);
-    emu::launch(pipe::sum_code_lengths, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
-    emu::launch(pipe::scan_block_sums, dim3(count), dim3(64), 0, descs, wk);
     emu::launch(pipe::write_raw_bits, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
     emu::launch(pipe::stuff_scan, dim3(count), dim3(64), 0, descs, wk, results);
     for (void* q : allocs)
