@@ -169,10 +169,16 @@ size_t fast_decode_lds(const ScanDesc& d)
     return (d.bits_per_sample > 8 ? fast::fixed_lds<uint16_t>() : fast::fixed_lds<uint8_t>()) + line_bytes;
 }
 
+// Lines a scan of the group decoder keeps in LDS: one, or one per component of a line-interleaved scan.
+uint32_t group_lines(const ScanDesc& d)
+{
+    return d.interleave_mode == 1 ? static_cast<uint32_t>(d.components) : 1u;
+}
+
 size_t group_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
 {
-    return d.bits_per_sample > 8 ? grp::workgroup_lds_bytes<uint16_t>(d.width, scans_per_wave)
-                                 : grp::workgroup_lds_bytes<uint8_t>(d.width, scans_per_wave);
+    return d.bits_per_sample > 8 ? grp::workgroup_lds_bytes<uint16_t>(d.width, scans_per_wave, group_lines(d))
+                                 : grp::workgroup_lds_bytes<uint8_t>(d.width, scans_per_wave, group_lines(d));
 }
 
 // Lanes per scan of the speed path (scan_group_decode.hip) for a launch of `count` scans; 0 = the one-scan-per-wavefront
@@ -249,8 +255,10 @@ int pixel_group_lanes(const ScanDesc& d, uint32_t count)
 // exact kernels whenever the scan does not end cleanly.
 bool fast_decode_eligible(const ScanDesc& d)
 {
-    return wave_decode_eligible(d) && d.near_lossless == 0 && d.interleave_mode == 0 && d.components == 1 &&
-           (fast_decode_lds(d) <= kMaxDynamicLds || decode_group_lanes(d, 1) != 0) &&
+    const bool planar = d.interleave_mode == 0 && d.components == 1;
+    const bool by_line = d.interleave_mode == 1 && d.components >= 2 && d.components <= 4; // group kernel only
+    return wave_decode_eligible(d) && d.near_lossless == 0 && (planar || by_line) &&
+           ((planar && fast_decode_lds(d) <= kMaxDynamicLds) || decode_group_lanes(d, 1) != 0) &&
            std::getenv("CHARLS_AMD_EXACT_DECODER") == nullptr;
 }
 
@@ -457,13 +465,22 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
         const uint32_t per_wave = 64u / static_cast<uint32_t>(group);
         const dim3 grid((count + per_wave - 1) / per_wave);
         const size_t lds = group_lds_bytes(proto, per_wave);
-#define JLS_LAUNCH_GROUP(S, G)                                                                                           \
+#define JLS_LAUNCH_GROUP_N(S, G, N)                                                                                      \
     do                                                                                                                   \
     {                                                                                                                    \
         if (lds > kMaxDynamicLds) /* more than the default limit of dynamic LDS per workgroup */                          \
-            hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_scans_group<S, G>),                      \
+            hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_scans_group<S, G, N>),                   \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
-        hipLaunchKernelGGL((decode_scans_group<S, G>), grid, dim3(64), lds, stream, d_descs, d_results, count);          \
+        hipLaunchKernelGGL((decode_scans_group<S, G, N>), grid, dim3(64), lds, stream, d_descs, d_results, count);       \
+    } while (0)
+#define JLS_LAUNCH_GROUP(S, G)                                                                                           \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        const uint32_t nl = group_lines(proto);                                                                          \
+        if (nl == 1) JLS_LAUNCH_GROUP_N(S, G, 1);                                                                        \
+        else if (nl == 2) JLS_LAUNCH_GROUP_N(S, G, 2);                                                                   \
+        else if (nl == 3) JLS_LAUNCH_GROUP_N(S, G, 3);                                                                   \
+        else JLS_LAUNCH_GROUP_N(S, G, 4);                                                                                \
     } while (0)
         const bool wide = proto.bits_per_sample > 8;
         if (group == 4)
@@ -483,6 +500,7 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
             if (wide) JLS_LAUNCH_GROUP(uint16_t, 32); else JLS_LAUNCH_GROUP(uint8_t, 32);
         }
 #undef JLS_LAUNCH_GROUP
+#undef JLS_LAUNCH_GROUP_N
     }
     }
     hip_check(hipGetLastError());

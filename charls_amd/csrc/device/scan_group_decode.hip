@@ -48,16 +48,32 @@ struct Layout
     static constexpr uint32_t kLine = kRing + kRingWords * 4 + 16 + 16 - sizeof(S);
 };
 
-template <typename S>
-__host__ __device__ constexpr uint32_t region_bytes(uint32_t width)
+// Regions follow each other at a stride of 16 bytes more than a multiple of 128: the scans of a wavefront run in step and
+// address their regions at equal offsets, and a stride that is a multiple of the 32 banks x 4 bytes (or of half of it)
+// puts all of them, or every other one, on the same banks -- every LDS instruction of the step loop then takes its
+// bank-conflict cycles, which is what wavefronts sharing a CU queue for.
+__host__ __device__ constexpr uint32_t bank_spread(uint32_t bytes)
 {
-    return (Layout<S>::kLine + (width + 6) * (uint32_t)sizeof(S) + 15u) & ~15u;
+    return ((bytes + 127u) & ~127u) + 16u;
+}
+
+// Bytes from one line of a scan to the next (line-interleaved scans keep one line per component).
+template <typename S>
+__host__ __device__ constexpr uint32_t line_stride_bytes(uint32_t width)
+{
+    return ((width + 6) * (uint32_t)sizeof(S) + 15u) & ~15u;
 }
 
 template <typename S>
-__host__ __device__ constexpr uint32_t workgroup_lds_bytes(uint32_t width, uint32_t scans_per_wave)
+__host__ __device__ constexpr uint32_t region_bytes(uint32_t width, uint32_t lines = 1)
 {
-    return Layout<S>::kLutBytes + scans_per_wave * region_bytes<S>(width);
+    return bank_spread(Layout<S>::kLine + lines * line_stride_bytes<S>(width));
+}
+
+template <typename S>
+__host__ __device__ constexpr uint32_t workgroup_lds_bytes(uint32_t width, uint32_t scans_per_wave, uint32_t lines = 1)
+{
+    return Layout<S>::kLutBytes + scans_per_wave * region_bytes<S>(width, lines);
 }
 
 // Regular-mode context record: word 0 = A, word 1 = N | (C & 0xFF) << 8 | B << 16.  N <= RESET <= 255, -128 <= C <= 127
@@ -268,13 +284,20 @@ JLS_DEV int take_unary(const uint32_t* ring, uint32_t& p, int most)
 // is one packed register that slides with v_alignbit, the two gradients that depend on the previous line only are
 // carried as T = 9 Q1 + Q2, sign handling is three multiply-adds with +-1, the RESET halving is a rarely taken block, and
 // what an event needs (run mode or an unusual code) is worked out after the loop from the state it leaves behind.
-template <typename S, int G>
+//
+// NL = 1: a single-component scan.  NL = 2..4: a LINE-INTERLEAVED scan of NL components (reference
+// src/scan_decoder_impl.hpp:62-129): the lines of a pixel row are coded one component after the other, each against the
+// line of its own component above it and with its own RUNindex, on the ONE set of contexts; a line is decoded exactly like
+// a line of a single-component scan, so the step loop is the same code, and what changes is which of the NL lines in LDS
+// it works on and that a finished pixel row goes to the user's row interleaved (and through the inverse colour transform).
+template <typename S, int G, int NL = 1>
 __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restrict__ descs, ScanResult* __restrict__ results,
                                                          uint32_t count)
 {
     using namespace grp;
     using L = Layout<S>;
     static_assert(G == 4 || G == 8 || G == 16 || G == 32, "lanes per scan");
+    static_assert(NL >= 1 && NL <= 4, "lines per pixel row");
     constexpr int kScansPerWave = 64 / G;
     constexpr bool kWide = sizeof(S) > 1;
     JLS_DYNAMIC_LDS(smem);
@@ -287,7 +310,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
     const Traits t = make_traits(d);
     const uint32_t width = d.width;
 
-    unsigned char* region = smem + L::kLutBytes + (size_t)sid * region_bytes<S>(width);
+    unsigned char* region = smem + L::kLutBytes + (size_t)sid * region_bytes<S>(width, NL);
     Record* records = reinterpret_cast<Record*>(region + L::kRecords);
     RunCtx* run_ctx = reinterpret_cast<RunCtx*>(region + L::kRun);
     uint32_t* ring = reinterpret_cast<uint32_t*>(region + L::kRing);
@@ -299,7 +322,9 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
     unsigned char* lut = smem;
     const ScanDesc& d_first = descs[blockIdx.x * kScansPerWave];
     const Traits t_first = make_traits(d_first);
-    S* line = reinterpret_cast<S*>(region + L::kLine);
+    S* const line0 = reinterpret_cast<S*>(region + L::kLine);
+    const uint32_t line_stride = line_stride_bytes<S>(width) / (uint32_t)sizeof(S); // samples from one component's line to the next
+    S* line = line0; // the line being decoded
     const int cap = kWide ? t_first.t3 : 255;
     const bool own_table = t.t1 == t_first.t1 && t.t2 == t_first.t2 && t.t3 == t_first.t3 && t.bpp == t_first.bpp;
 
@@ -311,8 +336,8 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             run_ctx[sub] = RunCtx{sub, initial_a(t), 1, 0};
         for (int q = lane; q <= 2 * cap; q += 64)
             lut[q] = (unsigned char)(quantize(t_first, q - cap) + 4);
-        for (uint32_t q = sub; q < width + 6; q += G)
-            line[q] = 0;
+        for (uint32_t q = sub; q < (NL == 1 ? width + 6 : NL * line_stride); q += G)
+            line0[q] = 0;
         for (uint32_t q = sub; q <= kRingWords + 1; q += G)
             ring[q] = 0;
     }
@@ -337,6 +362,12 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
     uint32_t p = 0;     // consumed dense bits
     uint32_t y = 0, i = 1;
     int corner = 0, first = 0, run_index = 0;
+    // line-interleaved scans: the component whose line is being decoded, and what every component keeps from row to row
+    int comp = 0;
+    int corner_of[NL], run_index_of[NL];
+#pragma unroll
+    for (int c = 0; c < NL; ++c)
+        corner_of[c] = run_index_of[c] = 0;
     // Window of the previous line around sample i: prev[i - 1], prev[i], prev[i + 1], prev[i + 2] = Rc, Rb, Rd and the
     // sample after it.  8-bit samples: one byte each in w0; wider samples: two halves each in w0 (Rc, Rb) and w1.
     uint32_t w0 = 0, w1 = 0;
@@ -391,6 +422,16 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             const bool starting = phase == kLineStart;
             if (__any(starting))
             {
+                if (NL > 1 && starting)
+                {
+                    line = line0 + (uint32_t)comp * line_stride;
+#pragma unroll
+                    for (int c = 0; c < NL; ++c)
+                    {
+                        corner = comp == c ? corner_of[c] : corner;
+                        run_index = comp == c ? run_index_of[c] : run_index;
+                    }
+                }
                 if (starting && sub == 0)
                     line[width + 1] = line[width];
                 JLS_LOCKSTEP();
@@ -748,6 +789,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             phase = kDone;
 
         // ---- finished line -> user's row
+        if (NL == 1)
         {
             const bool ending = phase == kInLine && i > width;
             if (__any(ending))
@@ -777,6 +819,60 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 {
                     corner = first;
                     ++y;
+                    phase = y == d.height ? kDrain : kLineStart;
+                }
+            }
+        }
+        else
+        { // a component's line; behind the last component the pixel row: interleave, inverse colour transform
+          // (src/copy_from_line_buffer.hpp:19-191)
+            const bool ending = phase == kInLine && i > width;
+            if (__any(ending))
+            {
+                const bool row_done = ending && comp == NL - 1;
+                if (__any(row_done))
+                {
+                    uint8_t* row = d.pixels + (size_t)y * d.pixel_stride;
+                    const bool transformed = NL == 3 && d.color_transformation != 0;
+                    uint32_t xx = (uint32_t)sub;
+                    while (__any(row_done && xx < width))
+                    {
+                        if (row_done && xx < width)
+                        {
+                            unsigned v[4];
+#pragma unroll
+                            for (int c = 0; c < NL; ++c)
+                                v[c] = line0[(uint32_t)c * line_stride + 1 + xx];
+                            if (transformed)
+                                hp_inverse(d.color_transformation, kWide, (int)v[0], (int)v[1], (int)v[NL > 2 ? 2 : 0], v);
+#pragma unroll
+                            for (int c = 0; c < NL; ++c)
+                            { // (bytes: the user's row of 16-bit pixels need not be aligned)
+                                uint8_t* q = row + ((size_t)xx * NL + c) * sizeof(S);
+                                q[0] = (uint8_t)v[c];
+                                if (kWide)
+                                    q[1] = (uint8_t)(v[c] >> 8);
+                            }
+                        }
+                        xx += G;
+                    }
+                }
+                JLS_LOCKSTEP();
+                if (ending)
+                {
+#pragma unroll
+                    for (int c = 0; c < NL; ++c)
+                    {
+                        corner_of[c] = comp == c ? first : corner_of[c];
+                        run_index_of[c] = comp == c ? run_index : run_index_of[c];
+                    }
+                    if (comp == NL - 1)
+                    {
+                        comp = 0;
+                        ++y;
+                    }
+                    else
+                        ++comp;
                     phase = y == d.height ? kDrain : kLineStart;
                 }
             }

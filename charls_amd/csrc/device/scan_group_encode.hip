@@ -56,7 +56,7 @@ __host__ __device__ constexpr uint32_t encode_lines_offset(uint32_t components)
 template <typename S>
 __host__ __device__ constexpr uint32_t encode_region_bytes(uint32_t width, uint32_t components)
 {
-    return (encode_lines_offset<S>(components) + 2 * pixel_line_bytes<S>(width, components) + 15u) & ~15u;
+    return bank_spread(encode_lines_offset<S>(components) + 2 * pixel_line_bytes<S>(width, components));
 }
 
 template <typename S>

@@ -157,9 +157,18 @@ int emu_decode_scans_group(const jls::ScanDesc* descs, jls::ScanResult* results,
     const jls::ScanDesc& d = descs[0];
     const bool wide = d.bits_per_sample > 8;
     const int per_wave = 64 / group;
-    const size_t lds = wide ? jls::grp::workgroup_lds_bytes<uint16_t>(d.width, per_wave) : jls::grp::workgroup_lds_bytes<uint8_t>(d.width, per_wave);
+    const int nl = d.interleave_mode == 1 ? d.components : 1; // a line-interleaved scan keeps one line per component
+    const size_t lds = wide ? jls::grp::workgroup_lds_bytes<uint16_t>(d.width, per_wave, nl) : jls::grp::workgroup_lds_bytes<uint8_t>(d.width, per_wave, nl);
     const dim3 grid((count + per_wave - 1) / per_wave);
-#define EMU_GROUP(S, G) emu::launch(jls::decode_scans_group<S, G>, grid, dim3(64), lds, descs, results, (uint32_t)count)
+#define EMU_GROUP_N(S, G, N) emu::launch(jls::decode_scans_group<S, G, N>, grid, dim3(64), lds, descs, results, (uint32_t)count)
+#define EMU_GROUP(S, G)                                     \
+    do                                                      \
+    {                                                       \
+        if (nl == 1) EMU_GROUP_N(S, G, 1);                  \
+        else if (nl == 2) EMU_GROUP_N(S, G, 2);             \
+        else if (nl == 3) EMU_GROUP_N(S, G, 3);             \
+        else EMU_GROUP_N(S, G, 4);                          \
+    } while (0)
     if (group == 4)
     {
         if (wide) EMU_GROUP(uint16_t, 4); else EMU_GROUP(uint8_t, 4);
@@ -179,6 +188,7 @@ int emu_decode_scans_group(const jls::ScanDesc* descs, jls::ScanResult* results,
     else
         return -1;
 #undef EMU_GROUP
+#undef EMU_GROUP_N
     return 0;
 }
 

@@ -80,6 +80,35 @@ def test_group_decoder_batches_of_different_frames(group, w, h, bits, kind, coun
         assert outs[f].tobytes() == imgs[f].tobytes(), f
 
 
+@pytest.mark.parametrize("group", [4, 8, 16, 32])
+@pytest.mark.parametrize("w,h,bits,comps,xform,kind,count",
+                         [(40, 12, 8, 3, 1, "mixed", 5), (300, 4, 8, 3, 2, "noise", 3), (33, 7, 16, 3, 3, "mixed", 3),
+                          (1, 5, 8, 2, 0, "mixed", 2), (64, 6, 8, 3, 0, "zero", 3), (90, 8, 8, 4, 0, "hard", 3),
+                          (130, 6, 5, 3, 0, "mixed", 3), (57, 9, 12, 2, 0, "gradient", 4)])
+def test_group_decoder_line_interleaved_batches(group, w, h, bits, comps, xform, kind, count):
+    """Line-interleaved scans (one line per component in LDS, one RUNindex per component, the ONE set of contexts): `count`
+    different frames per launch decode to the source pixels."""
+    L = emu_bind.lib()
+    bps = 1 if bits <= 8 else 2
+    keep, descs, outs, wants, ends = [], [], [], [], []
+    for f in range(count):
+        img = synth.frame_numpy(w, h, seed=13 * f + bits + comps, bits=bits, components=comps, kind=kind, interleaved=True)
+        jls = ob.encode(img, width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=1,
+                        color_transformation=xform)
+        cont = jls_container.parse(jls)
+        pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+        pix = np.zeros(w * h * comps * bps, dtype=np.uint8)
+        descs.append(emu_bind.make_desc(w, h, comps, 1, bits, 0, xform, pc, 0, pix, w * comps * bps,
+                                        _stream_copy(jls, cont.scans[0].data_start), keep))
+        outs.append(pix)
+        wants.append(img.tobytes())
+        ends.append(cont.scans[0].data_end - cont.scans[0].data_start)
+    res = _launch(L, descs, group)
+    for f in range(count):
+        assert (res[f].errc, res[f].flags, res[f].bytes) == (0, 0, ends[f]), f
+        assert outs[f].tobytes() == wants[f], f
+
+
 def test_group_decoder_leaves_other_thresholds_to_the_exact_decoder():
     """The gradient table is shared by the scans of a wavefront and built from the first one's thresholds: a scan with
     other thresholds reports kFastRetry, its neighbours decode."""

@@ -75,6 +75,12 @@ if "5a" in only:
     del rgb
     torch.cuda.empty_cache()
     batch.release_work_areas(lib)
+if "5c" in only:
+    rgb = rgb_frames(args.rgb_frames, 4096, 5)
+    run("config 4 line-interleaved (5c): 4096x4096 RGB ILV_LINE HP1 lossless", rgb, bits=8, comps=3, ilv=1, xform=1)
+    del rgb
+    torch.cuda.empty_cache()
+    batch.release_work_areas(lib)
 if "5b" in only:
     rgb = rgb_frames(args.rgb_frames, 4096, 5)
     run("config 4 as 5b: 4096x4096 RGB ILV_SAMPLE NEAR=2", rgb, bits=8, comps=3, ilv=2, near=2)
