@@ -220,15 +220,18 @@ int decode_group_lanes(const ScanDesc& d, uint32_t count)
 
 size_t pixel_group_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
 {
-    return d.bits_per_sample > 8 ? grp::pixel_workgroup_lds_bytes<uint16_t>(d.width, static_cast<uint32_t>(d.components), scans_per_wave)
-                                 : grp::pixel_workgroup_lds_bytes<uint8_t>(d.width, static_cast<uint32_t>(d.components), scans_per_wave);
+    const uint32_t nc = d.interleave_mode == 2 ? static_cast<uint32_t>(d.components) : 1u;
+    return d.bits_per_sample > 8 ? grp::pixel_workgroup_lds_bytes<uint16_t>(d.width, nc, scans_per_wave)
+                                 : grp::pixel_workgroup_lds_bytes<uint8_t>(d.width, nc, scans_per_wave);
 }
 
-// Lanes per scan of the speed path of sample-interleaved scans (scan_group_pixels.hip), lossless or near-lossless; 0 = the
-// exact decoder.  Packing as in decode_group_lanes.
+// Lanes per scan of the speed path of sample-interleaved scans, lossless or near-lossless, and of near-lossless
+// single-component scans (scan_group_pixels.hip); 0 = the exact decoder.  Packing as in decode_group_lanes.
 int pixel_group_lanes(const ScanDesc& d, uint32_t count)
 {
-    if (d.interleave_mode != 2 || d.components < 2 || d.components > 4 || !wave_decode_eligible(d))
+    const bool by_sample = d.interleave_mode == 2 && d.components >= 2 && d.components <= 4;
+    const bool near_planar = d.interleave_mode == 0 && d.components == 1 && d.near_lossless != 0;
+    if ((!by_sample && !near_planar) || !wave_decode_eligible(d))
         return 0;
     if ((d.bits_per_sample > 8 && d.t3 > grp::kMaxTableT3) || std::getenv("CHARLS_AMD_EXACT_DECODER") != nullptr)
         return 0;
@@ -425,8 +428,9 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
 #define JLS_LAUNCH_PIXELS_N(S, G)                                                                                        \
     do                                                                                                                   \
     {                                                                                                                    \
-        if (proto.components == 2) JLS_LAUNCH_PIXELS(S, G, 2);                                                           \
-        else if (proto.components == 3) JLS_LAUNCH_PIXELS(S, G, 3);                                                      \
+        if (nc == 1) JLS_LAUNCH_PIXELS(S, G, 1);                                                                         \
+        else if (nc == 2) JLS_LAUNCH_PIXELS(S, G, 2);                                                                    \
+        else if (nc == 3) JLS_LAUNCH_PIXELS(S, G, 3);                                                                    \
         else JLS_LAUNCH_PIXELS(S, G, 4);                                                                                 \
     } while (0)
         const bool wide = proto.bits_per_sample > 8;

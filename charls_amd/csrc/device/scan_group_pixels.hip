@@ -1,5 +1,7 @@
 // scan_group_pixels.hip -- speed path of the scan decoder for SAMPLE-INTERLEAVED scans (ILV_SAMPLE: 2..4 components coded
-// pixel by pixel, reference src/scan_decoder_impl.hpp:162-261), lossless and near-lossless, several scans per wavefront.
+// pixel by pixel, reference src/scan_decoder_impl.hpp:162-261), lossless and near-lossless, several scans per wavefront;
+// with one component per pixel also the speed path of NEAR-LOSSLESS single-component scans (the lossless ones have
+// scan_group_decode.hip).
 //
 // Same organisation as scan_group_decode.hip -- the 64 lanes are split into groups of G lanes, every group decodes a scan
 // of its own with all its state replicated over the group's lanes, control flow convergent for the wavefront, the lanes
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
     using namespace grp;
     using L = Layout<S>;
     static_assert(G == 8 || G == 16 || G == 32, "lanes per scan");
-    static_assert(NC >= 2 && NC <= 4, "components per pixel");
+    static_assert(NC >= 1 && NC <= 4, "components per pixel");
     constexpr int kScansPerWave = 64 / G;
     constexpr bool kWide = sizeof(S) > 1;
     JLS_DYNAMIC_LDS(smem);
@@ -540,9 +542,12 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
             int x[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-            { // every component against run context 0, in component order (src/scan_decoder_impl.hpp:300-337)
+            { // sample-interleaved: every component against run context 0, in component order
+              // (src/scan_decoder_impl.hpp:300-337); a single component: context 1 when Ra and Rb are within NEAR
+              // (src/scan_decoder_impl.hpp:264-298)
                 const int rb_at = (int)prev[(interrupted ? at : 1u) * NC + c];
-                RunCtx ctx = run_ctx[0];
+                const int which = (NC == 1 && is_near(t, a[c], rb_at)) ? 1 : 0;
+                RunCtx ctx = run_ctx[which];
                 x[c] = 0;
                 if (interrupted)
                 {
@@ -563,12 +568,12 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                             em = (int)take_bits(ring, p, t.qbpp) + 1;
                         const int e = run_error_value(ctx, em + ctx.ritype, k);
                         run_update(ctx, e, em, t.reset);
-                        x[c] = reconstruct(t, rb_at, e * ((rb_at - a[c]) < 0 ? -1 : 1));
+                        x[c] = which ? reconstruct(t, a[c], e) : reconstruct(t, rb_at, e * ((rb_at - a[c]) < 0 ? -1 : 1));
                     }
                 }
                 JLS_LOCKSTEP();
                 if (interrupted)
-                    run_ctx[0] = ctx;
+                    run_ctx[which] = ctx;
                 JLS_LOCKSTEP();
             }
             if (interrupted)

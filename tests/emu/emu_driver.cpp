@@ -198,7 +198,7 @@ int emu_decode_pixels_group(const jls::ScanDesc* descs, jls::ScanResult* results
     const jls::ScanDesc& d = descs[0];
     const bool wide = d.bits_per_sample > 8;
     const int per_wave = 64 / group;
-    const int nc = d.components;
+    const int nc = d.interleave_mode == 2 ? d.components : 1;
     const size_t lds = wide ? jls::grp::pixel_workgroup_lds_bytes<uint16_t>(d.width, nc, per_wave)
                             : jls::grp::pixel_workgroup_lds_bytes<uint8_t>(d.width, nc, per_wave);
     const dim3 grid((count + per_wave - 1) / per_wave);
@@ -213,11 +213,11 @@ int emu_decode_pixels_group(const jls::ScanDesc* descs, jls::ScanResult* results
     } while (0)
     if (!wide)
     {
-        if (nc == 2) EMU_PIXELS_G(uint8_t, 2); else if (nc == 3) EMU_PIXELS_G(uint8_t, 3); else if (nc == 4) EMU_PIXELS_G(uint8_t, 4); else return -1;
+        if (nc == 1) EMU_PIXELS_G(uint8_t, 1); else if (nc == 2) EMU_PIXELS_G(uint8_t, 2); else if (nc == 3) EMU_PIXELS_G(uint8_t, 3); else if (nc == 4) EMU_PIXELS_G(uint8_t, 4); else return -1;
     }
     else
     {
-        if (nc == 2) EMU_PIXELS_G(uint16_t, 2); else if (nc == 3) EMU_PIXELS_G(uint16_t, 3); else if (nc == 4) EMU_PIXELS_G(uint16_t, 4); else return -1;
+        if (nc == 1) EMU_PIXELS_G(uint16_t, 1); else if (nc == 2) EMU_PIXELS_G(uint16_t, 2); else if (nc == 3) EMU_PIXELS_G(uint16_t, 3); else if (nc == 4) EMU_PIXELS_G(uint16_t, 4); else return -1;
     }
 #undef EMU_PIXELS_G
 #undef EMU_PIXELS

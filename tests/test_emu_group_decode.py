@@ -309,6 +309,32 @@ def test_pixel_group_decoder_batches(group, w, h, bits, comps, near, xform, kind
         assert outs[f].tobytes() == wants[f], f
 
 
+@pytest.mark.parametrize("group", [8, 16, 32])
+@pytest.mark.parametrize("w,h,bits,near,kind,count", [(64, 20, 8, 3, "mixed", 5), (300, 5, 8, 1, "noise", 3), (37, 9, 16, 5, "gradient", 3),
+                                                      (1, 9, 8, 2, "mixed", 3), (70, 6, 8, 2, "zero", 4), (41, 7, 12, 2, "hard", 3),
+                                                      (130, 6, 5, 1, "mixed", 3), (50, 8, 8, 100, "mixed", 2)])
+def test_pixel_group_decoder_near_lossless_single_component(group, w, h, bits, near, kind, count):
+    """Near-lossless single-component scans on the pixel kernel with one component per pixel (run interruptions choose
+    between the two run contexts by |Ra - Rb| <= NEAR): what they decode to is what the oracle decodes, bit for bit."""
+    L = emu_bind.lib()
+    bps = 1 if bits <= 8 else 2
+    keep, descs, outs, wants, ends = [], [], [], [], []
+    for f in range(count):
+        img = synth.frame_numpy(w, h, seed=19 * f + bits + near, bits=bits, kind=kind)
+        jls = ob.encode(img, width=w, height=h, bits_per_sample=bits, near_lossless=near)
+        wants.append(ob.decode(jls)[1].tobytes())
+        cont = jls_container.parse(jls)
+        pc = jls_container.validated_pc(cont.pc, cont.bits, near)
+        pix = np.zeros(w * h * bps, dtype=np.uint8)
+        descs.append(emu_bind.make_desc(w, h, 1, 0, bits, near, 0, pc, 0, pix, w * bps, _stream_copy(jls, cont.scans[0].data_start), keep))
+        outs.append(pix)
+        ends.append(cont.scans[0].data_end - cont.scans[0].data_start)
+    res = _launch_pixels(L, descs, group)
+    for f in range(count):
+        assert (res[f].errc, res[f].flags, res[f].bytes) == (0, 0, ends[f]), f
+        assert outs[f].tobytes() == wants[f], f
+
+
 def test_pixel_group_dispatch_on_mutated_scan_data_matches_the_oracle():
     """Group kernel, then the exact wave decoder for the scans that reported kFastRetry, on mutated RGB streams."""
     L = emu_bind.lib()

@@ -75,6 +75,12 @@ if "5a" in only:
     del rgb
     torch.cuda.empty_cache()
     batch.release_work_areas(lib)
+if "6" in only:
+    f = synth.frames_torch(1024, 4096, 4096, seed0=2, bits=8, device=dev)
+    run("near-lossless gray (6): 4096x4096 8-bit gray NEAR=2", f, bits=8, near=2)
+    del f
+    torch.cuda.empty_cache()
+    batch.release_work_areas(lib)
 if "5c" in only:
     rgb = rgb_frames(args.rgb_frames, 4096, 5)
     run("config 4 line-interleaved (5c): 4096x4096 RGB ILV_LINE HP1 lossless", rgb, bits=8, comps=3, ilv=1, xform=1)
