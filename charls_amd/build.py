@@ -17,9 +17,14 @@ OUT_ALIAS = os.path.join(OUT_DIR, "libcharls.so.3")
 VERSION_SCRIPT = os.path.join(CSRC, "charls_amd.version")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-# translation units; the *.hip kernel sources are #included by runtime.hip so that launches and kernels share a TU
+# translation units; the *.hip kernel sources are #included by the launch code that instantiates them (runtime.hip, and
+# units of their own, one per sample width, for the kernels with the most instantiations, so that the build stays parallel)
 SOURCES = [
     "device/runtime.hip",
+    "device/launch_pixels_u8.hip",
+    "device/launch_pixels_u16.hip",
+    "device/launch_group_encode_u8.hip",
+    "device/launch_group_encode_u16.hip",
     "host/stream_reader.cpp",
     "host/scan_engine.cpp",
     "host/encoder_api.cpp",

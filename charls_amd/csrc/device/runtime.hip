@@ -14,8 +14,7 @@
 #include "lossless_pipeline.hip"
 #include "scan_fast_decode.hip"
 #include "scan_group_decode.hip"
-#include "scan_group_pixels.hip"
-#include "scan_group_encode.hip"
+#include "group_launch.h"
 #include "restart_intervals.hip"
 
 namespace jls::dev {
@@ -135,8 +134,6 @@ void launch_decode_serial(const ScanDesc* d_descs, ScanResult* d_results, uint32
 }
 
 namespace {
-constexpr size_t kMaxDynamicLds = 64 * 1024;
-constexpr size_t kGroupDecodeLds = 160 * 1024; // a workgroup of the group decoder may take the whole LDS of a CU
 
 size_t wave_decode_lds(const ScanDesc& d)
 {
@@ -218,21 +215,17 @@ int decode_group_lanes(const ScanDesc& d, uint32_t count)
     return best;
 }
 
-size_t pixel_group_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
-{
-    const uint32_t nc = d.interleave_mode == 2 ? static_cast<uint32_t>(d.components) : 1u;
-    return d.bits_per_sample > 8 ? grp::pixel_workgroup_lds_bytes<uint16_t>(d.width, nc, scans_per_wave)
-                                 : grp::pixel_workgroup_lds_bytes<uint8_t>(d.width, nc, scans_per_wave);
-}
-
 // Lanes per scan of the speed path of sample-interleaved scans, lossless or near-lossless, and of near-lossless
 // single-component scans (scan_group_pixels.hip); 0 = the exact decoder.  Packing as in decode_group_lanes.
 int pixel_group_lanes(const ScanDesc& d, uint32_t count)
 {
     const bool by_sample = d.interleave_mode == 2 && d.components >= 2 && d.components <= 4;
     const bool near_planar = d.interleave_mode == 0 && d.components == 1 && d.near_lossless != 0;
-    if ((!by_sample && !near_planar) || !wave_decode_eligible(d))
+    const bool near_by_line = d.interleave_mode == 1 && d.components >= 2 && d.components <= 4 && d.near_lossless != 0;
+    if ((!by_sample && !near_planar && !near_by_line) || !wave_decode_eligible(d))
         return 0;
+    if (by_sample && d.bits_per_sample > 8 && ((reinterpret_cast<uintptr_t>(d.pixels) | d.pixel_stride) & 1u) != 0)
+        return 0; // odd row address for 16-bit samples
     if ((d.bits_per_sample > 8 && d.t3 > grp::kMaxTableT3) || std::getenv("CHARLS_AMD_EXACT_DECODER") != nullptr)
         return 0;
     const char* env = std::getenv("CHARLS_AMD_DECODE_GROUP");
@@ -414,40 +407,7 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
     const int pixel_lanes = pixel_group_lanes(proto, count);
     if (pixel_lanes != 0)
     { // sample-interleaved scans, lossless or near-lossless
-        const uint32_t per_wave = 64u / static_cast<uint32_t>(pixel_lanes);
-        const dim3 grid((count + per_wave - 1) / per_wave);
-        const size_t lds = pixel_group_lds_bytes(proto, per_wave);
-#define JLS_LAUNCH_PIXELS(S, G, N)                                                                                       \
-    do                                                                                                                   \
-    {                                                                                                                    \
-        if (lds > kMaxDynamicLds)                                                                                        \
-            hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_pixels_group<S, G, N>),                  \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
-        hipLaunchKernelGGL((decode_pixels_group<S, G, N>), grid, dim3(64), lds, stream, d_descs, d_results, count);      \
-    } while (0)
-#define JLS_LAUNCH_PIXELS_N(S, G)                                                                                        \
-    do                                                                                                                   \
-    {                                                                                                                    \
-        if (nc == 1) JLS_LAUNCH_PIXELS(S, G, 1);                                                                         \
-        else if (nc == 2) JLS_LAUNCH_PIXELS(S, G, 2);                                                                    \
-        else if (nc == 3) JLS_LAUNCH_PIXELS(S, G, 3);                                                                    \
-        else JLS_LAUNCH_PIXELS(S, G, 4);                                                                                 \
-    } while (0)
-        const bool wide = proto.bits_per_sample > 8;
-        if (pixel_lanes == 8)
-        {
-            if (wide) JLS_LAUNCH_PIXELS_N(uint16_t, 8); else JLS_LAUNCH_PIXELS_N(uint8_t, 8);
-        }
-        else if (pixel_lanes == 16)
-        {
-            if (wide) JLS_LAUNCH_PIXELS_N(uint16_t, 16); else JLS_LAUNCH_PIXELS_N(uint8_t, 16);
-        }
-        else
-        {
-            if (wide) JLS_LAUNCH_PIXELS_N(uint16_t, 32); else JLS_LAUNCH_PIXELS_N(uint8_t, 32);
-        }
-#undef JLS_LAUNCH_PIXELS_N
-#undef JLS_LAUNCH_PIXELS
+        launch_decode_pixels(proto, pixel_lanes, d_descs, d_results, count, stream);
     }
     else if (!fast_decode_eligible(proto))
     {
@@ -960,18 +920,11 @@ void launch_encode_intervals(const ScanDesc& proto, ScanDesc* d_descs, ScanResul
 } // namespace
 
 namespace {
-size_t group_encode_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
-{
-    const uint32_t nc = d.interleave_mode == 2 ? static_cast<uint32_t>(d.components) : 1u;
-    return d.bits_per_sample > 8 ? grp::encode_workgroup_lds_bytes<uint16_t>(d.width, nc, scans_per_wave)
-                                 : grp::encode_workgroup_lds_bytes<uint8_t>(d.width, nc, scans_per_wave);
-}
-
 // Lanes per scan of the group encoder (scan_group_encode.hip) for scans the parallel pipeline cannot take -- near-lossless
-// single-component and sample-interleaved scans; 0 = the one-lane kernel (line-interleaved scans, lines that do not fit LDS).
+// single-component, sample-interleaved and line-interleaved scans; 0 = the one-lane kernel (lines that do not fit LDS).
 int group_encode_lanes(const ScanDesc& d, uint32_t count)
 {
-    const bool shape = (d.interleave_mode == 2 && d.components >= 2 && d.components <= 4) || (d.interleave_mode == 0 && d.components == 1);
+    const bool shape = (d.interleave_mode != 0 && d.components >= 2 && d.components <= 4) || (d.interleave_mode == 0 && d.components == 1);
     if (!shape || encode_engine() == EncodeEngine::serial)
         return 0;
     int best = 0;
@@ -987,50 +940,6 @@ int group_encode_lanes(const ScanDesc& d, uint32_t count)
     return best;
 }
 
-void launch_encode_group(const ScanDesc& proto, int lanes, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count,
-                         hipStream_t stream)
-{
-    const uint32_t per_wave = 64u / static_cast<uint32_t>(lanes);
-    const dim3 grid((count + per_wave - 1) / per_wave);
-    const size_t lds = group_encode_lds_bytes(proto, per_wave);
-    const int nc = proto.interleave_mode == 2 ? proto.components : 1;
-#define JLS_LAUNCH_ENCODE(S, G, N)                                                                                       \
-    do                                                                                                                   \
-    {                                                                                                                    \
-        if (lds > kMaxDynamicLds)                                                                                        \
-            hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_pixels_group<S, G, N>),                  \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
-        hipLaunchKernelGGL((encode_pixels_group<S, G, N>), grid, dim3(64), lds, stream, d_descs, d_results, count);      \
-    } while (0)
-#define JLS_LAUNCH_ENCODE_N(S, G)                                                                                        \
-    do                                                                                                                   \
-    {                                                                                                                    \
-        if (nc == 1) JLS_LAUNCH_ENCODE(S, G, 1);                                                                         \
-        else if (nc == 2) JLS_LAUNCH_ENCODE(S, G, 2);                                                                    \
-        else if (nc == 3) JLS_LAUNCH_ENCODE(S, G, 3);                                                                    \
-        else JLS_LAUNCH_ENCODE(S, G, 4);                                                                                 \
-    } while (0)
-    const bool wide = proto.bits_per_sample > 8;
-    if (lanes == 8)
-    {
-        if (wide) JLS_LAUNCH_ENCODE_N(uint16_t, 8); else JLS_LAUNCH_ENCODE_N(uint8_t, 8);
-    }
-    else if (lanes == 16)
-    {
-        if (wide) JLS_LAUNCH_ENCODE_N(uint16_t, 16); else JLS_LAUNCH_ENCODE_N(uint8_t, 16);
-    }
-    else if (lanes == 32)
-    {
-        if (wide) JLS_LAUNCH_ENCODE_N(uint16_t, 32); else JLS_LAUNCH_ENCODE_N(uint8_t, 32);
-    }
-    else
-    {
-        if (wide) JLS_LAUNCH_ENCODE_N(uint16_t, 64); else JLS_LAUNCH_ENCODE_N(uint8_t, 64);
-    }
-#undef JLS_LAUNCH_ENCODE_N
-#undef JLS_LAUNCH_ENCODE
-    hip_check(hipGetLastError());
-}
 } // namespace
 
 void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)

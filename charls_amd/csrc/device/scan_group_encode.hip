@@ -53,16 +53,19 @@ __host__ __device__ constexpr uint32_t encode_lines_offset(uint32_t components)
     return ((EncodeLayout<S>::kAfterOut + components * (uint32_t)sizeof(S) + 15u) & ~15u) - components * (uint32_t)sizeof(S);
 }
 
+// `rows` = 1, or the number of components of a LINE-INTERLEAVED scan (then `components` is 1: every component keeps its
+// own pair of lines).
 template <typename S>
-__host__ __device__ constexpr uint32_t encode_region_bytes(uint32_t width, uint32_t components)
+__host__ __device__ constexpr uint32_t encode_region_bytes(uint32_t width, uint32_t components, uint32_t rows = 1)
 {
-    return bank_spread(encode_lines_offset<S>(components) + 2 * pixel_line_bytes<S>(width, components));
+    return bank_spread(encode_lines_offset<S>(components) + 2 * rows * pixel_line_bytes<S>(width, components));
 }
 
 template <typename S>
-__host__ __device__ constexpr uint32_t encode_workgroup_lds_bytes(uint32_t width, uint32_t components, uint32_t scans_per_wave)
+__host__ __device__ constexpr uint32_t encode_workgroup_lds_bytes(uint32_t width, uint32_t components, uint32_t scans_per_wave,
+                                                                  uint32_t rows = 1)
 {
-    return Layout<S>::kLutBytes + scans_per_wave * encode_region_bytes<S>(width, components);
+    return Layout<S>::kLutBytes + scans_per_wave * encode_region_bytes<S>(width, components, rows);
 }
 
 // The reference's bit writer (src/scan_encoder.hpp:75-186) onto a staging ring; every member replicated over the lanes.
@@ -184,9 +187,12 @@ struct RingWriter
 
 } // namespace grp
 
-// Dynamic LDS: grp::encode_workgroup_lds_bytes<S>(width, NC, 64 / G).  NC = 1: a single-component scan (planar);
-// NC = 2..4: a sample-interleaved scan of NC components.
-template <typename S, int G, int NC>
+// Dynamic LDS: grp::encode_workgroup_lds_bytes<S>(width, NC, 64 / G, NL).  NC = 1: a single-component scan (planar);
+// NC = 2..4: a sample-interleaved scan of NC components.  NL = 2..4 (with NC = 1): a LINE-interleaved scan of NL components
+// (src/scan_encoder_impl.hpp:109-160): the lines of a pixel row one component after the other, each against the line of
+// its own component above it and with its own RUNindex, on the one set of contexts; every component keeps its own pair
+// of lines, the user's row is de-interleaved into the NL current lines when its first component starts.
+template <typename S, int G, int NC, int NL = 1>
 __global__ void __launch_bounds__(64) encode_pixels_group(const ScanDesc* __restrict__ descs, ScanResult* __restrict__ results,
                                                           uint32_t count)
 {
@@ -194,6 +200,7 @@ __global__ void __launch_bounds__(64) encode_pixels_group(const ScanDesc* __rest
     using L = EncodeLayout<S>;
     static_assert(G == 8 || G == 16 || G == 32 || G == 64, "lanes per scan");
     static_assert(NC >= 1 && NC <= 4, "components per pixel");
+    static_assert(NL >= 1 && NL <= 4 && (NL == 1 || NC == 1), "lines per pixel row");
     constexpr int kScansPerWave = 64 / G;
     constexpr bool kWide = sizeof(S) > 1;
     JLS_DYNAMIC_LDS(smem);
@@ -206,9 +213,10 @@ __global__ void __launch_bounds__(64) encode_pixels_group(const ScanDesc* __rest
     const Traits t = make_traits(d);
     const uint32_t width = d.width;
     const uint32_t line_bytes = pixel_line_bytes<S>(width, NC);
+    const uint32_t line_samples = line_bytes / (uint32_t)sizeof(S);
     const int mask = (1 << d.bits_per_sample) - 1;
 
-    unsigned char* region = smem + Layout<S>::kLutBytes + (size_t)sid * encode_region_bytes<S>(width, NC);
+    unsigned char* region = smem + Layout<S>::kLutBytes + (size_t)sid * encode_region_bytes<S>(width, NC, NL);
     Record* records = reinterpret_cast<Record*>(region + L::kRecords);
     RunCtx* run_ctx = reinterpret_cast<RunCtx*>(region + L::kRun);
     uint8_t* out_ring = region + L::kOut;
@@ -231,7 +239,7 @@ __global__ void __launch_bounds__(64) encode_pixels_group(const ScanDesc* __rest
         if (!kWide)
             for (int q = lane; q <= 510; q += 64)
                 lut[q] = (unsigned char)(quantize(t_first, q - 255) + 4);
-        for (uint32_t q = sub; q < 2 * line_bytes / (uint32_t)sizeof(S); q += G)
+        for (uint32_t q = sub; q < 2 * NL * line_samples; q += G)
             line_a[q] = 0;
     }
     RingWriter bw;
@@ -251,6 +259,13 @@ __global__ void __launch_bounds__(64) encode_pixels_group(const ScanDesc* __rest
     int run_index = 0;
     S* prev = line_a; // the two lines swap after every row
     S* cur = line_b;
+    // line-interleaved scans: the component whose line is being coded, which of its two lines is the current one, and the
+    // RUNindex of every component
+    int comp = 0, flip = 0;
+    int run_index_of[NL];
+#pragma unroll
+    for (int c = 0; c < NL; ++c)
+        run_index_of[c] = 0;
     const bool quick = !kWide && __all(!live || own_table) && lds_address(smem) == 0; // (see lds_load)
 
     // staged bytes -> destination, by the lanes of the group (everything written so far, or whole 256-byte pieces)
@@ -434,52 +449,90 @@ __global__ void __launch_bounds__(64) encode_pixels_group(const ScanDesc* __rest
             if (__any(starting))
             {
                 const uint8_t* row = d.pixels + (size_t)y * d.pixel_stride;
-                S* samples = cur + NC; // pixel 1
-                const bool transformed = NC == 3 && d.color_transformation != 0;
-                const bool plain = !transformed && mask == (kWide ? 0xFFFF : 0xFF);
-                const uint32_t row_bytes = width * NC * (uint32_t)sizeof(S);
-                const bool aligned = ((reinterpret_cast<uintptr_t>(d.pixels) | d.pixel_stride) & 15u) == 0;
-                const uint32_t wide_bytes = aligned && plain ? row_bytes & ~15u : 0u;
-                uint32_t off = (uint32_t)sub * 16u;
-                while (__any(starting && off < wide_bytes))
+                if (NL > 1)
                 {
-                    if (starting && off < wide_bytes)
-                        *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(samples) + off) =
-                            *reinterpret_cast<const uint4*>(row + off);
-                    off += G * 16u;
-                }
-                // the samples behind the 16-byte pieces, or the whole row when it needs masking
-                uint32_t ss = wide_bytes / (uint32_t)sizeof(S) + (uint32_t)sub;
-                while (__any(starting && !transformed && ss < width * NC))
-                {
-                    if (starting && !transformed && ss < width * NC)
+                    if (starting)
                     {
-                        const uint8_t* q = row + (size_t)ss * sizeof(S);
-                        const unsigned v = kWide ? (unsigned)q[0] | ((unsigned)q[1] << 8) : (unsigned)q[0];
-                        samples[ss] = (S)(v & (unsigned)mask);
-                    }
-                    ss += G;
-                }
-                // ... or the colour transform
-                uint32_t xx = (uint32_t)sub;
-                while (__any(starting && transformed && xx < width))
-                {
-                    if (starting && transformed && xx < width)
-                    {
-                        unsigned v[3];
+                        prev = line_a + (uint32_t)(2 * comp + flip) * line_samples;
+                        cur = line_a + (uint32_t)(2 * comp + (flip ^ 1)) * line_samples;
 #pragma unroll
-                        for (int c = 0; c < 3; ++c)
+                        for (int c = 0; c < NL; ++c)
+                            run_index = comp == c ? run_index_of[c] : run_index;
+                    }
+                    // the first component of a pixel row: the user's row goes, de-interleaved, into the NL current lines
+                    const bool fetching = starting && comp == 0;
+                    const bool transformed = NL == 3 && d.color_transformation != 0;
+                    uint32_t xx = (uint32_t)sub;
+                    while (__any(fetching && xx < width))
+                    {
+                        if (fetching && xx < width)
                         {
-                            const uint8_t* q = row + ((size_t)xx * NC + (c < NC ? c : 0)) * sizeof(S);
-                            v[c] = kWide ? (unsigned)q[0] | ((unsigned)q[1] << 8) : (unsigned)q[0];
-                        }
-                        hp_forward(d.color_transformation, kWide, (int)v[0], (int)v[1], (int)v[2], v);
+                            unsigned v[4] = {0, 0, 0, 0};
 #pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            samples[xx * NC + (c < NC ? c : 0)] = (S)v[c];
+                            for (int c = 0; c < NL; ++c)
+                            {
+                                const uint8_t* q = row + ((size_t)xx * NL + c) * sizeof(S);
+                                v[c] = kWide ? (unsigned)q[0] | ((unsigned)q[1] << 8) : (unsigned)q[0];
+                            }
+                            if (transformed)
+                                hp_forward(d.color_transformation, kWide, (int)v[0], (int)v[1], (int)v[2], v);
+#pragma unroll
+                            for (int c = 0; c < NL; ++c)
+                                line_a[(uint32_t)(2 * c + (flip ^ 1)) * line_samples + 1 + xx] = (S)(transformed ? v[c] : v[c] & (unsigned)mask);
+                        }
+                        xx += G;
                     }
-                    xx += G;
                 }
+                else
+                {
+                    S* samples = cur + NC; // pixel 1
+                    const bool transformed = NC == 3 && d.color_transformation != 0;
+                    const bool plain = !transformed && mask == (kWide ? 0xFFFF : 0xFF);
+                    const uint32_t row_bytes = width * NC * (uint32_t)sizeof(S);
+                    const bool aligned = ((reinterpret_cast<uintptr_t>(d.pixels) | d.pixel_stride) & 15u) == 0;
+                    const uint32_t wide_bytes = aligned && plain ? row_bytes & ~15u : 0u;
+                    uint32_t off = (uint32_t)sub * 16u;
+                    while (__any(starting && off < wide_bytes))
+                    {
+                        if (starting && off < wide_bytes)
+                            *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(samples) + off) =
+                                *reinterpret_cast<const uint4*>(row + off);
+                        off += G * 16u;
+                    }
+                    // the samples behind the 16-byte pieces, or the whole row when it needs masking
+                    uint32_t ss = wide_bytes / (uint32_t)sizeof(S) + (uint32_t)sub;
+                    while (__any(starting && !transformed && ss < width * NC))
+                    {
+                        if (starting && !transformed && ss < width * NC)
+                        {
+                            const uint8_t* q = row + (size_t)ss * sizeof(S);
+                            const unsigned v = kWide ? (unsigned)q[0] | ((unsigned)q[1] << 8) : (unsigned)q[0];
+                            samples[ss] = (S)(v & (unsigned)mask);
+                        }
+                        ss += G;
+                    }
+                    // ... or the colour transform
+                    uint32_t xx = (uint32_t)sub;
+                    while (__any(starting && transformed && xx < width))
+                    {
+                        if (starting && transformed && xx < width)
+                        {
+                            unsigned v[3];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                            {
+                                const uint8_t* q = row + ((size_t)xx * NC + (c < NC ? c : 0)) * sizeof(S);
+                                v[c] = kWide ? (unsigned)q[0] | ((unsigned)q[1] << 8) : (unsigned)q[0];
+                            }
+                            hp_forward(d.color_transformation, kWide, (int)v[0], (int)v[1], (int)v[2], v);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                samples[xx * NC + (c < NC ? c : 0)] = (S)v[c];
+                        }
+                        xx += G;
+                    }
+                }
+                JLS_LOCKSTEP();
                 if (starting && sub < NC)
                     cur[sub] = prev[NC + sub];
                 JLS_LOCKSTEP();
@@ -732,12 +785,27 @@ __global__ void __launch_bounds__(64) encode_pixels_group(const ScanDesc* __rest
                 if (ending && sub < NC)
                     cur[(width + 1) * NC + sub] = cur[width * NC + sub];
                 JLS_LOCKSTEP();
-                if (ending)
+                if (ending && NL == 1)
                 {
                     S* const was_prev = prev;
                     prev = cur;
                     cur = was_prev;
                     ++y;
+                    phase = y == d.height ? kFinish : kLineStart;
+                }
+                if (ending && NL > 1)
+                { // the next component of this pixel row, or the first of the next one (lines are chosen at the line start)
+#pragma unroll
+                    for (int c = 0; c < NL; ++c)
+                        run_index_of[c] = comp == c ? run_index : run_index_of[c];
+                    if (comp == NL - 1)
+                    {
+                        comp = 0;
+                        flip ^= 1;
+                        ++y;
+                    }
+                    else
+                        ++comp;
                     phase = y == d.height ? kFinish : kLineStart;
                 }
             }

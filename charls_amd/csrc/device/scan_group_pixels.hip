@@ -56,16 +56,19 @@ __host__ __device__ constexpr uint32_t pixel_lines_offset(uint32_t components)
     return ((after_ring + components * (uint32_t)sizeof(S) + 15u) & ~15u) - components * (uint32_t)sizeof(S);
 }
 
+// `rows` = 1, or the number of components of a LINE-INTERLEAVED scan (then `components` is 1: every component keeps its
+// own pair of lines).
 template <typename S>
-__host__ __device__ constexpr uint32_t pixel_region_bytes(uint32_t width, uint32_t components)
+__host__ __device__ constexpr uint32_t pixel_region_bytes(uint32_t width, uint32_t components, uint32_t rows = 1)
 {
-    return bank_spread(pixel_lines_offset<S>(components) + 2 * pixel_line_bytes<S>(width, components));
+    return bank_spread(pixel_lines_offset<S>(components) + 2 * rows * pixel_line_bytes<S>(width, components));
 }
 
 template <typename S>
-__host__ __device__ constexpr uint32_t pixel_workgroup_lds_bytes(uint32_t width, uint32_t components, uint32_t scans_per_wave)
+__host__ __device__ constexpr uint32_t pixel_workgroup_lds_bytes(uint32_t width, uint32_t components, uint32_t scans_per_wave,
+                                                                 uint32_t rows = 1)
 {
-    return Layout<S>::kLutBytes + scans_per_wave * pixel_region_bytes<S>(width, components);
+    return Layout<S>::kLutBytes + scans_per_wave * pixel_region_bytes<S>(width, components, rows);
 }
 
 // The three ring words around bit p (see ring_words_at).
@@ -81,8 +84,12 @@ JLS_DEV RingWords3 ring_words3_at(uint32_t ring_address, uint32_t p)
 
 } // namespace grp
 
-// Dynamic LDS: grp::pixel_workgroup_lds_bytes<S>(width, NC, 64 / G).
-template <typename S, int G, int NC>
+// Dynamic LDS: grp::pixel_workgroup_lds_bytes<S>(width, NC, 64 / G, NL).  NL = 2..4 (with NC = 1): a LINE-INTERLEAVED scan of
+// NL components -- the lines of a pixel row are coded one component after the other, each against the line of its own
+// component above it and with its own RUNindex, on the one set of contexts (src/scan_decoder_impl.hpp:62-129); every
+// component keeps its own pair of lines, and a finished pixel row goes out interleaved.  (The lossless ones have the same
+// arrangement in scan_group_decode.hip; these are the near-lossless ones.)
+template <typename S, int G, int NC, int NL = 1>
 __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __restrict__ descs, ScanResult* __restrict__ results,
                                                           uint32_t count)
 {
@@ -90,6 +97,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
     using L = Layout<S>;
     static_assert(G == 8 || G == 16 || G == 32, "lanes per scan");
     static_assert(NC >= 1 && NC <= 4, "components per pixel");
+    static_assert(NL >= 1 && NL <= 4 && (NL == 1 || NC == 1), "lines per pixel row");
     constexpr int kScansPerWave = 64 / G;
     constexpr bool kWide = sizeof(S) > 1;
     JLS_DYNAMIC_LDS(smem);
@@ -103,7 +111,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
     const uint32_t width = d.width;
     const uint32_t line_bytes = pixel_line_bytes<S>(width, NC);
 
-    unsigned char* region = smem + L::kLutBytes + (size_t)sid * pixel_region_bytes<S>(width, NC);
+    unsigned char* region = smem + L::kLutBytes + (size_t)sid * pixel_region_bytes<S>(width, NC, NL);
     Record* records = reinterpret_cast<Record*>(region + L::kRecords);
     RunCtx* run_ctx = reinterpret_cast<RunCtx*>(region + L::kRun);
     uint32_t* ring = reinterpret_cast<uint32_t*>(region + L::kRing);
@@ -125,7 +133,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
             run_ctx[sub] = RunCtx{sub, initial_a(t), 1, 0};
         for (int q = lane; q <= 2 * cap; q += 64)
             lut[q] = (unsigned char)(quantize(t_first, q - cap) + 4);
-        for (uint32_t q = sub; q < 2 * line_bytes / (uint32_t)sizeof(S); q += G)
+        for (uint32_t q = sub; q < 2 * NL * line_bytes / (uint32_t)sizeof(S); q += G)
             line_a[q] = 0;
         for (uint32_t q = sub; q <= kRingWords + 1; q += G)
             ring[q] = 0;
@@ -153,6 +161,14 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
     int run_index = 0;
     S* prev = line_a; // the two lines swap after every row
     S* cur = line_b;
+    // line-interleaved scans: the component whose line is being decoded, which of its two lines is the current one, and the
+    // RUNindex of every component
+    int comp = 0, flip = 0;
+    int run_index_of[NL];
+#pragma unroll
+    for (int c = 0; c < NL; ++c)
+        run_index_of[c] = 0;
+    const uint32_t line_samples = line_bytes / (uint32_t)sizeof(S);
     const uint32_t margin_bits = (uint32_t)(kPixelStepsPerCheck + 1) * NC * (uint32_t)t.limit + 320u;
     // the pixel loop takes scans of 8-bit samples (the scans of a wavefront share NEAR: it is part of their gradient table)
     const bool quick = !kWide;
@@ -171,7 +187,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
         const int k = regular_k(ctx);
         if (k >= 16)
             return false;
-        const int u = take_unary(ring, p, 47); // anything longer: let the exact decoder classify it
+        const int u = take_unary(ring, p, t.limit); // no code has more zeros than LIMIT; anything longer: the exact decoder classifies it
         if (u < 0)
             return false;
         int mm;
@@ -258,6 +274,14 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
             const bool starting = phase == kLineStart;
             if (__any(starting))
             {
+                if (NL > 1 && starting)
+                {
+                    prev = line_a + (uint32_t)(2 * comp + flip) * line_samples;
+                    cur = line_a + (uint32_t)(2 * comp + (flip ^ 1)) * line_samples;
+#pragma unroll
+                    for (int c = 0; c < NL; ++c)
+                        run_index = comp == c ? run_index_of[c] : run_index;
+                }
                 if (starting && sub < NC)
                     cur[sub] = prev[NC + sub];
                 JLS_LOCKSTEP();
@@ -553,7 +577,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                 {
                     const int k = run_k(ctx);
                     const int limit = t.limit - run_j(run_index) - 1;
-                    const int u = k > 24 ? -1 : take_unary(ring, p, 47);
+                    const int u = k > 24 ? -1 : take_unary(ring, p, t.limit);
                     if (u < 0)
                     {
                         retry = true;
@@ -595,6 +619,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
 
         // ---- finished line -> user's row (inverse colour transform: src/copy_from_line_buffer.hpp:19-191); the line
         // becomes the previous one
+        if (NL == 1)
         {
             const bool ending = phase == kInLine && i > width;
             if (__any(ending))
@@ -646,6 +671,59 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                     prev = cur;
                     cur = was_prev;
                     ++y;
+                    phase = y == d.height ? kDrain : kLineStart;
+                }
+            }
+        }
+        else
+        { // a component's line; behind the last component the pixel row goes out, interleaved
+            const bool ending = phase == kInLine && i > width;
+            if (__any(ending))
+            {
+                const bool row_done = ending && comp == NL - 1;
+                if (__any(row_done))
+                {
+                    uint8_t* row = d.pixels + (size_t)y * d.pixel_stride;
+                    const bool transformed = NL == 3 && d.color_transformation != 0;
+                    uint32_t xx = (uint32_t)sub;
+                    while (__any(row_done && xx < width))
+                    {
+                        if (row_done && xx < width)
+                        {
+                            unsigned v[4];
+#pragma unroll
+                            for (int c = 0; c < NL; ++c)
+                                v[c] = line_a[(uint32_t)(2 * c + (flip ^ 1)) * line_samples + 1 + xx];
+                            if (transformed)
+                                hp_inverse(d.color_transformation, kWide, (int)v[0], (int)v[1], (int)v[NL > 2 ? 2 : 0], v);
+#pragma unroll
+                            for (int c = 0; c < NL; ++c)
+                            { // (bytes: the user's row of 16-bit pixels need not be aligned)
+                                uint8_t* q = row + ((size_t)xx * NL + c) * sizeof(S);
+                                q[0] = (uint8_t)v[c];
+                                if (kWide)
+                                    q[1] = (uint8_t)(v[c] >> 8);
+                            }
+                        }
+                        xx += G;
+                    }
+                }
+                if (ending && sub == 0)
+                    cur[width + 1] = cur[width]; // the right edge of the next row's previous line
+                JLS_LOCKSTEP();
+                if (ending)
+                {
+#pragma unroll
+                    for (int c = 0; c < NL; ++c)
+                        run_index_of[c] = comp == c ? run_index : run_index_of[c];
+                    if (comp == NL - 1)
+                    {
+                        comp = 0;
+                        flip ^= 1;
+                        ++y;
+                    }
+                    else
+                        ++comp;
                     phase = y == d.height ? kDrain : kLineStart;
                 }
             }

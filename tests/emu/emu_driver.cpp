@@ -199,9 +199,33 @@ int emu_decode_pixels_group(const jls::ScanDesc* descs, jls::ScanResult* results
     const bool wide = d.bits_per_sample > 8;
     const int per_wave = 64 / group;
     const int nc = d.interleave_mode == 2 ? d.components : 1;
-    const size_t lds = wide ? jls::grp::pixel_workgroup_lds_bytes<uint16_t>(d.width, nc, per_wave)
-                            : jls::grp::pixel_workgroup_lds_bytes<uint8_t>(d.width, nc, per_wave);
+    const int nl = d.interleave_mode == 1 ? d.components : 1;
+    const size_t lds = wide ? jls::grp::pixel_workgroup_lds_bytes<uint16_t>(d.width, nc, per_wave, nl)
+                            : jls::grp::pixel_workgroup_lds_bytes<uint8_t>(d.width, nc, per_wave, nl);
     const dim3 grid((count + per_wave - 1) / per_wave);
+#define EMU_PIXELS_L(S, G, NLINES) emu::launch(jls::decode_pixels_group<S, G, 1, NLINES>, grid, dim3(64), lds, descs, results, (uint32_t)count)
+#define EMU_PIXELS_LG(S, NLINES)                                 \
+    do                                                           \
+    {                                                            \
+        if (group == 8) EMU_PIXELS_L(S, 8, NLINES);              \
+        else if (group == 16) EMU_PIXELS_L(S, 16, NLINES);       \
+        else if (group == 32) EMU_PIXELS_L(S, 32, NLINES);       \
+        else return -1;                                          \
+    } while (0)
+    if (nl > 1)
+    {
+        if (!wide)
+        {
+            if (nl == 2) EMU_PIXELS_LG(uint8_t, 2); else if (nl == 3) EMU_PIXELS_LG(uint8_t, 3); else EMU_PIXELS_LG(uint8_t, 4);
+        }
+        else
+        {
+            if (nl == 2) EMU_PIXELS_LG(uint16_t, 2); else if (nl == 3) EMU_PIXELS_LG(uint16_t, 3); else EMU_PIXELS_LG(uint16_t, 4);
+        }
+        return 0;
+    }
+#undef EMU_PIXELS_LG
+#undef EMU_PIXELS_L
 #define EMU_PIXELS(S, G, N) emu::launch(jls::decode_pixels_group<S, G, N>, grid, dim3(64), lds, descs, results, (uint32_t)count)
 #define EMU_PIXELS_G(S, N)                                       \
     do                                                           \
@@ -231,8 +255,33 @@ int emu_encode_pixels_group(const jls::ScanDesc* descs, jls::ScanResult* results
     const bool wide = d.bits_per_sample > 8;
     const int per_wave = 64 / group;
     const int nc = d.interleave_mode == 2 ? d.components : 1;
-    const size_t lds = wide ? jls::grp::encode_workgroup_lds_bytes<uint16_t>(d.width, nc, per_wave) : jls::grp::encode_workgroup_lds_bytes<uint8_t>(d.width, nc, per_wave);
+    const int nl = d.interleave_mode == 1 ? d.components : 1;
+    const size_t lds = wide ? jls::grp::encode_workgroup_lds_bytes<uint16_t>(d.width, nc, per_wave, nl) : jls::grp::encode_workgroup_lds_bytes<uint8_t>(d.width, nc, per_wave, nl);
     const dim3 grid((count + per_wave - 1) / per_wave);
+#define EMU_ENC_L(S, G, NLINES) emu::launch(jls::encode_pixels_group<S, G, 1, NLINES>, grid, dim3(64), lds, descs, results, (uint32_t)count)
+#define EMU_ENC_LG(S, NLINES)                                  \
+    do                                                         \
+    {                                                          \
+        if (group == 8) EMU_ENC_L(S, 8, NLINES);               \
+        else if (group == 16) EMU_ENC_L(S, 16, NLINES);        \
+        else if (group == 32) EMU_ENC_L(S, 32, NLINES);        \
+        else if (group == 64) EMU_ENC_L(S, 64, NLINES);        \
+        else return -1;                                        \
+    } while (0)
+    if (nl > 1)
+    {
+        if (!wide)
+        {
+            if (nl == 2) EMU_ENC_LG(uint8_t, 2); else if (nl == 3) EMU_ENC_LG(uint8_t, 3); else EMU_ENC_LG(uint8_t, 4);
+        }
+        else
+        {
+            if (nl == 2) EMU_ENC_LG(uint16_t, 2); else if (nl == 3) EMU_ENC_LG(uint16_t, 3); else EMU_ENC_LG(uint16_t, 4);
+        }
+        return 0;
+    }
+#undef EMU_ENC_LG
+#undef EMU_ENC_L
 #define EMU_ENC(S, G, N) emu::launch(jls::encode_pixels_group<S, G, N>, grid, dim3(64), lds, descs, results, (uint32_t)count)
 #define EMU_ENC_G(S, N)                                        \
     do                                                         \

@@ -335,6 +335,31 @@ def test_pixel_group_decoder_near_lossless_single_component(group, w, h, bits, n
         assert outs[f].tobytes() == wants[f], f
 
 
+@pytest.mark.parametrize("group", [8, 16, 32])
+@pytest.mark.parametrize("w,h,bits,comps,near,kind,count", [(40, 12, 8, 3, 2, "mixed", 4), (300, 4, 8, 3, 1, "noise", 3), (33, 7, 16, 3, 5, "mixed", 2),
+                                                            (1, 5, 8, 2, 2, "mixed", 2), (64, 6, 8, 3, 2, "zero", 3), (90, 8, 8, 4, 3, "hard", 2)])
+def test_pixel_group_decoder_near_lossless_line_interleaved(group, w, h, bits, comps, near, kind, count):
+    """Near-lossless LINE-interleaved scans: every component keeps its own pair of lines and its RUNindex."""
+    L = emu_bind.lib()
+    bps = 1 if bits <= 8 else 2
+    keep, descs, outs, wants, ends = [], [], [], [], []
+    for f in range(count):
+        img = synth.frame_numpy(w, h, seed=23 * f + bits + comps, bits=bits, components=comps, kind=kind, interleaved=True)
+        jls = ob.encode(img, width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=1, near_lossless=near)
+        wants.append(ob.decode(jls)[1].tobytes())
+        cont = jls_container.parse(jls)
+        pc = jls_container.validated_pc(cont.pc, cont.bits, near)
+        pix = np.zeros(w * h * comps * bps, dtype=np.uint8)
+        descs.append(emu_bind.make_desc(w, h, comps, 1, bits, near, 0, pc, 0, pix, w * comps * bps,
+                                        _stream_copy(jls, cont.scans[0].data_start), keep))
+        outs.append(pix)
+        ends.append(cont.scans[0].data_end - cont.scans[0].data_start)
+    res = _launch_pixels(L, descs, group)
+    for f in range(count):
+        assert (res[f].errc, res[f].flags, res[f].bytes) == (0, 0, ends[f]), f
+        assert outs[f].tobytes() == wants[f], f
+
+
 def test_pixel_group_dispatch_on_mutated_scan_data_matches_the_oracle():
     """Group kernel, then the exact wave decoder for the scans that reported kFastRetry, on mutated RGB streams."""
     L = emu_bind.lib()
@@ -413,6 +438,34 @@ def test_group_encoder_matches_reference_scan_bytes(group, w, h, bits, comps, ne
         out = np.zeros(len(wants[-1]) + 64, dtype=np.uint8)
         outs.append(out)
         descs.append(emu_bind.make_desc(w, h, comps, ilv, bits, near, xform, pc, 0, pix, w * bps * comps, out, keep))
+    res = _encode_group(L, descs, group)
+    for f in range(count):
+        assert res[f].errc == 0 and outs[f][:res[f].bytes].tobytes() == wants[f], f
+
+
+@pytest.mark.parametrize("group", [8, 16, 32, 64])
+@pytest.mark.parametrize("w,h,bits,comps,near,xform,kind,count",
+                         [(40, 12, 8, 3, 2, 0, "mixed", 3), (300, 4, 8, 3, 1, 0, "noise", 2), (33, 7, 16, 3, 5, 0, "mixed", 2),
+                          (1, 5, 8, 2, 2, 0, "mixed", 2), (64, 6, 8, 3, 2, 0, "zero", 2), (90, 8, 8, 4, 3, 0, "hard", 2),
+                          (48, 9, 8, 3, 0, 1, "mixed", 2), (57, 6, 12, 2, 3, 0, "gradient", 2)])
+def test_group_encoder_line_interleaved_matches_reference_scan_bytes(group, w, h, bits, comps, near, xform, kind, count):
+    """LINE-interleaved scans on the group encoder (a pair of lines and a RUNindex per component, the user's row
+    de-interleaved when its first component starts): every scan's bytes equal the reference's entropy-coded segment."""
+    L = emu_bind.lib()
+    bps = 1 if bits <= 8 else 2
+    keep, descs, outs, wants = [], [], [], []
+    for f in range(count):
+        img = synth.frame_numpy(w, h, seed=29 * f + bits + near, bits=bits, components=comps, kind=kind, interleaved=True)
+        jls = ob.encode(img, width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=1,
+                        near_lossless=near, color_transformation=xform)
+        cont = jls_container.parse(jls)
+        scan = cont.scans[0]
+        wants.append(jls[scan.data_start:scan.data_end])
+        pc = jls_container.validated_pc(cont.pc, cont.bits, near)
+        pix = np.frombuffer(np.ascontiguousarray(img).tobytes(), dtype=np.uint8).copy()
+        out = np.zeros(len(wants[-1]) + 64, dtype=np.uint8)
+        outs.append(out)
+        descs.append(emu_bind.make_desc(w, h, comps, 1, bits, near, xform, pc, 0, pix, w * bps * comps, out, keep))
     res = _encode_group(L, descs, group)
     for f in range(count):
         assert res[f].errc == 0 and outs[f][:res[f].bytes].tobytes() == wants[f], f

@@ -87,6 +87,12 @@ if "5c" in only:
     del rgb
     torch.cuda.empty_cache()
     batch.release_work_areas(lib)
+if "5d" in only:
+    rgb = rgb_frames(args.rgb_frames, 4096, 5)
+    run("config 4 line-interleaved near-lossless (5d): 4096x4096 RGB ILV_LINE NEAR=2", rgb, bits=8, comps=3, ilv=1, near=2)
+    del rgb
+    torch.cuda.empty_cache()
+    batch.release_work_areas(lib)
 if "5b" in only:
     rgb = rgb_frames(args.rgb_frames, 4096, 5)
     run("config 4 as 5b: 4096x4096 RGB ILV_SAMPLE NEAR=2", rgb, bits=8, comps=3, ilv=2, near=2)
