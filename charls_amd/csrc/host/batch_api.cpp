@@ -4,6 +4,8 @@
 // separate chain of work for the GPU (frames shard with no exchange).  The container bytes around the
 // entropy-coded segments are produced by the same StreamWriter the part-1 encoder uses, and parsed by the same
 // StreamReader the part-1 decoder uses, so each frame's .jls file / error code is what part 1 gives for that frame.
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -18,6 +20,24 @@ using namespace jls;
 using dev::hip_check;
 
 namespace {
+// One window of every listed stream -> a contiguous staging buffer (then ONE device-to-host copy instead of one small,
+// synchronously staged copy per frame: 4096 of those were 60 ms per round of the batch decoder).
+struct WindowSpec
+{
+    uint64_t offset; // from the first slot
+    uint32_t bytes;
+    uint32_t pad;
+};
+__global__ void gather_windows(const uint8_t* __restrict__ slots, const WindowSpec* __restrict__ specs, uint8_t* __restrict__ out,
+                               uint32_t window)
+{
+    const WindowSpec w = specs[blockIdx.x];
+    const uint8_t* src = slots + w.offset;
+    uint8_t* dst = out + (size_t)blockIdx.x * window;
+    for (uint32_t b = threadIdx.x; b < w.bytes; b += blockDim.x)
+        dst[b] = src[b];
+}
+
 
 struct EventTimer
 {
@@ -303,6 +323,37 @@ try
         if (n)
             hip_check(hipMemcpyAsync(x.window.data(), slots + i * stream_pitch_bytes + base, n, hipMemcpyDeviceToHost, stream));
     };
+    // the same for many frames at once (bases[k] is the offset of frame which[k]'s window): one gather on the device, one copy
+    dev::DeviceBuffer d_specs, d_windows;
+    dev::PinnedBuffer h_specs, h_windows;
+    auto fetch_many = [&](const std::vector<uint32_t>& which, const std::vector<size_t>& bases) {
+        const size_t n = which.size();
+        if (n == 0)
+            return;
+        auto* specs = static_cast<WindowSpec*>(h_specs.ensure(sizeof(WindowSpec) * n));
+        for (size_t k = 0; k < n; ++k)
+        {
+            const uint32_t i = which[k];
+            const size_t avail = bases[k] < sizes[i] ? static_cast<size_t>(sizes[i]) - bases[k] : 0;
+            specs[k] = WindowSpec{static_cast<uint64_t>(i) * stream_pitch_bytes + bases[k],
+                                  static_cast<uint32_t>(std::min(kWindow, avail)), 0};
+        }
+        d_specs.ensure(sizeof(WindowSpec) * n);
+        d_windows.ensure(kWindow * n);
+        auto* staged = static_cast<uint8_t*>(h_windows.ensure(kWindow * n));
+        hip_check(hipMemcpyAsync(d_specs.as<WindowSpec>(), specs, sizeof(WindowSpec) * n, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(gather_windows, dim3(static_cast<uint32_t>(n)), dim3(256), 0, stream, slots, d_specs.as<const WindowSpec>(),
+                           d_windows.as<uint8_t>(), static_cast<uint32_t>(kWindow));
+        hip_check(hipGetLastError());
+        hip_check(hipMemcpyAsync(staged, d_windows.as<uint8_t>(), kWindow * n, hipMemcpyDeviceToHost, stream));
+        hip_check(hipStreamSynchronize(stream));
+        for (size_t k = 0; k < n; ++k)
+        {
+            Frame& x = fr[which[k]];
+            x.window.assign(staged + k * kWindow, staged + k * kWindow + specs[k].bytes);
+            x.window_base = bases[k];
+        }
+    };
     // A parse that runs off the end of the window while the stream has more bytes is retried with a larger window.
     auto parse = [&](uint32_t i, auto&& body) {
         Frame& x = fr[i];
@@ -337,13 +388,16 @@ try
 
     if (stream_pitch_bytes == 0)
         raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
-    for (uint32_t i = 0; i < frame_count; ++i)
     {
-        if (sizes[i] > stream_pitch_bytes)
-            raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
-        fetch(i, 0, kWindow);
+        std::vector<uint32_t> all(frame_count);
+        for (uint32_t i = 0; i < frame_count; ++i)
+        {
+            if (sizes[i] > stream_pitch_bytes)
+                raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
+            all[i] = i;
+        }
+        fetch_many(all, std::vector<size_t>(frame_count, 0));
     }
-    hip_check(hipStreamSynchronize(stream));
     for (uint32_t i = 0; i < frame_count; ++i)
         parse(i, [&](Frame& x) {
             x.reader.set_source(x.window.data(), x.window.size());
@@ -454,19 +508,26 @@ try
         scan_ms += total.ms();
 
         // advance every frame past its scan; fetch the bytes that follow (next SOS or EOI)
-        for (uint32_t k = 0; k < n; ++k)
         {
-            Frame& x = fr[active[k]];
-            if (results[k].errc != kOk)
+            std::vector<uint32_t> which;
+            std::vector<size_t> bases;
+            which.reserve(n);
+            bases.reserve(n);
+            for (uint32_t k = 0; k < n; ++k)
             {
-                x.errc = static_cast<charls_jpegls_errc>(results[k].errc);
-                x.done = true;
-                continue;
+                Frame& x = fr[active[k]];
+                if (results[k].errc != kOk)
+                {
+                    x.errc = static_cast<charls_jpegls_errc>(results[k].errc);
+                    x.done = true;
+                    continue;
+                }
+                x.cursor += results[k].bytes;
+                which.push_back(active[k]);
+                bases.push_back(x.cursor);
             }
-            x.cursor += results[k].bytes;
-            fetch(active[k], x.cursor, kWindow);
+            fetch_many(which, bases);
         }
-        hip_check(hipStreamSynchronize(stream));
         for (uint32_t k = 0; k < n; ++k)
         {
             const uint32_t i = active[k];
