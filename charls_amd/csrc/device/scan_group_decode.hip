@@ -32,7 +32,7 @@ namespace grp {
 
 constexpr uint32_t kRingWords = 256;               // dense bits resident per scan: 8192 (words kRingWords, kRingWords + 1 mirror words 0, 1)
 constexpr uint32_t kRingBits = kRingWords * 32;
-constexpr int kStepsPerCheck = 32;                 // regular-mode steps between two looks at the producer
+constexpr int kStepsPerCheck = 64;                 // regular-mode steps between two looks at the producer
 constexpr uint32_t kMarginBits = kStepsPerCheck * 32 + 320; // dense bits the step loop and one event handler may consume
 constexpr int kMaxTableT3 = 1023;                  // widest gradient table (2 * T3 + 1 entries) for samples wider than 8 bits
 
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             uint32_t steps = kStepsPerCheck;
             while (lanes_where(in_line && rest_of_line < steps) != 0)
                 --steps;
-            uint32_t ticker = 1u << (steps - 1); // one-hot step counter, 1 <= steps <= kStepsPerCheck
+            uint64_t ticker = 1ull << (steps - 1); // one-hot step counter, 1 <= steps <= kStepsPerCheck
             // lanes outside their line never pass the `u < limit` test below
             const uint32_t limit_v = opaque(in_line ? limit_m : 0u);
             // The loop is rotated.  An iteration first does the bookkeeping the PREVIOUS step left behind -- Ra, bit position,

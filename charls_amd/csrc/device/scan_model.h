@@ -183,6 +183,15 @@ JLS_DEV uint32_t tick(uint32_t ticker, LaneMask busy, LaneMask ok)
                  : "scc");
     return ticker;
 }
+JLS_DEV uint64_t tick(uint64_t ticker, LaneMask busy, LaneMask ok) // up to 64 steps
+{
+    LaneMask missing;
+    asm volatile("s_andn2_b64 %1, %2, %3\n\ts_cselect_b64 %0, 0, %0\n\ts_lshr_b64 %0, %0, 1"
+                 : "+s"(ticker), "=&s"(missing)
+                 : "s"(busy), "s"(ok)
+                 : "scc");
+    return ticker;
+}
 // Hides how a per-lane value was computed (the compiler would otherwise fold a select into the predicates that use it).
 JLS_DEV uint32_t opaque(uint32_t v)
 {
@@ -261,6 +270,10 @@ JLS_DEV uint32_t abs_difference(uint32_t a, uint32_t b)
 JLS_DEV uint32_t tick(uint32_t ticker, LaneMask busy, LaneMask ok)
 {
     return (busy & ~ok) != 0 ? 0u : ticker >> 1;
+}
+JLS_DEV uint64_t tick(uint64_t ticker, LaneMask busy, LaneMask ok)
+{
+    return (busy & ~ok) != 0 ? 0ull : ticker >> 1;
 }
 JLS_DEV uint32_t opaque(uint32_t v)
 {
