@@ -39,6 +39,7 @@ constexpr int kRegularChains = 365;   // chains coded by code_events: 1..364 and
 constexpr int kInterruptChain = 365;  // no recurrence of its own: the run chain codes these samples, in the same order
 constexpr int kZeroContextChain = 366; // ILV_SAMPLE only: a component whose own gradients are all zero while the pixel
                                        // as a whole is not in run mode is coded with regular context 0
+constexpr uint32_t kGradientTable = 512; // LDS bytes of stage A's gradient table (8-bit samples)
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint16_t kNoEvent = 0xFFFF; // key of a sample that produces no code of its own
 constexpr uint32_t kPackBlock = 4096; // samples per D1/D2 workgroup (256 threads x 16)
@@ -156,10 +157,20 @@ __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ 
     uint64_t* s_q0 = s_eq + chunks;
     uint32_t* s_next = reinterpret_cast<uint32_t*>(s_q0 + chunks);
     uint32_t* s_hist = s_next + chunks;
+    unsigned char* s_grad = reinterpret_cast<unsigned char*>(s_hist + kChains); // kGradientTable bytes
     const int mask = (1 << d.bits_per_sample) - 1;
 
     for (int c = lane; c < kChains; c += 64)
         s_hist[c] = 0;
+    // 8-bit samples: the quantised gradient (+ 4) of every difference -255 .. 255 from a table -- the arithmetic form of
+    // src/jpegls_algorithm.hpp:173-194 is eight comparisons per gradient, three gradients per sample, and this stage is
+    // bound by the instructions it issues (143 per 64 samples, of which the table takes 40 away)
+    if (sizeof(S) == 1)
+    {
+        for (int q = lane; q < 511; q += 64)
+            s_grad[q] = (unsigned char)(quantize(t, q - 255) + 4);
+        __syncthreads();
+    }
 
     // edge samples of the line (src/scan_codec.hpp:189-195 and the two-line ping-pong of src/scan_encoder_impl.hpp:55-106)
     const int edge_a = y >= step ? load_sample<S, ILV>(d, y - step, 0, mask) : 0;     // cur[0]  = prev[1]
@@ -185,10 +196,12 @@ __global__ void __launch_bounds__(64) analyze_rows(const ScanDesc* __restrict__ 
             }
             else
                 rc = x > 0 ? 0 : edge_c;
-            const int qs = context_id(t, ra, rb, rc, rd);
+            const int qs = sizeof(S) == 1
+                               ? ((int)s_grad[rd - rb + 255] * 9 + (int)s_grad[rb - rc + 255]) * 9 + (int)s_grad[rc - ra + 255] - 364
+                               : context_id(t, ra, rb, rc, rd);
             const int sg = qs >> 31;
             const int ctx = (qs ^ sg) - sg;
-            const int px = med_predict(ra, rb, rc);
+            const int px = med3(ra + rb - rc, ra, rb); // MED predictor = median(Ra, Rb, Ra + Rb - Rc), src/jpegls_algorithm.hpp:143-161
             key_row[x] = (uint16_t)(ctx | ((sg & 1) << 9));
             val_row[x] = (uint32_t)v | ((uint32_t)px << 16);
             eq = v == ra;

@@ -750,7 +750,7 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
 
         const ScanDesc* descs = d_descs + first;
         const uint32_t chunks = (proto.width + 63) / 64;
-        const size_t lds_a = static_cast<size_t>(chunks) * 20 + pipe::kChains * 4;
+        const size_t lds_a = static_cast<size_t>(chunks) * 20 + pipe::kChains * 4 + pipe::kGradientTable;
         const uint32_t blocks = static_cast<uint32_t>(lay.blocks);
         const uint32_t rows_grid = 8 * ((static_cast<uint32_t>(lay.lines) + 7) / 8); // analyze_pixels idles the surplus
         timers.emplace_back(s);

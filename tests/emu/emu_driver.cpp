@@ -97,7 +97,7 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
         w.status = (uint32_t*)zalloc(4);
     }
     const uint32_t chunks = (p.width + 63) / 64;
-    const size_t lds_a = (size_t)chunks * 20 + pipe::kChains * 4;
+    const size_t lds_a = (size_t)chunks * 20 + pipe::kChains * 4 + pipe::kGradientTable;
     const pipe::Work* wk = works.data();
     const unsigned rows_grid = 8 * (((unsigned)lines + 7) / 8);
     if (p.interleave_mode == 2)

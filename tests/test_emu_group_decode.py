@@ -16,6 +16,12 @@ from test_emu_serial_kernels import FAST_CASES, _stream_copy
 GROUPS = [4, 8, 16, 32]  # lanes per scan: 16, 8, 4, 2 scans per wavefront
 
 
+def _rotating(groups, cases):
+    """Every case with ONE lanes-per-scan setting, the settings taken in turn (all of them occur over the list; running every
+    case with every setting made this file half of the CPU suite)."""
+    return [(groups[i % len(groups)],) + tuple(c) for i, c in enumerate(cases)]
+
+
 def _group_eligible(bits, pc):
     return (pc[4] & 0xFF) != 0 and (bits <= 8 or pc[3] <= 1023)
 
@@ -53,10 +59,9 @@ def test_group_decoder_matches_reference_pixels(c):
     assert common.sha(b"".join(o.tobytes() for o in outs)) == c["decoded_sha256"]
 
 
-@pytest.mark.parametrize("group", GROUPS)
-@pytest.mark.parametrize("w,h,bits,kind,count", [(64, 20, 8, "mixed", 7), (300, 5, 8, "noise", 5), (33, 9, 16, "mixed", 5),
+@pytest.mark.parametrize("group,w,h,bits,kind,count", _rotating(GROUPS, [(64, 20, 8, "mixed", 7), (300, 5, 8, "noise", 5), (33, 9, 16, "mixed", 5),
                                                  (41, 7, 12, "hard", 3), (1, 9, 8, "mixed", 3), (520, 3, 2, "noise", 9),
-                                                 (70, 6, 8, "zero", 4)])
+                                                 (70, 6, 8, "zero", 4)]))
 def test_group_decoder_batches_of_different_frames(group, w, h, bits, kind, count):
     """`count` different frames of one geometry per launch (count is not a multiple of the scans per wavefront, so the last
     wavefront has idle lane groups); runs, escapes, several refills of the bit ring and lines of a few samples."""
@@ -80,11 +85,9 @@ def test_group_decoder_batches_of_different_frames(group, w, h, bits, kind, coun
         assert outs[f].tobytes() == imgs[f].tobytes(), f
 
 
-@pytest.mark.parametrize("group", [4, 8, 16, 32])
-@pytest.mark.parametrize("w,h,bits,comps,xform,kind,count",
-                         [(40, 12, 8, 3, 1, "mixed", 5), (300, 4, 8, 3, 2, "noise", 3), (33, 7, 16, 3, 3, "mixed", 3),
+@pytest.mark.parametrize("group,w,h,bits,comps,xform,kind,count", _rotating([4, 8, 16, 32], [(40, 12, 8, 3, 1, "mixed", 5), (300, 4, 8, 3, 2, "noise", 3), (33, 7, 16, 3, 3, "mixed", 3),
                           (1, 5, 8, 2, 0, "mixed", 2), (64, 6, 8, 3, 0, "zero", 3), (90, 8, 8, 4, 0, "hard", 3),
-                          (130, 6, 5, 3, 0, "mixed", 3), (57, 9, 12, 2, 0, "gradient", 4)])
+                          (130, 6, 5, 3, 0, "mixed", 3), (57, 9, 12, 2, 0, "gradient", 4)]))
 def test_group_decoder_line_interleaved_batches(group, w, h, bits, comps, xform, kind, count):
     """Line-interleaved scans (one line per component in LDS, one RUNindex per component, the ONE set of contexts): `count`
     different frames per launch decode to the source pixels."""
@@ -278,13 +281,11 @@ def test_pixel_group_decoder_matches_reference_pixels(c):
     assert common.sha(pix.tobytes()) == c["decoded_sha256"]
 
 
-@pytest.mark.parametrize("group", [8, 16, 32])
-@pytest.mark.parametrize("w,h,bits,comps,near,xform,kind,count",
-                         [(40, 12, 8, 3, 0, 1, "mixed", 5), (37, 9, 8, 3, 2, 0, "gradient", 3), (33, 7, 16, 3, 0, 3, "mixed", 3),
+@pytest.mark.parametrize("group,w,h,bits,comps,near,xform,kind,count", _rotating([8, 16, 32], [(40, 12, 8, 3, 0, 1, "mixed", 5), (37, 9, 8, 3, 2, 0, "gradient", 3), (33, 7, 16, 3, 0, 3, "mixed", 3),
                           (33, 7, 8, 4, 1, 0, "mixed", 5), (300, 4, 8, 3, 0, 2, "noise", 3), (1, 5, 8, 2, 0, 0, "mixed", 2),
                           (64, 6, 8, 3, 0, 0, "zero", 3), (20, 6, 12, 3, 3, 0, "hard", 2), (90, 8, 8, 4, 0, 0, "hard", 3),
                           (130, 6, 5, 3, 0, 0, "mixed", 3), (257, 5, 8, 2, 0, 0, "noise", 4), (75, 10, 8, 3, 0, 3, "gradient", 5), (200, 6, 8, 3, 3, 0, "noise", 3),
-                          (90, 8, 7, 2, 1, 0, "mixed", 3), (64, 10, 8, 3, 5, 0, "hard", 2), (50, 8, 8, 3, 100, 0, "mixed", 2)])
+                          (90, 8, 7, 2, 1, 0, "mixed", 3), (64, 10, 8, 3, 5, 0, "hard", 2), (50, 8, 8, 3, 100, 0, "mixed", 2)]))
 def test_pixel_group_decoder_batches(group, w, h, bits, comps, near, xform, kind, count):
     """`count` different frames per launch; what they decode to is what the oracle decodes (near-lossless: the reconstructed
     samples, bit for bit)."""
@@ -309,10 +310,9 @@ def test_pixel_group_decoder_batches(group, w, h, bits, comps, near, xform, kind
         assert outs[f].tobytes() == wants[f], f
 
 
-@pytest.mark.parametrize("group", [8, 16, 32])
-@pytest.mark.parametrize("w,h,bits,near,kind,count", [(64, 20, 8, 3, "mixed", 5), (300, 5, 8, 1, "noise", 3), (37, 9, 16, 5, "gradient", 3),
+@pytest.mark.parametrize("group,w,h,bits,near,kind,count", _rotating([8, 16, 32], [(64, 20, 8, 3, "mixed", 5), (300, 5, 8, 1, "noise", 3), (37, 9, 16, 5, "gradient", 3),
                                                       (1, 9, 8, 2, "mixed", 3), (70, 6, 8, 2, "zero", 4), (41, 7, 12, 2, "hard", 3),
-                                                      (130, 6, 5, 1, "mixed", 3), (50, 8, 8, 100, "mixed", 2)])
+                                                      (130, 6, 5, 1, "mixed", 3), (50, 8, 8, 100, "mixed", 2)]))
 def test_pixel_group_decoder_near_lossless_single_component(group, w, h, bits, near, kind, count):
     """Near-lossless single-component scans on the pixel kernel with one component per pixel (run interruptions choose
     between the two run contexts by |Ra - Rb| <= NEAR): what they decode to is what the oracle decodes, bit for bit."""
@@ -335,9 +335,8 @@ def test_pixel_group_decoder_near_lossless_single_component(group, w, h, bits, n
         assert outs[f].tobytes() == wants[f], f
 
 
-@pytest.mark.parametrize("group", [8, 16, 32])
-@pytest.mark.parametrize("w,h,bits,comps,near,kind,count", [(40, 12, 8, 3, 2, "mixed", 4), (300, 4, 8, 3, 1, "noise", 3), (33, 7, 16, 3, 5, "mixed", 2),
-                                                            (1, 5, 8, 2, 2, "mixed", 2), (64, 6, 8, 3, 2, "zero", 3), (90, 8, 8, 4, 3, "hard", 2)])
+@pytest.mark.parametrize("group,w,h,bits,comps,near,kind,count", _rotating([8, 16, 32], [(40, 12, 8, 3, 2, "mixed", 4), (300, 4, 8, 3, 1, "noise", 3), (33, 7, 16, 3, 5, "mixed", 2),
+                                                            (1, 5, 8, 2, 2, "mixed", 2), (64, 6, 8, 3, 2, "zero", 3), (90, 8, 8, 4, 3, "hard", 2)]))
 def test_pixel_group_decoder_near_lossless_line_interleaved(group, w, h, bits, comps, near, kind, count):
     """Near-lossless LINE-interleaved scans: every component keeps its own pair of lines and its RUNindex."""
     L = emu_bind.lib()
@@ -412,14 +411,12 @@ def _encode_group(L, descs, group):
     return res
 
 
-@pytest.mark.parametrize("group", [8, 16, 32, 64])
-@pytest.mark.parametrize("w,h,bits,comps,near,xform,kind,count",
-                         [(40, 12, 8, 3, 2, 0, "mixed", 3), (64, 20, 8, 1, 3, 0, "mixed", 5), (37, 9, 16, 1, 5, 0, "gradient", 3),
+@pytest.mark.parametrize("group,w,h,bits,comps,near,xform,kind,count", _rotating([8, 16, 32, 64], [(40, 12, 8, 3, 2, 0, "mixed", 3), (64, 20, 8, 1, 3, 0, "mixed", 5), (37, 9, 16, 1, 5, 0, "gradient", 3),
                           (33, 7, 16, 3, 0, 3, "mixed", 2), (33, 7, 8, 4, 1, 0, "mixed", 3), (700, 4, 8, 1, 1, 0, "noise", 3),
                           (300, 4, 8, 3, 2, 0, "noise", 2), (64, 6, 8, 3, 2, 0, "zero", 2), (1, 5, 8, 1, 2, 0, "mixed", 2),
                           (20, 6, 12, 3, 2, 0, "hard", 2), (48, 9, 8, 2, 0, 0, "mixed", 3), (90, 8, 8, 3, 0, 1, "hard", 2),
                           (130, 6, 5, 3, 1, 0, "mixed", 3), (50, 8, 8, 3, 100, 0, "mixed", 2), (257, 5, 8, 1, 0, 0, "noise", 3),
-                          (75, 10, 7, 1, 2, 0, "gradient", 3), (300, 5, 8, 4, 3, 0, "noise", 2)])
+                          (75, 10, 7, 1, 2, 0, "gradient", 3), (300, 5, 8, 4, 3, 0, "noise", 2)]))
 def test_group_encoder_matches_reference_scan_bytes(group, w, h, bits, comps, near, xform, kind, count):
     """`count` different frames per launch: every scan's bytes equal the reference's (the oracle's) entropy-coded segment."""
     L = emu_bind.lib()
@@ -443,11 +440,9 @@ def test_group_encoder_matches_reference_scan_bytes(group, w, h, bits, comps, ne
         assert res[f].errc == 0 and outs[f][:res[f].bytes].tobytes() == wants[f], f
 
 
-@pytest.mark.parametrize("group", [8, 16, 32, 64])
-@pytest.mark.parametrize("w,h,bits,comps,near,xform,kind,count",
-                         [(40, 12, 8, 3, 2, 0, "mixed", 3), (300, 4, 8, 3, 1, 0, "noise", 2), (33, 7, 16, 3, 5, 0, "mixed", 2),
+@pytest.mark.parametrize("group,w,h,bits,comps,near,xform,kind,count", _rotating([8, 16, 32, 64], [(40, 12, 8, 3, 2, 0, "mixed", 3), (300, 4, 8, 3, 1, 0, "noise", 2), (33, 7, 16, 3, 5, 0, "mixed", 2),
                           (1, 5, 8, 2, 2, 0, "mixed", 2), (64, 6, 8, 3, 2, 0, "zero", 2), (90, 8, 8, 4, 3, 0, "hard", 2),
-                          (48, 9, 8, 3, 0, 1, "mixed", 2), (57, 6, 12, 2, 3, 0, "gradient", 2)])
+                          (48, 9, 8, 3, 0, 1, "mixed", 2), (57, 6, 12, 2, 3, 0, "gradient", 2)]))
 def test_group_encoder_line_interleaved_matches_reference_scan_bytes(group, w, h, bits, comps, near, xform, kind, count):
     """LINE-interleaved scans on the group encoder (a pair of lines and a RUNindex per component, the user's row
     de-interleaved when its first component starts): every scan's bytes equal the reference's entropy-coded segment."""
