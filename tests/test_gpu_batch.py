@@ -54,6 +54,31 @@ def test_batch_rgb_modes(torch):
             assert (out.int() - frames.int()).abs().max().item() <= near
 
 
+@pytest.mark.parametrize("comps,ilv,near,ct,bits", [(1, 0, 2, 0, 8), (3, 1, 2, 0, 8), (3, 1, 0, 1, 8), (3, 2, 3, 0, 8), (1, 0, 3, 0, 12),
+                                                   (3, 1, 2, 0, 12), (3, 2, 0, 2, 16), (4, 2, 1, 0, 8)])
+def test_batch_midsize_modes_equal_oracle(torch, comps, ilv, near, ct, bits):
+    """The lanes-per-scan kernels of the modes without a pipeline form (near-lossless, interleaved) on frames wide and tall
+    enough for many refills of the bit ring and drains of the staging ring: the coded bytes are the oracle's, and what they
+    decode to is what the oracle decodes (near-lossless: the reconstruction, bit for bit)."""
+    n, w, h = 3, 1000, 300
+    imgs = [synth.frame_numpy(w, h, seed=90 + f, bits=bits, components=comps, kind="mixed", interleaved=(ilv != 0)) for f in range(n)]
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    if comps > 1 and ilv == 0:
+        pytest.skip("planar multi-component frames have their own test")
+    enc = batch.encode_batch(frames, bits_per_sample=bits, component_count=comps, interleave_mode=ilv, near_lossless=near,
+                             color_transformation=ct)
+    host = enc.streams.cpu().numpy()
+    out = torch.empty_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+    assert (errcs == 0).all()
+    got = out.cpu().numpy()
+    for f in range(n):
+        want = ob.encode(imgs[f], width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=ilv,
+                         near_lossless=near, color_transformation=ct)
+        assert enc.errcs[f] == 0 and host[f, :int(enc.sizes[f])].tobytes() == want, f
+        assert got[f].tobytes() == ob.decode(want)[1].tobytes(), f
+
+
 def test_batch_destination_too_small_is_per_frame(torch):
     w, h = 64, 64
     frames = torch.stack([synth.frames_torch(1, w, h, seed0=1, kind="noise", device="cuda:0")[0],
