@@ -5,24 +5,25 @@
 // function of the image (reference src/scan_encoder_impl.hpp:109-144).  The scan is therefore coded in
 // stages that each expose the parallelism they really have:
 //
-//   A  analyze_rows      one wavefront per scan line: context id, sign, MED prediction for every sample (coalesced,
-//                        HBM-bound); run-mode segmentation of the line resolved as a carry chain over ballot masks
+//   A  analyze_rows      one wavefront per scan line: context id, sign, MED prediction for every sample (coalesced; bound
+//                        by the instructions it issues); run-mode segmentation of the line resolved as a carry chain
+//                        over ballot masks
 //   B1 chain_offsets     per-line histograms of the 365 statistic chains (364 regular contexts + the run chain) ->
 //                        exclusive offsets (a stable counting sort by context, raster order kept inside a chain)
 //   B2 scatter_events    events move to their chain, stable ranks from a wave-level sort (deterministic, no atomics on order);
-//                        the slot of every sample is recorded (inv) so that codes can stay in chain order until D2
+//                        the slot of every sample is recorded (inv) so that codes can stay in chain order until D
 //   C1 bias_chains       one LANE per chain: the {B,C,N} recurrence turns the chain's samples into Errval (the only
 //                        serial dependency of regular mode); the run chain carries RUNindex and the two run-interruption
 //                        contexts and codes its events directly.  Chains of different contexts never interact in
 //                        lossless mode, so 365 x scans lanes run concurrently.
 //   C2 code_events       one wavefront per chain: A is a segmented prefix sum of |Errval|, N a function of the event
 //                        index -> k and the Golomb words of 64 events per step, stored in chain order (coalesced)
-//   D1 sum/scan          code lengths (gathered through inv) -> bit offsets (two-level prefix sum per scan)
-//   D2 write_raw_bits    codes are gathered in raster order and concatenated MSB-first into the unstuffed bit stream
+//   D  write_raw_bits    codes are gathered in raster order and concatenated MSB-first into the unstuffed bit stream
 //                        (a line's samples of one chain are neighbours in chain order: the gathers hit whole cache
-//                        lines, where a scatter of 8-byte codes by chain wrote every line many times)
-//   D3 stuff_scan        JPEG-LS 0xFF bit stuffing + end-of-scan padding (src/scan_encoder.hpp:103-180), one wavefront
-//                        per scan streaming through LDS
+//                        lines, where a scatter of 8-byte codes by chain wrote every line many times); the bit offset of
+//                        a block comes from a chained look-back scan among the blocks of the scan
+//   E  stuff_scan        JPEG-LS 0xFF bit stuffing + end-of-scan padding (src/scan_encoder.hpp:103-180), one wavefront
+//                        per scan streaming through LDS; run by runtime.hip on a side stream, under the next pass
 //
 // Output is byte-identical to scan_encoder::encode_scan.  MFMA is not used anywhere: nothing here is a contraction.
 #pragma once
@@ -42,7 +43,7 @@ constexpr int kZeroContextChain = 366; // ILV_SAMPLE only: a component whose own
 constexpr uint32_t kGradientTable = 512; // LDS bytes of stage A's gradient table (8-bit samples)
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint16_t kNoEvent = 0xFFFF; // key of a sample that produces no code of its own
-constexpr uint32_t kPackBlock = 4096; // samples per D1/D2 workgroup (256 threads x 16)
+constexpr uint32_t kPackBlock = 4096; // samples per workgroup of stage D (256 threads x 16)
 constexpr uint32_t kStatusInvalid = 1u;
 constexpr uint32_t kChainPad = 16;    // chains start on multiples of 16 records (four 16-byte groups = one cache line), see bias_chains
 constexpr uint32_t kChainSlack = kChains * kChainPad + 64; // spare records of sval/spos: padding + read-ahead
@@ -61,7 +62,7 @@ struct Work
     uint8_t* len;          // [H*W + kChainSlack] code length per slot
     uint64_t* code;        // [H*W + kChainSlack] code bits per slot, right aligned (re-uses key/val, dead after B2)
     uint64_t* blockbase;   // [ceil(H*W / kPackBlock)] look-back states of write_raw_bits
-    uint32_t* raw;         // unstuffed bit stream, 32-bit words in big-endian bit order; zeroed before D2
+    uint32_t* raw;         // unstuffed bit stream, 32-bit words in big-endian bit order; zeroed before stage D
     uint64_t raw_words;    // capacity of raw
     uint64_t* total_bits;  // [1]
     uint32_t* status;      // [1] kStatusInvalid when the reference would raise invalid_data
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(384) chain_offsets(const ScanDesc* __restrict_
     }
     s_total[c] = c < kChains ? running : 0;
     if (c == 383)
-    { // the two result words of the later stages start at zero (stage C2 / D1 write them)
+    { // the two result words of the later stages start at zero (stages C2 / D write them)
         *w.total_bits = 0;
         *w.status = 0;
     }
@@ -1045,6 +1046,16 @@ __global__ void __launch_bounds__(64) code_events(const ScanDesc* __restrict__ d
 // Workgroups start in the order of their index, x fastest: a block only ever waits for blocks that were started before it.
 // blockbase[b]: bits 62..63 = state (0 nothing, 1 own bits, 2 bits up to and including b), bits 0..61 the value; zero
 // before the launch.
+// Zeroes the look-back states and the raw bit stream of every scan of a pass (they are contiguous in a work area): grid
+// (any, scans) x 256 threads, 16 bytes per thread and step.
+__global__ void __launch_bounds__(256) clear_pack_state(const Work* __restrict__ works, uint32_t bytes_per_scan)
+{
+    uint4* at = reinterpret_cast<uint4*>(works[blockIdx.y].blockbase);
+    const uint32_t groups = bytes_per_scan / 16;
+    for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < groups; g += gridDim.x * 256u)
+        at[g] = make_uint4(0, 0, 0, 0);
+}
+
 constexpr uint64_t kBlockOwn = 1ull << 62, kBlockUpTo = 2ull << 62, kBlockValue = (1ull << 62) - 1ull;
 
 __global__ void __launch_bounds__(256) write_raw_bits(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
@@ -1155,7 +1166,7 @@ __global__ void __launch_bounds__(256) write_raw_bits(const ScanDesc* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// D3: one wavefront per scan: raw bits -> stuffed bytes.  After a 0xFF byte the next byte carries 7 bits (MSB 0); a final
+// E: one wavefront per scan: raw bits -> stuffed bytes.  After a 0xFF byte the next byte carries 7 bits (MSB 0); a final
 // 0xFF is followed by 0x00; the last partial byte is zero padded (src/scan_encoder.hpp:103-180).
 //
 // Stuffing is sequential only through the (rare) 0xFF bytes, so the wavefront speculates: lane l cuts output byte l of

@@ -783,8 +783,9 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         t.mark();
         if (overlap_stuffing && pass > 0)
             hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
-        for (uint32_t i = 0; i < n; ++i)
-            hip_check(hipMemsetAsync(works[pass][i].blockbase, 0, lay.off_raw + lay.raw_bytes - lay.off_bbase, s)); // look-back states; write_raw_bits ORs its words into raw
+        // look-back states and raw bits start at zero (one region per work area; both multiples of 16 bytes)
+        hipLaunchKernelGGL(pipe::clear_pack_state, dim3(64, n), dim3(256), 0, s, d_works,
+                           static_cast<uint32_t>(lay.off_raw + lay.raw_bytes - lay.off_bbase));
         hipLaunchKernelGGL(pipe::write_raw_bits, dim3(blocks, n), dim3(256), 0, s, descs, d_works);
         t.mark();
         if (overlap_stuffing)
