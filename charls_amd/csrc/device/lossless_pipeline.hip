@@ -66,6 +66,7 @@ struct Work
     uint64_t raw_words;    // capacity of raw
     uint64_t* total_bits;  // [1]
     uint32_t* status;      // [1] kStatusInvalid when the reference would raise invalid_data
+    uint32_t* stuff_tables; // block_stuffing.hip: kStuffWords words per chunk of the raw stream
 };
 
 // Workgroup -> scan line.  Workgroup b runs on XCD b % 8 (each XCD has its own L2): giving every XCD a contiguous band of

@@ -12,6 +12,7 @@
 #include "container_kernels.hip"
 #include "scan_wave_decode.hip"
 #include "lossless_pipeline.hip"
+#include "block_stuffing.hip"
 #include "scan_fast_decode.hip"
 #include "scan_group_decode.hip"
 #include "group_launch.h"
@@ -540,7 +541,7 @@ struct PipeLayout
 {
     size_t samples, lines, blocks, raw_bytes;
     size_t off_key, off_val, off_hist, off_total, off_base, off_sval, off_spos, off_inv, off_len, off_code, off_bbase,
-        off_raw, off_bits, off_status, bytes;
+        off_raw, off_bits, off_status, off_stuff, bytes;
     PipeLayout(const ScanDesc& d, size_t capacity_hint)
     {
         const int32_t comps = d.interleave_mode != 0 ? d.components : 1;
@@ -571,6 +572,7 @@ struct PipeLayout
         off_raw = take(raw_bytes);
         off_bits = take(16);  // total_bits and status in two copies: the stuffing of one pass runs under the next pass
         off_status = take(8);
+        off_stuff = take((raw_bytes / pipe::kStuffChunk + 1) * pipe::kStuffWords * 4); // block_stuffing.hip (1.3 MB of 376)
         bytes = o;
     }
 };
@@ -745,6 +747,7 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
             w.raw_words = lay.raw_bytes / 4;
             w.total_bits = reinterpret_cast<uint64_t*>(base + lay.off_bits) + copy; // (zeroed by chain_offsets)
             w.status = reinterpret_cast<uint32_t*>(base + lay.off_status) + copy;
+            w.stuff_tables = reinterpret_cast<uint32_t*>(base + lay.off_stuff);
         }
         hip_check(hipMemcpyAsync(d_works, works[pass].data(), sizeof(pipe::Work) * n, hipMemcpyHostToDevice, s));
 
@@ -794,7 +797,19 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
             hip_check(hipStreamWaitEvent(stuff_stream, packed[pass], 0));
         }
         t.mark_on(stuff_stream);
-        hipLaunchKernelGGL(pipe::stuff_scan, dim3(n), dim3(64), 0, stuff_stream, descs, d_works, d_results + first);
+        static const bool block_stuffing = [] {
+            const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); // opt-in: see block_stuffing.hip
+            return env != nullptr && std::atoi(env) != 0;
+        }();
+        if (block_stuffing)
+        {
+            const uint32_t chunk_waves = static_cast<uint32_t>((lay.raw_bytes / pipe::kStuffChunk + 1 + 63) / 64);
+            hipLaunchKernelGGL(pipe::stuff_survey, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, d_works);
+            hipLaunchKernelGGL(pipe::stuff_resolve, dim3(n), dim3(64), 0, stuff_stream, d_works);
+            hipLaunchKernelGGL(pipe::stuff_emit, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, descs, d_works, d_results + first);
+        }
+        else
+            hipLaunchKernelGGL(pipe::stuff_scan, dim3(n), dim3(64), 0, stuff_stream, descs, d_works, d_results + first);
         t.mark_on(stuff_stream);
         if (overlap_stuffing)
             hip_check(hipEventRecord(stuffed[pass], stuff_stream));

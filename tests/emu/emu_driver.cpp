@@ -8,12 +8,14 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 
 #include "../../charls_amd/csrc/device/scan_serial.hip"
 #include "../../charls_amd/csrc/device/lossless_pipeline.hip"
+#include "../../charls_amd/csrc/device/block_stuffing.hip"
 #include "../../charls_amd/csrc/device/scan_fast_decode.hip"
 #include "../../charls_amd/csrc/device/scan_group_decode.hip"
 #include "../../charls_amd/csrc/device/scan_group_pixels.hip"
 #include "../../charls_amd/csrc/device/scan_group_encode.hip"
 #include "../../charls_amd/csrc/device/restart_intervals.hip"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -95,6 +97,7 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
         w.raw_words = raw_bytes / 4;
         w.total_bits = (uint64_t*)zalloc(8);
         w.status = (uint32_t*)zalloc(4);
+        w.stuff_tables = (uint32_t*)galloc((raw_bytes / pipe::kStuffChunk + 2) * pipe::kStuffWords * 4);
     }
     const uint32_t chunks = (p.width + 63) / 64;
     const size_t lds_a = (size_t)chunks * 20 + pipe::kChains * 4 + pipe::kGradientTable;
@@ -123,7 +126,18 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
     }
     emu::launch(pipe::code_events, dim3(pipe::kRegularChains, count), dim3(64), 0, descs, wk);
     emu::launch(pipe::write_raw_bits, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
-    emu::launch(pipe::stuff_scan, dim3(count), dim3(64), 0, descs, wk, results);
+    if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env != nullptr && std::atoi(env) != 0)
+    { // the block-parallel form of the stage (block_stuffing.hip), grids as in runtime.hip
+        size_t most = 0;
+        for (int i = 0; i < count; ++i)
+            most = std::max(most, (size_t)works[i].raw_words * 4);
+        const unsigned chunk_waves = (unsigned)((most / pipe::kStuffChunk + 1 + 63) / 64);
+        emu::launch(pipe::stuff_survey, dim3(chunk_waves, count), dim3(64), 0, wk);
+        emu::launch(pipe::stuff_resolve, dim3(count), dim3(64), 0, wk);
+        emu::launch(pipe::stuff_emit, dim3(chunk_waves, count), dim3(64), 0, descs, wk, results);
+    }
+    else
+        emu::launch(pipe::stuff_scan, dim3(count), dim3(64), 0, descs, wk, results);
     for (void* q : allocs)
         std::free(q);
 }
@@ -149,6 +163,37 @@ int emu_decode_scans_fast(const jls::ScanDesc* descs, jls::ScanResult* results, 
     else
         emu::launch(jls::decode_scans_fast<uint8_t>, dim3(count), dim3(64), lds, descs, results);
     return 0;
+}
+
+// Stage E alone on a given raw bit stream (`raw_bytes` readable and zero behind the stream): stuff_scan or, with `blocks`,
+// the block-parallel form; both must produce the same bytes and result words.
+void emu_stuff_raw(const uint8_t* raw, uint64_t total_bits, uint64_t raw_bytes, uint8_t* out, uint64_t capacity, int blocks,
+                   jls::ScanResult* result)
+{
+    using namespace jls;
+    std::vector<uint32_t> words(raw_bytes / 4 + 32, 0);
+    std::memcpy(words.data(), raw, (size_t)raw_bytes);
+    uint64_t bits = total_bits;
+    uint32_t status = 0;
+    std::vector<uint32_t> tables((size_t)(raw_bytes / pipe::kStuffChunk + 2) * pipe::kStuffWords, 0xA5A5A5A5u);
+    pipe::Work w{};
+    w.raw = words.data();
+    w.raw_words = (uint32_t)(raw_bytes / 4);
+    w.total_bits = &bits;
+    w.status = &status;
+    w.stuff_tables = tables.data();
+    ScanDesc d{};
+    d.stream = out;
+    d.stream_capacity = capacity;
+    if (blocks)
+    {
+        const unsigned chunk_waves = (unsigned)((raw_bytes / pipe::kStuffChunk + 1 + 63) / 64);
+        emu::launch(pipe::stuff_survey, dim3(chunk_waves, 1), dim3(64), 0, (const pipe::Work*)&w);
+        emu::launch(pipe::stuff_resolve, dim3(1), dim3(64), 0, (const pipe::Work*)&w);
+        emu::launch(pipe::stuff_emit, dim3(chunk_waves, 1), dim3(64), 0, (const ScanDesc*)&d, (const pipe::Work*)&w, result);
+    }
+    else
+        emu::launch(pipe::stuff_scan, dim3(1), dim3(64), 0, (const ScanDesc*)&d, (const pipe::Work*)&w, result);
 }
 
 // scan_group_decode.hip: `group` lanes per scan, 64 / group scans per workgroup (all scans share descs[0]'s geometry).
