@@ -834,7 +834,6 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
         // interruption sample to the next slot of chain kInterruptChain (its events are these samples, in this order).
         RunCtx rc[2] = {RunCtx{0, initial_a(t), 1, 0}, RunCtx{1, initial_a(t), 1, 0}};
         int run_indices[ILV == 1 ? 4 : 1] = {}; // ILV_LINE: one RUNindex per component (src/scan_encoder_impl.hpp:126-137)
-        const uint32_t step = ILV == 1 ? line_step(d) : 1u;
         const int mask = (1 << d.bits_per_sample) - 1;
         uint64_t* run_code = w.code + w.chain_base[0];
         uint8_t* run_len = w.len + w.chain_base[0];
