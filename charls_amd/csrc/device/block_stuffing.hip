@@ -18,7 +18,8 @@
 //
 // Output and result words are those of stuff_scan (a trailing 0xFF is followed by 0x00, the last partial byte is zero
 // padded, flags bit 1 when the capacity is within 3 bytes of the size).  OPT-IN (CHARLS_AMD_BLOCK_STUFFING=1): equal to
-// stuff_scan byte for byte on the CPU harness (tests/test_emu_pipeline.py), not yet the default on the GPU.
+// stuff_scan byte for byte on the CPU harness (tests/test_emu_block_stuffing.py) and in the GPU tests run with it so far;
+// not yet the default.
 #pragma once
 #include <hip/hip_runtime.h>
 
