@@ -536,6 +536,16 @@ size_t align_up(size_t v, size_t a)
     return (v + a - 1) / a * a;
 }
 
+// CHARLS_AMD_BLOCK_STUFFING=1: stage E in its block-parallel form (opt-in: see block_stuffing.hip).
+bool block_stuffing_enabled()
+{
+    static const bool enabled = [] {
+        const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING");
+        return env != nullptr && std::atoi(env) != 0;
+    }();
+    return enabled;
+}
+
 // Bytes of work area one scan needs (21 B per sample + per-line histograms + the unstuffed stream).
 struct PipeLayout
 {
@@ -572,7 +582,8 @@ struct PipeLayout
         off_raw = take(raw_bytes);
         off_bits = take(16);  // total_bits and status in two copies: the stuffing of one pass runs under the next pass
         off_status = take(8);
-        off_stuff = take((raw_bytes / pipe::kStuffChunk + 1) * pipe::kStuffWords * 4); // block_stuffing.hip (1.3 MB of 376)
+        // the tables of block_stuffing.hip (1.3 MB of 376) only when that form of stage E is switched on
+        off_stuff = take(block_stuffing_enabled() ? (raw_bytes / pipe::kStuffChunk + 1) * pipe::kStuffWords * 4 : 0);
         bytes = o;
     }
 };
@@ -797,11 +808,7 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
             hip_check(hipStreamWaitEvent(stuff_stream, packed[pass], 0));
         }
         t.mark_on(stuff_stream);
-        static const bool block_stuffing = [] {
-            const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); // opt-in: see block_stuffing.hip
-            return env != nullptr && std::atoi(env) != 0;
-        }();
-        if (block_stuffing)
+        if (block_stuffing_enabled())
         {
             const uint32_t chunk_waves = static_cast<uint32_t>((lay.raw_bytes / pipe::kStuffChunk + 1 + 63) / 64);
             hipLaunchKernelGGL(pipe::stuff_survey, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, d_works);
