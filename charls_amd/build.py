@@ -39,6 +39,62 @@ def _newest_source() -> float:
     return max(os.path.getmtime(f) for f in files if os.path.isfile(f))
 
 
+LLVM_BIN = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+
+def kernel_resources(obj: str) -> list[dict]:
+    """Kernels of one hipcc object with what their code-object notes say about them: name, private segment (scratch) bytes,
+    VGPRs, SGPRs, static LDS.  The gfx950 code object is cut out of the object's .hip_fatbin section."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, dev = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.check_call([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj])
+        if not os.path.exists(fat) or os.path.getsize(fat) == 0:
+            return []
+        subprocess.check_call([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + dev])
+        notes = subprocess.check_output([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", dev]).decode()
+    kernels, cur = [], None
+    keys = {".private_segment_fixed_size": "scratch", ".vgpr_count": "vgprs", ".sgpr_count": "sgprs",
+            ".group_segment_fixed_size": "lds", ".name": "name"}
+    for line in notes.splitlines():
+        line = line.strip()
+        if line.startswith("- .") or line.startswith("- .agpr_count") or line.startswith("- .args"):
+            if line.startswith("- .agpr_count") or line.startswith("- .args"):
+                cur = {}
+                kernels.append(cur)
+            line = line[2:]
+        if cur is None or ":" not in line:
+            continue
+        key, value = line.split(":", 1)
+        if key in keys:
+            value = value.strip()
+            cur[keys[key]] = value if key == ".name" else int(value)
+    return [k for k in kernels if "name" in k and "scratch" in k]
+
+
+# Kernels that may keep a private segment: none.  Every kernel of the library is on some speed path or is the exact
+# fallback of one; a private segment means a register array that is indexed dynamically or a lambda the compiler did not
+# inline (DESIGN 4.5: the scan state of a group kernel in scratch, green on the CPU harness and a fault on the GPU).
+SCRATCH_ALLOWED: tuple[str, ...] = ()
+
+
+def check_no_scratch(objs: list[str]) -> list[dict]:
+    """Raises when a kernel of the library has a private segment; returns the resource table otherwise."""
+    table = []
+    for obj in objs:
+        if not obj.endswith(".hip.o"):
+            continue
+        table.extend(kernel_resources(obj))
+    if not table:
+        raise RuntimeError("no kernels found in the device objects: the scratch check cannot see them")
+    offenders = [k for k in table if k["scratch"] > 0 and not any(a in k["name"] for a in SCRATCH_ALLOWED)]
+    if offenders:
+        raise RuntimeError("kernels with a private segment (scratch): " +
+                           ", ".join(f"{k['name']} ({k['scratch']} B)" for k in offenders))
+    return table
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(OUT) and os.path.exists(OUT_ALIAS) and os.path.getmtime(OUT) >= _newest_source():
         return OUT
@@ -66,6 +122,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             sys.stderr.write(out.decode())
     if failed:
         raise RuntimeError("hipcc failed")
+    table = check_no_scratch(objs)
+    if verbose:
+        sys.stderr.write(f"scratch check: {len(table)} kernels, none with a private segment\n")
     for out, soname in ((OUT, "libcharls_amd.so"), (OUT_ALIAS, "libcharls.so.3")):
         link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out, "-Wl,-soname," + soname,
                 "-Wl,--no-undefined", "-Wl,--version-script=" + VERSION_SCRIPT]

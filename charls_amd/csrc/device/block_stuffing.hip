@@ -17,9 +17,9 @@
 //   emit     one lane per chunk walks once more, from its real entry state, and stores its bytes.
 //
 // Output and result words are those of stuff_scan (a trailing 0xFF is followed by 0x00, the last partial byte is zero
-// padded, flags bit 1 when the capacity is within 3 bytes of the size).  OPT-IN (CHARLS_AMD_BLOCK_STUFFING=1): equal to
-// stuff_scan byte for byte on the CPU harness (tests/test_emu_block_stuffing.py) and in the GPU tests run with it so far;
-// not yet the default.
+// padded, flags bit 1 when the capacity is within 3 bytes of the size).  The default form of stage E since round 3
+// (CHARLS_AMD_BLOCK_STUFFING=0 selects stuff_scan): equal to stuff_scan byte for byte on the CPU harness
+// (tests/test_emu_block_stuffing.py) and in the GPU suite.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -124,6 +124,10 @@ __global__ void __launch_bounds__(64) stuff_resolve(const Work* __restrict__ wor
     __shared__ uint32_t s_first[kStuffTile * 2];
     const Work w = works[blockIdx.x];
     const uint64_t total_bits = *w.total_bits;
+    // Nothing was surveyed for a scan that is invalid or whose raw stream did not fit its buffer (write_raw_bits clamps
+    // its stores but still reports the full bit count): its chunk count would run past the tables of this work area.
+    if ((*w.status & kStatusInvalid) != 0 || (uint64_t)(total_bits + 7) / 8 > (uint64_t)w.raw_words * 4)
+        return;
     const uint32_t chunks = (uint32_t)((total_bits + kStuffChunkBits - 1) / kStuffChunkBits);
     const int lane = threadIdx.x;
     uint32_t state = 0;  // the first byte of the stream starts at bit 0 and is an 8-bit one
@@ -168,9 +172,15 @@ __global__ void __launch_bounds__(64) stuff_emit(const ScanDesc* __restrict__ de
     const bool invalid = (*w.status & kStatusInvalid) != 0;
     const bool overflow = (uint64_t)(total_bits + 7) / 8 > (uint64_t)w.raw_words * 4;
     if (invalid || overflow || chunks == 0)
-    { // nothing to stuff: the first lane of the scan reports
+    { // nothing to stuff: the first lane of the scan reports, with stuff_scan's words (an empty stream still meets the
+      // capacity rules: flags 2 when fewer than 4 bytes are left)
         if (chunk == 0)
-            results[blockIdx.y] = ScanResult{invalid ? kInvalidData : (overflow ? kDestinationTooSmall : kOk), 0, 0};
+        {
+            ScanResult res{invalid ? kInvalidData : (overflow ? kDestinationTooSmall : kOk), 0, 0};
+            if (res.errc == kOk && d.stream_capacity < 4)
+                res.flags = 2;
+            results[blockIdx.y] = res;
+        }
         return;
     }
     if (chunk >= chunks)

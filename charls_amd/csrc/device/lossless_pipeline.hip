@@ -832,8 +832,10 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
     { // ---- run mode: src/scan_encoder.hpp:53-73, src/scan_encoder_impl.hpp:249-275, src/scan_encoder_core.hpp:105-125
         // Codes go to the slot of the sample they belong to: the run-length code to the run's own slot, the code of the
         // interruption sample to the next slot of chain kInterruptChain (its events are these samples, in this order).
-        RunCtx rc[2] = {RunCtx{0, initial_a(t), 1, 0}, RunCtx{1, initial_a(t), 1, 0}};
-        int run_indices[ILV == 1 ? 4 : 1] = {}; // ILV_LINE: one RUNindex per component (src/scan_encoder_impl.hpp:126-137)
+        // (two named records selected by value and the RUNindex values packed into one word: an indexed pair / array of
+        // registers lives in scratch -- 48 bytes of private segment per lane until round 3)
+        RunCtx rc0{0, initial_a(t), 1, 0}, rc1{1, initial_a(t), 1, 0};
+        uint32_t run_indices = 0; // ILV_LINE: one RUNindex per component (src/scan_encoder_impl.hpp:126-137), 8 bits each
         const int mask = (1 << d.bits_per_sample) - 1;
         uint64_t* run_code = w.code + w.chain_base[0];
         uint8_t* run_len = w.len + w.chain_base[0];
@@ -853,7 +855,9 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
                 y = p / samples_per_line; // coded line
                 x0 = (p - y * samples_per_line) / (uint32_t)d.components;
             }
-            int& run_index = run_indices[ILV == 1 ? (p >> 18) & 3u : 0];
+            const uint32_t index_shift = ILV == 1 ? ((p >> 18) & 3u) * 8u : 0u;
+            int run_index = (int)((run_indices >> index_shift) & 0xFFu);
+            auto keep_run_index = [&] { run_indices = (run_indices & ~(0xFFu << index_shift)) | ((uint32_t)run_index << index_shift); };
             const uint32_t full = run;
             // run-length part: ones for every completed 2^J block, then either the end-of-line one or 0 + remainder
             uint64_t bits = 0;
@@ -875,6 +879,7 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
                 }
                 run_code[e] = bits;
                 run_len[e] = (uint8_t)len;
+                keep_run_index();
                 continue;
             }
             const int jb = run_j(run_index);
@@ -899,7 +904,7 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
                 {
                     const int sg = (rb[c] - ra[c]) < 0 ? -1 : 1;
                     const int err = error_value(t, (xv[c] - rb[c]) * sg);
-                    RunCtx& ctx = rc[0];
+                    RunCtx& ctx = rc0;
                     const int k = run_k(ctx);
                     const int map = run_map(ctx, err, k);
                     const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - map;
@@ -924,19 +929,25 @@ __global__ void __launch_bounds__(64) bias_chains(const ScanDesc* __restrict__ d
                 }
                 if (run_index > 0)
                     --run_index;
+                keep_run_index();
                 continue;
             }
             // type and error value of the interruption come from prepare_run_events
             const int which = (int)((p >> 17) & 1u);
             const int err = (int)(p << 15) >> 15;
-            RunCtx& ctx = rc[which];
+            RunCtx ctx = which ? rc1 : rc0;
             const int k = run_k(ctx);
             const int map = run_map(ctx, err, k);
             const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - map;
             const CodeWord c = golomb_word(t, k, em, t.limit - jb - 1);
             run_update(ctx, err, em, t.reset);
+            if (which)
+                rc1 = ctx;
+            else
+                rc0 = ctx;
             if (run_index > 0)
                 --run_index;
+            keep_run_index();
             if (full == 0)
             { // both codes belong to the same sample: J+1 zero bits followed by the interruption code (<= LIMIT bits)
                 run_code[e] = (bits << c.len) | c.bits;

@@ -13,6 +13,7 @@
 #include "scan_wave_decode.hip"
 #include "lossless_pipeline.hip"
 #include "block_stuffing.hip"
+#include "tile_pipeline.hip"
 #include "scan_fast_decode.hip"
 #include "scan_group_decode.hip"
 #include "group_launch.h"
@@ -536,12 +537,12 @@ size_t align_up(size_t v, size_t a)
     return (v + a - 1) / a * a;
 }
 
-// CHARLS_AMD_BLOCK_STUFFING=1: stage E in its block-parallel form (opt-in: see block_stuffing.hip).
+// Stage E in its block-parallel form (block_stuffing.hip) unless CHARLS_AMD_BLOCK_STUFFING=0 asks for stuff_scan.
 bool block_stuffing_enabled()
 {
     static const bool enabled = [] {
         const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING");
-        return env != nullptr && std::atoi(env) != 0;
+        return env == nullptr || std::atoi(env) != 0;
     }();
     return enabled;
 }
@@ -859,6 +860,248 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         (void)hipEventDestroy(e);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tile pipeline (tile_pipeline.hip): planar and line-interleaved lossless scans whose lines fit a tile.
+
+// CHARLS_AMD_TILE_PIPELINE=0 keeps such scans on the round-2 pipeline (for A/B measurements).
+bool tile_pipeline_enabled()
+{
+    static const bool enabled = [] {
+        const char* env = std::getenv("CHARLS_AMD_TILE_PIPELINE");
+        return env == nullptr || std::atoi(env) != 0;
+    }();
+    return enabled;
+}
+
+bool tile_pipeline_eligible(const ScanDesc& d)
+{
+    return tile_pipeline_enabled() && d.interleave_mode != 2 && d.width <= tile::kTileSamples;
+}
+
+// Work area of one scan: 10 B per sample (key / slot 2, record 4, code 4), the (tiles + 1) x 367 piece table, the job
+// states and the unstuffed stream.
+struct TileLayout
+{
+    size_t samples, lines, raw_bytes, max_jobs;
+    uint32_t lines_per_tile, tiles, job_events, warm_events;
+    size_t off_keyinv, off_seg, off_total, off_base, off_jobfirst, off_rec, off_code, off_jobs, off_bbase, off_raw, off_bits,
+        off_status, off_stuff, bytes;
+    TileLayout(const ScanDesc& d, size_t capacity_hint, uint32_t count)
+    {
+        lines = static_cast<size_t>(d.height) * (d.interleave_mode == 1 ? static_cast<size_t>(d.components) : 1);
+        samples = static_cast<size_t>(d.width) * lines;
+        lines_per_tile = std::max<uint32_t>(1, std::min<uint32_t>(tile::kTileLines, tile::kTileSamples / d.width));
+        tiles = static_cast<uint32_t>((lines + lines_per_tile - 1) / lines_per_tile);
+        // Jobs: every job pays warm_events of warm-up, so long jobs are cheaper; but ONE frame needs thousands of lanes to
+        // fill the chip.  Aim at a quarter of a million lanes per launch, between 1024 and 8192 events per job.
+        const char* env_job = std::getenv("CHARLS_AMD_JOB_EVENTS");
+        const char* env_warm = std::getenv("CHARLS_AMD_WARM_EVENTS");
+        uint64_t job = 1024;
+        while (job < 8192 && samples * count / (job * 2) >= (uint64_t{1} << 18))
+            job *= 2;
+        job_events = env_job ? static_cast<uint32_t>(std::max(16, std::atoi(env_job)) / 16 * 16) : static_cast<uint32_t>(job);
+        warm_events = env_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_warm))) : 1024u;
+        max_jobs = samples / job_events + pipe::kChains;
+        const size_t worst = worst_case_scan_bytes(d.width, static_cast<uint32_t>(lines), 1, d.bits_per_sample);
+        raw_bytes = align_up((capacity_hint < worst ? capacity_hint : worst) + 64, 16);
+        size_t o = 0;
+        auto take = [&](size_t n) {
+            const size_t at = o;
+            o = align_up(o + n, 256);
+            return at;
+        };
+        off_keyinv = take(samples * 2);
+        off_seg = take(static_cast<size_t>(tiles + 1) * pipe::kChains * 4);
+        off_total = take(pipe::kChains * 4);
+        off_base = take(pipe::kChains * 4);
+        off_jobfirst = take((pipe::kChains + 1) * 4);
+        off_rec = take((samples + tile::kSlack) * 4);
+        off_code = take((samples + tile::kSlack) * 4);
+        off_jobs = take(max_jobs * sizeof(tile::JobState));
+        off_bbase = take(static_cast<size_t>(tiles) * 8);
+        off_raw = take(raw_bytes);
+        off_bits = take(16);
+        off_status = take(8);
+        off_stuff = take(block_stuffing_enabled() ? (raw_bytes / pipe::kStuffChunk + 1) * pipe::kStuffWords * 4 : 0);
+        bytes = o;
+    }
+};
+
+template <typename S>
+void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
+{
+    const size_t budget = arena_budget(pipeline_arena().capacity());
+    // the layout depends on the number of scans of a pass only through the job size: settle on it for a full pass
+    TileLayout lay(proto, proto.stream_capacity, count);
+    size_t per_scan = lay.bytes + 2 * (sizeof(tile::Work) + sizeof(pipe::Work));
+    uint32_t resident = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, budget / per_scan)));
+    if (resident < count)
+    {
+        lay = TileLayout(proto, proto.stream_capacity, resident);
+        per_scan = lay.bytes + 2 * (sizeof(tile::Work) + sizeof(pipe::Work));
+        resident = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, budget / per_scan)));
+    }
+    uint8_t* arena = nullptr;
+    for (;;)
+    {
+        arena = static_cast<uint8_t*>(try_ensure(pipeline_arena(), per_scan * resident));
+        if (arena != nullptr || resident == 1)
+            break;
+        resident = (resident + 1) / 2;
+    }
+    if (arena == nullptr)
+    {
+        launch_encode_serial(d_descs, d_results, count, stream);
+        last_timings().count = 2;
+        return;
+    }
+    const uint32_t per_pass = resident;
+    const uint32_t passes = (count + per_pass - 1) / per_pass;
+    std::vector<std::vector<tile::Work>> works(passes);
+    std::vector<std::vector<pipe::Work>> stuff_works(passes);
+    std::vector<StageTimer> timers;
+    timers.reserve(passes);
+    // As in run_pipeline: the stuffing stage of a pass runs on a side stream under the next pass's stages A - C.
+    const bool overlap_stuffing = passes > 1;
+    hipStream_t stuff_stream = stream;
+    std::vector<hipEvent_t> packed, stuffed;
+    if (overlap_stuffing)
+    {
+        pipeline_lanes().ensure();
+        stuff_stream = pipeline_lanes().streams[0];
+        packed.resize(passes);
+        stuffed.resize(passes);
+        for (uint32_t pass = 0; pass < passes; ++pass)
+        {
+            hip_check(hipEventCreateWithFlags(&packed[pass], hipEventDisableTiming));
+            hip_check(hipEventCreateWithFlags(&stuffed[pass], hipEventDisableTiming));
+        }
+    }
+    static const bool attributes_set = [] {
+        // (the sort stage asks for more than the 64 KB of LDS a kernel gets by default)
+        const int lds = 160 * 1024;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        return true;
+    }();
+    (void)attributes_set;
+
+    for (uint32_t pass = 0; pass < passes; ++pass)
+    {
+        const uint32_t first = pass * per_pass;
+        const uint32_t n = std::min(per_pass, count - first);
+        hipStream_t s = stream;
+        const size_t copy = pass & 1u;
+        uint8_t* tables = arena + lay.bytes * per_pass;
+        auto* d_works = reinterpret_cast<tile::Work*>(tables) + copy * per_pass;
+        auto* d_stuff = reinterpret_cast<pipe::Work*>(tables + 2 * sizeof(tile::Work) * per_pass) + copy * per_pass;
+        works[pass].resize(n);
+        stuff_works[pass].resize(n);
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            uint8_t* base = arena + lay.bytes * i;
+            tile::Work& w = works[pass][i];
+            w.keyinv = reinterpret_cast<uint16_t*>(base + lay.off_keyinv);
+            w.seg = reinterpret_cast<uint32_t*>(base + lay.off_seg);
+            w.chain_total = reinterpret_cast<uint32_t*>(base + lay.off_total);
+            w.chain_base = reinterpret_cast<uint32_t*>(base + lay.off_base);
+            w.job_first = reinterpret_cast<uint32_t*>(base + lay.off_jobfirst);
+            w.rec = reinterpret_cast<uint32_t*>(base + lay.off_rec);
+            w.code = reinterpret_cast<uint32_t*>(base + lay.off_code);
+            w.jobs = reinterpret_cast<tile::JobState*>(base + lay.off_jobs);
+            w.blockbase = reinterpret_cast<uint64_t*>(base + lay.off_bbase);
+            w.raw = reinterpret_cast<uint32_t*>(base + lay.off_raw);
+            w.raw_words = lay.raw_bytes / 4;
+            w.total_bits = reinterpret_cast<uint64_t*>(base + lay.off_bits) + copy; // (zeroed by plan_chains)
+            w.status = reinterpret_cast<uint32_t*>(base + lay.off_status) + copy;
+            w.lines_per_tile = lay.lines_per_tile;
+            w.tiles = lay.tiles;
+            w.job_events = lay.job_events;
+            w.warm_events = lay.warm_events;
+            pipe::Work& sw = stuff_works[pass][i];
+            std::memset(&sw, 0, sizeof sw);
+            sw.raw = w.raw;
+            sw.raw_words = w.raw_words;
+            sw.total_bits = w.total_bits;
+            sw.status = w.status;
+            sw.stuff_tables = reinterpret_cast<uint32_t*>(base + lay.off_stuff);
+        }
+        hip_check(hipMemcpyAsync(d_works, works[pass].data(), sizeof(tile::Work) * n, hipMemcpyHostToDevice, s));
+        hip_check(hipMemcpyAsync(d_stuff, stuff_works[pass].data(), sizeof(pipe::Work) * n, hipMemcpyHostToDevice, s));
+
+        const ScanDesc* descs = d_descs + first;
+        const uint32_t tiles_grid = 8 * ((lay.tiles + 7) / 8);
+        const size_t lds_a = tile::analyze_lds_bytes(proto.width);
+        const size_t lds_b = tile::sort_lds_bytes(proto.width, lay.lines_per_tile);
+        timers.emplace_back(s);
+        StageTimer& t = timers.back();
+        t.mark();
+        if (proto.interleave_mode == 1)
+            hipLaunchKernelGGL((tile::analyze_tiles<S, 1>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_a, s, descs, d_works);
+        else
+            hipLaunchKernelGGL((tile::analyze_tiles<S, 0>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_a, s, descs, d_works);
+        t.mark();
+        hipLaunchKernelGGL(tile::plan_chains, dim3(n), dim3(1024), 0, s, descs, d_works);
+        if (proto.interleave_mode == 1)
+            hipLaunchKernelGGL((tile::sort_tiles<S, 1>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_b, s, descs, d_works);
+        else
+            hipLaunchKernelGGL((tile::sort_tiles<S, 0>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_b, s, descs, d_works);
+        t.mark();
+        hipLaunchKernelGGL((tile::walk_jobs<S>), dim3(static_cast<uint32_t>((lay.max_jobs + 63) / 64), n), dim3(64), 0, s, descs, d_works);
+        hipLaunchKernelGGL((tile::settle_chains<S>), dim3((n * pipe::kChains + 63) / 64), dim3(64), 0, s, descs, d_works, n);
+        if (proto.interleave_mode == 1)
+            hipLaunchKernelGGL((tile::code_runs<S, 1>), dim3((n + 63) / 64), dim3(64), 0, s, descs, d_works, n);
+        else
+            hipLaunchKernelGGL((tile::code_runs<S, 0>), dim3((n + 63) / 64), dim3(64), 0, s, descs, d_works, n);
+        t.mark();
+        if (overlap_stuffing && pass > 0)
+            hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
+        hipLaunchKernelGGL(tile::clear_pack_state, dim3(64, n), dim3(256), 0, s, d_works,
+                           static_cast<uint32_t>(lay.off_raw + lay.raw_bytes - lay.off_bbase));
+        hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::kThreads), tile::pack_lds_bytes(), s, descs, d_works);
+        t.mark();
+        if (overlap_stuffing)
+        {
+            hip_check(hipEventRecord(packed[pass], s));
+            hip_check(hipStreamWaitEvent(stuff_stream, packed[pass], 0));
+        }
+        t.mark_on(stuff_stream);
+        if (block_stuffing_enabled())
+        {
+            const uint32_t chunk_waves = static_cast<uint32_t>((lay.raw_bytes / pipe::kStuffChunk + 1 + 63) / 64);
+            hipLaunchKernelGGL(pipe::stuff_survey, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, d_stuff);
+            hipLaunchKernelGGL(pipe::stuff_resolve, dim3(n), dim3(64), 0, stuff_stream, d_stuff);
+            hipLaunchKernelGGL(pipe::stuff_emit, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, descs, d_stuff, d_results + first);
+        }
+        else
+            hipLaunchKernelGGL(pipe::stuff_scan, dim3(n), dim3(64), 0, stuff_stream, descs, d_stuff, d_results + first);
+        t.mark_on(stuff_stream);
+        if (overlap_stuffing)
+            hip_check(hipEventRecord(stuffed[pass], stuff_stream));
+        hip_check(hipGetLastError());
+    }
+    if (overlap_stuffing)
+        hip_check(hipStreamWaitEvent(stream, stuffed[passes - 1], 0));
+    hip_check(hipStreamSynchronize(stream)); // the host copies of the work descriptors and the timers go out of scope
+    Timings& tm = last_timings();
+    double stage_ms[5] = {0, 0, 0, 0, 0};
+    for (StageTimer& t : timers)
+    {
+        for (int i = 0; i < 4; ++i)
+            stage_ms[i] += t.between(i, i + 1);
+        stage_ms[4] += t.between(5, 6);
+    }
+    for (int i = 0; i < 5; ++i)
+        tm.values[2 + i] = stage_ms[i];
+    tm.count = 7;
+    for (hipEvent_t e : packed)
+        (void)hipEventDestroy(e);
+    for (hipEvent_t e : stuffed)
+        (void)hipEventDestroy(e);
+}
+
 } // namespace
 
 bool pipeline_eligible(const ScanDesc& d) noexcept
@@ -875,6 +1118,8 @@ bool pipeline_eligible(const ScanDesc& d) noexcept
     const uint64_t samples = static_cast<uint64_t>(d.width) * d.height * static_cast<uint64_t>(d.components);
     if (samples >= (uint64_t{1} << 31) || d.width > 65536)
         return false;
+    if (d.reset == 0 && samples >= (uint64_t{1} << 23))
+        return false; // N never halves (RESET = 256 m through the reference's uint8): it would outgrow the 24-bit multiplies of the chain stage
     if (d.bits_per_sample > 8 && ((reinterpret_cast<uintptr_t>(d.pixels) | d.pixel_stride) & 1u) != 0)
         return false;
     return true;
@@ -985,7 +1230,14 @@ void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_resul
             launch_encode_serial(d_descs, d_results, count, stream);
         return;
     }
-    if (proto.bits_per_sample > 8)
+    if (tile_pipeline_eligible(proto))
+    {
+        if (proto.bits_per_sample > 8)
+            run_tile_pipeline<uint16_t>(proto, d_descs, d_results, count, stream);
+        else
+            run_tile_pipeline<uint8_t>(proto, d_descs, d_results, count, stream);
+    }
+    else if (proto.bits_per_sample > 8)
         run_pipeline<uint16_t>(proto, d_descs, d_results, count, stream);
     else
         run_pipeline<uint8_t>(proto, d_descs, d_results, count, stream);

@@ -1,0 +1,1025 @@
+// tile_pipeline.hip -- round-3 parallel JPEG-LS encoder for lossless single-component and line-interleaved scans.
+//
+// Same idea as lossless_pipeline.hip (in lossless mode everything except the adaptive statistics is a pure function of
+// the image, reference src/scan_encoder_impl.hpp:109-144), rebuilt around two observations:
+//
+//  1. HBM traffic.  The round-2 pipeline moved 1.48 GB per 4096 x 4096 frame (61 x the algorithmic bytes): 6 B/sample of
+//     analysis results written and read back, 4-byte records scattered line by line to ~30 chains per 64 samples (every
+//     32-byte sector written several times), 8-byte codes + 1-byte lengths + a 4-byte slot map gathered back.  Here the
+//     image is cut into TILES of up to kTileSamples samples (whole lines); a tile's events are sorted by chain INSIDE LDS
+//     and leave as contiguous pieces (one per chain, hundreds of bytes), the slot map is a 2-byte tile-local index that
+//     overwrites the 2-byte key in place, and a code is one 4-byte word.  10 B/sample of work area instead of 21.
+//
+//  2. The chain floor.  {A,B,C,N} of a context is a serial recurrence over the context's samples; round 2
+//     walked every chain with ONE lane (58 ms for the 1.09 M events of the longest chain of a test frame, whatever the
+//     batch).  But the recurrence FORGETS: N is a function of the event index alone, C is a feedback loop that pulls B into
+//     (-N, 0], A is halved every RESET/2 events.  Two walks of the same events from different states meet after a few
+//     hundred events and are identical from then on.  So a chain is cut into JOBS of job_events events; every job is
+//     walked by its own lane from a guessed state warm_events before its first event (no output), records the state in
+//     which it reaches its first event and the state in which it ends; settle_chains then checks, chain by chain, that
+//     every job started in exactly the state its predecessor ended in.  Where that holds -- everywhere, on anything but
+//     noise-like data (tools/spec_convergence.c: 0 of 16 253 jobs of the test frame disagree with a warm-up of 1024
+//     events) -- the job's codes are the sequential ones by construction; a job that disagrees is walked again from the
+//     true state by the settling lane, so the result is exact in every case and only the time depends on the data.
+//     One walker computes k, the error correction and the Golomb word as well: bias_chains + code_events became one pass.
+//
+// Stages (planar scan; ILV_LINE: "coded lines", see lossless_pipeline.hip):
+//   A  analyze_tiles   one workgroup per tile, one wavefront per line at a time: chain id + sign of every sample (key,
+//                      2 B), run-mode segmentation as a carry chain over ballot masks, events per (tile, chain)
+//   B1 plan_chains     per scan: exclusive prefix over tiles per chain -> where each tile's piece of each chain goes;
+//                      chain bases; jobs per chain
+//   B2 sort_tiles      one workgroup per tile: stable ranks (ballot per key bit, no order-dependent atomics), records
+//                      {x, Px, sign} into LDS in (chain, line, column) order, out as pieces; key -> tile-local slot
+//   C1 walk_jobs       one LANE per job: warm-up, then record -> code word, in chain order
+//   C2 settle_chains   one lane per chain: job boundaries checked, disagreeing jobs re-walked
+//   C3 code_runs       one lane per scan: RUNindex and the two run-interruption contexts (serial, few events)
+//   D  pack_tiles      one workgroup per tile: the tile's codes back into LDS piece by piece, gathered in raster order
+//                      through the 2-byte slots, concatenated MSB-first; bit offset of a tile by chained look-back
+//   E  stuff_scan / block_stuffing.hip  (unchanged)
+//
+// Output is byte-identical to scan_encoder::encode_scan.  No MFMA: nothing here is a contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lossless_pipeline.hip"
+
+namespace jls {
+namespace tile {
+
+using pipe::kChains;
+using pipe::kInterruptChain;
+using pipe::kNoEvent;
+using pipe::kStatusInvalid;
+using pipe::kZeroContextChain;
+
+constexpr uint32_t kTileSamples = 8192;  // samples of a tile (whole lines); also the widest line the pipeline takes
+constexpr uint32_t kTileLines = 16;      // lines of a tile at most (per-line counters in LDS)
+constexpr uint32_t kThreads = 256;       // workgroup of the tile kernels
+constexpr uint32_t kWaves = kThreads / 64;
+constexpr uint16_t kNoLocalSlot = 0xFFFF;
+constexpr uint32_t kChainPad = 16;       // chains start on multiples of 16 records (one 64-byte line)
+constexpr uint32_t kSlack = kChains * kChainPad + 64; // spare records behind rec / code: padding + read-ahead of the walkers
+constexpr uint32_t kPlanGroups = 16;     // plan_chains sums the tiles of a scan in this many groups
+constexpr uint32_t kRunTag = 1u << 31;   // code word of a run-length code: ones : 6 | tail length : 5 | tail : 20
+
+// State of a job at its first event (after the warm-up) and behind its last one (N is a function of the event index);
+// bad: an event of the job would make the reference raise invalid_data.
+struct JobState
+{
+    int32_t in_a, in_b, in_c, out_a, out_b, out_c;
+    uint32_t bad, pad;
+};
+
+struct Work
+{
+    uint16_t* keyinv;      // [lines * width] A: chain | sign << 9 or kNoEvent; after B2: tile-local slot or kNoLocalSlot
+    uint32_t* seg;         // [(tiles + 1) * kChains] A: events per (tile, chain); B1: first slot of the tile's piece; row `tiles` = chain ends
+    uint32_t* chain_total; // [kChains]
+    uint32_t* chain_base;  // [kChains]
+    uint32_t* job_first;   // [kChains + 1] first job of the chain (chains coded by walk_jobs), number of jobs at the end
+    uint32_t* rec;         // [samples + kSlack] records in chain order
+    uint32_t* code;        // [samples + kSlack] code words in chain order (run starts: interruption record until C3)
+    JobState* jobs;        // [samples / job_events + kChains]
+    uint64_t* blockbase;   // [tiles] look-back states of pack_tiles; followed by raw (cleared together)
+    uint32_t* raw;
+    uint64_t raw_words;
+    uint64_t* total_bits;
+    uint32_t* status;
+    uint32_t lines_per_tile, tiles, job_events, warm_events;
+};
+
+JLS_DEV uint32_t tile_of_block(uint32_t block, uint32_t tiles) // XCD-aware: workgroup b runs on XCD b % 8; each XCD gets a band of tiles
+{
+    const uint32_t band = (tiles + 7) / 8;
+    const uint32_t t = (block & 7u) * band + (block >> 3);
+    return (block >> 3) < band && t < tiles ? t : tiles;
+}
+
+// Exclusive prefix sum of n <= 512 values held one or two per thread (value of index threadIdx.x and threadIdx.x + 256);
+// s_tmp: kWaves + 1 words.  All 256 threads call it.
+JLS_DEV void block_exclusive_scan(uint32_t& lo, uint32_t& hi, uint32_t* s_tmp)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (int half = 0; half < 2; ++half)
+    {
+        uint32_t& v = half == 0 ? lo : hi;
+        uint32_t incl = v;
+        for (int delta = 1; delta < 64; delta <<= 1)
+        {
+            const uint32_t up = __shfl_up(incl, delta);
+            if (lane >= delta)
+                incl += up;
+        }
+        __syncthreads(); // s_tmp free again
+        if (lane == 63)
+            s_tmp[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int w2 = 0; w2 < wave; ++w2)
+            before += s_tmp[w2];
+        uint32_t all = 0;
+        for (int w2 = 0; w2 < (int)kWaves; ++w2)
+            all += s_tmp[w2];
+        v = before + incl - v;
+        carry += all;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A: grid (8 * ceil(tiles / 8), scans) x 256.  LDS: hist[kChains] | gradient table (512 B) | per wave: eq[chunks], q0[chunks].
+template <typename S, int ILV>
+__global__ void __launch_bounds__(kThreads) analyze_tiles(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    JLS_DYNAMIC_LDS(smem);
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const Traits t = make_traits(d);
+    const uint32_t tile = tile_of_block(blockIdx.x, w.tiles);
+    if (tile >= w.tiles)
+        return;
+    const uint32_t lines = ILV == 1 ? pipe::coded_lines(d) : d.height;
+    const uint32_t step = ILV == 1 ? pipe::line_step(d) : 1u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t width = d.width;
+    const uint32_t chunks = (width + 63) / 64;
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem);
+    unsigned char* s_grad = reinterpret_cast<unsigned char*>(s_hist + kChains + 1);
+    uint64_t* s_eq = reinterpret_cast<uint64_t*>(s_grad + pipe::kGradientTable) + (size_t)wave * 2 * chunks;
+    uint64_t* s_q0 = s_eq + chunks;
+    const int mask = (1 << d.bits_per_sample) - 1;
+
+    for (uint32_t c = threadIdx.x; c < (uint32_t)kChains; c += kThreads)
+        s_hist[c] = 0;
+    if (sizeof(S) == 1)
+        for (uint32_t q = threadIdx.x; q < 511; q += kThreads)
+            s_grad[q] = (unsigned char)(quantize(t, (int)q - 255) + 4);
+    __syncthreads();
+
+    const uint32_t first_line = tile * w.lines_per_tile;
+    const uint32_t tile_lines = lines - first_line < w.lines_per_tile ? lines - first_line : w.lines_per_tile;
+    for (uint32_t r = wave; r < tile_lines; r += kWaves)
+    {
+        const uint32_t y = first_line + r; // coded line
+        // edge samples of the line (src/scan_codec.hpp:189-195 and the two-line ping-pong of src/scan_encoder_impl.hpp:55-106)
+        const int edge_a = y >= step ? pipe::load_sample<S, ILV>(d, y - step, 0, mask) : 0;         // cur[0]  = prev[1]
+        const int edge_c = y >= 2 * step ? pipe::load_sample<S, ILV>(d, y - 2 * step, 0, mask) : 0; // prev[0]
+        uint16_t* key_row = w.keyinv + (size_t)y * width;
+        JLS_LOCKSTEP();
+        // ---- pass 1: every sample as if coded in regular mode; equality / zero-context masks per 64-sample chunk
+        for (uint32_t k = 0; k < chunks; ++k)
+        {
+            const uint32_t x = k * 64 + lane;
+            bool eq = false, q0 = false;
+            if (x < width)
+            {
+                const int v = pipe::load_sample<S, ILV>(d, y, x, mask);
+                const int ra = x > 0 ? pipe::load_sample<S, ILV>(d, y, x - 1, mask) : edge_a;
+                int rb = 0, rc = 0, rd = 0;
+                if (y >= step)
+                {
+                    rb = pipe::load_sample<S, ILV>(d, y - step, x, mask);
+                    rc = x > 0 ? pipe::load_sample<S, ILV>(d, y - step, x - 1, mask) : edge_c;
+                    rd = pipe::load_sample<S, ILV>(d, y - step, x + 1 < width ? x + 1 : width - 1, mask);
+                }
+                else
+                    rc = x > 0 ? 0 : edge_c;
+                const int qs = sizeof(S) == 1
+                                   ? ((int)s_grad[rd - rb + 255] * 9 + (int)s_grad[rb - rc + 255]) * 9 + (int)s_grad[rc - ra + 255] - 364
+                                   : context_id(t, ra, rb, rc, rd);
+                const int sg = qs >> 31;
+                const int ctx = (qs ^ sg) - sg;
+                key_row[x] = (uint16_t)(ctx | ((sg & 1) << 9));
+                eq = v == ra;
+                q0 = qs == 0;
+            }
+            const unsigned long long m_eq = __ballot(eq);
+            const unsigned long long m_q0 = __ballot(q0);
+            if (lane == 0)
+            {
+                s_eq[k] = m_eq;
+                s_q0[k] = m_q0;
+            }
+        }
+        JLS_LOCKSTEP();
+        // ---- pass 2: run-mode state before every sample.  s' = eq & (s | q0) is a carry chain: generate = eq & q0,
+        // propagate = eq, so one 64-bit addition per chunk resolves 64 samples (src/scan_encoder_impl.hpp:249-275).
+        unsigned long long carry = 0;
+        for (uint32_t k = 0; k < chunks; ++k)
+        {
+            const unsigned long long a = s_eq[k];
+            const unsigned long long b = s_eq[k] & s_q0[k];
+            const unsigned long long sum = a + b + carry;
+            const unsigned long long st = sum ^ a ^ b; // bit i: in-run state before sample i
+            carry = (((a & b) | ((a | b) & st)) >> 63) & 1ull;
+            const uint32_t x = k * 64 + lane;
+            if (x < width)
+            {
+                const bool s = (st >> lane) & 1ull;
+                const bool q0 = (s_q0[k] >> lane) & 1ull;
+                const bool eq = (a >> lane) & 1ull;
+                if (!(s || q0))
+                    atomicAdd(&s_hist[key_row[x] & 0x1FF], 1u); // regular sample, key already written by this lane
+                else if (s && eq)
+                    key_row[x] = kNoEvent; // inside a run
+                else if (s)
+                { // the sample that ends a run started earlier: coded by the run lane, owns a slot of its own
+                    key_row[x] = (uint16_t)kInterruptChain;
+                    atomicAdd(&s_hist[kInterruptChain], 1u);
+                }
+                else
+                { // a run starts here (possibly of length 0); its length is the number of kNoEvent keys that follow
+                    key_row[x] = 0;
+                    atomicAdd(&s_hist[0], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < (uint32_t)kChains; c += kThreads)
+        w.seg[(size_t)tile * kChains + c] = s_hist[c];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// B1: grid (scans) x 1024.  Column-wise exclusive prefix of the (tiles x kChains) count matrix: where the piece of every
+// (tile, chain) starts in rec / code.  The tiles are summed in kPlanGroups groups so that the loads of a thread do not form
+// one long dependent chain.
+__global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    __shared__ uint32_t s_part[kPlanGroups][kChains + 1];
+    __shared__ uint32_t s_base[kChains + 1];
+    const Work w = works[blockIdx.x];
+    const uint32_t tiles = w.tiles;
+    const uint32_t per_group = (tiles + kPlanGroups - 1) / kPlanGroups;
+    const uint32_t pairs = kPlanGroups * (uint32_t)kChains;
+    for (uint32_t p = threadIdx.x; p < pairs; p += 1024)
+    {
+        const uint32_t g = p / kChains, c = p % kChains;
+        const uint32_t t0 = g * per_group, t1 = t0 + per_group < tiles ? t0 + per_group : tiles;
+        uint32_t sum = 0;
+        for (uint32_t t = t0; t < t1; ++t)
+            sum += w.seg[(size_t)t * kChains + c];
+        s_part[g][c] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)kChains)
+    {
+        const uint32_t c = threadIdx.x;
+        uint32_t running = 0;
+        for (uint32_t g = 0; g < kPlanGroups; ++g)
+        {
+            const uint32_t n = s_part[g][c];
+            s_part[g][c] = running;
+            running += n;
+        }
+        w.chain_total[c] = running;
+        s_base[c] = running;
+    }
+    if (threadIdx.x == 1023)
+    { // the two result words of the later stages start at zero
+        *w.total_bits = 0;
+        *w.status = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    { // 367 values: a serial scan is cheaper than its synchronisation
+        uint32_t acc = 0, jobs = 0;
+        for (int c = 0; c < kChains; ++c)
+        {
+            const uint32_t n = s_base[c];
+            s_base[c] = acc;
+            w.chain_base[c] = acc;
+            acc += (n + kChainPad - 1) / kChainPad * kChainPad;
+            w.job_first[c] = jobs;
+            if (c != 0 && c != kInterruptChain)
+                jobs += (n + w.job_events - 1) / w.job_events;
+        }
+        w.job_first[kChains] = jobs;
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < pairs; p += 1024)
+    {
+        const uint32_t g = p / kChains, c = p % kChains;
+        const uint32_t t0 = g * per_group, t1 = t0 + per_group < tiles ? t0 + per_group : tiles;
+        uint32_t running = s_base[c] + s_part[g][c];
+        for (uint32_t t = t0; t < t1; ++t)
+        {
+            const uint32_t n = w.seg[(size_t)t * kChains + c];
+            w.seg[(size_t)t * kChains + c] = running;
+            running += n;
+        }
+        if (t1 == tiles && t0 < t1)
+            w.seg[(size_t)tiles * kChains + c] = running;
+    }
+    if (tiles == 0 && threadIdx.x < (uint32_t)kChains)
+        w.seg[threadIdx.x] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Records.  Samples of up to 8 bits: x | Px << 16 | sign << 31.  Wider samples: what the walker needs of x and Px is
+// d = sign * (x - Px) mod 2^16 and how far Px is from the end of the sample range it is nearer to (the bias C only ever
+// moves the prediction by up to 128, so only one end can clip it): d | room << 16 | side << 24 | sign << 31 with
+// room = min(distance, 255), side = 1 for the upper end.  src/scan_encoder_core.hpp:57-67.
+template <typename S>
+JLS_DEV uint32_t make_record(int x, int px, int sign_bit, int maxval)
+{
+    if (sizeof(S) == 1)
+        return (uint32_t)x | ((uint32_t)px << 16) | ((uint32_t)sign_bit << 31);
+    const int d = sign_bit ? px - x : x - px;
+    const int lo = px, hi = maxval - px;
+    const int side = hi < lo ? 1 : 0;
+    int room = side ? hi : lo;
+    room = room > 255 ? 255 : room;
+    return ((uint32_t)d & 0xFFFFu) | ((uint32_t)room << 16) | ((uint32_t)side << 24) | ((uint32_t)sign_bit << 31);
+}
+
+// B2: grid (8 * ceil(tiles / 8), scans) x 256.
+// LDS: stage[kTileSamples] u32 | keys[kTileSamples] u16 | lineoff[lines_per_tile][kChains] u32 | tileoff[kChains] | delta[kChains] |
+//      per wave: noev[chunks] u64, lead[chunks + 1] u32 | scan scratch
+template <typename S, int ILV>
+__global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    JLS_DYNAMIC_LDS(smem);
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const Traits t = make_traits(d);
+    const uint32_t tile = tile_of_block(blockIdx.x, w.tiles);
+    if (tile >= w.tiles)
+        return;
+    const uint32_t lines = ILV == 1 ? pipe::coded_lines(d) : d.height;
+    const uint32_t step = ILV == 1 ? pipe::line_step(d) : 1u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t width = d.width;
+    const uint32_t chunks = (width + 63) / 64;
+    uint32_t* s_stage = reinterpret_cast<uint32_t*>(smem);
+    uint16_t* s_key = reinterpret_cast<uint16_t*>(s_stage + kTileSamples);
+    uint32_t* s_lineoff = reinterpret_cast<uint32_t*>(s_key + kTileSamples); // [kTileLines][kChains]
+    uint32_t* s_tileoff = s_lineoff + w.lines_per_tile * kChains;            // first local slot of the chain
+    uint32_t* s_count = s_tileoff + kChains + 1;                             // events of the chain in this tile
+    uint32_t* s_global = s_count + kChains + 1;                              // first global slot of the tile's piece
+    uint32_t* s_tmp = s_global + kChains + 1;                                // kWaves + 1
+    uint64_t* s_noev = reinterpret_cast<uint64_t*>(s_tmp + 8) + (size_t)wave * chunks;
+    uint32_t* s_lead = reinterpret_cast<uint32_t*>(reinterpret_cast<uint64_t*>(s_tmp + 8) + (size_t)kWaves * chunks) + (size_t)wave * (chunks + 1);
+    const int mask = (1 << d.bits_per_sample) - 1;
+
+    const uint32_t first_line = tile * w.lines_per_tile;
+    const uint32_t tile_lines = lines - first_line < w.lines_per_tile ? lines - first_line : w.lines_per_tile;
+    const uint32_t tile_samples = tile_lines * width;
+    const uint16_t* key_tile = w.keyinv + (size_t)first_line * width;
+
+    for (uint32_t i = threadIdx.x; i < w.lines_per_tile * (uint32_t)kChains; i += kThreads)
+        s_lineoff[i] = 0;
+    __syncthreads();
+    // ---- P1: keys into LDS, events per (line, chain)
+    for (uint32_t r = wave; r < tile_lines; r += kWaves)
+        for (uint32_t k = 0; k < chunks; ++k)
+        {
+            const uint32_t x = k * 64 + lane;
+            if (x < width)
+            {
+                const uint16_t key = key_tile[(size_t)r * width + x];
+                s_key[r * width + x] = key;
+                if (key != kNoEvent)
+                    atomicAdd(&s_lineoff[r * kChains + (key & 0x1FF)], 1u);
+            }
+        }
+    __syncthreads();
+    // ---- offsets: chains in order, inside a chain the lines in order
+    {
+        uint32_t n[2] = {0, 0};
+        for (int half = 0; half < 2; ++half)
+        {
+            const uint32_t c = threadIdx.x + (uint32_t)half * kThreads;
+            if (c < (uint32_t)kChains)
+                for (uint32_t r = 0; r < tile_lines; ++r)
+                    n[half] += s_lineoff[r * kChains + c];
+        }
+        uint32_t off[2] = {n[0], n[1]};
+        block_exclusive_scan(off[0], off[1], s_tmp);
+        for (int half = 0; half < 2; ++half)
+        {
+            const uint32_t c = threadIdx.x + (uint32_t)half * kThreads;
+            if (c < (uint32_t)kChains)
+            {
+                s_tileoff[c] = off[half];
+                s_count[c] = n[half];
+                s_global[c] = w.seg[(size_t)tile * kChains + c];
+                uint32_t running = off[half];
+                for (uint32_t r = 0; r < tile_lines; ++r)
+                {
+                    const uint32_t m = s_lineoff[r * kChains + c];
+                    s_lineoff[r * kChains + c] = running;
+                    running += m;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- P2: ranks, records
+    for (uint32_t r = wave; r < tile_lines; r += kWaves)
+    {
+        const uint32_t y = first_line + r;
+        const uint16_t* keys = s_key + r * width;
+        uint32_t* lineoff = s_lineoff + r * kChains;
+        JLS_LOCKSTEP();
+        // samples inside runs, per chunk; lead[k] = number of such samples from the first sample of chunk k on
+        for (uint32_t k = 0; k < chunks; ++k)
+        {
+            const uint32_t x = k * 64 + lane;
+            const unsigned long long m = __ballot(x < width && keys[x] == kNoEvent);
+            if (lane == 0)
+                s_noev[k] = m;
+        }
+        JLS_LOCKSTEP();
+        if (lane == 0)
+        {
+            uint32_t lead = 0;
+            s_lead[chunks] = 0;
+            for (uint32_t k = chunks; k-- > 0;)
+            {
+                const unsigned long long m = s_noev[k];
+                lead = m == ~0ull ? 64 + lead : (uint32_t)__ffsll(~m) - 1;
+                s_lead[k] = lead;
+            }
+        }
+        JLS_LOCKSTEP();
+        const int edge_a = y >= step ? pipe::load_sample<S, ILV>(d, y - step, 0, mask) : 0;
+        const int edge_c = y >= 2 * step ? pipe::load_sample<S, ILV>(d, y - 2 * step, 0, mask) : 0;
+        for (uint32_t k = 0; k < chunks; ++k)
+        {
+            const uint32_t x = k * 64 + lane;
+            const uint16_t key = x < width ? keys[x] : kNoEvent;
+            const bool has = key != kNoEvent;
+            const uint32_t chain = key & 0x1FFu;
+            // stable rank among the lanes of the same chain: nine ballots, one per key bit
+            unsigned long long same = __ballot(has);
+#pragma unroll
+            for (int b = 0; b < 9; ++b)
+            {
+                const bool bit = ((chain >> b) & 1u) != 0;
+                const unsigned long long bal = __ballot(bit);
+                same &= bit ? bal : ~bal;
+            }
+            const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            uint32_t slot = 0;
+            JLS_LOCKSTEP();
+            if (has)
+                slot = lineoff[chain] + rank;
+            JLS_LOCKSTEP();
+            if (has && rank == 0)
+                lineoff[chain] += (uint32_t)__popcll(same);
+            JLS_LOCKSTEP();
+            if (has)
+            {
+                uint32_t record = 0;
+                if (chain == 0)
+                { // run start: length | end-of-line << 31; what the run lane needs of the interruption sample goes to code[]
+                    const int v = pipe::load_sample<S, ILV>(d, y, x, mask);
+                    const int ra = x > 0 ? pipe::load_sample<S, ILV>(d, y, x - 1, mask) : edge_a;
+                    uint32_t run = 0;
+                    if (v == ra)
+                    {
+                        const unsigned long long after = lane == 63 ? 0ull : s_noev[k] >> (lane + 1);
+                        const uint32_t rest = 63u - (uint32_t)lane;
+                        uint32_t n = (uint32_t)__ffsll(~after) - 1;
+                        if (n >= rest)
+                            n = rest + s_lead[k + 1];
+                        run = 1 + n;
+                    }
+                    const uint32_t xi = x + run;
+                    const bool eol = xi >= width;
+                    record = run | ((uint32_t)eol << 31);
+                    uint32_t packed = ILV == 1 ? (y % step) << 18 : 0u;
+                    if (!eol)
+                    { // src/scan_encoder_core.hpp:105-125: type and error value of the interruption are functions of the image
+                        const int xv = pipe::load_sample<S, ILV>(d, y, xi, mask);
+                        const int ia = xi > 0 ? pipe::load_sample<S, ILV>(d, y, xi - 1, mask) : edge_a;
+                        const int ib = y >= step ? pipe::load_sample<S, ILV>(d, y - step, xi, mask) : 0;
+                        const int which = ia == ib ? 1 : 0;
+                        const int err = which ? error_value(t, xv - ia) : error_value(t, (xv - ib) * ((ib - ia) < 0 ? -1 : 1));
+                        packed |= ((uint32_t)err & 0x1FFFFu) | ((uint32_t)which << 17);
+                    }
+                    w.code[s_global[0] + (slot - s_tileoff[0])] = packed;
+                }
+                else if (chain != (uint32_t)kInterruptChain)
+                {
+                    const int v = pipe::load_sample<S, ILV>(d, y, x, mask);
+                    const int ra = x > 0 ? pipe::load_sample<S, ILV>(d, y, x - 1, mask) : edge_a;
+                    int rb = 0, rc = 0;
+                    if (y >= step)
+                    {
+                        rb = pipe::load_sample<S, ILV>(d, y - step, x, mask);
+                        rc = x > 0 ? pipe::load_sample<S, ILV>(d, y - step, x - 1, mask) : edge_c;
+                    }
+                    else
+                        rc = x > 0 ? 0 : edge_c;
+                    record = make_record<S>(v, med3(ra + rb - rc, ra, rb), (key >> 9) & 1, t.maxval);
+                }
+                s_stage[slot] = record;
+            }
+            if (x < width)
+                w.keyinv[(size_t)y * width + x] = has ? (uint16_t)slot : kNoLocalSlot;
+        }
+    }
+    __syncthreads();
+    // ---- P3: pieces out (the interruption chain has no records)
+    for (uint32_t c = wave; c < (uint32_t)kChains; c += kWaves)
+    {
+        if (c == (uint32_t)kInterruptChain)
+            continue;
+        const uint32_t n = s_count[c], from = s_tileoff[c], to = s_global[c];
+        for (uint32_t i = lane; i < n; i += 64)
+            w.rec[to + i] = s_stage[from + i];
+    }
+    (void)tile_samples;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C: the regular-mode recurrence, src/scan_encoder_core.hpp:40-103 + src/regular_mode_context.hpp:45-136, one event.
+struct Chain
+{
+    int a, b, c, n;
+    uint32_t bad;
+};
+
+// N before event i of a chain (it counts 1..RESET, then cycles RESET/2 + 1 .. RESET).
+JLS_DEV int chain_n_before(uint32_t i, uint32_t reset)
+{
+    if (reset == 0 || i < reset)
+        return (int)(i + 1);
+    const uint32_t half = reset >> 1, period = reset - half;
+    return (int)(half + 1 + (i - reset) % period);
+}
+
+template <typename S>
+JLS_DEV uint32_t code_event(Chain& s, uint32_t rec, const Traits& t)
+{
+    const int sgn = ((int)rec >> 31) | 1;
+    int err;
+    if (sizeof(S) == 1)
+    {
+        const int px = med3(mad24(s.c, sgn, (int)((rec >> 16) & 0x7FFFu)), 0, t.maxval);
+        err = sign_extend(__mul24((int)(rec & 0xFFFFu) - px, sgn), t.bpp);
+    }
+    else
+    {
+        const int room = (int)((rec >> 16) & 0xFFu);
+        const int sc = __mul24(s.c, sgn);
+        const int delta = (rec >> 24) & 1u ? (sc < room ? sc : room) : (sc > -room ? sc : -room);
+        err = sign_extend((int)(rec & 0xFFFFu) - __mul24(delta, sgn), t.bpp);
+    }
+    int k = regular_k(RegCtx{s.a, 0, 0, s.n});
+    s.bad |= (uint32_t)(k >= 16);
+    k = k > 15 ? 15 : k;
+    const int corr = k == 0 ? ((2 * s.b + s.n - 1) >> 31) : 0;
+    const pipe::CodeWord cw = pipe::golomb_word(t, k, map_error(corr ^ err), t.limit);
+    // A.12 / A.13 in the median form of lossless_pipeline.hip
+    s.a += err < 0 ? -err : err;
+    s.bad |= (uint32_t)(s.a >= (1 << 24));
+    int tb = s.b + err;
+    if (s.n == t.reset)
+    {
+        s.a >>= 1;
+        tb >>= 1;
+        s.n >>= 1;
+    }
+    s.n += 1;
+    const int minus_delta = 1 - med3(tb, 0, 1) - med3(tb + s.n, 0, 1);
+    s.b = med3(mad24(minus_delta, s.n, tb), 1 - s.n, 0);
+    s.c = med3(s.c - minus_delta, -128, 127);
+    return ((uint32_t)cw.len << 24) | (uint32_t)cw.bits;
+}
+
+typedef uint32_t u32x4 __attribute__((vector_size(16)));
+
+// Which chain job `job` of a scan belongs to (job_first is non-decreasing; chains without jobs repeat their successor's value).
+JLS_DEV uint32_t chain_of_job(const uint32_t* job_first, uint32_t job)
+{
+    uint32_t lo = 0, hi = kChains; // job_first[lo] <= job < job_first[hi]
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = (lo + hi) / 2;
+        if (job_first[mid] <= job)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// C1: grid (ceil(max_jobs / 64), scans) x 64; max_jobs = samples / job_events + kChains.
+template <typename S>
+__global__ void __launch_bounds__(64) walk_jobs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    __shared__ uint32_t s_first[kChains + 1];
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const Traits t = make_traits(d);
+    const uint32_t jobs = w.job_first[kChains];
+    if (blockIdx.x * 64u >= jobs)
+        return;
+    for (int c = threadIdx.x; c <= kChains; c += 64)
+        s_first[c] = w.job_first[c];
+    __syncthreads();
+    const uint32_t job = blockIdx.x * 64u + threadIdx.x;
+    if (job >= jobs)
+        return;
+    const uint32_t chain = chain_of_job(s_first, job);
+    const uint32_t n = w.chain_total[chain];
+    const uint32_t start = (job - s_first[chain]) * w.job_events; // multiple of 16
+    const uint32_t end = start + w.job_events < n ? start + w.job_events : n;
+    const uint32_t warm = start > w.warm_events ? (start - w.warm_events) & ~15u : 0u;
+    const JLS_GLOBAL_AS u32x4* in = (const JLS_GLOBAL_AS u32x4*)(w.rec + w.chain_base[chain]);
+    JLS_GLOBAL_AS u32x4* out = (JLS_GLOBAL_AS u32x4*)(w.code + w.chain_base[chain]);
+
+    Chain s{initial_a(t), 0, 0, chain_n_before(warm, (uint32_t)t.reset), 0};
+    // ---- warm-up: the state forgets where it started (no output)
+    uint32_t g = warm / 16;
+    u32x4 next[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        next[j] = in[g * 4 + j];
+    for (; g < start / 16; ++g)
+    {
+        u32x4 cur[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            cur[j] = next[j];
+            next[j] = in[(g + 1) * 4 + j]; // behind the last chain: kSlack
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                (void)code_event<S>(s, cur[j][e], t);
+    }
+    s.bad = 0;
+    JobState st;
+    st.in_a = s.a;
+    st.in_b = s.b;
+    st.in_c = s.c;
+    // ---- the job's own events, 16 at a time
+    for (; g < end / 16; ++g)
+    {
+        u32x4 cur[4], o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            cur[j] = next[j];
+            next[j] = in[(g + 1) * 4 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[j][e] = code_event<S>(s, cur[j][e], t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            out[g * 4 + j] = o[j];
+    }
+    // ---- the last, partial group of a chain (its tail is the chain's padding)
+    if ((end & 15u) != 0)
+    {
+        const JLS_GLOBAL_AS uint32_t* in1 = (const JLS_GLOBAL_AS uint32_t*)in;
+        JLS_GLOBAL_AS uint32_t* out1 = (JLS_GLOBAL_AS uint32_t*)out;
+        for (uint32_t i = end & ~15u; i < end; ++i)
+            out1[i] = code_event<S>(s, in1[i], t);
+    }
+    st.out_a = s.a;
+    st.out_b = s.b;
+    st.out_c = s.c;
+    st.bad = s.bad;
+    st.pad = 0;
+    w.jobs[job] = st;
+}
+
+// C2: grid (ceil(kChains * scans / 64)) x 64, one lane per (chain, scan), lanes of a wavefront = the same chain of
+// different scans.  A job whose predecessor did not end in the state the job assumed is walked again from the true state.
+template <typename S>
+__global__ void __launch_bounds__(64) settle_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
+{
+    const uint32_t tid = blockIdx.x * 64u + threadIdx.x;
+    if (tid >= scans * (uint32_t)kChains)
+        return;
+    const uint32_t chain = tid / scans, frame = tid % scans;
+    if (chain == 0 || chain == (uint32_t)kInterruptChain)
+        return;
+    const ScanDesc d = descs[frame];
+    const Work w = works[frame];
+    const Traits t = make_traits(d);
+    const uint32_t j0 = w.job_first[chain], j1 = w.job_first[chain + 1];
+    if (j0 == j1)
+        return;
+    const uint32_t n = w.chain_total[chain];
+    const uint32_t* in = w.rec + w.chain_base[chain];
+    uint32_t* out = w.code + w.chain_base[chain];
+    uint32_t bad = 0;
+    JobState prev = w.jobs[j0];
+    bad |= prev.bad;
+    for (uint32_t j = j0 + 1; j < j1; ++j)
+    {
+        JobState cur = w.jobs[j];
+        if (cur.in_a != prev.out_a || cur.in_b != prev.out_b || cur.in_c != prev.out_c)
+        { // walk the job again from the state its predecessor really ended in
+            const uint32_t start = (j - j0) * w.job_events;
+            const uint32_t end = start + w.job_events < n ? start + w.job_events : n;
+            Chain s{prev.out_a, prev.out_b, prev.out_c, chain_n_before(start, (uint32_t)t.reset), 0};
+            for (uint32_t i = start; i < end; ++i)
+                out[i] = code_event<S>(s, in[i], t);
+            cur.out_a = s.a;
+            cur.out_b = s.b;
+            cur.out_c = s.c;
+            cur.bad = s.bad;
+        }
+        bad |= cur.bad;
+        prev = cur;
+    }
+    if (bad)
+        atomicOr(w.status, kStatusInvalid);
+}
+
+// Code word of a run-length code: `ones` one-bits, then `tail_len` bits holding `tail`.
+JLS_DEV uint32_t run_word(int ones, int tail_len, uint32_t tail)
+{
+    return kRunTag | ((uint32_t)ones << 25) | ((uint32_t)tail_len << 20) | tail;
+}
+
+// C3: grid (ceil(scans / 64)) x 64, one lane per scan: src/scan_encoder.hpp:53-73, src/scan_encoder_impl.hpp:249-275,
+// src/scan_encoder_core.hpp:105-125.  The run-length code goes to the slot of the sample where the run starts, the code
+// of the interruption sample to the next slot of chain kInterruptChain (its events are these samples, in this order).
+template <typename S, int ILV>
+__global__ void __launch_bounds__(64) code_runs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
+{
+    const uint32_t frame = blockIdx.x * 64u + threadIdx.x;
+    if (frame >= scans)
+        return;
+    const ScanDesc d = descs[frame];
+    const Work w = works[frame];
+    const Traits t = make_traits(d);
+    const uint32_t n = w.chain_total[0];
+    const uint32_t* runs = w.rec + w.chain_base[0];
+    uint32_t* run_code = w.code + w.chain_base[0];
+    uint32_t* int_code = w.code + w.chain_base[kInterruptChain];
+    RunCtx rc0{0, initial_a(t), 1, 0}, rc1{1, initial_a(t), 1, 0}; // (two named records, selected by value: an indexed pair lives in scratch)
+    uint32_t run_index_packed = 0; // ILV_LINE: one RUNindex per component (src/scan_encoder_impl.hpp:126-137), 8 bits each
+    uint32_t interruptions = 0;
+    for (uint32_t e = 0; e < n; ++e)
+    {
+        const uint32_t v = runs[e];
+        const uint32_t p = run_code[e]; // sort_tiles' record of the interruption sample
+        uint32_t run = v & 0x7FFFFFFFu;
+        const bool eol = (v >> 31) != 0;
+        const uint32_t shift = ILV == 1 ? ((p >> 18) & 3u) * 8u : 0u;
+        int run_index = (int)((run_index_packed >> shift) & 0xFFu);
+        const uint32_t full = run;
+        int ones = 0;
+        while (run >= (1u << run_j(run_index)))
+        {
+            ++ones;
+            run -= 1u << run_j(run_index);
+            if (run_index < 31)
+                ++run_index;
+        }
+        if (eol)
+        {
+            if (run != 0)
+                ++ones;
+            run_code[e] = run_word(ones, 0, 0);
+        }
+        else
+        {
+            const int jb = run_j(run_index);
+            const int which = (int)((p >> 17) & 1u);
+            const int err = (int)(p << 15) >> 15;
+            RunCtx ctx = which ? rc1 : rc0;
+            const int k = run_k(ctx);
+            const int map = run_map(ctx, err, k);
+            const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - map;
+            const pipe::CodeWord c = pipe::golomb_word(t, k, em, t.limit - jb - 1);
+            run_update(ctx, err, em, t.reset);
+            if (which)
+                rc1 = ctx;
+            else
+                rc0 = ctx;
+            if (run_index > 0)
+                --run_index;
+            if (full == 0) // both codes belong to the same sample: J + 1 zero bits, then the interruption code (<= LIMIT bits in all)
+                run_code[e] = ((uint32_t)(jb + 1 + c.len) << 24) | (uint32_t)c.bits;
+            else
+            {
+                run_code[e] = run_word(ones, jb + 1, run);
+                int_code[interruptions++] = ((uint32_t)c.len << 24) | (uint32_t)c.bits;
+            }
+        }
+        run_index_packed = (run_index_packed & ~(0xFFu << shift)) | ((uint32_t)run_index << shift);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// D: grid (tiles, scans) x 256; tiles in index order (a tile only waits for tiles that were started before it).
+// LDS: codes[kTileSamples] u32 | tileoff / count / global [kChains + 1] each | scan[256] | tmp
+constexpr uint32_t kPerThread = kTileSamples / kThreads; // 32 consecutive samples
+
+JLS_DEV void expand_code(uint32_t word, uint64_t& bits, int& len)
+{
+    if (word & kRunTag)
+    {
+        const int ones = (int)((word >> 25) & 63u), tail_len = (int)((word >> 20) & 31u);
+        bits = ((((uint64_t)1 << ones) - 1ull) << tail_len) | (uint64_t)(word & 0xFFFFFu);
+        len = ones + tail_len;
+    }
+    else
+    {
+        bits = word & 0xFFFFFFu;
+        len = (int)(word >> 24);
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) pack_tiles(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    JLS_DYNAMIC_LDS(smem);
+    __shared__ uint64_t s_start;
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= w.tiles)
+        return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* s_code = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* s_tileoff = s_code + kTileSamples;
+    uint32_t* s_count = s_tileoff + kChains + 1;
+    uint32_t* s_global = s_count + kChains + 1;
+    uint32_t* s_scan = s_global + kChains + 1; // 256
+    uint32_t* s_tmp = s_scan + kThreads;       // kWaves + 1
+    const uint32_t lines = d.interleave_mode == 1 ? pipe::coded_lines(d) : d.height;
+    const uint32_t first_line = tile * w.lines_per_tile;
+    const uint32_t tile_lines = lines - first_line < w.lines_per_tile ? lines - first_line : w.lines_per_tile;
+    const uint32_t tile_samples = tile_lines * d.width;
+    const uint16_t* inv = w.keyinv + (size_t)first_line * d.width;
+
+    { // the tile's pieces, chain by chain, in the order sort_tiles laid them out
+        uint32_t n[2] = {0, 0}, g[2] = {0, 0};
+        for (int half = 0; half < 2; ++half)
+        {
+            const uint32_t c = threadIdx.x + (uint32_t)half * kThreads;
+            if (c < (uint32_t)kChains)
+            {
+                g[half] = w.seg[(size_t)tile * kChains + c];
+                n[half] = w.seg[(size_t)(tile + 1) * kChains + c] - g[half];
+            }
+        }
+        uint32_t off[2] = {n[0], n[1]};
+        block_exclusive_scan(off[0], off[1], s_tmp);
+        for (int half = 0; half < 2; ++half)
+        {
+            const uint32_t c = threadIdx.x + (uint32_t)half * kThreads;
+            if (c < (uint32_t)kChains)
+            {
+                s_tileoff[c] = off[half];
+                s_count[c] = n[half];
+                s_global[c] = g[half];
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t c = wave; c < (uint32_t)kChains; c += kWaves)
+    {
+        const uint32_t n = s_count[c], to = s_tileoff[c], from = s_global[c];
+        for (uint32_t i = lane; i < n; i += 64)
+            s_code[to + i] = w.code[from + i];
+    }
+    __syncthreads();
+
+    // ---- bits of this thread's samples
+    const uint32_t base = threadIdx.x * kPerThread;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < kPerThread; ++i)
+    {
+        const uint16_t slot = base + i < tile_samples ? inv[base + i] : kNoLocalSlot;
+        if (slot != kNoLocalSlot)
+        {
+            uint64_t bits;
+            int len;
+            expand_code(s_code[slot], bits, len);
+            sum += (uint32_t)len;
+        }
+    }
+    s_scan[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t stride = 1; stride < kThreads; stride <<= 1) // Hillis-Steele inclusive scan
+    {
+        const uint32_t add = threadIdx.x >= stride ? s_scan[threadIdx.x - stride] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += add;
+        __syncthreads();
+    }
+    // ---- where this tile starts: the first wavefront looks back, 64 predecessors at a time (see write_raw_bits)
+    if (threadIdx.x < 64)
+    {
+        const uint64_t own = s_scan[kThreads - 1];
+        const uint32_t b = tile;
+        if (lane == 0)
+            store_relaxed(&w.blockbase[b], (b == 0 ? pipe::kBlockUpTo : pipe::kBlockOwn) | own);
+        uint64_t start = 0;
+        uint32_t reach = b; // tiles [reach, b) are accounted for in `start`
+        while (reach > 0)
+        {
+            const bool mine = (uint32_t)lane < reach;
+            const uint32_t j = mine ? reach - 1 - (uint32_t)lane : 0;
+            uint64_t state = 0;
+            do
+            {
+                state = mine ? load_relaxed(&w.blockbase[j]) : pipe::kBlockOwn;
+            } while (__any((state >> 62) == 0));
+            const unsigned long long knows = __ballot(mine && (state >> 62) == 2);
+            const int last = knows ? (int)__ffsll(knows) - 1 : 63;
+            uint64_t part = mine && lane <= last ? state & pipe::kBlockValue : 0;
+            for (int delta = 32; delta > 0; delta >>= 1)
+                part += __shfl_xor(part, delta);
+            start += part;
+            if (knows)
+                break;
+            reach = reach > 64 ? reach - 64 : 0;
+        }
+        if (lane == 0)
+        {
+            if (b != 0)
+                store_relaxed(&w.blockbase[b], pipe::kBlockUpTo | (start + own));
+            s_start = start;
+            if (b + 1 == w.tiles)
+                *w.total_bits = start + own;
+        }
+    }
+    __syncthreads();
+    if (sum == 0)
+        return;
+    const uint64_t bitpos = s_start + s_scan[threadIdx.x] - sum;
+    uint64_t word = bitpos >> 5;
+    const uint64_t first_word = word;
+    int acc_bits = (int)(bitpos & 31); // the leading bits of the first word belong to the previous thread
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < kPerThread; ++i)
+    {
+        const uint16_t slot = base + i < tile_samples ? inv[base + i] : kNoLocalSlot; // (second read: the line is in the cache)
+        if (slot == kNoLocalSlot)
+            continue;
+        uint64_t v;
+        int left;
+        expand_code(s_code[slot], v, left);
+        while (left > 0)
+        {
+            const int room = 64 - acc_bits;
+            const int n = left < room ? left : room;
+            const uint64_t piece = n == 64 ? v : ((v >> (left - n)) & ((1ull << n) - 1ull));
+            acc |= piece << (room - n);
+            acc_bits += n;
+            left -= n;
+            while (acc_bits >= 32)
+            {
+                const uint32_t o = __builtin_bswap32((uint32_t)(acc >> 32));
+                if (word < w.raw_words)
+                {
+                    if (word == first_word)
+                        atomicOr(&w.raw[word], o); // shared with the previous thread's tail
+                    else
+                        w.raw[word] = o; // entirely ours
+                }
+                acc <<= 32;
+                acc_bits -= 32;
+                ++word;
+            }
+        }
+    }
+    if (acc_bits > 0 && word < w.raw_words)
+        atomicOr(&w.raw[word], __builtin_bswap32((uint32_t)(acc >> 32))); // tail shared with the next thread
+}
+
+// Zeroes the look-back states and the raw bit stream of every scan of a pass (contiguous in a work area).
+__global__ void __launch_bounds__(256) clear_pack_state(const Work* __restrict__ works, uint32_t bytes_per_scan)
+{
+    uint4* at = reinterpret_cast<uint4*>(works[blockIdx.y].blockbase);
+    const uint32_t groups = bytes_per_scan / 16;
+    for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < groups; g += gridDim.x * 256u)
+        at[g] = make_uint4(0, 0, 0, 0);
+}
+
+// LDS bytes of the tile kernels for a line of `width` samples.
+inline size_t analyze_lds_bytes(uint32_t width)
+{
+    const size_t chunks = (width + 63) / 64;
+    return ((size_t)kChains + 1) * 4 + pipe::kGradientTable + (size_t)kWaves * 2 * chunks * 8;
+}
+inline size_t sort_lds_bytes(uint32_t width, uint32_t lines_per_tile)
+{
+    const size_t chunks = (width + 63) / 64;
+    return (size_t)kTileSamples * 4 + (size_t)kTileSamples * 2 + (size_t)lines_per_tile * kChains * 4 + 3 * ((size_t)kChains + 1) * 4 + 8 * 4 +
+           (size_t)kWaves * chunks * 8 + (size_t)kWaves * (chunks + 1) * 4;
+}
+inline size_t pack_lds_bytes()
+{
+    return (size_t)kTileSamples * 4 + 3 * ((size_t)kChains + 1) * 4 + (size_t)kThreads * 4 + 8 * 4;
+}
+
+} // namespace tile
+} // namespace jls

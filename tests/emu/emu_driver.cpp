@@ -126,7 +126,7 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
     }
     emu::launch(pipe::code_events, dim3(pipe::kRegularChains, count), dim3(64), 0, descs, wk);
     emu::launch(pipe::write_raw_bits, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
-    if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env != nullptr && std::atoi(env) != 0)
+    if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env == nullptr || std::atoi(env) != 0)
     { // the block-parallel form of the stage (block_stuffing.hip), grids as in runtime.hip
         size_t most = 0;
         for (int i = 0; i < count; ++i)

@@ -1,0 +1,122 @@
+// TEST-ONLY driver of the tile pipeline (tile_pipeline.hip compiled for the host), a library of its own so that it
+// builds in seconds (tests/test_emu_tile_pipeline.py).
+#include "emu_launch.h"
+
+namespace emu {
+BlockState* g_block = nullptr;
+thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+} // namespace emu
+
+#include "../../charls_amd/csrc/device/tile_pipeline.hip"
+#include "../../charls_amd/csrc/device/block_stuffing.hip"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+// The tile pipeline (tile_pipeline.hip), kernel by kernel, in the order and with the launch geometry runtime.hip uses.
+// job_events / warm_events as given: the tests use small values so that small images have many jobs, and warm-ups too
+// short to converge so that settle_chains has to walk jobs again.
+template <typename S>
+static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count, uint32_t job_events, uint32_t warm_events)
+{
+    using namespace jls;
+    const ScanDesc& p = descs[0];
+    const size_t lines = (size_t)p.height * (size_t)(p.interleave_mode == 1 ? p.components : 1);
+    const size_t samples = (size_t)p.width * lines;
+    uint32_t lines_per_tile = tile::kTileSamples / p.width;
+    lines_per_tile = lines_per_tile < 1 ? 1 : (lines_per_tile > tile::kTileLines ? tile::kTileLines : lines_per_tile);
+    const uint32_t tiles = (uint32_t)((lines + lines_per_tile - 1) / lines_per_tile);
+    const size_t max_jobs = samples / job_events + pipe::kChains;
+    std::vector<tile::Work> works(count);
+    std::vector<pipe::Work> stuff(count);
+    std::vector<void*> allocs;
+    auto zalloc = [&](size_t bytes) {
+        void* q = std::calloc(bytes + 64, 1);
+        allocs.push_back(q);
+        return q;
+    };
+    auto galloc = [&](size_t bytes) { // work areas the product does not clear are filled with garbage here
+        void* q = std::malloc(bytes + 64);
+        std::memset(q, 0xA5, bytes + 64);
+        allocs.push_back(q);
+        return q;
+    };
+    for (int i = 0; i < count; ++i)
+    {
+        tile::Work& w = works[i];
+        const size_t raw_bytes = ((size_t)descs[i].stream_capacity + 64 + 15) / 16 * 16;
+        w.keyinv = (uint16_t*)galloc(samples * 2);
+        w.seg = (uint32_t*)galloc((size_t)(tiles + 1) * pipe::kChains * 4);
+        w.chain_total = (uint32_t*)galloc(pipe::kChains * 4);
+        w.chain_base = (uint32_t*)galloc(pipe::kChains * 4);
+        w.job_first = (uint32_t*)galloc((pipe::kChains + 1) * 4);
+        w.rec = (uint32_t*)galloc((samples + tile::kSlack) * 4);
+        w.code = (uint32_t*)galloc((samples + tile::kSlack) * 4);
+        w.jobs = (tile::JobState*)galloc(max_jobs * sizeof(tile::JobState));
+        uint8_t* pack_state = (uint8_t*)zalloc((size_t)tiles * 8 + 16 + raw_bytes);
+        w.blockbase = (uint64_t*)pack_state;
+        w.raw = (uint32_t*)(pack_state + ((size_t)tiles * 8 + 15) / 16 * 16);
+        w.raw_words = raw_bytes / 4;
+        w.total_bits = (uint64_t*)galloc(8);
+        w.status = (uint32_t*)galloc(4);
+        w.lines_per_tile = lines_per_tile;
+        w.tiles = tiles;
+        w.job_events = job_events;
+        w.warm_events = warm_events;
+        pipe::Work& sw = stuff[i];
+        std::memset(&sw, 0, sizeof sw);
+        sw.raw = w.raw;
+        sw.raw_words = w.raw_words;
+        sw.total_bits = w.total_bits;
+        sw.status = w.status;
+        sw.stuff_tables = (uint32_t*)galloc((raw_bytes / pipe::kStuffChunk + 2) * pipe::kStuffWords * 4);
+    }
+    const tile::Work* wk = works.data();
+    const unsigned tiles_grid = 8 * ((tiles + 7) / 8);
+    if (p.interleave_mode == 1)
+        emu::launch(tile::analyze_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::analyze_lds_bytes(p.width), descs, wk);
+    else
+        emu::launch(tile::analyze_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::analyze_lds_bytes(p.width), descs, wk);
+    emu::launch(tile::plan_chains, dim3(count), dim3(1024), 0, descs, wk);
+    if (p.interleave_mode == 1)
+        emu::launch(tile::sort_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::sort_lds_bytes(p.width, lines_per_tile), descs, wk);
+    else
+        emu::launch(tile::sort_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::sort_lds_bytes(p.width, lines_per_tile), descs, wk);
+    emu::launch(tile::walk_jobs<S>, dim3((unsigned)((max_jobs + 63) / 64), count), dim3(64), 0, descs, wk);
+    emu::launch(tile::settle_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    if (p.interleave_mode == 1)
+        emu::launch(tile::code_runs<S, 1>, dim3((count + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    else
+        emu::launch(tile::code_runs<S, 0>, dim3((count + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::kThreads), tile::pack_lds_bytes(), descs, wk);
+    const pipe::Work* sk = stuff.data();
+    if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env == nullptr || std::atoi(env) != 0)
+    {
+        size_t most = 0;
+        for (int i = 0; i < count; ++i)
+            most = std::max(most, (size_t)works[i].raw_words * 4);
+        const unsigned chunk_waves = (unsigned)((most / pipe::kStuffChunk + 1 + 63) / 64);
+        emu::launch(pipe::stuff_survey, dim3(chunk_waves, count), dim3(64), 0, sk);
+        emu::launch(pipe::stuff_resolve, dim3(count), dim3(64), 0, sk);
+        emu::launch(pipe::stuff_emit, dim3(chunk_waves, count), dim3(64), 0, descs, sk, results);
+    }
+    else
+        emu::launch(pipe::stuff_scan, dim3(count), dim3(64), 0, descs, sk, results);
+    for (void* q : allocs)
+        std::free(q);
+}
+
+extern "C" {
+
+void emu_encode_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count, uint32_t job_events, uint32_t warm_events)
+{
+    if (descs[0].bits_per_sample > 8)
+        emu_tile_pipeline<uint16_t>(descs, results, count, job_events, warm_events);
+    else
+        emu_tile_pipeline<uint8_t>(descs, results, count, job_events, warm_events);
+}
+
+size_t emu_sizeof_scan_desc() { return sizeof(jls::ScanDesc); }
+}

@@ -27,6 +27,32 @@ class ScanResult(C.Structure):
 
 
 _lib = None
+_libs = {}
+
+
+def _build_and_load(driver, out):
+    srcs = glob.glob(os.path.join(EMU_DIR, "*")) + glob.glob(os.path.join(EMU_DIR, "hip", "*")) + \
+        glob.glob(os.path.join(DEV, "*"))
+    newest = max(os.path.getmtime(s) for s in srcs)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    import fcntl
+    with open(out + ".lock", "w") as lock:  # pytest-xdist workers must not rebuild / replace the library concurrently
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not os.path.exists(out) or os.path.getmtime(out) < newest:
+            tmp = out + f".{os.getpid()}.tmp"
+            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + EMU_DIR,
+                                   "-I" + DEV, "-x", "c++", os.path.join(EMU_DIR, driver), "-o", tmp])
+            os.replace(tmp, out)
+    L = C.CDLL(out)
+    assert L.emu_sizeof_scan_desc() == C.sizeof(ScanDesc)
+    return L
+
+
+def tile_lib():
+    """The tile pipeline's kernels alone (a translation unit of its own: builds in seconds)."""
+    if "tile" not in _libs:
+        _libs["tile"] = _build_and_load("emu_tile_driver.cpp", os.path.join(ROOT, "tests", "_emu_build", "libjls_emu_tile.so"))
+    return _libs["tile"]
 
 
 def lib():

@@ -1,0 +1,240 @@
+"""Kernel-logic check on the CPU for the tile pipeline (tile_pipeline.hip compiled for the host by tests/emu): every stage
+runs with the launch geometry of the product; the scan bytes must equal the reference's.
+
+The speculative chain stage is exercised on purpose: small job sizes give small images many jobs per chain, and warm-ups
+too short to converge (0, 16) make settle_chains walk jobs again -- the bytes have to be the reference's either way."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+import emu_bind
+import jls_container
+import oracle_bind as ob
+from charls_amd import synth
+
+FULL = os.environ.get("CHARLS_AMD_QUICK_EMU") != "1"
+_SUBSET = {"gray8_64x48", "gray8_w1", "gray8_h1", "gray8_1x1", "tiny_gray12", "tiny_gray16_noise", "tiny_gray2",
+           "tiny_gray8_noise", "tiny_rgb8_ilv0", "gray8_maxval100"}
+ELIGIBLE = [c for c in common.cases()
+            if c["errc"] == 0 and "file" in c and c["near_lossless"] == 0 and c["width"] * c["height"] <= 128 * 128 and
+            (c["component_count"] == 1 or c["interleave_mode"] == 0) and (FULL or c["name"] in _SUBSET)]
+
+
+def _encode_planes(planes, width, height, bits, pc, capacity, job=64, warm=32):
+    L = emu_bind.tile_lib()
+    keep, descs, outs = [], [], []
+    for pl in planes:
+        pix = np.frombuffer(np.ascontiguousarray(pl).tobytes(), dtype=np.uint8).copy()
+        out = np.zeros(capacity, dtype=np.uint8)
+        outs.append(out)
+        descs.append(emu_bind.make_desc(width, height, 1, 0, bits, 0, 0, pc, 0, pix, width * (1 if bits <= 8 else 2), out, keep))
+    arr = (emu_bind.ScanDesc * len(descs))(*descs)
+    res = (emu_bind.ScanResult * len(descs))()
+    L.emu_encode_tile_pipeline(arr, res, len(descs), job, warm)
+    return [(r.errc, r.flags, o[:r.bytes].tobytes()) for r, o in zip(res, outs)]
+
+
+def _scan_bytes(jls, index=0):
+    cont = jls_container.parse(jls)
+    return jls[cont.scans[index].data_start:cont.scans[index].data_end]
+
+
+@pytest.mark.parametrize("c", ELIGIBLE, ids=lambda c: c["name"])
+def test_tile_pipeline_matches_reference_scan_bytes(c):
+    with open(f"{common.GOLDEN}/{c['file']}", "rb") as f:
+        jls = f.read()
+    cont = jls_container.parse(jls)
+    pc = jls_container.validated_pc(tuple(c["preset"]) if c["preset"] else (0,) * 5, c["bits_per_sample"], 0)
+    img = common.case_input(c)
+    planes = [img] if img.ndim == 2 else [img[i] for i in range(img.shape[0])]
+    size = max(s.data_end - s.data_start for s in cont.scans) + 64
+    got = _encode_planes(planes, c["width"], c["height"], c["bits_per_sample"], pc, size, job=256, warm=128)
+    for (errc, flags, data), scan in zip(got, cont.scans):
+        assert errc == 0
+        assert data == jls[scan.data_start:scan.data_end]
+
+
+@pytest.mark.parametrize("job,warm", [(16, 0), (16, 16), (64, 32), (64, 1024), (1024, 1024)])
+@pytest.mark.parametrize("kind,bits,w,h,seed", [("mixed", 8, 130, 11, 1), ("zero", 8, 130, 9, 2), ("hard", 12, 65, 9, 4),
+                                                ("mixed", 16, 129, 7, 5), ("mixed", 8, 1, 50, 7), ("noise", 16, 40, 12, 9),
+                                                ("gradient", 8, 300, 40, 3), ("noise", 8, 96, 20, 11)])
+def test_tile_pipeline_batch_of_seeded_frames(kind, bits, w, h, seed, job, warm):
+    """Several frames in one launch, every job / warm-up setting: each frame equals the oracle."""
+    frames = [synth.frame_numpy(w, h, seed=seed * 10 + f, bits=bits, kind=kind) for f in range(3)]
+    pc = jls_container.validated_pc((0,) * 5, bits, 0)
+    got = _encode_planes(frames, w, h, bits, pc, w * h * 4 + 1024, job=job, warm=warm)
+    for img, (errc, flags, data) in zip(frames, got):
+        assert errc == 0
+        assert data == _scan_bytes(ob.encode(img, width=w, height=h, bits_per_sample=bits))
+
+
+def test_tile_pipeline_several_tiles_and_lines_per_tile():
+    """Geometries that give several tiles (a tile is up to 8192 samples, at most 16 lines): pieces of a chain from many
+    tiles, the look-back of the pack stage across tiles, a last tile with fewer lines."""
+    for w, h, kind, bits in [(700, 30, "mixed", 8), (64, 70, "gradient", 8), (3000, 7, "mixed", 8), (8192, 3, "gradient", 8),
+                             (513, 40, "hard", 12)]:
+        img = synth.frame_numpy(w, h, seed=w + h, bits=bits, kind=kind)
+        pc = jls_container.validated_pc((0,) * 5, bits, 0)
+        (errc, flags, data), = _encode_planes([img], w, h, bits, pc, w * h * 3 + 1024, job=512, warm=256)
+        assert errc == 0 and data == _scan_bytes(ob.encode(img, width=w, height=h, bits_per_sample=bits)), (w, h, kind)
+
+
+def test_tile_pipeline_long_runs_walk_run_index():
+    """Runs that walk RUNindex up to 24 and back (J = 8), runs that end exactly at the line end, runs across chunks."""
+    w, h = 3000, 3
+    img = np.zeros((h, w), dtype=np.uint8)
+    img[1, 2000:] = 9
+    img[2, ::2] = 3
+    pc = jls_container.validated_pc((0,) * 5, 8, 0)
+    (errc, flags, data), = _encode_planes([img], w, h, 8, pc, w * h * 2 + 1024)
+    assert errc == 0 and data == _scan_bytes(ob.encode(img, width=w, height=h))
+
+
+def test_tile_pipeline_runs_of_every_length_at_every_phase():
+    """Runs that start and end at every position relative to the 64-sample chunks (run length from the keys that follow)."""
+    rng = np.random.default_rng(5)
+    w, h = 200, 24
+    img = np.full((h, w), 77, dtype=np.uint8)
+    for y in range(1, h):
+        x = int(rng.integers(0, 70))
+        while x < w:
+            n = int(rng.integers(1, 140))
+            img[y, x:x + n] = int(rng.integers(0, 256))
+            x += n + int(rng.integers(0, 3))
+    pc = jls_container.validated_pc((0,) * 5, 8, 0)
+    (errc, flags, data), = _encode_planes([img], w, h, 8, pc, w * h * 2 + 1024)
+    assert errc == 0 and data == _scan_bytes(ob.encode(img, width=w, height=h))
+
+
+def test_tile_pipeline_destination_too_small_and_knife_edge(monkeypatch):
+    img = synth.frame_numpy(64, 64, seed=3, kind="mixed")[:16, :40].copy()
+    img = np.ascontiguousarray(np.pad(img, ((0, 48), (0, 24))))
+    want = ob.encode(img, width=64, height=64)
+    n = len(_scan_bytes(want))
+    pc = jls_container.validated_pc((0,) * 5, 8, 0)
+    for stuffing in ("1", "0"):
+        monkeypatch.setenv("CHARLS_AMD_BLOCK_STUFFING", stuffing)
+        (errc, flags, data), = _encode_planes([img], 64, 64, 8, pc, n - 1)
+        assert errc == 3
+        for slack in (0, 1, 3):
+            (errc, flags, data), = _encode_planes([img], 64, 64, 8, pc, n + slack)
+            assert errc == 0 and flags == 2  # the host re-runs the exact serial kernel for these
+        (errc, flags, data), = _encode_planes([img], 64, 64, 8, pc, n + 4)
+        assert errc == 0 and flags == 0 and len(data) == n
+
+
+def test_tile_pipeline_raw_stream_overflows_its_buffer(monkeypatch):
+    """A destination far smaller than the unstuffed stream (stuff_resolve must not walk chunk tables that
+    were never made): destination_too_small with both forms of the stuffing stage, and nothing written out of bounds."""
+    img = synth.frame_numpy(96, 64, seed=8, bits=8, kind="noise")
+    pc = jls_container.validated_pc((0,) * 5, 8, 0)
+    for stuffing in ("1", "0"):
+        monkeypatch.setenv("CHARLS_AMD_BLOCK_STUFFING", stuffing)
+        (errc, flags, data), = _encode_planes([img], 96, 64, 8, pc, 700)
+        assert errc == 3
+
+
+@pytest.mark.parametrize("bits,reset", [(8, 3), (8, 31), (8, 64), (8, 255), (16, 256), (16, 257), (8, 4), (16, 258), (16, 300)])
+def test_tile_pipeline_reset_values_with_long_chains(bits, reset):
+    """Few contexts, chains of thousands of events: jobs start at every phase of the halving cycle (N is a closed form of
+    the event index; RESET is stored through a uint8 by the reference, so 256/257/258 behave as 0/1/2 -- SURVEY F8)."""
+    w, h = 96, 48
+    rng = np.random.default_rng(reset)
+    base = (np.arange(w)[None, :] // 7 + np.arange(h)[:, None] // 5) * (3 if bits == 8 else 700)
+    noise = rng.integers(-2, 3, size=(h, w)) * (1 if bits == 8 else 900)
+    img = np.clip(base + noise + (40 if bits == 8 else 9000), 0, (1 << bits) - 1).astype(np.uint8 if bits == 8 else np.uint16)
+    preset = (0, 0, 0, 0, reset)
+    pc = jls_container.validated_pc(preset, bits, 0)
+    want = _scan_bytes(ob.encode(img, width=w, height=h, bits_per_sample=bits, preset=preset))
+    for job, warm in ((48, 16), (80, 200)):
+        (errc, flags, data), = _encode_planes([img], w, h, bits, pc, w * h * 4 + 1024, job=job, warm=warm)
+        assert errc == 0 and data == want, (job, warm)
+
+
+def test_tile_pipeline_prediction_clipped_at_both_ends_of_wide_samples():
+    """Samples wider than 8 bits keep only the distance of the prediction from the nearer end of the range in their record:
+    images that sit at 0 and at MAXVAL with a bias that pushes the prediction over the end."""
+    rng = np.random.default_rng(17)
+    for bits in (9, 12, 16):
+        maxval = (1 << bits) - 1
+        w, h = 80, 40
+        img = np.zeros((h, w), dtype=np.uint16)
+        img[:, : w // 2] = (rng.integers(0, 40, size=(h, w // 2)) ** 2 // 30).astype(np.uint16)              # hugging 0, skewed
+        img[:, w // 2:] = (maxval - rng.integers(0, 40, size=(h, w - w // 2)) ** 2 // 30).astype(np.uint16)  # hugging MAXVAL
+        pc = jls_container.validated_pc((0,) * 5, bits, 0)
+        (errc, flags, data), = _encode_planes([img], w, h, bits, pc, w * h * 5 + 1024, job=64, warm=64)
+        assert errc == 0 and data == _scan_bytes(ob.encode(img, width=w, height=h, bits_per_sample=bits)), bits
+
+
+def _encode_line_interleaved(img, width, height, comps, bits, xform, capacity, job=64, warm=32):
+    L = emu_bind.tile_lib()
+    keep = []
+    pix = np.frombuffer(np.ascontiguousarray(img).tobytes(), dtype=np.uint8).copy()
+    out = np.zeros(capacity, dtype=np.uint8)
+    pc = jls_container.validated_pc((0,) * 5, bits, 0)
+    d = emu_bind.make_desc(width, height, comps, 1, bits, 0, xform, pc, 0, pix, width * comps * (1 if bits <= 8 else 2), out, keep)
+    res = (emu_bind.ScanResult * 1)()
+    L.emu_encode_tile_pipeline((emu_bind.ScanDesc * 1)(d), res, 1, job, warm)
+    return res[0].errc, res[0].flags, out[:res[0].bytes].tobytes()
+
+
+def test_tile_pipeline_line_interleaved_scans():
+    """ILV_LINE lossless: the components of a pixel row are coded as lines of their own, sharing the contexts but each
+    with its own RUNindex."""
+    rng = np.random.default_rng(21)
+    cases = [("mixed", 8, 3, 0, 33, 7), ("mixed", 8, 3, 1, 20, 5), ("mixed", 16, 3, 3, 12, 4), ("hard", 12, 2, 0, 19, 5),
+             ("mixed", 8, 4, 0, 9, 4), ("mixed", 8, 3, 1, 700, 9)]
+    for kind, bits, comps, xform, w, h in cases:
+        img = np.stack([synth.frame_numpy(w, h, seed=80 + c, bits=bits, kind=kind) for c in range(comps)], axis=-1)
+        want = ob.encode(img, width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=1,
+                         color_transformation=xform)
+        errc, flags, data = _encode_line_interleaved(img, w, h, comps, bits, xform, w * h * comps * 4 + 1024)
+        assert errc == 0 and data == _scan_bytes(want), (kind, bits, comps, xform)
+    for trial in range(24 if FULL else 10):  # few grey levels: runs in every component, RUNindex walks per component
+        comps = int(rng.choice([2, 3, 4]))
+        w, h = int(rng.integers(1, 40)), int(rng.integers(1, 6))
+        img = (rng.integers(0, 2, size=(h, w, comps)) * 200).astype(np.uint8)
+        img[:, w // 3:, 0] = img[:, w // 3:w // 3 + 1, 0]
+        xform = int(rng.integers(0, 4)) if comps == 3 else 0
+        want = ob.encode(img, width=w, height=h, component_count=comps, interleave_mode=1, color_transformation=xform)
+        errc, flags, data = _encode_line_interleaved(img, w, h, comps, 8, xform, w * h * comps * 4 + 1024)
+        assert errc == 0 and data == _scan_bytes(want), (trial, w, h, comps, xform)
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_tile_pipeline_random_parameters(chunk):
+    """Random lossless parameter sets (bits 2..16, custom thresholds / RESET, odd sizes, planar and line-interleaved)."""
+    from test_oracle_vs_reference import _image
+    L = emu_bind.tile_lib()
+    rng = np.random.default_rng(900 + chunk)
+    for it in range(30):
+        bits = int(rng.integers(2, 17))
+        comps = int(rng.choice([1, 1, 1, 2, 3, 4]))
+        ilv = 0 if comps == 1 else 1
+        w, h = int(rng.choice([1, 2, 5, 17, 64, 65, 130, 300])), int(rng.choice([1, 2, 3, 8, 21, 40]))
+        maxval = (1 << bits) - 1
+        kind = str(rng.choice(["rand", "smooth", "gradient", "mixed", "zero", "hard"]))
+        preset = (0,) * 5
+        if rng.random() < 0.4:
+            t1 = int(rng.integers(1, maxval + 1))
+            t2 = int(rng.integers(t1, maxval + 1))
+            t3 = int(rng.integers(t2, maxval + 1))
+            preset = (0, t1, t2, t3, int(rng.integers(3, max(255, maxval) + 1)))
+        xform = int(rng.integers(0, 4)) if (comps == 3 and bits in (8, 16) and rng.random() < 0.5) else 0
+        img = _image(rng, w, h, bits, comps, ilv, kind, it)
+        want = ob.encode(img, width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=ilv,
+                         color_transformation=xform, preset=preset if any(preset) else None)
+        pc = jls_container.validated_pc(preset, bits, 0)
+        keep = []
+        pix = np.frombuffer(np.ascontiguousarray(img).tobytes(), dtype=np.uint8).copy()
+        out = np.zeros(w * h * comps * 5 + 1024, dtype=np.uint8)
+        bps = 1 if bits <= 8 else 2
+        d = emu_bind.make_desc(w, h, comps, ilv, bits, 0, xform, pc, 0, pix, w * comps * bps, out, keep)
+        res = (emu_bind.ScanResult * 1)()
+        job = int(rng.choice([16, 32, 64, 256, 1024]))
+        warm = int(rng.choice([0, 16, 64, 1024]))
+        L.emu_encode_tile_pipeline((emu_bind.ScanDesc * 1)(d), res, 1, job, warm)
+        tag = (chunk, it, bits, comps, ilv, w, h, kind, preset, xform, job, warm)
+        assert res[0].errc == 0 and out[:res[0].bytes].tobytes() == _scan_bytes(want), tag
