@@ -547,6 +547,8 @@ bool block_stuffing_enabled()
     return enabled;
 }
 
+constexpr uint32_t kBlockStuffingScans = 128; // scans per pass up to which stage E runs in its block-parallel form
+
 // Bytes of work area one scan needs (21 B per sample + per-line histograms + the unstuffed stream).
 struct PipeLayout
 {
@@ -809,7 +811,7 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
             hip_check(hipStreamWaitEvent(stuff_stream, packed[pass], 0));
         }
         t.mark_on(stuff_stream);
-        if (block_stuffing_enabled())
+        if (block_stuffing_enabled() && n <= kBlockStuffingScans)
         {
             const uint32_t chunk_waves = static_cast<uint32_t>((lay.raw_bytes / pipe::kStuffChunk + 1 + 63) / 64);
             hipLaunchKernelGGL(pipe::stuff_survey, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, d_works);
@@ -875,7 +877,8 @@ bool tile_pipeline_enabled()
 
 bool tile_pipeline_eligible(const ScanDesc& d)
 {
-    return tile_pipeline_enabled() && d.interleave_mode != 2 && d.width <= tile::kTileSamples;
+    return tile_pipeline_enabled() && d.interleave_mode != 2 &&
+           d.width <= (d.bits_per_sample > 8 ? tile::kMaxTileSamples / 2 : tile::kMaxTileSamples);
 }
 
 // Work area of one scan: 10 B per sample (key / slot 2, record 4, code 4), the (tiles + 1) x 367 piece table, the job
@@ -890,7 +893,7 @@ struct TileLayout
     {
         lines = static_cast<size_t>(d.height) * (d.interleave_mode == 1 ? static_cast<size_t>(d.components) : 1);
         samples = static_cast<size_t>(d.width) * lines;
-        lines_per_tile = std::max<uint32_t>(1, std::min<uint32_t>(tile::kTileLines, tile::kTileSamples / d.width));
+        lines_per_tile = tile::lines_per_tile_for(d.width, d.bits_per_sample > 8 ? 2u : 1u);
         tiles = static_cast<uint32_t>((lines + lines_per_tile - 1) / lines_per_tile);
         // Jobs: every job pays warm_events of warm-up, so long jobs are cheaper; but ONE frame needs thousands of lanes to
         // fill the chip.  Aim at a quarter of a million lanes per launch, between 1024 and 8192 events per job.
@@ -955,8 +958,8 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         last_timings().count = 2;
         return;
     }
-    const uint32_t per_pass = resident;
-    const uint32_t passes = (count + per_pass - 1) / per_pass;
+    const uint32_t passes = (count + resident - 1) / resident;
+    const uint32_t per_pass = (count + passes - 1) / passes; // passes of equal size (a short last pass fills the chip badly)
     std::vector<std::vector<tile::Work>> works(passes);
     std::vector<std::vector<pipe::Work>> stuff_works(passes);
     std::vector<StageTimer> timers;
@@ -980,6 +983,8 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     static const bool attributes_set = [] {
         // (the sort stage asks for more than the 64 KB of LDS a kernel gets by default)
         const int lds = 160 * 1024;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::analyze_tiles<uint8_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::analyze_tiles<uint16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1033,8 +1038,8 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
 
         const ScanDesc* descs = d_descs + first;
         const uint32_t tiles_grid = 8 * ((lay.tiles + 7) / 8);
-        const size_t lds_a = tile::analyze_lds_bytes(proto.width);
-        const size_t lds_b = tile::sort_lds_bytes(proto.width, lay.lines_per_tile);
+        const size_t lds_a = tile::analyze_lds_bytes(proto.width, lay.lines_per_tile, sizeof(S), proto.interleave_mode);
+        const size_t lds_b = tile::sort_lds_bytes(proto.width, lay.lines_per_tile, sizeof(S), proto.interleave_mode);
         timers.emplace_back(s);
         StageTimer& t = timers.back();
         t.mark();
@@ -1060,7 +1065,8 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
         hipLaunchKernelGGL(tile::clear_pack_state, dim3(64, n), dim3(256), 0, s, d_works,
                            static_cast<uint32_t>(lay.off_raw + lay.raw_bytes - lay.off_bbase));
-        hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::kThreads), tile::pack_lds_bytes(), s, descs, d_works);
+        hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::kPackThreads), tile::pack_lds_bytes(proto.width, lay.lines_per_tile), s,
+                           descs, d_works);
         t.mark();
         if (overlap_stuffing)
         {
@@ -1068,7 +1074,9 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             hip_check(hipStreamWaitEvent(stuff_stream, packed[pass], 0));
         }
         t.mark_on(stuff_stream);
-        if (block_stuffing_enabled())
+        // Block-parallel stuffing is what ONE frame needs (a lane per KB of stream instead of a wavefront per frame); it
+        // walks every chunk from 16 entry states, so with a wavefront's worth of frames per SIMD pair stuff_scan is cheaper.
+        if (block_stuffing_enabled() && n <= kBlockStuffingScans)
         {
             const uint32_t chunk_waves = static_cast<uint32_t>((lay.raw_bytes / pipe::kStuffChunk + 1 + 63) / 64);
             hipLaunchKernelGGL(pipe::stuff_survey, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, d_stuff);

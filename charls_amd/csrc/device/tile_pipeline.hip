@@ -6,7 +6,7 @@
 //  1. HBM traffic.  The round-2 pipeline moved 1.48 GB per 4096 x 4096 frame (61 x the algorithmic bytes): 6 B/sample of
 //     analysis results written and read back, 4-byte records scattered line by line to ~30 chains per 64 samples (every
 //     32-byte sector written several times), 8-byte codes + 1-byte lengths + a 4-byte slot map gathered back.  Here the
-//     image is cut into TILES of up to kTileSamples samples (whole lines); a tile's events are sorted by chain INSIDE LDS
+//     image is cut into TILES of up to kMaxTileSamples samples (whole lines); a tile's events are sorted by chain INSIDE LDS
 //     and leave as contiguous pieces (one per chain, hundreds of bytes), the slot map is a 2-byte tile-local index that
 //     overwrites the 2-byte key in place, and a code is one 4-byte word.  10 B/sample of work area instead of 21.
 //
@@ -52,15 +52,18 @@ using pipe::kNoEvent;
 using pipe::kStatusInvalid;
 using pipe::kZeroContextChain;
 
-constexpr uint32_t kTileSamples = 8192;  // samples of a tile (whole lines); also the widest line the pipeline takes
-constexpr uint32_t kTileLines = 16;      // lines of a tile at most (per-line counters in LDS)
-constexpr uint32_t kThreads = 256;       // workgroup of the tile kernels
+
+constexpr uint32_t kMaxTileSamples = 8192; // samples of a tile at most (whole lines); also the widest line the pipeline takes
+constexpr uint32_t kTileLines = 16;        // lines of a tile at most
+constexpr uint32_t kSegments = 16;         // pieces of lines that the wavefronts of a tile workgroup work on, at most
+constexpr uint32_t kThreads = 512;         // workgroup of analyze_tiles / sort_tiles
 constexpr uint32_t kWaves = kThreads / 64;
+constexpr uint32_t kPackThreads = 256;     // workgroup of pack_tiles
 constexpr uint16_t kNoLocalSlot = 0xFFFF;
-constexpr uint32_t kChainPad = 16;       // chains start on multiples of 16 records (one 64-byte line)
+constexpr uint32_t kChainPad = 16;         // chains start on multiples of 16 records (one 64-byte line)
 constexpr uint32_t kSlack = kChains * kChainPad + 64; // spare records behind rec / code: padding + read-ahead of the walkers
-constexpr uint32_t kPlanGroups = 16;     // plan_chains sums the tiles of a scan in this many groups
-constexpr uint32_t kRunTag = 1u << 31;   // code word of a run-length code: ones : 6 | tail length : 5 | tail : 20
+constexpr uint32_t kPlanGroups = 16;       // plan_chains sums the tiles of a scan in this many groups
+constexpr uint32_t kRunTag = 1u << 31;     // code word of a run-length code: ones : 6 | tail length : 5 | tail : 20
 
 // State of a job at its first event (after the warm-up) and behind its last one (N is a function of the event index);
 // bad: an event of the job would make the reference raise invalid_data.
@@ -85,6 +88,8 @@ struct Work
     uint64_t raw_words;
     uint64_t* total_bits;
     uint32_t* status;
+    // the launch's geometry (all scans of a launch share width, sample type and interleave mode; a scan may have FEWER
+    // lines than the launch was sized for -- the last restart interval of a frame -- and then has fewer tiles)
     uint32_t lines_per_tile, tiles, job_events, warm_events;
 };
 
@@ -95,11 +100,41 @@ JLS_DEV uint32_t tile_of_block(uint32_t block, uint32_t tiles) // XCD-aware: wor
     return (block >> 3) < band && t < tiles ? t : tiles;
 }
 
-// Exclusive prefix sum of n <= 512 values held one or two per thread (value of index threadIdx.x and threadIdx.x + 256);
-// s_tmp: kWaves + 1 words.  All 256 threads call it.
+JLS_DEV uint32_t scan_lines(const ScanDesc& d)
+{
+    return d.interleave_mode == 1 ? pipe::coded_lines(d) : d.height;
+}
+JLS_DEV uint32_t scan_tiles(const ScanDesc& d, const Work& w) // tiles of THIS scan (<= w.tiles)
+{
+    return (scan_lines(d) + w.lines_per_tile - 1) / w.lines_per_tile;
+}
+
+// How the wavefronts of a tile workgroup share a tile: every line is cut into `pieces` runs of chunks (64 samples), a
+// "segment" is one piece of one line, segments are numbered in raster order.  Tiles of few long lines get several pieces
+// per line so that all wavefronts have work.
+struct TileGeometry
+{
+    uint32_t first_line, tile_lines, width, chunks, pieces, chunks_per_piece, segments;
+};
+JLS_DEV TileGeometry tile_geometry(const ScanDesc& d, const Work& w, uint32_t tile)
+{
+    TileGeometry g;
+    const uint32_t lines = scan_lines(d);
+    g.first_line = tile * w.lines_per_tile;
+    g.tile_lines = lines - g.first_line < w.lines_per_tile ? lines - g.first_line : w.lines_per_tile;
+    g.width = d.width;
+    g.chunks = (d.width + 63) / 64;
+    g.pieces = w.lines_per_tile >= kWaves ? 1u : kWaves / w.lines_per_tile;
+    g.chunks_per_piece = (g.chunks + g.pieces - 1) / g.pieces;
+    g.segments = g.tile_lines * g.pieces;
+    return g;
+}
+
+// Exclusive prefix sum of up to 2 * kThreads values held one or two per thread (index threadIdx.x and threadIdx.x +
+// blockDim.x); s_tmp: one word per wavefront.  All threads of the workgroup call it.
 JLS_DEV void block_exclusive_scan(uint32_t& lo, uint32_t& hi, uint32_t* s_tmp)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = (int)(blockDim.x >> 6);
     uint32_t carry = 0;
     for (int half = 0; half < 2; ++half)
     {
@@ -115,19 +150,93 @@ JLS_DEV void block_exclusive_scan(uint32_t& lo, uint32_t& hi, uint32_t* s_tmp)
         if (lane == 63)
             s_tmp[wave] = incl;
         __syncthreads();
-        uint32_t before = carry;
-        for (int w2 = 0; w2 < wave; ++w2)
-            before += s_tmp[w2];
-        uint32_t all = 0;
-        for (int w2 = 0; w2 < (int)kWaves; ++w2)
-            all += s_tmp[w2];
+        uint32_t before = carry, all = 0;
+        for (int w2 = 0; w2 < waves; ++w2)
+        {
+            const uint32_t n = s_tmp[w2];
+            before += w2 < wave ? n : 0;
+            all += n;
+        }
         v = before + incl - v;
         carry += all;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// A: grid (8 * ceil(tiles / 8), scans) x 256.  LDS: hist[kChains] | gradient table (512 B) | per wave: eq[chunks], q0[chunks].
+// The lines of a tile and the line above it, staged in LDS (planar scans): analysis reads every sample five times (x, Ra,
+// Rb, Rc, Rd); out of LDS those reads cost an LDS latency instead of a trip to the L2, and the staging itself is wide
+// coalesced loads issued back to back.  Line-interleaved scans (a colour transform may sit between the source and the
+// samples) read through pipe::load_sample.
+template <typename S, int ILV>
+struct Samples
+{
+    const ScanDesc& d;
+    const S* rows;       // LDS: line first_line - 1, then the tile's lines
+    uint32_t first_line; // of the tile
+    int mask;
+    JLS_DEV int operator()(uint32_t line, uint32_t x) const
+    {
+        if (ILV == 1)
+            return pipe::load_sample<S, 1>(d, line, x, mask);
+        return (int)rows[(size_t)(line + 1 - first_line) * d.width + x] & mask;
+    }
+};
+
+template <typename S, int ILV>
+JLS_DEV void stage_lines(const ScanDesc& d, const TileGeometry& g, S* rows)
+{
+    if (ILV == 1)
+        return;
+    const uint32_t width = g.width;
+    for (uint32_t r = 0; r <= g.tile_lines; ++r)
+    {
+        S* to = rows + (size_t)r * width;
+        if (g.first_line + r == 0)
+        { // above the first line of the scan: zeros (src/scan_encoder_impl.hpp:55-70)
+            for (uint32_t x = threadIdx.x; x < width; x += blockDim.x)
+                to[x] = 0;
+            continue;
+        }
+        const uint8_t* from = d.pixels + (size_t)(g.first_line + r - 1) * d.pixel_stride;
+        const uint32_t bytes = width * (uint32_t)sizeof(S);
+        if (((reinterpret_cast<uintptr_t>(from) | reinterpret_cast<uintptr_t>(to) | bytes) & 3u) == 0)
+        {
+            const uint32_t* from4 = reinterpret_cast<const uint32_t*>(from);
+            uint32_t* to4 = reinterpret_cast<uint32_t*>(to);
+            for (uint32_t i = threadIdx.x; i < bytes / 4; i += blockDim.x)
+                to4[i] = from4[i];
+        }
+        else
+        {
+            const S* from1 = reinterpret_cast<const S*>(from);
+            for (uint32_t x = threadIdx.x; x < width; x += blockDim.x)
+                to[x] = from1[x];
+        }
+    }
+}
+
+// LDS carve-up shared by analyze_tiles and sort_tiles (byte offsets; every region 16-byte aligned).
+struct TileLds
+{
+    uint32_t rows, keys, masks, table, end;
+};
+template <typename S, int ILV>
+JLS_DEV TileLds tile_lds(uint32_t width, uint32_t lines_per_tile)
+{
+    auto up = [](uint32_t v) { return (v + 15u) & ~15u; };
+    TileLds l;
+    const uint32_t chunks = (width + 63) / 64;
+    l.rows = 0;
+    l.keys = up(ILV == 1 ? 0u : (lines_per_tile + 1) * width * (uint32_t)sizeof(S));
+    l.masks = l.keys + up(lines_per_tile * width * 2u);
+    l.table = l.masks + up(lines_per_tile * chunks * 16u);
+    l.end = l.table;
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A: grid (8 * ceil(tiles / 8), scans) x 512.
+// LDS: lines | keys[tile] u16 | per line and chunk: eq, q0 masks | hist[kChains + 1] | gradient table (512 B)
 template <typename S, int ILV>
 __global__ void __launch_bounds__(kThreads) analyze_tiles(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
@@ -135,20 +244,24 @@ __global__ void __launch_bounds__(kThreads) analyze_tiles(const ScanDesc* __rest
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const Traits t = make_traits(d);
-    const uint32_t tile = tile_of_block(blockIdx.x, w.tiles);
-    if (tile >= w.tiles)
+    const uint32_t tile = tile_of_block(blockIdx.x, scan_tiles(d, w));
+    if (tile >= scan_tiles(d, w))
         return;
-    const uint32_t lines = ILV == 1 ? pipe::coded_lines(d) : d.height;
+    const TileGeometry g = tile_geometry(d, w, tile);
     const uint32_t step = ILV == 1 ? pipe::line_step(d) : 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t width = d.width;
-    const uint32_t chunks = (width + 63) / 64;
-    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t width = g.width, chunks = g.chunks;
+    const TileLds lds = tile_lds<S, ILV>(width, w.lines_per_tile);
+    S* s_rows = reinterpret_cast<S*>(smem + lds.rows);
+    uint16_t* s_key = reinterpret_cast<uint16_t*>(smem + lds.keys);
+    uint64_t* s_eq = reinterpret_cast<uint64_t*>(smem + lds.masks); // [line][chunk]
+    uint64_t* s_q0 = s_eq + (size_t)w.lines_per_tile * chunks;
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + lds.table);
     unsigned char* s_grad = reinterpret_cast<unsigned char*>(s_hist + kChains + 1);
-    uint64_t* s_eq = reinterpret_cast<uint64_t*>(s_grad + pipe::kGradientTable) + (size_t)wave * 2 * chunks;
-    uint64_t* s_q0 = s_eq + chunks;
     const int mask = (1 << d.bits_per_sample) - 1;
+    const Samples<S, ILV> sample{d, s_rows, g.first_line, mask};
 
+    stage_lines<S, ILV>(d, g, s_rows);
     for (uint32_t c = threadIdx.x; c < (uint32_t)kChains; c += kThreads)
         s_hist[c] = 0;
     if (sizeof(S) == 1)
@@ -156,31 +269,30 @@ __global__ void __launch_bounds__(kThreads) analyze_tiles(const ScanDesc* __rest
             s_grad[q] = (unsigned char)(quantize(t, (int)q - 255) + 4);
     __syncthreads();
 
-    const uint32_t first_line = tile * w.lines_per_tile;
-    const uint32_t tile_lines = lines - first_line < w.lines_per_tile ? lines - first_line : w.lines_per_tile;
-    for (uint32_t r = wave; r < tile_lines; r += kWaves)
+    // ---- pass 1: every sample as if coded in regular mode; equality / zero-context masks per 64-sample chunk
+    for (uint32_t sgm = wave; sgm < g.segments; sgm += kWaves)
     {
-        const uint32_t y = first_line + r; // coded line
+        const uint32_t r = sgm / g.pieces, piece = sgm % g.pieces;
+        const uint32_t y = g.first_line + r; // coded line
+        const uint32_t k0 = piece * g.chunks_per_piece;
+        const uint32_t k1 = k0 + g.chunks_per_piece < chunks ? k0 + g.chunks_per_piece : chunks;
         // edge samples of the line (src/scan_codec.hpp:189-195 and the two-line ping-pong of src/scan_encoder_impl.hpp:55-106)
-        const int edge_a = y >= step ? pipe::load_sample<S, ILV>(d, y - step, 0, mask) : 0;         // cur[0]  = prev[1]
-        const int edge_c = y >= 2 * step ? pipe::load_sample<S, ILV>(d, y - 2 * step, 0, mask) : 0; // prev[0]
-        uint16_t* key_row = w.keyinv + (size_t)y * width;
-        JLS_LOCKSTEP();
-        // ---- pass 1: every sample as if coded in regular mode; equality / zero-context masks per 64-sample chunk
-        for (uint32_t k = 0; k < chunks; ++k)
+        const int edge_a = y >= step ? sample(y - step, 0) : 0; // cur[0]  = prev[1]
+        const int edge_c = y >= 2 * step ? (ILV == 1 || r >= 1 ? sample(y - 2 * step, 0) : pipe::load_sample<S, ILV>(d, y - 2, 0, mask)) : 0; // prev[0]
+        for (uint32_t k = k0; k < k1; ++k)
         {
             const uint32_t x = k * 64 + lane;
             bool eq = false, q0 = false;
             if (x < width)
             {
-                const int v = pipe::load_sample<S, ILV>(d, y, x, mask);
-                const int ra = x > 0 ? pipe::load_sample<S, ILV>(d, y, x - 1, mask) : edge_a;
+                const int v = sample(y, x);
+                const int ra = x > 0 ? sample(y, x - 1) : edge_a;
                 int rb = 0, rc = 0, rd = 0;
                 if (y >= step)
                 {
-                    rb = pipe::load_sample<S, ILV>(d, y - step, x, mask);
-                    rc = x > 0 ? pipe::load_sample<S, ILV>(d, y - step, x - 1, mask) : edge_c;
-                    rd = pipe::load_sample<S, ILV>(d, y - step, x + 1 < width ? x + 1 : width - 1, mask);
+                    rb = sample(y - step, x);
+                    rc = x > 0 ? sample(y - step, x - 1) : edge_c;
+                    rd = sample(y - step, x + 1 < width ? x + 1 : width - 1);
                 }
                 else
                     rc = x > 0 ? 0 : edge_c;
@@ -189,7 +301,7 @@ __global__ void __launch_bounds__(kThreads) analyze_tiles(const ScanDesc* __rest
                                    : context_id(t, ra, rb, rc, rd);
                 const int sg = qs >> 31;
                 const int ctx = (qs ^ sg) - sg;
-                key_row[x] = (uint16_t)(ctx | ((sg & 1) << 9));
+                s_key[r * width + x] = (uint16_t)(ctx | ((sg & 1) << 9));
                 eq = v == ra;
                 q0 = qs == 0;
             }
@@ -197,41 +309,52 @@ __global__ void __launch_bounds__(kThreads) analyze_tiles(const ScanDesc* __rest
             const unsigned long long m_q0 = __ballot(q0);
             if (lane == 0)
             {
-                s_eq[k] = m_eq;
-                s_q0[k] = m_q0;
+                s_eq[r * chunks + k] = m_eq;
+                s_q0[r * chunks + k] = m_q0;
             }
         }
-        JLS_LOCKSTEP();
-        // ---- pass 2: run-mode state before every sample.  s' = eq & (s | q0) is a carry chain: generate = eq & q0,
-        // propagate = eq, so one 64-bit addition per chunk resolves 64 samples (src/scan_encoder_impl.hpp:249-275).
+    }
+    __syncthreads();
+    // ---- pass 2: run-mode state before every sample.  s' = eq & (s | q0) is a carry chain: generate = eq & q0,
+    // propagate = eq, so one 64-bit addition per chunk resolves 64 samples (src/scan_encoder_impl.hpp:249-275).  A piece
+    // that does not start its line first runs the (scalar) chain over the chunks before it.
+    for (uint32_t sgm = wave; sgm < g.segments; sgm += kWaves)
+    {
+        const uint32_t r = sgm / g.pieces, piece = sgm % g.pieces;
+        const uint32_t y = g.first_line + r;
+        const uint32_t k0 = piece * g.chunks_per_piece;
+        const uint32_t k1 = k0 + g.chunks_per_piece < chunks ? k0 + g.chunks_per_piece : chunks;
+        uint16_t* key_row = w.keyinv + (size_t)y * width;
         unsigned long long carry = 0;
-        for (uint32_t k = 0; k < chunks; ++k)
+        for (uint32_t k = 0; k < k1; ++k)
         {
-            const unsigned long long a = s_eq[k];
-            const unsigned long long b = s_eq[k] & s_q0[k];
+            const unsigned long long a = s_eq[r * chunks + k];
+            const unsigned long long b = a & s_q0[r * chunks + k];
             const unsigned long long sum = a + b + carry;
             const unsigned long long st = sum ^ a ^ b; // bit i: in-run state before sample i
             carry = (((a & b) | ((a | b) & st)) >> 63) & 1ull;
             const uint32_t x = k * 64 + lane;
-            if (x < width)
+            if (k >= k0 && x < width)
             {
                 const bool s = (st >> lane) & 1ull;
-                const bool q0 = (s_q0[k] >> lane) & 1ull;
+                const bool q0 = (s_q0[r * chunks + k] >> lane) & 1ull;
                 const bool eq = (a >> lane) & 1ull;
+                uint16_t key = s_key[r * width + x];
                 if (!(s || q0))
-                    atomicAdd(&s_hist[key_row[x] & 0x1FF], 1u); // regular sample, key already written by this lane
+                    atomicAdd(&s_hist[key & 0x1FF], 1u); // regular sample
                 else if (s && eq)
-                    key_row[x] = kNoEvent; // inside a run
+                    key = kNoEvent; // inside a run
                 else if (s)
                 { // the sample that ends a run started earlier: coded by the run lane, owns a slot of its own
-                    key_row[x] = (uint16_t)kInterruptChain;
+                    key = (uint16_t)kInterruptChain;
                     atomicAdd(&s_hist[kInterruptChain], 1u);
                 }
                 else
                 { // a run starts here (possibly of length 0); its length is the number of kNoEvent keys that follow
-                    key_row[x] = 0;
+                    key = 0;
                     atomicAdd(&s_hist[0], 1u);
                 }
+                key_row[x] = key;
             }
         }
     }
@@ -248,14 +371,15 @@ __global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__
 {
     __shared__ uint32_t s_part[kPlanGroups][kChains + 1];
     __shared__ uint32_t s_base[kChains + 1];
+    const ScanDesc d = descs[blockIdx.x];
     const Work w = works[blockIdx.x];
-    const uint32_t tiles = w.tiles;
+    const uint32_t tiles = scan_tiles(d, w);
     const uint32_t per_group = (tiles + kPlanGroups - 1) / kPlanGroups;
     const uint32_t pairs = kPlanGroups * (uint32_t)kChains;
     for (uint32_t p = threadIdx.x; p < pairs; p += 1024)
     {
         const uint32_t g = p / kChains, c = p % kChains;
-        const uint32_t t0 = g * per_group, t1 = t0 + per_group < tiles ? t0 + per_group : tiles;
+        const uint32_t t0 = g * per_group < tiles ? g * per_group : tiles, t1 = t0 + per_group < tiles ? t0 + per_group : tiles;
         uint32_t sum = 0;
         for (uint32_t t = t0; t < t1; ++t)
             sum += w.seg[(size_t)t * kChains + c];
@@ -300,7 +424,7 @@ __global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__
     for (uint32_t p = threadIdx.x; p < pairs; p += 1024)
     {
         const uint32_t g = p / kChains, c = p % kChains;
-        const uint32_t t0 = g * per_group, t1 = t0 + per_group < tiles ? t0 + per_group : tiles;
+        const uint32_t t0 = g * per_group < tiles ? g * per_group : tiles, t1 = t0 + per_group < tiles ? t0 + per_group : tiles;
         uint32_t running = s_base[c] + s_part[g][c];
         for (uint32_t t = t0; t < t1; ++t)
         {
@@ -311,8 +435,6 @@ __global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__
         if (t1 == tiles && t0 < t1)
             w.seg[(size_t)tiles * kChains + c] = running;
     }
-    if (tiles == 0 && threadIdx.x < (uint32_t)kChains)
-        w.seg[threadIdx.x] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -333,9 +455,9 @@ JLS_DEV uint32_t make_record(int x, int px, int sign_bit, int maxval)
     return ((uint32_t)d & 0xFFFFu) | ((uint32_t)room << 16) | ((uint32_t)side << 24) | ((uint32_t)sign_bit << 31);
 }
 
-// B2: grid (8 * ceil(tiles / 8), scans) x 256.
-// LDS: stage[kTileSamples] u32 | keys[kTileSamples] u16 | lineoff[lines_per_tile][kChains] u32 | tileoff[kChains] | delta[kChains] |
-//      per wave: noev[chunks] u64, lead[chunks + 1] u32 | scan scratch
+// B2: grid (8 * ceil(tiles / 8), scans) x 512.
+// LDS: lines | keys[tile] u16 | noev[line][chunk] u64, lead[line][chunk + 1] u32 | segoff[kSegments][kChains] u32 |
+//      tileoff, count, global [kChains + 1] | scan scratch | stage[tile] u32
 template <typename S, int ILV>
 __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
@@ -343,56 +465,65 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const Traits t = make_traits(d);
-    const uint32_t tile = tile_of_block(blockIdx.x, w.tiles);
-    if (tile >= w.tiles)
+    const uint32_t tile = tile_of_block(blockIdx.x, scan_tiles(d, w));
+    if (tile >= scan_tiles(d, w))
         return;
-    const uint32_t lines = ILV == 1 ? pipe::coded_lines(d) : d.height;
+    const TileGeometry g = tile_geometry(d, w, tile);
     const uint32_t step = ILV == 1 ? pipe::line_step(d) : 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t width = d.width;
-    const uint32_t chunks = (width + 63) / 64;
-    uint32_t* s_stage = reinterpret_cast<uint32_t*>(smem);
-    uint16_t* s_key = reinterpret_cast<uint16_t*>(s_stage + kTileSamples);
-    uint32_t* s_lineoff = reinterpret_cast<uint32_t*>(s_key + kTileSamples); // [kTileLines][kChains]
-    uint32_t* s_tileoff = s_lineoff + w.lines_per_tile * kChains;            // first local slot of the chain
-    uint32_t* s_count = s_tileoff + kChains + 1;                             // events of the chain in this tile
-    uint32_t* s_global = s_count + kChains + 1;                              // first global slot of the tile's piece
-    uint32_t* s_tmp = s_global + kChains + 1;                                // kWaves + 1
-    uint64_t* s_noev = reinterpret_cast<uint64_t*>(s_tmp + 8) + (size_t)wave * chunks;
-    uint32_t* s_lead = reinterpret_cast<uint32_t*>(reinterpret_cast<uint64_t*>(s_tmp + 8) + (size_t)kWaves * chunks) + (size_t)wave * (chunks + 1);
+    const uint32_t width = g.width, chunks = g.chunks;
+    const TileLds lds = tile_lds<S, ILV>(width, w.lines_per_tile);
+    S* s_rows = reinterpret_cast<S*>(smem + lds.rows);
+    uint16_t* s_key = reinterpret_cast<uint16_t*>(smem + lds.keys);
+    uint64_t* s_noev = reinterpret_cast<uint64_t*>(smem + lds.masks);                                // [line][chunk]
+    uint32_t* s_lead = reinterpret_cast<uint32_t*>(s_noev + (size_t)w.lines_per_tile * chunks);       // [line][chunk + 1] (fits: 16 B per (line, chunk) reserved)
+    uint32_t* s_segoff = reinterpret_cast<uint32_t*>(smem + lds.table);                               // [kSegments][kChains]
+    uint32_t* s_tileoff = s_segoff + kSegments * kChains; // first local slot of the chain
+    uint32_t* s_count = s_tileoff + kChains + 1;          // events of the chain in this tile
+    uint32_t* s_global = s_count + kChains + 1;           // first global slot of the tile's piece
+    uint32_t* s_tmp = s_global + kChains + 1;             // kWaves words (+ padding to 16 words)
+    uint32_t* s_stage = s_tmp + 16;
     const int mask = (1 << d.bits_per_sample) - 1;
+    const Samples<S, ILV> sample{d, s_rows, g.first_line, mask};
+    const uint16_t* key_tile = w.keyinv + (size_t)g.first_line * width;
 
-    const uint32_t first_line = tile * w.lines_per_tile;
-    const uint32_t tile_lines = lines - first_line < w.lines_per_tile ? lines - first_line : w.lines_per_tile;
-    const uint32_t tile_samples = tile_lines * width;
-    const uint16_t* key_tile = w.keyinv + (size_t)first_line * width;
-
-    for (uint32_t i = threadIdx.x; i < w.lines_per_tile * (uint32_t)kChains; i += kThreads)
-        s_lineoff[i] = 0;
+    stage_lines<S, ILV>(d, g, s_rows);
+    for (uint32_t i = threadIdx.x; i < kSegments * (uint32_t)kChains; i += kThreads)
+        s_segoff[i] = 0;
     __syncthreads();
-    // ---- P1: keys into LDS, events per (line, chain)
-    for (uint32_t r = wave; r < tile_lines; r += kWaves)
-        for (uint32_t k = 0; k < chunks; ++k)
+    // ---- P1: keys into LDS, events per (segment, chain), samples inside runs per chunk
+    for (uint32_t sgm = wave; sgm < g.segments; sgm += kWaves)
+    {
+        const uint32_t r = sgm / g.pieces, piece = sgm % g.pieces;
+        const uint32_t k0 = piece * g.chunks_per_piece;
+        const uint32_t k1 = k0 + g.chunks_per_piece < chunks ? k0 + g.chunks_per_piece : chunks;
+        for (uint32_t k = k0; k < k1; ++k)
         {
             const uint32_t x = k * 64 + lane;
+            uint16_t key = kNoEvent;
             if (x < width)
             {
-                const uint16_t key = key_tile[(size_t)r * width + x];
+                key = key_tile[(size_t)r * width + x];
                 s_key[r * width + x] = key;
                 if (key != kNoEvent)
-                    atomicAdd(&s_lineoff[r * kChains + (key & 0x1FF)], 1u);
+                    atomicAdd(&s_segoff[sgm * kChains + (key & 0x1FF)], 1u);
             }
+            const unsigned long long m = __ballot(x < width && key == kNoEvent);
+            if (lane == 0)
+                s_noev[r * chunks + k] = m;
         }
+    }
     __syncthreads();
-    // ---- offsets: chains in order, inside a chain the lines in order
+    // ---- offsets: chains in order, inside a chain the segments in (raster) order; per line, the number of samples
+    // inside runs from the first sample of every chunk on
     {
         uint32_t n[2] = {0, 0};
         for (int half = 0; half < 2; ++half)
         {
             const uint32_t c = threadIdx.x + (uint32_t)half * kThreads;
             if (c < (uint32_t)kChains)
-                for (uint32_t r = 0; r < tile_lines; ++r)
-                    n[half] += s_lineoff[r * kChains + c];
+                for (uint32_t sgm = 0; sgm < g.segments; ++sgm)
+                    n[half] += s_segoff[sgm * kChains + c];
         }
         uint32_t off[2] = {n[0], n[1]};
         block_exclusive_scan(off[0], off[1], s_tmp);
@@ -405,47 +536,40 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
                 s_count[c] = n[half];
                 s_global[c] = w.seg[(size_t)tile * kChains + c];
                 uint32_t running = off[half];
-                for (uint32_t r = 0; r < tile_lines; ++r)
+                for (uint32_t sgm = 0; sgm < g.segments; ++sgm)
                 {
-                    const uint32_t m = s_lineoff[r * kChains + c];
-                    s_lineoff[r * kChains + c] = running;
+                    const uint32_t m = s_segoff[sgm * kChains + c];
+                    s_segoff[sgm * kChains + c] = running;
                     running += m;
                 }
+            }
+        }
+        if (threadIdx.x >= kThreads - g.tile_lines)
+        { // (the last threads: they have no chain of their own to scan)
+            const uint32_t r = kThreads - 1 - threadIdx.x;
+            uint32_t lead = 0;
+            s_lead[r * (chunks + 1) + chunks] = 0;
+            for (uint32_t k = chunks; k-- > 0;)
+            {
+                const unsigned long long m = s_noev[r * chunks + k];
+                lead = m == ~0ull ? 64 + lead : (uint32_t)__ffsll(~m) - 1;
+                s_lead[r * (chunks + 1) + k] = lead;
             }
         }
     }
     __syncthreads();
     // ---- P2: ranks, records
-    for (uint32_t r = wave; r < tile_lines; r += kWaves)
+    for (uint32_t sgm = wave; sgm < g.segments; sgm += kWaves)
     {
-        const uint32_t y = first_line + r;
+        const uint32_t r = sgm / g.pieces, piece = sgm % g.pieces;
+        const uint32_t y = g.first_line + r;
+        const uint32_t k0 = piece * g.chunks_per_piece;
+        const uint32_t k1 = k0 + g.chunks_per_piece < chunks ? k0 + g.chunks_per_piece : chunks;
         const uint16_t* keys = s_key + r * width;
-        uint32_t* lineoff = s_lineoff + r * kChains;
-        JLS_LOCKSTEP();
-        // samples inside runs, per chunk; lead[k] = number of such samples from the first sample of chunk k on
-        for (uint32_t k = 0; k < chunks; ++k)
-        {
-            const uint32_t x = k * 64 + lane;
-            const unsigned long long m = __ballot(x < width && keys[x] == kNoEvent);
-            if (lane == 0)
-                s_noev[k] = m;
-        }
-        JLS_LOCKSTEP();
-        if (lane == 0)
-        {
-            uint32_t lead = 0;
-            s_lead[chunks] = 0;
-            for (uint32_t k = chunks; k-- > 0;)
-            {
-                const unsigned long long m = s_noev[k];
-                lead = m == ~0ull ? 64 + lead : (uint32_t)__ffsll(~m) - 1;
-                s_lead[k] = lead;
-            }
-        }
-        JLS_LOCKSTEP();
-        const int edge_a = y >= step ? pipe::load_sample<S, ILV>(d, y - step, 0, mask) : 0;
-        const int edge_c = y >= 2 * step ? pipe::load_sample<S, ILV>(d, y - 2 * step, 0, mask) : 0;
-        for (uint32_t k = 0; k < chunks; ++k)
+        uint32_t* segoff = s_segoff + sgm * kChains;
+        const int edge_a = y >= step ? sample(y - step, 0) : 0;
+        const int edge_c = y >= 2 * step ? (ILV == 1 || r >= 1 ? sample(y - 2 * step, 0) : pipe::load_sample<S, ILV>(d, y - 2, 0, mask)) : 0;
+        for (uint32_t k = k0; k < k1; ++k)
         {
             const uint32_t x = k * 64 + lane;
             const uint16_t key = x < width ? keys[x] : kNoEvent;
@@ -464,26 +588,26 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
             uint32_t slot = 0;
             JLS_LOCKSTEP();
             if (has)
-                slot = lineoff[chain] + rank;
+                slot = segoff[chain] + rank;
             JLS_LOCKSTEP();
             if (has && rank == 0)
-                lineoff[chain] += (uint32_t)__popcll(same);
+                segoff[chain] += (uint32_t)__popcll(same);
             JLS_LOCKSTEP();
             if (has)
             {
                 uint32_t record = 0;
                 if (chain == 0)
                 { // run start: length | end-of-line << 31; what the run lane needs of the interruption sample goes to code[]
-                    const int v = pipe::load_sample<S, ILV>(d, y, x, mask);
-                    const int ra = x > 0 ? pipe::load_sample<S, ILV>(d, y, x - 1, mask) : edge_a;
+                    const int v = sample(y, x);
+                    const int ra = x > 0 ? sample(y, x - 1) : edge_a;
                     uint32_t run = 0;
                     if (v == ra)
                     {
-                        const unsigned long long after = lane == 63 ? 0ull : s_noev[k] >> (lane + 1);
+                        const unsigned long long after = lane == 63 ? 0ull : s_noev[r * chunks + k] >> (lane + 1);
                         const uint32_t rest = 63u - (uint32_t)lane;
                         uint32_t n = (uint32_t)__ffsll(~after) - 1;
                         if (n >= rest)
-                            n = rest + s_lead[k + 1];
+                            n = rest + s_lead[r * (chunks + 1) + k + 1];
                         run = 1 + n;
                     }
                     const uint32_t xi = x + run;
@@ -492,9 +616,9 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
                     uint32_t packed = ILV == 1 ? (y % step) << 18 : 0u;
                     if (!eol)
                     { // src/scan_encoder_core.hpp:105-125: type and error value of the interruption are functions of the image
-                        const int xv = pipe::load_sample<S, ILV>(d, y, xi, mask);
-                        const int ia = xi > 0 ? pipe::load_sample<S, ILV>(d, y, xi - 1, mask) : edge_a;
-                        const int ib = y >= step ? pipe::load_sample<S, ILV>(d, y - step, xi, mask) : 0;
+                        const int xv = sample(y, xi);
+                        const int ia = xi > 0 ? sample(y, xi - 1) : edge_a;
+                        const int ib = y >= step ? sample(y - step, xi) : 0;
                         const int which = ia == ib ? 1 : 0;
                         const int err = which ? error_value(t, xv - ia) : error_value(t, (xv - ib) * ((ib - ia) < 0 ? -1 : 1));
                         packed |= ((uint32_t)err & 0x1FFFFu) | ((uint32_t)which << 17);
@@ -503,13 +627,13 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
                 }
                 else if (chain != (uint32_t)kInterruptChain)
                 {
-                    const int v = pipe::load_sample<S, ILV>(d, y, x, mask);
-                    const int ra = x > 0 ? pipe::load_sample<S, ILV>(d, y, x - 1, mask) : edge_a;
+                    const int v = sample(y, x);
+                    const int ra = x > 0 ? sample(y, x - 1) : edge_a;
                     int rb = 0, rc = 0;
                     if (y >= step)
                     {
-                        rb = pipe::load_sample<S, ILV>(d, y - step, x, mask);
-                        rc = x > 0 ? pipe::load_sample<S, ILV>(d, y - step, x - 1, mask) : edge_c;
+                        rb = sample(y - step, x);
+                        rc = x > 0 ? sample(y - step, x - 1) : edge_c;
                     }
                     else
                         rc = x > 0 ? 0 : edge_c;
@@ -531,7 +655,6 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
         for (uint32_t i = lane; i < n; i += 64)
             w.rec[to + i] = s_stage[from + i];
     }
-    (void)tile_samples;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -818,9 +941,7 @@ __global__ void __launch_bounds__(64) code_runs(const ScanDesc* __restrict__ des
 
 // ---------------------------------------------------------------------------------------------------------------
 // D: grid (tiles, scans) x 256; tiles in index order (a tile only waits for tiles that were started before it).
-// LDS: codes[kTileSamples] u32 | tileoff / count / global [kChains + 1] each | scan[256] | tmp
-constexpr uint32_t kPerThread = kTileSamples / kThreads; // 32 consecutive samples
-
+// LDS: codes[tile] u32 | tileoff / count / global [kChains + 1] each | scan[256] | tmp
 JLS_DEV void expand_code(uint32_t word, uint64_t& bits, int& len)
 {
     if (word & kRunTag)
@@ -836,23 +957,27 @@ JLS_DEV void expand_code(uint32_t word, uint64_t& bits, int& len)
     }
 }
 
-__global__ void __launch_bounds__(kThreads) pack_tiles(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+__global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
     JLS_DYNAMIC_LDS(smem);
     __shared__ uint64_t s_start;
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const uint32_t tile = blockIdx.x;
-    if (tile >= w.tiles)
+    const uint32_t tiles = scan_tiles(d, w);
+    if (tile >= tiles)
         return;
+    const uint32_t tile_capacity = w.lines_per_tile * d.width;
+    const uint32_t per_thread = (tile_capacity + kPackThreads - 1) / kPackThreads; // consecutive samples of a thread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr uint32_t kPackWaves = kPackThreads / 64;
     uint32_t* s_code = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* s_tileoff = s_code + kTileSamples;
+    uint32_t* s_tileoff = s_code + tile_capacity;
     uint32_t* s_count = s_tileoff + kChains + 1;
     uint32_t* s_global = s_count + kChains + 1;
     uint32_t* s_scan = s_global + kChains + 1; // 256
-    uint32_t* s_tmp = s_scan + kThreads;       // kWaves + 1
-    const uint32_t lines = d.interleave_mode == 1 ? pipe::coded_lines(d) : d.height;
+    uint32_t* s_tmp = s_scan + kPackThreads;   // one word per wavefront
+    const uint32_t lines = scan_lines(d);
     const uint32_t first_line = tile * w.lines_per_tile;
     const uint32_t tile_lines = lines - first_line < w.lines_per_tile ? lines - first_line : w.lines_per_tile;
     const uint32_t tile_samples = tile_lines * d.width;
@@ -862,7 +987,7 @@ __global__ void __launch_bounds__(kThreads) pack_tiles(const ScanDesc* __restric
         uint32_t n[2] = {0, 0}, g[2] = {0, 0};
         for (int half = 0; half < 2; ++half)
         {
-            const uint32_t c = threadIdx.x + (uint32_t)half * kThreads;
+            const uint32_t c = threadIdx.x + (uint32_t)half * kPackThreads;
             if (c < (uint32_t)kChains)
             {
                 g[half] = w.seg[(size_t)tile * kChains + c];
@@ -873,7 +998,7 @@ __global__ void __launch_bounds__(kThreads) pack_tiles(const ScanDesc* __restric
         block_exclusive_scan(off[0], off[1], s_tmp);
         for (int half = 0; half < 2; ++half)
         {
-            const uint32_t c = threadIdx.x + (uint32_t)half * kThreads;
+            const uint32_t c = threadIdx.x + (uint32_t)half * kPackThreads;
             if (c < (uint32_t)kChains)
             {
                 s_tileoff[c] = off[half];
@@ -883,7 +1008,7 @@ __global__ void __launch_bounds__(kThreads) pack_tiles(const ScanDesc* __restric
         }
     }
     __syncthreads();
-    for (uint32_t c = wave; c < (uint32_t)kChains; c += kWaves)
+    for (uint32_t c = wave; c < (uint32_t)kChains; c += kPackWaves)
     {
         const uint32_t n = s_count[c], to = s_tileoff[c], from = s_global[c];
         for (uint32_t i = lane; i < n; i += 64)
@@ -892,9 +1017,9 @@ __global__ void __launch_bounds__(kThreads) pack_tiles(const ScanDesc* __restric
     __syncthreads();
 
     // ---- bits of this thread's samples
-    const uint32_t base = threadIdx.x * kPerThread;
+    const uint32_t base = threadIdx.x * per_thread;
     uint32_t sum = 0;
-    for (uint32_t i = 0; i < kPerThread; ++i)
+    for (uint32_t i = 0; i < per_thread; ++i)
     {
         const uint16_t slot = base + i < tile_samples ? inv[base + i] : kNoLocalSlot;
         if (slot != kNoLocalSlot)
@@ -907,7 +1032,7 @@ __global__ void __launch_bounds__(kThreads) pack_tiles(const ScanDesc* __restric
     }
     s_scan[threadIdx.x] = sum;
     __syncthreads();
-    for (uint32_t stride = 1; stride < kThreads; stride <<= 1) // Hillis-Steele inclusive scan
+    for (uint32_t stride = 1; stride < kPackThreads; stride <<= 1) // Hillis-Steele inclusive scan
     {
         const uint32_t add = threadIdx.x >= stride ? s_scan[threadIdx.x - stride] : 0;
         __syncthreads();
@@ -917,7 +1042,7 @@ __global__ void __launch_bounds__(kThreads) pack_tiles(const ScanDesc* __restric
     // ---- where this tile starts: the first wavefront looks back, 64 predecessors at a time (see write_raw_bits)
     if (threadIdx.x < 64)
     {
-        const uint64_t own = s_scan[kThreads - 1];
+        const uint64_t own = s_scan[kPackThreads - 1];
         const uint32_t b = tile;
         if (lane == 0)
             store_relaxed(&w.blockbase[b], (b == 0 ? pipe::kBlockUpTo : pipe::kBlockOwn) | own);
@@ -947,7 +1072,7 @@ __global__ void __launch_bounds__(kThreads) pack_tiles(const ScanDesc* __restric
             if (b != 0)
                 store_relaxed(&w.blockbase[b], pipe::kBlockUpTo | (start + own));
             s_start = start;
-            if (b + 1 == w.tiles)
+            if (b + 1 == tiles)
                 *w.total_bits = start + own;
         }
     }
@@ -959,7 +1084,7 @@ __global__ void __launch_bounds__(kThreads) pack_tiles(const ScanDesc* __restric
     const uint64_t first_word = word;
     int acc_bits = (int)(bitpos & 31); // the leading bits of the first word belong to the previous thread
     uint64_t acc = 0;
-    for (uint32_t i = 0; i < kPerThread; ++i)
+    for (uint32_t i = 0; i < per_thread; ++i)
     {
         const uint16_t slot = base + i < tile_samples ? inv[base + i] : kNoLocalSlot; // (second read: the line is in the cache)
         if (slot == kNoLocalSlot)
@@ -1004,21 +1129,34 @@ __global__ void __launch_bounds__(256) clear_pack_state(const Work* __restrict__
         at[g] = make_uint4(0, 0, 0, 0);
 }
 
-// LDS bytes of the tile kernels for a line of `width` samples.
-inline size_t analyze_lds_bytes(uint32_t width)
+// LDS bytes of the tile kernels for lines of `width` samples of `sample_bytes` bytes, `lines_per_tile` lines per tile.
+inline size_t tile_common_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t sample_bytes, int interleave_mode)
 {
+    auto up = [](size_t v) { return (v + 15) & ~size_t{15}; };
     const size_t chunks = (width + 63) / 64;
-    return ((size_t)kChains + 1) * 4 + pipe::kGradientTable + (size_t)kWaves * 2 * chunks * 8;
+    return up(interleave_mode == 1 ? 0 : (size_t)(lines_per_tile + 1) * width * sample_bytes) + up((size_t)lines_per_tile * width * 2) +
+           up((size_t)lines_per_tile * chunks * 16);
 }
-inline size_t sort_lds_bytes(uint32_t width, uint32_t lines_per_tile)
+inline size_t analyze_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t sample_bytes, int interleave_mode)
 {
-    const size_t chunks = (width + 63) / 64;
-    return (size_t)kTileSamples * 4 + (size_t)kTileSamples * 2 + (size_t)lines_per_tile * kChains * 4 + 3 * ((size_t)kChains + 1) * 4 + 8 * 4 +
-           (size_t)kWaves * chunks * 8 + (size_t)kWaves * (chunks + 1) * 4;
+    return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode) + ((size_t)kChains + 1) * 4 + pipe::kGradientTable;
 }
-inline size_t pack_lds_bytes()
+inline size_t sort_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t sample_bytes, int interleave_mode)
 {
-    return (size_t)kTileSamples * 4 + 3 * ((size_t)kChains + 1) * 4 + (size_t)kThreads * 4 + 8 * 4;
+    return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode) + (size_t)kSegments * kChains * 4 +
+           3 * ((size_t)kChains + 1) * 4 + 16 * 4 + (size_t)lines_per_tile * width * 4;
+}
+inline size_t pack_lds_bytes(uint32_t width, uint32_t lines_per_tile)
+{
+    return (size_t)lines_per_tile * width * 4 + 3 * ((size_t)kChains + 1) * 4 + (size_t)kPackThreads * 4 + 16 * 4;
+}
+// Lines per tile for lines of `width` samples: as many whole lines as fit `tile_samples` (8192 for samples of one byte,
+// 4096 for two: the sort stage keeps the lines, the keys and the sorted records of a tile in LDS), at most kTileLines.
+inline uint32_t lines_per_tile_for(uint32_t width, uint32_t sample_bytes)
+{
+    const uint32_t tile_samples = sample_bytes == 1 ? kMaxTileSamples : kMaxTileSamples / 2;
+    const uint32_t n = tile_samples / width;
+    return n < 1 ? 1 : (n > kTileLines ? kTileLines : n);
 }
 
 } // namespace tile

@@ -25,8 +25,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     const ScanDesc& p = descs[0];
     const size_t lines = (size_t)p.height * (size_t)(p.interleave_mode == 1 ? p.components : 1);
     const size_t samples = (size_t)p.width * lines;
-    uint32_t lines_per_tile = tile::kTileSamples / p.width;
-    lines_per_tile = lines_per_tile < 1 ? 1 : (lines_per_tile > tile::kTileLines ? tile::kTileLines : lines_per_tile);
+    const uint32_t lines_per_tile = tile::lines_per_tile_for(p.width, (uint32_t)sizeof(S));
     const uint32_t tiles = (uint32_t)((lines + lines_per_tile - 1) / lines_per_tile);
     const size_t max_jobs = samples / job_events + pipe::kChains;
     std::vector<tile::Work> works(count);
@@ -76,21 +75,21 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     const tile::Work* wk = works.data();
     const unsigned tiles_grid = 8 * ((tiles + 7) / 8);
     if (p.interleave_mode == 1)
-        emu::launch(tile::analyze_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::analyze_lds_bytes(p.width), descs, wk);
+        emu::launch(tile::analyze_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::analyze_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode), descs, wk);
     else
-        emu::launch(tile::analyze_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::analyze_lds_bytes(p.width), descs, wk);
+        emu::launch(tile::analyze_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::analyze_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode), descs, wk);
     emu::launch(tile::plan_chains, dim3(count), dim3(1024), 0, descs, wk);
     if (p.interleave_mode == 1)
-        emu::launch(tile::sort_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::sort_lds_bytes(p.width, lines_per_tile), descs, wk);
+        emu::launch(tile::sort_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::sort_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode), descs, wk);
     else
-        emu::launch(tile::sort_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::sort_lds_bytes(p.width, lines_per_tile), descs, wk);
+        emu::launch(tile::sort_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::sort_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode), descs, wk);
     emu::launch(tile::walk_jobs<S>, dim3((unsigned)((max_jobs + 63) / 64), count), dim3(64), 0, descs, wk);
     emu::launch(tile::settle_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
     if (p.interleave_mode == 1)
         emu::launch(tile::code_runs<S, 1>, dim3((count + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
     else
         emu::launch(tile::code_runs<S, 0>, dim3((count + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
-    emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::kThreads), tile::pack_lds_bytes(), descs, wk);
+    emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::kPackThreads), tile::pack_lds_bytes(p.width, lines_per_tile), descs, wk);
     const pipe::Work* sk = stuff.data();
     if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env == nullptr || std::atoi(env) != 0)
     {

@@ -238,3 +238,25 @@ def test_tile_pipeline_random_parameters(chunk):
         L.emu_encode_tile_pipeline((emu_bind.ScanDesc * 1)(d), res, 1, job, warm)
         tag = (chunk, it, bits, comps, ilv, w, h, kind, preset, xform, job, warm)
         assert res[0].errc == 0 and out[:res[0].bytes].tobytes() == _scan_bytes(want), tag
+
+
+def test_tile_pipeline_scans_shorter_than_the_launch_geometry():
+    """The last restart interval of a frame has fewer lines than the intervals it shares a launch with (the launch is sized
+    for the first scan): fewer tiles, a last tile with fewer lines, the scan's result still the reference's bytes."""
+    L = emu_bind.tile_lib()
+    w = 200
+    pc = jls_container.validated_pc((0,) * 5, 8, 0)
+    for heights in ((64, 22, 1), (90, 41, 40)):  # lines per tile = 16 for this width
+        keep, descs, outs, imgs = [], [], [], []
+        for i, h in enumerate(heights):
+            img = synth.frame_numpy(w, h, seed=50 + i, bits=8, kind="mixed")
+            pix = np.frombuffer(np.ascontiguousarray(img).tobytes(), dtype=np.uint8).copy()
+            out = np.zeros(w * h * 3 + 1024, dtype=np.uint8)
+            imgs.append(img)
+            outs.append(out)
+            descs.append(emu_bind.make_desc(w, h, 1, 0, 8, 0, 0, pc, 0, pix, w, out, keep))
+        arr = (emu_bind.ScanDesc * len(descs))(*descs)
+        res = (emu_bind.ScanResult * len(descs))()
+        L.emu_encode_tile_pipeline(arr, res, len(descs), 128, 64)
+        for img, r, o, h in zip(imgs, res, outs, heights):
+            assert r.errc == 0 and o[:r.bytes].tobytes() == _scan_bytes(ob.encode(img, width=w, height=h)), heights
