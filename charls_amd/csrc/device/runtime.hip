@@ -980,6 +980,14 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             hip_check(hipEventCreateWithFlags(&stuffed[pass], hipEventDisableTiming));
         }
     }
+    pipeline_lanes().ensure();
+    hipStream_t runs_stream = pipeline_lanes().streams[1];
+    std::vector<hipEvent_t> sorted(passes), runs_coded(passes);
+    for (uint32_t pass = 0; pass < passes; ++pass)
+    {
+        hip_check(hipEventCreateWithFlags(&sorted[pass], hipEventDisableTiming));
+        hip_check(hipEventCreateWithFlags(&runs_coded[pass], hipEventDisableTiming));
+    }
     static const bool attributes_set = [] {
         // (the sort stage asks for more than the 64 KB of LDS a kernel gets by default)
         const int lds = 160 * 1024;
@@ -1054,12 +1062,18 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         else
             hipLaunchKernelGGL((tile::sort_tiles<S, 0>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_b, s, descs, d_works);
         t.mark();
+        // The run lane (one lane per scan, serial) on a side stream under the chain walkers: it touches the run chain and the
+        // interruption chain only, the walkers every other chain.
+        hip_check(hipEventRecord(sorted[pass], s));
+        hip_check(hipStreamWaitEvent(runs_stream, sorted[pass], 0));
+        if (proto.interleave_mode == 1)
+            hipLaunchKernelGGL((tile::code_runs<S, 1>), dim3((n + 63) / 64), dim3(64), 0, runs_stream, descs, d_works, n);
+        else
+            hipLaunchKernelGGL((tile::code_runs<S, 0>), dim3((n + 63) / 64), dim3(64), 0, runs_stream, descs, d_works, n);
+        hip_check(hipEventRecord(runs_coded[pass], runs_stream));
         hipLaunchKernelGGL((tile::walk_jobs<S>), dim3(static_cast<uint32_t>((lay.max_jobs + 63) / 64), n), dim3(64), 0, s, descs, d_works);
         hipLaunchKernelGGL((tile::settle_chains<S>), dim3((n * pipe::kChains + 63) / 64), dim3(64), 0, s, descs, d_works, n);
-        if (proto.interleave_mode == 1)
-            hipLaunchKernelGGL((tile::code_runs<S, 1>), dim3((n + 63) / 64), dim3(64), 0, s, descs, d_works, n);
-        else
-            hipLaunchKernelGGL((tile::code_runs<S, 0>), dim3((n + 63) / 64), dim3(64), 0, s, descs, d_works, n);
+        hip_check(hipStreamWaitEvent(s, runs_coded[pass], 0));
         t.mark();
         if (overlap_stuffing && pass > 0)
             hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
@@ -1107,6 +1121,10 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     for (hipEvent_t e : packed)
         (void)hipEventDestroy(e);
     for (hipEvent_t e : stuffed)
+        (void)hipEventDestroy(e);
+    for (hipEvent_t e : sorted)
+        (void)hipEventDestroy(e);
+    for (hipEvent_t e : runs_coded)
         (void)hipEventDestroy(e);
 }
 

@@ -188,31 +188,48 @@ JLS_DEV void stage_lines(const ScanDesc& d, const TileGeometry& g, S* rows)
     if (ILV == 1)
         return;
     const uint32_t width = g.width;
-    for (uint32_t r = 0; r <= g.tile_lines; ++r)
-    {
-        S* to = rows + (size_t)r * width;
-        if (g.first_line + r == 0)
-        { // above the first line of the scan: zeros (src/scan_encoder_impl.hpp:55-70)
-            for (uint32_t x = threadIdx.x; x < width; x += blockDim.x)
-                to[x] = 0;
-            continue;
-        }
-        const uint8_t* from = d.pixels + (size_t)(g.first_line + r - 1) * d.pixel_stride;
-        const uint32_t bytes = width * (uint32_t)sizeof(S);
-        if (((reinterpret_cast<uintptr_t>(from) | reinterpret_cast<uintptr_t>(to) | bytes) & 3u) == 0)
+    const uint32_t bytes = width * (uint32_t)sizeof(S);
+    const uint32_t first = g.first_line == 0 ? 1u : 0u; // line 0 of the staging area lies above the scan: zeros
+    if (first)
+        for (uint32_t x = threadIdx.x; x < width; x += blockDim.x)
+            rows[x] = 0; // src/scan_encoder_impl.hpp:55-70
+    const uint8_t* from = d.pixels + (size_t)(g.first_line + first - 1) * d.pixel_stride;
+    uint8_t* to = reinterpret_cast<uint8_t*>(rows) + (size_t)first * bytes;
+    const uint32_t lines = g.tile_lines + 1 - first;
+    if (((reinterpret_cast<uintptr_t>(from) | d.pixel_stride | bytes) & 3u) == 0 && (reinterpret_cast<uintptr_t>(to) & 3u) == 0)
+    { // words: all loads of a thread are requested before the first one is stored (a tile and the line above it are at
+      // most 16 KB: eight words per thread)
+        const uint32_t words_per_line = bytes / 4, total = lines * words_per_line;
+        constexpr int kMost = (kMaxTileSamples * 2 / 4 + kThreads - 1) / kThreads;
+        uint32_t held[kMost];
+#pragma unroll
+        for (int j = 0; j < kMost; ++j)
         {
-            const uint32_t* from4 = reinterpret_cast<const uint32_t*>(from);
-            uint32_t* to4 = reinterpret_cast<uint32_t*>(to);
-            for (uint32_t i = threadIdx.x; i < bytes / 4; i += blockDim.x)
-                to4[i] = from4[i];
+            const uint32_t i = threadIdx.x + (uint32_t)j * kThreads;
+            const uint32_t line = i / words_per_line, word = i - line * words_per_line;
+            held[j] = i < total ? reinterpret_cast<const uint32_t*>(from + (size_t)line * d.pixel_stride)[word] : 0u;
         }
-        else
+#pragma unroll
+        for (int j = 0; j < kMost; ++j)
         {
-            const S* from1 = reinterpret_cast<const S*>(from);
-            for (uint32_t x = threadIdx.x; x < width; x += blockDim.x)
-                to[x] = from1[x];
+            const uint32_t i = threadIdx.x + (uint32_t)j * kThreads;
+            if (i < total)
+                reinterpret_cast<uint32_t*>(to)[i] = held[j];
+        }
+        for (uint32_t i = threadIdx.x + kMost * kThreads; i < total; i += kThreads) // (tiles of many short lines of wide samples)
+        {
+            const uint32_t line = i / words_per_line, word = i - line * words_per_line;
+            reinterpret_cast<uint32_t*>(to)[i] = reinterpret_cast<const uint32_t*>(from + (size_t)line * d.pixel_stride)[word];
         }
     }
+    else
+        for (uint32_t r = 0; r < lines; ++r)
+        {
+            const S* from1 = reinterpret_cast<const S*>(from + (size_t)r * d.pixel_stride);
+            S* to1 = reinterpret_cast<S*>(to + (size_t)r * bytes);
+            for (uint32_t x = threadIdx.x; x < width; x += blockDim.x)
+                to1[x] = from1[x];
+        }
 }
 
 // LDS carve-up shared by analyze_tiles and sort_tiles (byte offsets; every region 16-byte aligned).
@@ -497,20 +514,34 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
         const uint32_t r = sgm / g.pieces, piece = sgm % g.pieces;
         const uint32_t k0 = piece * g.chunks_per_piece;
         const uint32_t k1 = k0 + g.chunks_per_piece < chunks ? k0 + g.chunks_per_piece : chunks;
-        for (uint32_t k = k0; k < k1; ++k)
-        {
-            const uint32_t x = k * 64 + lane;
-            uint16_t key = kNoEvent;
-            if (x < width)
+        for (uint32_t kb = k0; kb < k1; kb += 16)
+        { // the keys of up to 16 chunks are requested before the first one is used (one trip to memory, not sixteen)
+            uint16_t held[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
             {
-                key = key_tile[(size_t)r * width + x];
-                s_key[r * width + x] = key;
-                if (key != kNoEvent)
-                    atomicAdd(&s_segoff[sgm * kChains + (key & 0x1FF)], 1u);
+                const uint32_t x = (kb + j) * 64 + lane;
+                held[j] = kb + j < k1 && x < width ? key_tile[(size_t)r * width + x] : kNoEvent;
             }
-            const unsigned long long m = __ballot(x < width && key == kNoEvent);
-            if (lane == 0)
-                s_noev[r * chunks + k] = m;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+            {
+                const uint32_t k = kb + j;
+                if (k < k1) // (uniform)
+                {
+                    const uint32_t x = k * 64 + lane;
+                    const uint16_t key = held[j];
+                    if (x < width)
+                    {
+                        s_key[r * width + x] = key;
+                        if (key != kNoEvent)
+                            atomicAdd(&s_segoff[sgm * kChains + (key & 0x1FF)], 1u);
+                    }
+                    const unsigned long long m = __ballot(x < width && key == kNoEvent);
+                    if (lane == 0)
+                        s_noev[r * chunks + k] = m;
+                }
+            }
         }
     }
     __syncthreads();
@@ -647,13 +678,30 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     }
     __syncthreads();
     // ---- P3: pieces out (the interruption chain has no records)
-    for (uint32_t c = wave; c < (uint32_t)kChains; c += kWaves)
-    {
-        if (c == (uint32_t)kInterruptChain)
-            continue;
-        const uint32_t n = s_count[c], from = s_tileoff[c], to = s_global[c];
-        for (uint32_t i = lane; i < n; i += 64)
-            w.rec[to + i] = s_stage[from + i];
+    for (uint32_t c0 = wave; c0 < (uint32_t)kChains; c0 += kWaves * 4)
+    { // four pieces at a time: their LDS reads overlap
+        uint32_t n[4], from[4], to[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            const uint32_t c = c0 + (uint32_t)j * kWaves;
+            const bool live = c < (uint32_t)kChains && c != (uint32_t)kInterruptChain;
+            n[j] = live ? s_count[c] : 0u;
+            from[j] = live ? s_tileoff[c] : 0u;
+            to[j] = live ? s_global[c] : 0u;
+        }
+        uint32_t first[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            first[j] = (uint32_t)lane < n[j] ? s_stage[from[j] + lane] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            if ((uint32_t)lane < n[j])
+                w.rec[to[j] + lane] = first[j];
+            for (uint32_t i = lane + 64; i < n[j]; i += 64)
+                w.rec[to[j] + i] = s_stage[from[j] + i];
+        }
     }
 }
 
@@ -887,10 +935,8 @@ __global__ void __launch_bounds__(64) code_runs(const ScanDesc* __restrict__ des
     RunCtx rc0{0, initial_a(t), 1, 0}, rc1{1, initial_a(t), 1, 0}; // (two named records, selected by value: an indexed pair lives in scratch)
     uint32_t run_index_packed = 0; // ILV_LINE: one RUNindex per component (src/scan_encoder_impl.hpp:126-137), 8 bits each
     uint32_t interruptions = 0;
-    for (uint32_t e = 0; e < n; ++e)
-    {
-        const uint32_t v = runs[e];
-        const uint32_t p = run_code[e]; // sort_tiles' record of the interruption sample
+    // one run event: v = length | end-of-line << 31, p = sort_tiles' record of the interruption sample -> code word of the run
+    auto one = [&](uint32_t v, uint32_t p) -> uint32_t {
         uint32_t run = v & 0x7FFFFFFFu;
         const bool eol = (v >> 31) != 0;
         const uint32_t shift = ILV == 1 ? ((p >> 18) & 3u) * 8u : 0u;
@@ -904,11 +950,12 @@ __global__ void __launch_bounds__(64) code_runs(const ScanDesc* __restrict__ des
             if (run_index < 31)
                 ++run_index;
         }
+        uint32_t word;
         if (eol)
         {
             if (run != 0)
                 ++ones;
-            run_code[e] = run_word(ones, 0, 0);
+            word = run_word(ones, 0, 0);
         }
         else
         {
@@ -928,15 +975,41 @@ __global__ void __launch_bounds__(64) code_runs(const ScanDesc* __restrict__ des
             if (run_index > 0)
                 --run_index;
             if (full == 0) // both codes belong to the same sample: J + 1 zero bits, then the interruption code (<= LIMIT bits in all)
-                run_code[e] = ((uint32_t)(jb + 1 + c.len) << 24) | (uint32_t)c.bits;
+                word = ((uint32_t)(jb + 1 + c.len) << 24) | (uint32_t)c.bits;
             else
             {
-                run_code[e] = run_word(ones, jb + 1, run);
+                word = run_word(ones, jb + 1, run);
                 int_code[interruptions++] = ((uint32_t)c.len << 24) | (uint32_t)c.bits;
             }
         }
         run_index_packed = (run_index_packed & ~(0xFFu << shift)) | ((uint32_t)run_index << shift);
+        return word;
+    };
+    // The events are read eight at a time, the next eight requested before the current ones are coded: one lane alone
+    // would otherwise wait for two dependent-looking loads per event (27 ms for the 55 000 runs of a test frame).  Chains
+    // start on 64-byte boundaries and are followed by kSlack records, so whole groups can be read and written.
+    const JLS_GLOBAL_AS u32x4* runs4 = (const JLS_GLOBAL_AS u32x4*)runs;
+    JLS_GLOBAL_AS u32x4* code4 = (JLS_GLOBAL_AS u32x4*)run_code;
+    u32x4 nv[2] = {runs4[0], runs4[1]}, np[2] = {code4[0], code4[1]};
+    const uint32_t groups = n / 8;
+    for (uint32_t g = 0; g < groups; ++g)
+    {
+        const u32x4 cv[2] = {nv[0], nv[1]}, cp[2] = {np[0], np[1]};
+        nv[0] = runs4[g * 2 + 2];
+        nv[1] = runs4[g * 2 + 3];
+        np[0] = code4[g * 2 + 2];
+        np[1] = code4[g * 2 + 3];
+        u32x4 o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[h][j] = one(cv[h][j], cp[h][j]);
+        code4[g * 2] = o[0];
+        code4[g * 2 + 1] = o[1];
     }
+    for (uint32_t e = groups * 8; e < n; ++e)
+        run_code[e] = one(runs[e], run_code[e]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -976,7 +1049,9 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     uint32_t* s_count = s_tileoff + kChains + 1;
     uint32_t* s_global = s_count + kChains + 1;
     uint32_t* s_scan = s_global + kChains + 1; // 256
-    uint32_t* s_tmp = s_scan + kPackThreads;   // one word per wavefront
+    uint32_t* s_tmp = s_scan + kPackThreads;   // one word per wavefront (16 reserved)
+    uint32_t* s_rowbase = s_tmp + 16;          // [kChains + 1] first row of the chain's piece
+    uint16_t* s_rowchain = reinterpret_cast<uint16_t*>(s_rowbase + kChains + 1); // [tile / 64 + kChains]
     const uint32_t lines = scan_lines(d);
     const uint32_t first_line = tile * w.lines_per_tile;
     const uint32_t tile_lines = lines - first_line < w.lines_per_tile ? lines - first_line : w.lines_per_tile;
@@ -1008,11 +1083,50 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         }
     }
     __syncthreads();
-    for (uint32_t c = wave; c < (uint32_t)kChains; c += kPackWaves)
-    {
-        const uint32_t n = s_count[c], to = s_tileoff[c], from = s_global[c];
-        for (uint32_t i = lane; i < n; i += 64)
-            s_code[to + i] = w.code[from + i];
+    { // ---- the tile's code words into LDS.  The pieces are cut into rows of 64 words; row q belongs to chain s_rowchain[q].
+      // A wavefront takes eight rows at a time and requests them together: fetched piece by piece (a piece is ~80 events on
+      // average, a few are hundreds), it spent its time waiting for one trip to memory per row.
+        uint32_t rows[2] = {0, 0};
+        for (int half = 0; half < 2; ++half)
+        {
+            const uint32_t c = threadIdx.x + (uint32_t)half * kPackThreads;
+            rows[half] = c < (uint32_t)kChains ? (s_count[c] + 63) / 64 : 0u;
+        }
+        uint32_t row_base[2] = {rows[0], rows[1]};
+        block_exclusive_scan(row_base[0], row_base[1], s_tmp);
+        for (int half = 0; half < 2; ++half)
+        {
+            const uint32_t c = threadIdx.x + (uint32_t)half * kPackThreads;
+            if (c < (uint32_t)kChains)
+            {
+                s_rowbase[c] = row_base[half];
+                for (uint32_t j = 0; j < rows[half]; ++j)
+                    s_rowchain[row_base[half] + j] = (uint16_t)c;
+                if (c == (uint32_t)kChains - 1)
+                    s_rowbase[kChains] = row_base[half] + rows[half];
+            }
+        }
+        __syncthreads();
+        const uint32_t total_rows = s_rowbase[kChains];
+        for (uint32_t q0 = (uint32_t)wave * 8; q0 < total_rows; q0 += kPackWaves * 8)
+        {
+            uint32_t to[8], held[8];
+            bool live[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                const uint32_t q = q0 + (uint32_t)j;
+                const uint32_t c = q < total_rows ? s_rowchain[q] : 0u;
+                const uint32_t i = (q - s_rowbase[c]) * 64 + (uint32_t)lane;
+                live[j] = q < total_rows && i < s_count[c];
+                to[j] = s_tileoff[c] + i;
+                held[j] = live[j] ? w.code[s_global[c] + i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (live[j])
+                    s_code[to[j]] = held[j];
+        }
     }
     __syncthreads();
 
@@ -1148,7 +1262,8 @@ inline size_t sort_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t s
 }
 inline size_t pack_lds_bytes(uint32_t width, uint32_t lines_per_tile)
 {
-    return (size_t)lines_per_tile * width * 4 + 3 * ((size_t)kChains + 1) * 4 + (size_t)kPackThreads * 4 + 16 * 4;
+    return (size_t)lines_per_tile * width * 4 + 4 * ((size_t)kChains + 1) * 4 + (size_t)kPackThreads * 4 + 16 * 4 +
+           ((size_t)lines_per_tile * width / 64 + kChains + 8) * 2;
 }
 // Lines per tile for lines of `width` samples: as many whole lines as fit `tile_samples` (8192 for samples of one byte,
 // 4096 for two: the sort stage keeps the lines, the keys and the sorted records of a tile in LDS), at most kTileLines.
