@@ -885,10 +885,10 @@ bool tile_pipeline_eligible(const ScanDesc& d)
 // states and the unstuffed stream.
 struct TileLayout
 {
-    size_t samples, lines, raw_bytes, max_jobs;
-    uint32_t lines_per_tile, tiles, job_events, warm_events;
-    size_t off_keyinv, off_seg, off_total, off_base, off_jobfirst, off_rec, off_code, off_jobs, off_bbase, off_raw, off_bits,
-        off_status, off_stuff, bytes;
+    size_t samples, lines, raw_bytes, max_jobs, max_run_jobs;
+    uint32_t lines_per_tile, tiles, job_events, warm_events, run_job_events, run_warm_events;
+    size_t off_keyinv, off_seg, off_total, off_base, off_jobfirst, off_rec, off_code, off_jobs, off_runjobs, off_bbase, off_raw,
+        off_bits, off_status, off_stuff, bytes;
     TileLayout(const ScanDesc& d, size_t capacity_hint, uint32_t count)
     {
         lines = static_cast<size_t>(d.height) * (d.interleave_mode == 1 ? static_cast<size_t>(d.components) : 1);
@@ -905,6 +905,12 @@ struct TileLayout
         job_events = env_job ? static_cast<uint32_t>(std::max(16, std::atoi(env_job)) / 16 * 16) : static_cast<uint32_t>(job);
         warm_events = env_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_warm))) : 1024u;
         max_jobs = samples / job_events + pipe::kChains;
+        // the run chain: jobs of 2048 run events with a warm-up of as many (a test frame has 55 000 run events)
+        const char* env_run_job = std::getenv("CHARLS_AMD_RUN_JOB_EVENTS");
+        const char* env_run_warm = std::getenv("CHARLS_AMD_RUN_WARM_EVENTS");
+        run_job_events = env_run_job ? static_cast<uint32_t>(std::max(8, std::atoi(env_run_job)) / 8 * 8) : 2048u;
+        run_warm_events = env_run_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_warm))) : 2048u;
+        max_run_jobs = samples / run_job_events + 1;
         const size_t worst = worst_case_scan_bytes(d.width, static_cast<uint32_t>(lines), 1, d.bits_per_sample);
         raw_bytes = align_up((capacity_hint < worst ? capacity_hint : worst) + 64, 16);
         size_t o = 0;
@@ -921,6 +927,7 @@ struct TileLayout
         off_rec = take((samples + tile::kSlack) * 4);
         off_code = take((samples + tile::kSlack) * 4);
         off_jobs = take(max_jobs * sizeof(tile::JobState));
+        off_runjobs = take(max_run_jobs * sizeof(tile::RunJob));
         off_bbase = take(static_cast<size_t>(tiles) * 8);
         off_raw = take(raw_bytes);
         off_bits = take(16);
@@ -1024,6 +1031,9 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             w.rec = reinterpret_cast<uint32_t*>(base + lay.off_rec);
             w.code = reinterpret_cast<uint32_t*>(base + lay.off_code);
             w.jobs = reinterpret_cast<tile::JobState*>(base + lay.off_jobs);
+            w.run_jobs = reinterpret_cast<tile::RunJob*>(base + lay.off_runjobs);
+            w.run_job_events = lay.run_job_events;
+            w.run_warm_events = lay.run_warm_events;
             w.blockbase = reinterpret_cast<uint64_t*>(base + lay.off_bbase);
             w.raw = reinterpret_cast<uint32_t*>(base + lay.off_raw);
             w.raw_words = lay.raw_bytes / 4;
@@ -1062,14 +1072,26 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         else
             hipLaunchKernelGGL((tile::sort_tiles<S, 0>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_b, s, descs, d_works);
         t.mark();
-        // The run lane (one lane per scan, serial) on a side stream under the chain walkers: it touches the run chain and the
-        // interruption chain only, the walkers every other chain.
+        // The run chain on a side stream under the walkers of the regular chains: it touches the run chain and the
+        // interruption chain only, they every other chain.
         hip_check(hipEventRecord(sorted[pass], s));
         hip_check(hipStreamWaitEvent(runs_stream, sorted[pass], 0));
-        if (proto.interleave_mode == 1)
-            hipLaunchKernelGGL((tile::code_runs<S, 1>), dim3((n + 63) / 64), dim3(64), 0, runs_stream, descs, d_works, n);
-        else
-            hipLaunchKernelGGL((tile::code_runs<S, 0>), dim3((n + 63) / 64), dim3(64), 0, runs_stream, descs, d_works, n);
+        {
+            const uint32_t run_jobs = static_cast<uint32_t>(lay.max_run_jobs);
+            const dim3 lanes((static_cast<uint64_t>(run_jobs) * n + 63) / 64);
+            hipLaunchKernelGGL((tile::count_runs<S>), dim3(std::min<uint32_t>(run_jobs, 256), n), dim3(64), 0, runs_stream, d_works);
+            hipLaunchKernelGGL(tile::scan_runs, dim3(n), dim3(64), 0, runs_stream, d_works);
+            if (proto.interleave_mode == 1)
+            {
+                hipLaunchKernelGGL((tile::walk_run_jobs<S, 1>), lanes, dim3(64), 0, runs_stream, descs, d_works, n);
+                hipLaunchKernelGGL((tile::settle_runs<S, 1>), dim3((n + 63) / 64), dim3(64), 0, runs_stream, descs, d_works, n);
+            }
+            else
+            {
+                hipLaunchKernelGGL((tile::walk_run_jobs<S, 0>), lanes, dim3(64), 0, runs_stream, descs, d_works, n);
+                hipLaunchKernelGGL((tile::settle_runs<S, 0>), dim3((n + 63) / 64), dim3(64), 0, runs_stream, descs, d_works, n);
+            }
+        }
         hip_check(hipEventRecord(runs_coded[pass], runs_stream));
         hipLaunchKernelGGL((tile::walk_jobs<S>), dim3(static_cast<uint32_t>((lay.max_jobs + 63) / 64), n), dim3(64), 0, s, descs, d_works);
         hipLaunchKernelGGL((tile::settle_chains<S>), dim3((n * pipe::kChains + 63) / 64), dim3(64), 0, s, descs, d_works, n);

@@ -32,7 +32,8 @@
 //                      {x, Px, sign} into LDS in (chain, line, column) order, out as pieces; key -> tile-local slot
 //   C1 walk_jobs       one LANE per job: warm-up, then record -> code word, in chain order
 //   C2 settle_chains   one lane per chain: job boundaries checked, disagreeing jobs re-walked
-//   C3 code_runs       one lane per scan: RUNindex and the two run-interruption contexts (serial, few events)
+//   C3 count_runs / scan_runs / walk_run_jobs / settle_runs   the run chain (RUNindex, the two run-interruption contexts),
+//                      cut into jobs like the regular chains
 //   D  pack_tiles      one workgroup per tile: the tile's codes back into LDS piece by piece, gathered in raster order
 //                      through the 2-byte slots, concatenated MSB-first; bit offset of a tile by chained look-back
 //   E  stuff_scan / block_stuffing.hip  (unchanged)
@@ -83,6 +84,7 @@ struct Work
     uint32_t* rec;         // [samples + kSlack] records in chain order
     uint32_t* code;        // [samples + kSlack] code words in chain order (run starts: interruption record until C3)
     JobState* jobs;        // [samples / job_events + kChains]
+    struct RunJob* run_jobs; // [samples / run_job_events + 1] jobs of the run chain
     uint64_t* blockbase;   // [tiles] look-back states of pack_tiles; followed by raw (cleared together)
     uint32_t* raw;
     uint64_t raw_words;
@@ -91,6 +93,7 @@ struct Work
     // the launch's geometry (all scans of a launch share width, sample type and interleave mode; a scan may have FEWER
     // lines than the launch was sized for -- the last restart interval of a frame -- and then has fewer tiles)
     uint32_t lines_per_tile, tiles, job_events, warm_events;
+    uint32_t run_job_events, run_warm_events; // (multiples of 8)
 };
 
 JLS_DEV uint32_t tile_of_block(uint32_t block, uint32_t tiles) // XCD-aware: workgroup b runs on XCD b % 8; each XCD gets a band of tiles
@@ -472,9 +475,31 @@ JLS_DEV uint32_t make_record(int x, int px, int sign_bit, int maxval)
     return ((uint32_t)d & 0xFFFFu) | ((uint32_t)room << 16) | ((uint32_t)side << 24) | ((uint32_t)sign_bit << 31);
 }
 
+// Record of a run start: everything the run chain needs of the image.  The length of the run; whether it ends with the line;
+// otherwise type and error value of the interruption sample (src/scan_encoder_core.hpp:105-125: functions of the image in
+// lossless mode) and, in a line-interleaved scan, the component whose RUNindex counts.  One word: a run that does not end
+// with its line is shorter than the line (8192 / 4096 samples at most for samples of one / two bytes), Errval has as
+// many bits as the samples.
+template <typename S>
+struct RunRecord
+{
+    static constexpr uint32_t kRunBits = sizeof(S) == 1 ? 13 : 12, kErrBits = sizeof(S) == 1 ? 9 : 16;
+    static JLS_DEV uint32_t end_of_line(uint32_t run, uint32_t component) { return run | (component << 15) | (1u << 31); }
+    static JLS_DEV uint32_t interrupted(uint32_t run, int err, int which, uint32_t component)
+    {
+        return run | (((uint32_t)err & ((1u << kErrBits) - 1u)) << kRunBits) | ((uint32_t)which << (kRunBits + kErrBits)) |
+               (component << (kRunBits + kErrBits + 1));
+    }
+    static JLS_DEV bool is_end_of_line(uint32_t v) { return (v >> 31) != 0; }
+    static JLS_DEV uint32_t run(uint32_t v) { return is_end_of_line(v) ? v & 0x7FFFu : v & ((1u << kRunBits) - 1u); }
+    static JLS_DEV int err(uint32_t v) { return (int)(v << (32 - kRunBits - kErrBits)) >> (32 - kErrBits); }
+    static JLS_DEV int which(uint32_t v) { return (int)((v >> (kRunBits + kErrBits)) & 1u); }
+    static JLS_DEV uint32_t component(uint32_t v) { return (v >> (is_end_of_line(v) ? 15u : kRunBits + kErrBits + 1)) & 3u; }
+};
+
 // B2: grid (8 * ceil(tiles / 8), scans) x 512.
 // LDS: lines | keys[tile] u16 | noev[line][chunk] u64, lead[line][chunk + 1] u32 | segoff[kSegments][kChains] u32 |
-//      tileoff, count, global [kChains + 1] | scan scratch | stage[tile] u32
+//      tileoff, count, global [kChains + 1] | scan scratch | same[kWaves][kChains + 1] | stage[tile] u32
 template <typename S, int ILV>
 __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
@@ -499,7 +524,8 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     uint32_t* s_count = s_tileoff + kChains + 1;          // events of the chain in this tile
     uint32_t* s_global = s_count + kChains + 1;           // first global slot of the tile's piece
     uint32_t* s_tmp = s_global + kChains + 1;             // kWaves words (+ padding to 16 words)
-    uint32_t* s_stage = s_tmp + 16;
+    uint32_t* s_same = s_tmp + 16;                        // [kWaves][kChains + 1] lanes of a chunk per chain, see P2; zero between uses
+    uint32_t* s_stage = s_same + kWaves * (kChains + 1);
     const int mask = (1 << d.bits_per_sample) - 1;
     const Samples<S, ILV> sample{d, s_rows, g.first_line, mask};
     const uint16_t* key_tile = w.keyinv + (size_t)g.first_line * width;
@@ -507,6 +533,8 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     stage_lines<S, ILV>(d, g, s_rows);
     for (uint32_t i = threadIdx.x; i < kSegments * (uint32_t)kChains; i += kThreads)
         s_segoff[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kWaves * ((uint32_t)kChains + 1); i += kThreads)
+        s_same[i] = 0;
     __syncthreads();
     // ---- P1: keys into LDS, events per (segment, chain), samples inside runs per chunk
     for (uint32_t sgm = wave; sgm < g.segments; sgm += kWaves)
@@ -589,7 +617,10 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
         }
     }
     __syncthreads();
-    // ---- P2: ranks, records
+    // ---- P2: ranks, records.  The lanes of a chunk that share a chain find each other through a table in LDS: every lane
+    // ORs its own bit into the word of its chain (the result does not depend on the order in which the LDS serves the
+    // lanes), reads the word back and clears it -- 32 lanes at a time, six LDS instructions per chunk where a ballot per
+    // key bit took some sixty vector and scalar ones, and this stage is bound by the instructions it issues.
     for (uint32_t sgm = wave; sgm < g.segments; sgm += kWaves)
     {
         const uint32_t r = sgm / g.pieces, piece = sgm % g.pieces;
@@ -598,37 +629,72 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
         const uint32_t k1 = k0 + g.chunks_per_piece < chunks ? k0 + g.chunks_per_piece : chunks;
         const uint16_t* keys = s_key + r * width;
         uint32_t* segoff = s_segoff + sgm * kChains;
+        uint32_t* same_of = s_same + (uint32_t)wave * (kChains + 1);
+        uint16_t* inv_row = w.keyinv + (size_t)y * width;
+        const S* cur = s_rows + (r + 1) * width; // (planar scans: the line in LDS, the line above it `width` samples before)
         const int edge_a = y >= step ? sample(y - step, 0) : 0;
         const int edge_c = y >= 2 * step ? (ILV == 1 || r >= 1 ? sample(y - 2 * step, 0) : pipe::load_sample<S, ILV>(d, y - 2, 0, mask)) : 0;
+        const uint32_t lane_bit = 1u << (lane & 31), below = lane_bit - 1u;
+        const bool upper = lane >= 32;
         for (uint32_t k = k0; k < k1; ++k)
         {
             const uint32_t x = k * 64 + lane;
-            const uint16_t key = x < width ? keys[x] : kNoEvent;
+            const bool inside = x < width;
+            const uint16_t key = inside ? keys[x] : kNoEvent;
             const bool has = key != kNoEvent;
             const uint32_t chain = key & 0x1FFu;
-            // stable rank among the lanes of the same chain: nine ballots, one per key bit
-            unsigned long long same = __ballot(has);
-#pragma unroll
-            for (int b = 0; b < 9; ++b)
-            {
-                const bool bit = ((chain >> b) & 1u) != 0;
-                const unsigned long long bal = __ballot(bit);
-                same &= bit ? bal : ~bal;
-            }
-            const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-            uint32_t slot = 0;
+            if (has && !upper)
+                atomicOr(&same_of[chain], lane_bit);
             JLS_LOCKSTEP();
-            if (has)
-                slot = segoff[chain] + rank;
+            const uint32_t lo = has ? same_of[chain] : 0u;
             JLS_LOCKSTEP();
+            if (has && !upper)
+                same_of[chain] = 0;
+            JLS_LOCKSTEP();
+            if (has && upper)
+                atomicOr(&same_of[chain], lane_bit);
+            JLS_LOCKSTEP();
+            const uint32_t hi = has ? same_of[chain] : 0u;
+            const uint32_t base = has ? segoff[chain] : 0u;
+            JLS_LOCKSTEP();
+            if (has && upper)
+                same_of[chain] = 0;
+            const uint32_t rank = upper ? (uint32_t)__popc(lo) + (uint32_t)__popc(hi & below) : (uint32_t)__popc(lo & below);
             if (has && rank == 0)
-                segoff[chain] += (uint32_t)__popcll(same);
+                segoff[chain] = base + (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
             JLS_LOCKSTEP();
-            if (has)
+            const uint32_t slot = base + rank;
+            // the record of a regular sample, worked out for every lane (no divergence; lanes without an event discard it)
+            uint32_t record = 0;
+            if (ILV == 0)
             {
-                uint32_t record = 0;
-                if (chain == 0)
-                { // run start: length | end-of-line << 31; what the run lane needs of the interruption sample goes to code[]
+                if (inside)
+                {
+                    const int v = (int)cur[x] & mask;
+                    const int ra = x > 0 ? (int)cur[x - 1] & mask : edge_a;
+                    const int rb = (int)(cur - width)[x] & mask;
+                    const int rc = x > 0 ? (int)(cur - width)[x - 1] & mask : edge_c;
+                    record = make_record<S>(v, med3(ra + rb - rc, ra, rb), (key >> 9) & 1, t.maxval);
+                }
+            }
+            else if (has && chain != 0 && chain != (uint32_t)kInterruptChain)
+            {
+                const int v = sample(y, x);
+                const int ra = x > 0 ? sample(y, x - 1) : edge_a;
+                int rb = 0, rc = 0;
+                if (y >= step)
+                {
+                    rb = sample(y - step, x);
+                    rc = x > 0 ? sample(y - step, x - 1) : edge_c;
+                }
+                else
+                    rc = x > 0 ? 0 : edge_c;
+                record = make_record<S>(v, med3(ra + rb - rc, ra, rb), (key >> 9) & 1, t.maxval);
+            }
+            if (__any(has && chain == 0))
+            { // (rare) run starts
+                if (has && chain == 0)
+                {
                     const int v = sample(y, x);
                     const int ra = x > 0 ? sample(y, x - 1) : edge_a;
                     uint32_t run = 0;
@@ -642,38 +708,23 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
                         run = 1 + n;
                     }
                     const uint32_t xi = x + run;
-                    const bool eol = xi >= width;
-                    record = run | ((uint32_t)eol << 31);
-                    uint32_t packed = ILV == 1 ? (y % step) << 18 : 0u;
-                    if (!eol)
-                    { // src/scan_encoder_core.hpp:105-125: type and error value of the interruption are functions of the image
+                    if (xi >= width)
+                        record = RunRecord<S>::end_of_line(run, ILV == 1 ? y % step : 0u);
+                    else
+                    {
                         const int xv = sample(y, xi);
                         const int ia = xi > 0 ? sample(y, xi - 1) : edge_a;
                         const int ib = y >= step ? sample(y - step, xi) : 0;
                         const int which = ia == ib ? 1 : 0;
                         const int err = which ? error_value(t, xv - ia) : error_value(t, (xv - ib) * ((ib - ia) < 0 ? -1 : 1));
-                        packed |= ((uint32_t)err & 0x1FFFFu) | ((uint32_t)which << 17);
+                        record = RunRecord<S>::interrupted(run, err, which, ILV == 1 ? y % step : 0u);
                     }
-                    w.code[s_global[0] + (slot - s_tileoff[0])] = packed;
                 }
-                else if (chain != (uint32_t)kInterruptChain)
-                {
-                    const int v = sample(y, x);
-                    const int ra = x > 0 ? sample(y, x - 1) : edge_a;
-                    int rb = 0, rc = 0;
-                    if (y >= step)
-                    {
-                        rb = sample(y - step, x);
-                        rc = x > 0 ? sample(y - step, x - 1) : edge_c;
-                    }
-                    else
-                        rc = x > 0 ? 0 : edge_c;
-                    record = make_record<S>(v, med3(ra + rb - rc, ra, rb), (key >> 9) & 1, t.maxval);
-                }
-                s_stage[slot] = record;
             }
-            if (x < width)
-                w.keyinv[(size_t)y * width + x] = has ? (uint16_t)slot : kNoLocalSlot;
+            if (has)
+                s_stage[slot] = record;
+            if (inside)
+                inv_row[x] = has ? (uint16_t)slot : kNoLocalSlot;
         }
     }
     __syncthreads();
@@ -910,36 +961,54 @@ __global__ void __launch_bounds__(64) settle_chains(const ScanDesc* __restrict__
         atomicOr(w.status, kStatusInvalid);
 }
 
+// C3: the run chain.  RUNindex, the two run-interruption contexts and the slot counter of the interruption samples are a
+// serial recurrence over the run events of a scan (src/scan_encoder.hpp:53-73, src/scan_encoder_impl.hpp:249-275,
+// src/scan_encoder_core.hpp:105-125): one lane took 19.5 ms for the 55 000 runs of a test frame -- three quarters of the
+// time ONE frame takes to encode.  It is cut into jobs exactly like the regular chains:
+//   * what is a function of the event INDEX is computed, not guessed: the number of interruptions of either type before
+//     an event (-> N of the two contexts, chain_n_before) and the number of interruption samples with a slot of their own
+//     (count_runs / scan_runs: per-job counts, exclusive prefix);
+//   * what FORGETS is guessed: A and Nn of both contexts are halved every RESET/2 interruptions, RUNindex is pinned at 0 by
+//     every short run (and at 31 by long ones); a job starts run_warm_events earlier from the initial values;
+//   * settle_runs checks every job boundary and codes a job again, serially, where a guess was wrong.
+struct RunState
+{
+    uint32_t index;   // RUNindex, 8 bits per component of a line-interleaved scan (src/scan_encoder_impl.hpp:126-137)
+    int32_t a0, nn0;  // run-interruption context 0 (Ra != Rb)
+    int32_t a1, nn1;  // context 1
+};
+struct RunJob
+{
+    uint32_t type0, type1, own_slot, pad; // count_runs: events of the job; scan_runs: events before the job
+    RunState in, out;
+    uint32_t pad2[2];
+};
+
+JLS_DEV bool same_state(const RunState& x, const RunState& y)
+{
+    return x.index == y.index && x.a0 == y.a0 && x.nn0 == y.nn0 && x.a1 == y.a1 && x.nn1 == y.nn1;
+}
+
 // Code word of a run-length code: `ones` one-bits, then `tail_len` bits holding `tail`.
 JLS_DEV uint32_t run_word(int ones, int tail_len, uint32_t tail)
 {
     return kRunTag | ((uint32_t)ones << 25) | ((uint32_t)tail_len << 20) | tail;
 }
 
-// C3: grid (ceil(scans / 64)) x 64, one lane per scan: src/scan_encoder.hpp:53-73, src/scan_encoder_impl.hpp:249-275,
-// src/scan_encoder_core.hpp:105-125.  The run-length code goes to the slot of the sample where the run starts, the code
-// of the interruption sample to the next slot of chain kInterruptChain (its events are these samples, in this order).
-template <typename S, int ILV>
-__global__ void __launch_bounds__(64) code_runs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
+// One lane's walk over run events [from, to) of a scan.  counts = {type-0, type-1, own-slot} interruptions before `from`.
+// kStore: write the code words (the run-length code to the slot of the sample where the run starts, the code of the
+// interruption sample to the next slot of chain kInterruptChain: its events are these samples, in this order).
+template <typename S, int ILV, bool kStore>
+JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code, uint32_t* int_code, uint32_t from, uint32_t to,
+                       RunState& s, uint32_t type0, uint32_t type1, uint32_t own_slot)
 {
-    const uint32_t frame = blockIdx.x * 64u + threadIdx.x;
-    if (frame >= scans)
-        return;
-    const ScanDesc d = descs[frame];
-    const Work w = works[frame];
-    const Traits t = make_traits(d);
-    const uint32_t n = w.chain_total[0];
-    const uint32_t* runs = w.rec + w.chain_base[0];
-    uint32_t* run_code = w.code + w.chain_base[0];
-    uint32_t* int_code = w.code + w.chain_base[kInterruptChain];
-    RunCtx rc0{0, initial_a(t), 1, 0}, rc1{1, initial_a(t), 1, 0}; // (two named records, selected by value: an indexed pair lives in scratch)
-    uint32_t run_index_packed = 0; // ILV_LINE: one RUNindex per component (src/scan_encoder_impl.hpp:126-137), 8 bits each
-    uint32_t interruptions = 0;
-    // one run event: v = length | end-of-line << 31, p = sort_tiles' record of the interruption sample -> code word of the run
-    auto one = [&](uint32_t v, uint32_t p) -> uint32_t {
-        uint32_t run = v & 0x7FFFFFFFu;
-        const bool eol = (v >> 31) != 0;
-        const uint32_t shift = ILV == 1 ? ((p >> 18) & 3u) * 8u : 0u;
+    RunCtx rc0{0, s.a0, chain_n_before(type0, (uint32_t)t.reset), s.nn0};
+    RunCtx rc1{1, s.a1, chain_n_before(type1, (uint32_t)t.reset), s.nn1};
+    uint32_t run_index_packed = s.index;
+    auto one = [&](uint32_t v) -> uint32_t {
+        uint32_t run = RunRecord<S>::run(v);
+        const bool eol = RunRecord<S>::is_end_of_line(v);
+        const uint32_t shift = ILV == 1 ? RunRecord<S>::component(v) * 8u : 0u;
         int run_index = (int)((run_index_packed >> shift) & 0xFFu);
         const uint32_t full = run;
         int ones = 0;
@@ -960,9 +1029,9 @@ __global__ void __launch_bounds__(64) code_runs(const ScanDesc* __restrict__ des
         else
         {
             const int jb = run_j(run_index);
-            const int which = (int)((p >> 17) & 1u);
-            const int err = (int)(p << 15) >> 15;
-            RunCtx ctx = which ? rc1 : rc0;
+            const int which = RunRecord<S>::which(v);
+            const int err = RunRecord<S>::err(v);
+            RunCtx ctx = which ? rc1 : rc0; // (selected by value: an indexed pair of records lives in scratch)
             const int k = run_k(ctx);
             const int map = run_map(ctx, err, k);
             const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - map;
@@ -979,42 +1048,201 @@ __global__ void __launch_bounds__(64) code_runs(const ScanDesc* __restrict__ des
             else
             {
                 word = run_word(ones, jb + 1, run);
-                int_code[interruptions++] = ((uint32_t)c.len << 24) | (uint32_t)c.bits;
+                if (kStore)
+                    int_code[own_slot] = ((uint32_t)c.len << 24) | (uint32_t)c.bits;
+                ++own_slot;
             }
         }
         run_index_packed = (run_index_packed & ~(0xFFu << shift)) | ((uint32_t)run_index << shift);
         return word;
     };
-    // The events are read eight at a time, the next eight requested before the current ones are coded: one lane alone
-    // would otherwise wait for two dependent-looking loads per event (27 ms for the 55 000 runs of a test frame).  Chains
-    // start on 64-byte boundaries and are followed by kSlack records, so whole groups can be read and written.
+    // The events are read eight at a time, the next eight requested before the current ones are coded.  Chains start on
+    // 64-byte boundaries and are followed by kSlack records, so whole groups can be read; `from` is a multiple of 8.
     const JLS_GLOBAL_AS u32x4* runs4 = (const JLS_GLOBAL_AS u32x4*)runs;
     JLS_GLOBAL_AS u32x4* code4 = (JLS_GLOBAL_AS u32x4*)run_code;
-    u32x4 nv[2] = {runs4[0], runs4[1]}, np[2] = {code4[0], code4[1]};
-    const uint32_t groups = n / 8;
-    for (uint32_t g = 0; g < groups; ++g)
+    uint32_t g = from / 8;
+    u32x4 nv[2] = {runs4[g * 2], runs4[g * 2 + 1]};
+    for (; g < to / 8; ++g)
     {
-        const u32x4 cv[2] = {nv[0], nv[1]}, cp[2] = {np[0], np[1]};
+        const u32x4 cv[2] = {nv[0], nv[1]};
         nv[0] = runs4[g * 2 + 2];
         nv[1] = runs4[g * 2 + 3];
-        np[0] = code4[g * 2 + 2];
-        np[1] = code4[g * 2 + 3];
         u32x4 o[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                o[h][j] = one(cv[h][j], cp[h][j]);
-        code4[g * 2] = o[0];
-        code4[g * 2 + 1] = o[1];
+                o[h][j] = one(cv[h][j]);
+        if (kStore)
+        {
+            code4[g * 2] = o[0];
+            code4[g * 2 + 1] = o[1];
+        }
     }
-    for (uint32_t e = groups * 8; e < n; ++e)
-        run_code[e] = one(runs[e], run_code[e]);
+    for (uint32_t e = g * 8; e < to; ++e)
+    {
+        const uint32_t word = one(runs[e]);
+        if (kStore)
+            run_code[e] = word;
+    }
+    s.index = run_index_packed;
+    s.a0 = rc0.a;
+    s.nn0 = rc0.nn;
+    s.a1 = rc1.a;
+    s.nn1 = rc1.nn;
+}
+
+// grid (up to 256, scans) x 64: a wavefront counts the events of a job (and of every gridDim.x-th job after it).
+template <typename S>
+__global__ void __launch_bounds__(64) count_runs(const Work* __restrict__ works)
+{
+    const Work w = works[blockIdx.y];
+    const uint32_t n = w.chain_total[0];
+    const uint32_t* runs = w.rec + w.chain_base[0];
+    for (uint32_t job = blockIdx.x; job * w.run_job_events < n; job += gridDim.x)
+    {
+        const uint32_t from = job * w.run_job_events;
+        const uint32_t to = from + w.run_job_events < n ? from + w.run_job_events : n;
+        uint32_t type0 = 0, type1 = 0, own = 0;
+        for (uint32_t e = from + threadIdx.x; e < to; e += 64)
+        {
+            const uint32_t v = runs[e];
+            const bool interrupted = !RunRecord<S>::is_end_of_line(v);
+            type0 += interrupted && RunRecord<S>::which(v) == 0;
+            type1 += interrupted && RunRecord<S>::which(v) != 0;
+            own += interrupted && RunRecord<S>::run(v) != 0;
+        }
+        for (int delta = 32; delta > 0; delta >>= 1)
+        {
+            type0 += __shfl_xor(type0, delta);
+            type1 += __shfl_xor(type1, delta);
+            own += __shfl_xor(own, delta);
+        }
+        if (threadIdx.x == 0)
+        {
+            RunJob& j = w.run_jobs[job];
+            j.type0 = type0;
+            j.type1 = type1;
+            j.own_slot = own;
+        }
+    }
+}
+
+// grid (scans) x 64: counts of the jobs -> counts before the jobs.
+__global__ void __launch_bounds__(64) scan_runs(const Work* __restrict__ works)
+{
+    const Work w = works[blockIdx.x];
+    const uint32_t n = w.chain_total[0];
+    const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
+    const int lane = threadIdx.x;
+    uint32_t carry[3] = {0, 0, 0};
+    for (uint32_t j0 = 0; j0 < jobs; j0 += 64)
+    {
+        const uint32_t j = j0 + (uint32_t)lane;
+        uint32_t v[3] = {0, 0, 0};
+        if (j < jobs)
+        {
+            v[0] = w.run_jobs[j].type0;
+            v[1] = w.run_jobs[j].type1;
+            v[2] = w.run_jobs[j].own_slot;
+        }
+        uint32_t incl[3] = {v[0], v[1], v[2]};
+        for (int delta = 1; delta < 64; delta <<= 1)
+            for (int q = 0; q < 3; ++q)
+            {
+                const uint32_t up = __shfl_up(incl[q], delta);
+                if (lane >= delta)
+                    incl[q] += up;
+            }
+        if (j < jobs)
+        {
+            w.run_jobs[j].type0 = carry[0] + incl[0] - v[0];
+            w.run_jobs[j].type1 = carry[1] + incl[1] - v[1];
+            w.run_jobs[j].own_slot = carry[2] + incl[2] - v[2];
+        }
+        for (int q = 0; q < 3; ++q)
+            carry[q] += __shfl(incl[q], 63);
+    }
+}
+
+// grid (ceil(max_run_jobs * scans / 64)) x 64: one lane per (job, scan), lanes of a wavefront = the same job of different scans.
+template <typename S, int ILV>
+__global__ void __launch_bounds__(64) walk_run_jobs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
+{
+    const uint32_t tid = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t job = tid / scans, frame = tid % scans;
+    const ScanDesc d = descs[frame];
+    const Work w = works[frame];
+    const uint32_t n = w.chain_total[0];
+    const uint32_t from = job * w.run_job_events;
+    if (from >= n)
+        return;
+    const Traits t = make_traits(d);
+    const uint32_t to = from + w.run_job_events < n ? from + w.run_job_events : n;
+    const uint32_t* runs = w.rec + w.chain_base[0];
+    uint32_t* run_code = w.code + w.chain_base[0];
+    uint32_t* int_code = w.code + w.chain_base[kInterruptChain];
+    // the warm-up starts at a job boundary (that is where the counts are known)
+    const uint32_t warm_jobs = (w.run_warm_events + w.run_job_events - 1) / w.run_job_events;
+    const uint32_t warm_job = job > warm_jobs ? job - warm_jobs : 0u;
+    RunState s{0, initial_a(t), 0, initial_a(t), 0};
+    RunJob mine = w.run_jobs[job];
+    if (warm_job < job)
+    {
+        const RunJob before = w.run_jobs[warm_job];
+        walk_runs<S, ILV, false>(t, runs, run_code, int_code, warm_job * w.run_job_events, from, s, before.type0, before.type1, before.own_slot);
+    }
+    mine.in = s;
+    walk_runs<S, ILV, true>(t, runs, run_code, int_code, from, to, s, mine.type0, mine.type1, mine.own_slot);
+    mine.out = s;
+    w.run_jobs[job] = mine;
+}
+
+// grid (ceil(scans / 64)) x 64: one lane per scan checks its jobs' boundaries.
+template <typename S, int ILV>
+__global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
+{
+    const uint32_t frame = blockIdx.x * 64u + threadIdx.x;
+    if (frame >= scans)
+        return;
+    const ScanDesc d = descs[frame];
+    const Work w = works[frame];
+    const Traits t = make_traits(d);
+    const uint32_t n = w.chain_total[0];
+    const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
+    if (jobs < 2)
+        return;
+    const uint32_t* runs = w.rec + w.chain_base[0];
+    uint32_t* run_code = w.code + w.chain_base[0];
+    uint32_t* int_code = w.code + w.chain_base[kInterruptChain];
+    RunState prev = w.run_jobs[0].out;
+    for (uint32_t j = 1; j < jobs; ++j)
+    {
+        const RunJob cur = w.run_jobs[j];
+        RunState out = cur.out;
+        if (!same_state(cur.in, prev))
+        { // code the job again from the state its predecessor really ended in
+            out = prev;
+            const uint32_t from = j * w.run_job_events;
+            const uint32_t to = from + w.run_job_events < n ? from + w.run_job_events : n;
+            walk_runs<S, ILV, true>(t, runs, run_code, int_code, from, to, out, cur.type0, cur.type1, cur.own_slot);
+        }
+        prev = out;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // D: grid (tiles, scans) x 256; tiles in index order (a tile only waits for tiles that were started before it).
 // LDS: codes[tile] u32 | tileoff / count / global [kChains + 1] each | scan[256] | tmp
+#define JLS_HOST_DEV __host__ __device__ inline
+// LDS of pack_tiles: where the staged slot map starts (behind the code words, the piece tables and the row table)
+JLS_HOST_DEV uint32_t pack_inv_offset(uint32_t width, uint32_t lines_per_tile) // 16-byte aligned
+{
+    const uint32_t head = lines_per_tile * width * 4 + 4 * ((uint32_t)kChains + 1) * 4 + kPackThreads * 4 + 16 * 4 +
+                          (lines_per_tile * width / 64 + (uint32_t)kChains + 8) * 2;
+    return (head + 15u) & ~15u;
+}
+
 JLS_DEV void expand_code(uint32_t word, uint64_t& bits, int& len)
 {
     if (word & kRunTag)
@@ -1041,7 +1269,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     if (tile >= tiles)
         return;
     const uint32_t tile_capacity = w.lines_per_tile * d.width;
-    const uint32_t per_thread = (tile_capacity + kPackThreads - 1) / kPackThreads; // consecutive samples of a thread
+    const uint32_t per_thread = ((tile_capacity + kPackThreads - 1) / kPackThreads + 7u) & ~7u; // consecutive samples of a thread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr uint32_t kPackWaves = kPackThreads / 64;
     uint32_t* s_code = reinterpret_cast<uint32_t*>(smem);
@@ -1051,13 +1279,18 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     uint32_t* s_scan = s_global + kChains + 1; // 256
     uint32_t* s_tmp = s_scan + kPackThreads;   // one word per wavefront (16 reserved)
     uint32_t* s_rowbase = s_tmp + 16;          // [kChains + 1] first row of the chain's piece
-    uint16_t* s_rowchain = reinterpret_cast<uint16_t*>(s_rowbase + kChains + 1); // [tile / 64 + kChains]
+    uint16_t* s_rowchain = reinterpret_cast<uint16_t*>(s_rowbase + kChains + 1); // [tile / 64 + kChains + 8]
+    uint16_t* s_inv = reinterpret_cast<uint16_t*>(smem + pack_inv_offset(d.width, w.lines_per_tile)); // [kPackThreads * per_thread] slot map of the tile
     const uint32_t lines = scan_lines(d);
     const uint32_t first_line = tile * w.lines_per_tile;
     const uint32_t tile_lines = lines - first_line < w.lines_per_tile ? lines - first_line : w.lines_per_tile;
     const uint32_t tile_samples = tile_lines * d.width;
     const uint16_t* inv = w.keyinv + (size_t)first_line * d.width;
 
+    // the slot map of the tile: coalesced into LDS (a thread's 32 consecutive slots straight from memory were 32 requests
+    // of one cache line each per wavefront instruction)
+    for (uint32_t i = threadIdx.x; i < kPackThreads * per_thread; i += kPackThreads)
+        s_inv[i] = i < tile_samples ? inv[i] : kNoLocalSlot;
     { // the tile's pieces, chain by chain, in the order sort_tiles laid them out
         uint32_t n[2] = {0, 0}, g[2] = {0, 0};
         for (int half = 0; half < 2; ++half)
@@ -1130,20 +1363,27 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     }
     __syncthreads();
 
-    // ---- bits of this thread's samples
-    const uint32_t base = threadIdx.x * per_thread;
+    // ---- bits of this thread's samples.  The slots of a thread are 16-byte groups of the staged slot map (eight samples
+    // each), read once and kept in registers for both passes.
+    constexpr int kGroups = (int)(kMaxTileSamples / kPackThreads / 8); // 4 groups = 32 samples at most
+    uint4 mine[kGroups];
+#pragma unroll
+    for (int q = 0; q < kGroups; ++q)
+        mine[q] = (uint32_t)q * 8 < per_thread ? reinterpret_cast<const uint4*>(s_inv + threadIdx.x * per_thread)[q] : make_uint4(~0u, ~0u, ~0u, ~0u);
+    auto slot_of = [&](int q, int j) -> uint32_t { // sample 8 q + j of this thread
+        const uint32_t word = (j >> 1) == 0 ? mine[q].x : (j >> 1) == 1 ? mine[q].y : (j >> 1) == 2 ? mine[q].z : mine[q].w;
+        return (j & 1) ? word >> 16 : word & 0xFFFFu;
+    };
     uint32_t sum = 0;
-    for (uint32_t i = 0; i < per_thread; ++i)
-    {
-        const uint16_t slot = base + i < tile_samples ? inv[base + i] : kNoLocalSlot;
-        if (slot != kNoLocalSlot)
+#pragma unroll
+    for (int q = 0; q < kGroups; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
         {
-            uint64_t bits;
-            int len;
-            expand_code(s_code[slot], bits, len);
-            sum += (uint32_t)len;
+            const uint32_t slot = slot_of(q, j);
+            const uint32_t word = slot != kNoLocalSlot ? s_code[slot] : 0u; // (0: no bits)
+            sum += word & kRunTag ? ((word >> 25) & 63u) + ((word >> 20) & 31u) : word >> 24;
         }
-    }
     s_scan[threadIdx.x] = sum;
     __syncthreads();
     for (uint32_t stride = 1; stride < kPackThreads; stride <<= 1) // Hillis-Steele inclusive scan
@@ -1164,16 +1404,16 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         uint32_t reach = b; // tiles [reach, b) are accounted for in `start`
         while (reach > 0)
         {
-            const bool mine = (uint32_t)lane < reach;
-            const uint32_t j = mine ? reach - 1 - (uint32_t)lane : 0;
+            const bool in_window = (uint32_t)lane < reach;
+            const uint32_t j = in_window ? reach - 1 - (uint32_t)lane : 0;
             uint64_t state = 0;
             do
             {
-                state = mine ? load_relaxed(&w.blockbase[j]) : pipe::kBlockOwn;
+                state = in_window ? load_relaxed(&w.blockbase[j]) : pipe::kBlockOwn;
             } while (__any((state >> 62) == 0));
-            const unsigned long long knows = __ballot(mine && (state >> 62) == 2);
+            const unsigned long long knows = __ballot(in_window && (state >> 62) == 2);
             const int last = knows ? (int)__ffsll(knows) - 1 : 63;
-            uint64_t part = mine && lane <= last ? state & pipe::kBlockValue : 0;
+            uint64_t part = in_window && lane <= last ? state & pipe::kBlockValue : 0;
             for (int delta = 32; delta > 0; delta >>= 1)
                 part += __shfl_xor(part, delta);
             start += part;
@@ -1194,44 +1434,49 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     if (sum == 0)
         return;
     const uint64_t bitpos = s_start + s_scan[threadIdx.x] - sum;
-    uint64_t word = bitpos >> 5;
-    const uint64_t first_word = word;
-    int acc_bits = (int)(bitpos & 31); // the leading bits of the first word belong to the previous thread
-    uint64_t acc = 0;
-    for (uint32_t i = 0; i < per_thread; ++i)
-    {
-        const uint16_t slot = base + i < tile_samples ? inv[base + i] : kNoLocalSlot; // (second read: the line is in the cache)
-        if (slot == kNoLocalSlot)
-            continue;
-        uint64_t v;
-        int left;
-        expand_code(s_code[slot], v, left);
-        while (left > 0)
+    uint64_t word_at = bitpos >> 5;
+    const uint64_t first_word = word_at;
+    uint32_t pending = (uint32_t)(bitpos & 31); // the leading bits of the first word belong to the previous thread
+    uint64_t acc = 0;                           // bits [63 - pending, ...) downwards are ours
+    // n <= 32 bits of `part` behind what is pending; a full 32-bit word leaves at once
+    auto put = [&](uint32_t part, uint32_t n) {
+        acc |= (uint64_t)part << ((64u - pending - n) & 63u);
+        pending += n;
+        if (pending >= 32)
         {
-            const int room = 64 - acc_bits;
-            const int n = left < room ? left : room;
-            const uint64_t piece = n == 64 ? v : ((v >> (left - n)) & ((1ull << n) - 1ull));
-            acc |= piece << (room - n);
-            acc_bits += n;
-            left -= n;
-            while (acc_bits >= 32)
+            const uint32_t o = __builtin_bswap32((uint32_t)(acc >> 32));
+            if (word_at < w.raw_words)
             {
-                const uint32_t o = __builtin_bswap32((uint32_t)(acc >> 32));
-                if (word < w.raw_words)
-                {
-                    if (word == first_word)
-                        atomicOr(&w.raw[word], o); // shared with the previous thread's tail
-                    else
-                        w.raw[word] = o; // entirely ours
-                }
-                acc <<= 32;
-                acc_bits -= 32;
-                ++word;
+                if (word_at == first_word)
+                    atomicOr(&w.raw[word_at], o); // shared with the previous thread's tail
+                else
+                    w.raw[word_at] = o; // entirely ours
             }
+            acc <<= 32;
+            pending -= 32;
+            ++word_at;
         }
-    }
-    if (acc_bits > 0 && word < w.raw_words)
-        atomicOr(&w.raw[word], __builtin_bswap32((uint32_t)(acc >> 32))); // tail shared with the next thread
+    };
+#pragma unroll
+    for (int q = 0; q < kGroups; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+        {
+            const uint32_t slot = slot_of(q, j);
+            if (slot == kNoLocalSlot)
+                continue;
+            uint64_t v;
+            int len;
+            expand_code(s_code[slot], v, len);
+            if (len > 32)
+            { // (codes of wide samples, long runs: rare)
+                put((uint32_t)(v >> 32), (uint32_t)len - 32u);
+                len = 32;
+            }
+            put((uint32_t)v, (uint32_t)len);
+        }
+    if (pending > 0 && word_at < w.raw_words)
+        atomicOr(&w.raw[word_at], __builtin_bswap32((uint32_t)(acc >> 32))); // tail shared with the next thread
 }
 
 // Zeroes the look-back states and the raw bit stream of every scan of a pass (contiguous in a work area).
@@ -1258,12 +1503,12 @@ inline size_t analyze_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_
 inline size_t sort_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t sample_bytes, int interleave_mode)
 {
     return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode) + (size_t)kSegments * kChains * 4 +
-           3 * ((size_t)kChains + 1) * 4 + 16 * 4 + (size_t)lines_per_tile * width * 4;
+           3 * ((size_t)kChains + 1) * 4 + 16 * 4 + (size_t)kWaves * (kChains + 1) * 4 + (size_t)lines_per_tile * width * 4;
 }
 inline size_t pack_lds_bytes(uint32_t width, uint32_t lines_per_tile)
 {
-    return (size_t)lines_per_tile * width * 4 + 4 * ((size_t)kChains + 1) * 4 + (size_t)kPackThreads * 4 + 16 * 4 +
-           ((size_t)lines_per_tile * width / 64 + kChains + 8) * 2;
+    const uint32_t per_thread = ((lines_per_tile * width + kPackThreads - 1) / kPackThreads + 7u) & ~7u;
+    return (size_t)pack_inv_offset(width, lines_per_tile) + (size_t)kPackThreads * per_thread * 2;
 }
 // Lines per tile for lines of `width` samples: as many whole lines as fit `tile_samples` (8192 for samples of one byte,
 // 4096 for two: the sort stage keeps the lines, the keys and the sorted records of a tile in LDS), at most kTileLines.

@@ -19,7 +19,8 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 // job_events / warm_events as given: the tests use small values so that small images have many jobs, and warm-ups too
 // short to converge so that settle_chains has to walk jobs again.
 template <typename S>
-static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count, uint32_t job_events, uint32_t warm_events)
+static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count, uint32_t job_events, uint32_t warm_events,
+                              uint32_t run_job_events, uint32_t run_warm_events)
 {
     using namespace jls;
     const ScanDesc& p = descs[0];
@@ -28,6 +29,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     const uint32_t lines_per_tile = tile::lines_per_tile_for(p.width, (uint32_t)sizeof(S));
     const uint32_t tiles = (uint32_t)((lines + lines_per_tile - 1) / lines_per_tile);
     const size_t max_jobs = samples / job_events + pipe::kChains;
+    const size_t max_run_jobs = samples / run_job_events + 1;
     std::vector<tile::Work> works(count);
     std::vector<pipe::Work> stuff(count);
     std::vector<void*> allocs;
@@ -54,6 +56,9 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         w.rec = (uint32_t*)galloc((samples + tile::kSlack) * 4);
         w.code = (uint32_t*)galloc((samples + tile::kSlack) * 4);
         w.jobs = (tile::JobState*)galloc(max_jobs * sizeof(tile::JobState));
+        w.run_jobs = (tile::RunJob*)galloc(max_run_jobs * sizeof(tile::RunJob));
+        w.run_job_events = run_job_events;
+        w.run_warm_events = run_warm_events;
         uint8_t* pack_state = (uint8_t*)zalloc((size_t)tiles * 8 + 16 + raw_bytes);
         w.blockbase = (uint64_t*)pack_state;
         w.raw = (uint32_t*)(pack_state + ((size_t)tiles * 8 + 15) / 16 * 16);
@@ -85,10 +90,18 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         emu::launch(tile::sort_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::sort_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode), descs, wk);
     emu::launch(tile::walk_jobs<S>, dim3((unsigned)((max_jobs + 63) / 64), count), dim3(64), 0, descs, wk);
     emu::launch(tile::settle_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    emu::launch(tile::count_runs<S>, dim3((unsigned)std::min<size_t>(max_run_jobs, 256), count), dim3(64), 0, wk);
+    emu::launch(tile::scan_runs, dim3(count), dim3(64), 0, wk);
     if (p.interleave_mode == 1)
-        emu::launch(tile::code_runs<S, 1>, dim3((count + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    {
+        emu::launch(tile::walk_run_jobs<S, 1>, dim3((unsigned)((max_run_jobs * count + 63) / 64)), dim3(64), 0, descs, wk, (uint32_t)count);
+        emu::launch(tile::settle_runs<S, 1>, dim3((count + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    }
     else
-        emu::launch(tile::code_runs<S, 0>, dim3((count + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    {
+        emu::launch(tile::walk_run_jobs<S, 0>, dim3((unsigned)((max_run_jobs * count + 63) / 64)), dim3(64), 0, descs, wk, (uint32_t)count);
+        emu::launch(tile::settle_runs<S, 0>, dim3((count + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    }
     emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::kPackThreads), tile::pack_lds_bytes(p.width, lines_per_tile), descs, wk);
     const pipe::Work* sk = stuff.data();
     if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env == nullptr || std::atoi(env) != 0)
@@ -109,12 +122,13 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
 
 extern "C" {
 
-void emu_encode_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count, uint32_t job_events, uint32_t warm_events)
+void emu_encode_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count, uint32_t job_events, uint32_t warm_events,
+                              uint32_t run_job_events, uint32_t run_warm_events)
 {
     if (descs[0].bits_per_sample > 8)
-        emu_tile_pipeline<uint16_t>(descs, results, count, job_events, warm_events);
+        emu_tile_pipeline<uint16_t>(descs, results, count, job_events, warm_events, run_job_events, run_warm_events);
     else
-        emu_tile_pipeline<uint8_t>(descs, results, count, job_events, warm_events);
+        emu_tile_pipeline<uint8_t>(descs, results, count, job_events, warm_events, run_job_events, run_warm_events);
 }
 
 size_t emu_sizeof_scan_desc() { return sizeof(jls::ScanDesc); }
