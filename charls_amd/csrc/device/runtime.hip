@@ -886,7 +886,7 @@ bool tile_pipeline_eligible(const ScanDesc& d)
 struct TileLayout
 {
     size_t samples, lines, raw_bytes, max_jobs, max_run_jobs;
-    uint32_t lines_per_tile, tiles, job_events, warm_events, run_job_events, run_warm_events;
+    uint32_t lines_per_tile, tiles, job_events, warm_events, run_job_events, run_warm_events, run_long_warm_events;
     size_t off_keyinv, off_seg, off_total, off_base, off_jobfirst, off_rec, off_code, off_jobs, off_runjobs, off_bbase, off_raw,
         off_bits, off_status, off_stuff, bytes;
     TileLayout(const ScanDesc& d, size_t capacity_hint, uint32_t count)
@@ -905,11 +905,14 @@ struct TileLayout
         job_events = env_job ? static_cast<uint32_t>(std::max(16, std::atoi(env_job)) / 16 * 16) : static_cast<uint32_t>(job);
         warm_events = env_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_warm))) : 1024u;
         max_jobs = samples / job_events + pipe::kChains;
-        // the run chain: jobs of 2048 run events with a warm-up of as many (a test frame has 55 000 run events)
+        // the run chain: jobs of 2048 run events with a warm-up of as many, and of 32768 more for the rarer of the two
+        // run-interruption contexts (a test frame has 55 000 run events, 2 300 of them of the rarer type)
         const char* env_run_job = std::getenv("CHARLS_AMD_RUN_JOB_EVENTS");
         const char* env_run_warm = std::getenv("CHARLS_AMD_RUN_WARM_EVENTS");
         run_job_events = env_run_job ? static_cast<uint32_t>(std::max(8, std::atoi(env_run_job)) / 8 * 8) : 2048u;
         run_warm_events = env_run_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_warm))) : 2048u;
+        const char* env_run_long = std::getenv("CHARLS_AMD_RUN_LONG_WARM_EVENTS");
+        run_long_warm_events = env_run_long ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_long))) : 32768u;
         max_run_jobs = samples / run_job_events + 1;
         const size_t worst = worst_case_scan_bytes(d.width, static_cast<uint32_t>(lines), 1, d.bits_per_sample);
         raw_bytes = align_up((capacity_hint < worst ? capacity_hint : worst) + 64, 16);
@@ -1034,6 +1037,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             w.run_jobs = reinterpret_cast<tile::RunJob*>(base + lay.off_runjobs);
             w.run_job_events = lay.run_job_events;
             w.run_warm_events = lay.run_warm_events;
+            w.run_long_warm_events = lay.run_long_warm_events;
             w.blockbase = reinterpret_cast<uint64_t*>(base + lay.off_bbase);
             w.raw = reinterpret_cast<uint32_t*>(base + lay.off_raw);
             w.raw_words = lay.raw_bytes / 4;
@@ -1079,7 +1083,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         {
             const uint32_t run_jobs = static_cast<uint32_t>(lay.max_run_jobs);
             const dim3 lanes((static_cast<uint64_t>(run_jobs) * n + 63) / 64);
-            hipLaunchKernelGGL((tile::count_runs<S>), dim3(std::min<uint32_t>(run_jobs, 256), n), dim3(64), 0, runs_stream, d_works);
+            hipLaunchKernelGGL((tile::count_runs<S>), dim3(std::min<uint32_t>(run_jobs, 32), n), dim3(64), 0, runs_stream, d_works);
             hipLaunchKernelGGL(tile::scan_runs, dim3(n), dim3(64), 0, runs_stream, d_works);
             if (proto.interleave_mode == 1)
             {

@@ -93,7 +93,7 @@ struct Work
     // the launch's geometry (all scans of a launch share width, sample type and interleave mode; a scan may have FEWER
     // lines than the launch was sized for -- the last restart interval of a frame -- and then has fewer tiles)
     uint32_t lines_per_tile, tiles, job_events, warm_events;
-    uint32_t run_job_events, run_warm_events; // (multiples of 8)
+    uint32_t run_job_events, run_warm_events, run_long_warm_events; // (run_job_events: a multiple of 8)
 };
 
 JLS_DEV uint32_t tile_of_block(uint32_t block, uint32_t tiles) // XCD-aware: workgroup b runs on XCD b % 8; each XCD gets a band of tiles
@@ -998,7 +998,9 @@ JLS_DEV uint32_t run_word(int ones, int tail_len, uint32_t tail)
 // One lane's walk over run events [from, to) of a scan.  counts = {type-0, type-1, own-slot} interruptions before `from`.
 // kStore: write the code words (the run-length code to the slot of the sample where the run starts, the code of the
 // interruption sample to the next slot of chain kInterruptChain: its events are these samples, in this order).
-template <typename S, int ILV, bool kStore>
+// kOnly = 0 / 1: only the interruptions of that type are looked at, and only their context moves (the long warm-up of the
+// rarer context, see walk_run_jobs); -1: everything.
+template <typename S, int ILV, bool kStore, int kOnly = -1>
 JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code, uint32_t* int_code, uint32_t from, uint32_t to,
                        RunState& s, uint32_t type0, uint32_t type1, uint32_t own_slot)
 {
@@ -1006,6 +1008,18 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
     RunCtx rc1{1, s.a1, chain_n_before(type1, (uint32_t)t.reset), s.nn1};
     uint32_t run_index_packed = s.index;
     auto one = [&](uint32_t v) -> uint32_t {
+        if (kOnly >= 0)
+        { // the context of one type alone: it depends on the error values of its own interruptions and on nothing else
+            if (!RunRecord<S>::is_end_of_line(v) && RunRecord<S>::which(v) == kOnly)
+            {
+                RunCtx& ctx = kOnly ? rc1 : rc0;
+                const int err = RunRecord<S>::err(v);
+                const int k = run_k(ctx);
+                const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - run_map(ctx, err, k);
+                run_update(ctx, err, em, t.reset);
+            }
+            return 0u;
+        }
         uint32_t run = RunRecord<S>::run(v);
         const bool eol = RunRecord<S>::is_end_of_line(v);
         const uint32_t shift = ILV == 1 ? RunRecord<S>::component(v) * 8u : 0u;
@@ -1092,7 +1106,7 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
     s.nn1 = rc1.nn;
 }
 
-// grid (up to 256, scans) x 64: a wavefront counts the events of a job (and of every gridDim.x-th job after it).
+// grid (up to 32, scans) x 64: a wavefront counts the events of a job (and of every gridDim.x-th job after it).
 template <typename S>
 __global__ void __launch_bounds__(64) count_runs(const Work* __restrict__ works)
 {
@@ -1182,16 +1196,30 @@ __global__ void __launch_bounds__(64) walk_run_jobs(const ScanDesc* __restrict__
     const uint32_t* runs = w.rec + w.chain_base[0];
     uint32_t* run_code = w.code + w.chain_base[0];
     uint32_t* int_code = w.code + w.chain_base[kInterruptChain];
-    // the warm-up starts at a job boundary (that is where the counts are known)
+    // The warm-ups start at job boundaries (that is where the counts are known).  RUNindex and the context of the more
+    // frequent interruption type forget within run_warm_events run events; the context of the rarer type (4 % of the
+    // interruptions of a test frame) needs as many of ITS OWN events, so it alone is warmed up over run_long_warm_events
+    // before that -- a walk that looks at one bit of every other record.
+    const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
+    const RunJob last = w.run_jobs[jobs - 1]; // (counts before the last job: good enough to tell which type is the rarer one)
+    const bool rare1 = last.type1 < last.type0;
     const uint32_t warm_jobs = (w.run_warm_events + w.run_job_events - 1) / w.run_job_events;
+    const uint32_t long_jobs = warm_jobs + (w.run_long_warm_events + w.run_job_events - 1) / w.run_job_events;
     const uint32_t warm_job = job > warm_jobs ? job - warm_jobs : 0u;
+    const uint32_t long_job = job > long_jobs ? job - long_jobs : 0u;
     RunState s{0, initial_a(t), 0, initial_a(t), 0};
     RunJob mine = w.run_jobs[job];
-    if (warm_job < job)
+    const RunJob before = w.run_jobs[warm_job];
+    if (long_job < warm_job)
     {
-        const RunJob before = w.run_jobs[warm_job];
-        walk_runs<S, ILV, false>(t, runs, run_code, int_code, warm_job * w.run_job_events, from, s, before.type0, before.type1, before.own_slot);
+        const RunJob far = w.run_jobs[long_job];
+        if (rare1)
+            walk_runs<S, ILV, false, 1>(t, runs, run_code, int_code, long_job * w.run_job_events, warm_job * w.run_job_events, s, before.type0, far.type1, 0);
+        else
+            walk_runs<S, ILV, false, 0>(t, runs, run_code, int_code, long_job * w.run_job_events, warm_job * w.run_job_events, s, far.type0, before.type1, 0);
     }
+    if (warm_job < job)
+        walk_runs<S, ILV, false>(t, runs, run_code, int_code, warm_job * w.run_job_events, from, s, before.type0, before.type1, before.own_slot);
     mine.in = s;
     walk_runs<S, ILV, true>(t, runs, run_code, int_code, from, to, s, mine.type0, mine.type1, mine.own_slot);
     mine.out = s;

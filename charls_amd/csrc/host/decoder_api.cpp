@@ -2,7 +2,9 @@
 //
 // Same state machine, checks and error codes as the reference facade (src/charls_jpegls_decoder.cpp:21-533); the scan
 // itself (`make_scan_codec<scan_decoder>()->decode_scan`, :186-189) runs on the GPU through ScanEngine.
+#include <cstring>
 #include <new>
+#include <vector>
 
 #include "common.h"
 #include "scan_engine.h"
@@ -51,6 +53,102 @@ struct charls_jpegls_decoder
         return checked_mul(stride, f.height) - (stride - min_stride);
     }
 
+    // The component scans of a planar frame, decoded by ONE launch (the reference decodes them in a loop, :177-201; they
+    // share nothing, and where each one starts can be found without decoding: FF followed by a byte >= 0x80 cannot occur
+    // inside entropy-coded data, src/scan_decoder.hpp:272-284).  A copy of the reader -- without the caller's comment /
+    // application-data handlers -- walks from scan to scan over the markers in between; the scans must be single-component
+    // scans with the same coding parameters.  Returns false, with nothing changed, whenever anything is out of the ordinary
+    // (a segment that does not parse, different parameters, a scan that does not end where the next marker is, any decoding
+    // error): the scan-by-scan path then runs from the start and raises what the reference would.
+    bool decode_planes_together(uint8_t* dst, size_t dst_left, size_t stride_arg, const uint8_t* base)
+    {
+        const size_t count = reader.component_count();
+        if (count < 2 || reader.scan_interleave_mode() != 0 || reader.scan_component_count() != 1)
+            return false;
+        const charls_frame_info f = reader.frame_info();
+        const size_t min_stride = static_cast<size_t>(f.width) * bytes_per_sample(f.bits_per_sample);
+        const size_t stride = stride_arg == 0 ? min_stride : stride_arg;
+        if (stride < min_stride || dst_left < stride * f.height * count - (stride - min_stride))
+            return false;
+        std::vector<size_t> offsets;
+        std::vector<ScanSpec> specs;
+        try
+        {
+            StreamReader probe = reader;
+            probe.at_comment(nullptr, nullptr);
+            probe.at_application_data(nullptr, nullptr);
+            for (size_t c = 0; c < count; ++c)
+            {
+                if (probe.scan_interleave_mode() != 0 || probe.scan_component_count() != 1)
+                    return false;
+                specs.push_back(ScanSpec{f.width, f.height, 1, 0, f.bits_per_sample, probe.parameters().near_lossless,
+                                         probe.parameters().transformation, probe.validated_pc(), probe.parameters().restart_interval});
+                offsets.push_back(static_cast<size_t>(probe.position() - base));
+                if (c + 1 == count)
+                    break;
+                // the next marker that is not a restart marker ends this scan
+                const uint8_t* p = probe.position();
+                const uint8_t* end = p + probe.remaining();
+                for (;; ++p)
+                {
+                    p = static_cast<const uint8_t*>(std::memchr(p, 0xFF, static_cast<size_t>(end - p)));
+                    if (p == nullptr || p + 1 >= end)
+                        return false;
+                    if (p[1] >= 0x80 && !(p[1] >= 0xD0 && p[1] <= 0xD7))
+                        break;
+                }
+                probe.advance(static_cast<size_t>(p - probe.position()));
+                probe.read_next_start_of_scan();
+            }
+        }
+        catch (const error&)
+        {
+            return false;
+        }
+        for (size_t c = 1; c < count; ++c)
+        {
+            const ScanSpec &a = specs[0], &b = specs[c];
+            if (a.near_lossless != b.near_lossless || a.color_transformation != b.color_transformation ||
+                a.restart_interval != b.restart_interval || std::memcmp(&a.pc, &b.pc, sizeof a.pc) != 0)
+                return false;
+        }
+        engine.upload_stream(base, reader.remaining());
+        std::vector<ScanResult> results(count);
+        try
+        {
+            engine.decode_planes(specs[0], offsets.data(), static_cast<uint32_t>(count), results.data());
+        }
+        catch (const error&)
+        {
+            return false;
+        }
+        for (size_t c = 0; c < count; ++c)
+        {
+            if (results[c].errc != kOk)
+                return false;
+            if (c + 1 < count)
+            { // scan c must end exactly where the probe found the marker that leads to scan c + 1 (the SOS segment of a
+              // single-component scan is 10 bytes, other segments may sit before it: checked by replaying the reader below)
+                const size_t end_of_scan = offsets[c] + static_cast<size_t>(results[c].bytes);
+                if (end_of_scan > offsets[c + 1])
+                    return false;
+            }
+        }
+        // replay the real reader over the same path (handlers fire exactly as in the scan-by-scan path), planes out
+        for (size_t c = 0; c < count; ++c)
+        {
+            if (static_cast<size_t>(reader.position() - base) != offsets[c])
+                raise(CHARLS_JPEGLS_ERRC_INVALID_DATA); // (cannot happen: the probe took the same steps)
+            engine.fetch_decoded_plane(specs[0], static_cast<uint32_t>(c), dst + stride * f.height * c, stride);
+            reader.advance(static_cast<size_t>(results[c].bytes));
+            if (c + 1 < count)
+                reader.read_next_start_of_scan();
+        }
+        reader.read_end_of_image();
+        state = State::completed;
+        return true;
+    }
+
     void decode(void* destination, size_t destination_size_bytes, size_t stride_arg) // reference :177-201
     {
         check_buffer(destination, destination_size_bytes);
@@ -58,6 +156,8 @@ struct charls_jpegls_decoder
         auto* dst = static_cast<uint8_t*>(destination);
         size_t dst_left = destination_size_bytes;
         const uint8_t* base = reader.position();
+        if (decode_planes_together(dst, dst_left, stride_arg, base))
+            return;
         bool uploaded = false;
 
         for (size_t component = 0;;)

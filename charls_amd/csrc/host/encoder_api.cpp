@@ -9,6 +9,8 @@
 
 #include "common.h"
 #include "preset.h"
+#include <vector>
+
 #include "scan_engine.h"
 #include "stream_writer.h"
 
@@ -155,11 +157,28 @@ struct charls_jpegls_encoder
         if (interleave == 0)
         {
             const size_t plane_bytes = stride * frame.height;
+            // The component scans of a planar frame share nothing (own contexts, own bit stream): all of them are coded by
+            // one launch into private buffers and then placed one after the other, where the reference codes them in a
+            // loop (:209-224).  What the reference's scan c would have been given as its destination -- everything behind
+            // its own SOS header -- is only known once scans 0..c-1 have been placed: a scan that, placed, leaves fewer
+            // than 4 bytes (or does not fit) is coded again on its own with exactly that destination, so that
+            // destination_too_small is raised by the same rule as before (src/scan_encoder.hpp:117-120).
+            std::vector<ScanResult> planes(static_cast<size_t>(source_components));
+            const bool together = source_components > 1;
+            if (together)
+                engine.encode_planes(spec, static_cast<uint32_t>(source_components), plane_bytes, stride, writer.remaining(), planes.data());
             for (int32_t c = 0; c < source_components; ++c)
             {
                 writer.start_of_scan(1, near, interleave);
-                const size_t n = engine.encode_scan(spec, plane_bytes * static_cast<size_t>(c), stride, writer.position(),
-                                                    writer.remaining());
+                const ScanResult& r = planes[static_cast<size_t>(c)];
+                size_t n;
+                if (together && r.errc == kOk && r.bytes + 4 <= writer.remaining())
+                {
+                    n = static_cast<size_t>(r.bytes);
+                    engine.fetch_encoded_scan(static_cast<uint32_t>(c), writer.position(), n);
+                }
+                else
+                    n = engine.encode_scan(spec, plane_bytes * static_cast<size_t>(c), stride, writer.position(), writer.remaining());
                 writer.advance(n);
             }
         }

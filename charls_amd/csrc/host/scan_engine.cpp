@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 namespace jls {
 
@@ -60,6 +61,77 @@ ScanResult ScanEngine::run(const ScanDesc& desc, bool decode)
     ScanResult r;
     std::memcpy(&r, staged + sizeof desc, sizeof r);
     return r;
+}
+
+void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, ScanResult* results)
+{
+    const size_t desc_bytes = sizeof(ScanDesc) * count, result_bytes = sizeof(ScanResult) * count;
+    auto* staged = static_cast<uint8_t*>(staging_.ensure(desc_bytes + result_bytes));
+    std::memcpy(staged, descs, desc_bytes);
+    auto* d_descs = static_cast<ScanDesc*>(desc_.ensure(desc_bytes));
+    auto* d_results = static_cast<ScanResult*>(result_.ensure(result_bytes));
+    hip_check(hipMemcpyAsync(d_descs, staged, desc_bytes, hipMemcpyHostToDevice, stream_));
+    if (decode)
+        dev::launch_decode(descs[0], d_descs, d_results, count, stream_);
+    else
+        dev::launch_encode(descs[0], d_descs, d_results, count, stream_);
+    hip_check(hipMemcpyAsync(staged + desc_bytes, d_results, result_bytes, hipMemcpyDeviceToHost, stream_));
+    hip_check(hipStreamSynchronize(stream_));
+    if (dev::work_area_bytes() > (size_t{1} << 30))
+        dev::release_work_areas();
+    std::memcpy(results, staged + desc_bytes, result_bytes);
+}
+
+void ScanEngine::encode_planes(const ScanSpec& spec, uint32_t count, size_t plane_bytes, size_t stride, size_t capacity, ScanResult* results)
+{
+    ensure_stream();
+    const size_t bound = dev::worst_case_scan_bytes(spec.width, spec.height, spec.components, spec.bits_per_sample);
+    plane_capacity_ = (std::min(capacity, bound) + 255) & ~size_t{255};
+    auto* bits = static_cast<uint8_t*>(bits_.ensure(plane_capacity_ * count));
+    const size_t scratch_samples = dev::line_scratch_samples(spec.width, spec.interleave_mode, spec.components);
+    auto* scratch = static_cast<uint16_t*>(scratch_.ensure(scratch_samples * sizeof(uint16_t) * count));
+    std::vector<ScanDesc> descs(count, make_desc(spec));
+    for (uint32_t c = 0; c < count; ++c)
+    {
+        descs[c].pixels = pixels_.as<uint8_t>() + plane_bytes * c;
+        descs[c].pixel_stride = stride;
+        descs[c].stream = bits + plane_capacity_ * c;
+        descs[c].stream_capacity = std::min(capacity, bound);
+        descs[c].line_scratch = scratch + scratch_samples * c;
+    }
+    run_many(descs.data(), count, false, results);
+}
+
+void ScanEngine::fetch_encoded_scan(uint32_t index, uint8_t* destination, size_t bytes)
+{
+    hip_check(hipMemcpy(destination, bits_.as<uint8_t>() + plane_capacity_ * index, bytes, hipMemcpyDeviceToHost));
+}
+
+void ScanEngine::decode_planes(const ScanSpec& spec, const size_t* stream_offsets, uint32_t count, ScanResult* results)
+{
+    ensure_stream();
+    const size_t row_bytes = static_cast<size_t>(spec.width) * bytes_per_sample(spec.bits_per_sample);
+    const size_t plane = row_bytes * spec.height;
+    auto* pixels = static_cast<uint8_t*>(pixels_.ensure(plane * count));
+    const size_t scratch_samples = dev::line_scratch_samples(spec.width, spec.interleave_mode, spec.components);
+    auto* scratch = static_cast<uint16_t*>(scratch_.ensure(scratch_samples * sizeof(uint16_t) * count));
+    std::vector<ScanDesc> descs(count, make_desc(spec));
+    for (uint32_t c = 0; c < count; ++c)
+    {
+        descs[c].pixels = pixels + plane * c;
+        descs[c].pixel_stride = row_bytes;
+        descs[c].stream = bits_.as<uint8_t>() + stream_offsets[c];
+        descs[c].stream_capacity = stream_bytes_ - stream_offsets[c];
+        descs[c].line_scratch = scratch + scratch_samples * c;
+    }
+    run_many(descs.data(), count, true, results);
+}
+
+void ScanEngine::fetch_decoded_plane(const ScanSpec& spec, uint32_t index, uint8_t* destination, size_t stride)
+{
+    const size_t row_bytes = static_cast<size_t>(spec.width) * bytes_per_sample(spec.bits_per_sample);
+    hip_check(hipMemcpy2D(destination, stride, pixels_.as<uint8_t>() + row_bytes * spec.height * index, row_bytes, row_bytes,
+                          spec.height, hipMemcpyDeviceToHost));
 }
 
 void ScanEngine::upload_pixels(const uint8_t* source, size_t bytes)

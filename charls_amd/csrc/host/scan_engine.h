@@ -35,23 +35,35 @@ public:
     // segment to `destination` (host) and returns its size.  Raises what scan_encoder::encode_scan would throw.
     size_t encode_scan(const ScanSpec& spec, size_t pixel_offset, size_t stride, uint8_t* destination,
                        size_t destination_size);
+    // The `count` single-component scans of a planar frame at once (reference src/charls_jpegls_encoder.cpp:209-224 codes
+    // them in a plain loop; they share nothing).  Scan c starts c * plane_bytes into the uploaded pixels and is coded
+    // into a private device buffer of `capacity` bytes; results[c] is what scan_encoder::encode_scan would have done with a
+    // destination of that size.  The caller places the scans with fetch_encoded_scan.
+    void encode_planes(const ScanSpec& spec, uint32_t count, size_t plane_bytes, size_t stride, size_t capacity, ScanResult* results);
+    void fetch_encoded_scan(uint32_t index, uint8_t* destination, size_t bytes);
 
     // ---- decode: the remaining source bytes are uploaded once, then one call per scan
     void upload_stream(const uint8_t* source, size_t bytes);
     // Decodes the scan that starts `stream_offset` bytes into the uploaded stream into `destination` (host, rows
     // `stride` apart); returns the number of source bytes consumed.  Raises what scan_decoder::decode_scan would throw.
     size_t decode_scan(const ScanSpec& spec, size_t stream_offset, uint8_t* destination, size_t stride);
+    // `count` scans of identical geometry and coding parameters at once (the component scans of a planar frame are
+    // independent: own contexts, and FF DA cannot occur inside entropy-coded data, src/scan_decoder.hpp:272-284).
+    // results[c] is the result of scan c; fetch_decoded_plane copies its rows out.
+    void decode_planes(const ScanSpec& spec, const size_t* stream_offsets, uint32_t count, ScanResult* results);
+    void fetch_decoded_plane(const ScanSpec& spec, uint32_t index, uint8_t* destination, size_t stride);
 
 private:
     void ensure_stream();
     ScanDesc make_desc(const ScanSpec& spec) const;
     ScanResult run(const ScanDesc& desc, bool decode);
+    void run_many(const ScanDesc* descs, uint32_t count, bool decode, ScanResult* results);
 
     hipStream_t stream_{};
     bool have_stream_{};
     dev::DeviceBuffer pixels_, bits_, scratch_, desc_, result_;
     dev::PinnedBuffer staging_;
-    size_t pixel_bytes_{}, stream_bytes_{};
+    size_t pixel_bytes_{}, stream_bytes_{}, plane_capacity_{};
 };
 
 } // namespace jls

@@ -20,7 +20,7 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 // short to converge so that settle_chains has to walk jobs again.
 template <typename S>
 static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count, uint32_t job_events, uint32_t warm_events,
-                              uint32_t run_job_events, uint32_t run_warm_events)
+                              uint32_t run_job_events, uint32_t run_warm_events, uint32_t run_long_warm_events)
 {
     using namespace jls;
     const ScanDesc& p = descs[0];
@@ -59,6 +59,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         w.run_jobs = (tile::RunJob*)galloc(max_run_jobs * sizeof(tile::RunJob));
         w.run_job_events = run_job_events;
         w.run_warm_events = run_warm_events;
+        w.run_long_warm_events = run_long_warm_events;
         uint8_t* pack_state = (uint8_t*)zalloc((size_t)tiles * 8 + 16 + raw_bytes);
         w.blockbase = (uint64_t*)pack_state;
         w.raw = (uint32_t*)(pack_state + ((size_t)tiles * 8 + 15) / 16 * 16);
@@ -90,7 +91,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         emu::launch(tile::sort_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::sort_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode), descs, wk);
     emu::launch(tile::walk_jobs<S>, dim3((unsigned)((max_jobs + 63) / 64), count), dim3(64), 0, descs, wk);
     emu::launch(tile::settle_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
-    emu::launch(tile::count_runs<S>, dim3((unsigned)std::min<size_t>(max_run_jobs, 256), count), dim3(64), 0, wk);
+    emu::launch(tile::count_runs<S>, dim3((unsigned)std::min<size_t>(max_run_jobs, 32), count), dim3(64), 0, wk);
     emu::launch(tile::scan_runs, dim3(count), dim3(64), 0, wk);
     if (p.interleave_mode == 1)
     {
@@ -123,12 +124,12 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
 extern "C" {
 
 void emu_encode_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count, uint32_t job_events, uint32_t warm_events,
-                              uint32_t run_job_events, uint32_t run_warm_events)
+                              uint32_t run_job_events, uint32_t run_warm_events, uint32_t run_long_warm_events)
 {
     if (descs[0].bits_per_sample > 8)
-        emu_tile_pipeline<uint16_t>(descs, results, count, job_events, warm_events, run_job_events, run_warm_events);
+        emu_tile_pipeline<uint16_t>(descs, results, count, job_events, warm_events, run_job_events, run_warm_events, run_long_warm_events);
     else
-        emu_tile_pipeline<uint8_t>(descs, results, count, job_events, warm_events, run_job_events, run_warm_events);
+        emu_tile_pipeline<uint8_t>(descs, results, count, job_events, warm_events, run_job_events, run_warm_events, run_long_warm_events);
 }
 
 size_t emu_sizeof_scan_desc() { return sizeof(jls::ScanDesc); }

@@ -22,7 +22,7 @@ ELIGIBLE = [c for c in common.cases()
             (c["component_count"] == 1 or c["interleave_mode"] == 0) and (FULL or c["name"] in _SUBSET)]
 
 
-RUN_JOBS = (8, 8)  # events per job of the run chain, warm-up: tiny, so that small images have many jobs that do not converge
+RUN_JOBS = (8, 8, 24)  # events per job of the run chain, warm-up, long warm-up of the rarer context: tiny, so that small images have many jobs that do not converge
 
 
 def _encode_planes(planes, width, height, bits, pc, capacity, job=64, warm=32, runs=RUN_JOBS):
@@ -35,7 +35,7 @@ def _encode_planes(planes, width, height, bits, pc, capacity, job=64, warm=32, r
         descs.append(emu_bind.make_desc(width, height, 1, 0, bits, 0, 0, pc, 0, pix, width * (1 if bits <= 8 else 2), out, keep))
     arr = (emu_bind.ScanDesc * len(descs))(*descs)
     res = (emu_bind.ScanResult * len(descs))()
-    L.emu_encode_tile_pipeline(arr, res, len(descs), job, warm, runs[0], runs[1])
+    L.emu_encode_tile_pipeline(arr, res, len(descs), job, warm, runs[0], runs[1], runs[2])
     return [(r.errc, r.flags, o[:r.bytes].tobytes()) for r, o in zip(res, outs)]
 
 
@@ -179,7 +179,7 @@ def _encode_line_interleaved(img, width, height, comps, bits, xform, capacity, j
     pc = jls_container.validated_pc((0,) * 5, bits, 0)
     d = emu_bind.make_desc(width, height, comps, 1, bits, 0, xform, pc, 0, pix, width * comps * (1 if bits <= 8 else 2), out, keep)
     res = (emu_bind.ScanResult * 1)()
-    L.emu_encode_tile_pipeline((emu_bind.ScanDesc * 1)(d), res, 1, job, warm, 16, 8)
+    L.emu_encode_tile_pipeline((emu_bind.ScanDesc * 1)(d), res, 1, job, warm, 16, 8, 40)
     return res[0].errc, res[0].flags, out[:res[0].bytes].tobytes()
 
 
@@ -240,8 +240,9 @@ def test_tile_pipeline_random_parameters(chunk):
         warm = int(rng.choice([0, 16, 64, 1024]))
         run_job = int(rng.choice([8, 16, 64, 2048]))
         run_warm = int(rng.choice([0, 8, 64, 2048]))
-        L.emu_encode_tile_pipeline((emu_bind.ScanDesc * 1)(d), res, 1, job, warm, run_job, run_warm)
-        tag = (chunk, it, bits, comps, ilv, w, h, kind, preset, xform, job, warm, run_job, run_warm)
+        run_long = int(rng.choice([0, 16, 256]))
+        L.emu_encode_tile_pipeline((emu_bind.ScanDesc * 1)(d), res, 1, job, warm, run_job, run_warm, run_long)
+        tag = (chunk, it, bits, comps, ilv, w, h, kind, preset, xform, job, warm, run_job, run_warm, run_long)
         assert res[0].errc == 0 and out[:res[0].bytes].tobytes() == _scan_bytes(want), tag
 
 
@@ -262,13 +263,13 @@ def test_tile_pipeline_scans_shorter_than_the_launch_geometry():
             descs.append(emu_bind.make_desc(w, h, 1, 0, 8, 0, 0, pc, 0, pix, w, out, keep))
         arr = (emu_bind.ScanDesc * len(descs))(*descs)
         res = (emu_bind.ScanResult * len(descs))()
-        L.emu_encode_tile_pipeline(arr, res, len(descs), 128, 64, 16, 16)
+        L.emu_encode_tile_pipeline(arr, res, len(descs), 128, 64, 16, 16, 32)
         for img, r, o, h in zip(imgs, res, outs, heights):
             assert r.errc == 0 and o[:r.bytes].tobytes() == _scan_bytes(ob.encode(img, width=w, height=h)), heights
 
 
-@pytest.mark.parametrize("run_job,run_warm", [(8, 0), (8, 8), (16, 64), (64, 16), (2048, 2048)])
-def test_tile_pipeline_run_chain_in_jobs(run_job, run_warm):
+@pytest.mark.parametrize("run_job,run_warm,run_long", [(8, 0, 0), (8, 8, 64), (16, 64, 16), (64, 16, 512), (2048, 2048, 32768)])
+def test_tile_pipeline_run_chain_in_jobs(run_job, run_warm, run_long):
     """Images that are mostly runs (thousands of run events, both interruption types, RUNindex wandering): the run chain cut
     into jobs of every size, with warm-ups that converge and warm-ups that do not."""
     rng = np.random.default_rng(31)
@@ -282,9 +283,9 @@ def test_tile_pipeline_run_chain_in_jobs(run_job, run_warm):
             x += n
     img[10:14] = 7  # whole lines in one run
     pc = jls_container.validated_pc((0,) * 5, 8, 0)
-    (errc, flags, data), = _encode_planes([img], w, h, 8, pc, w * h * 2 + 1024, runs=(run_job, run_warm))
+    (errc, flags, data), = _encode_planes([img], w, h, 8, pc, w * h * 2 + 1024, runs=(run_job, run_warm, run_long))
     assert errc == 0 and data == _scan_bytes(ob.encode(img, width=w, height=h))
     wide = (img.astype(np.uint16) * 200)  # 16-bit records: Errval takes 16 bits of the run record
     pc16 = jls_container.validated_pc((0,) * 5, 16, 0)
-    (errc, flags, data), = _encode_planes([wide], w, h, 16, pc16, w * h * 4 + 1024, runs=(run_job, run_warm))
+    (errc, flags, data), = _encode_planes([wide], w, h, 16, pc16, w * h * 4 + 1024, runs=(run_job, run_warm, run_long))
     assert errc == 0 and data == _scan_bytes(ob.encode(wide, width=w, height=h, bits_per_sample=16))
