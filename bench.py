@@ -316,7 +316,8 @@ def main():
         jls_bytes = float(np.mean(enc.sizes.astype(np.float64)))
         raw_bytes = pixels * ((BITS + 7) // 8)
         # dominant kernel = largest HIP-event time per step (events recorded on the stream the kernels run on)
-        stage_names = ["analyze_rows", "chain_offsets+scatter_events", "bias_chains+code_events", "write_raw_bits", "stuff_scan"]
+        stage_names = ["analyze_tiles", "plan_chains+sort_tiles", "walk_jobs+settle_chains (run chain on a side stream)", "pack_tiles",
+                       "stuff_scan"]
         stages = (np.mean([k[2:7] for k in enc_kernel_ms], axis=0)
                   if enc_kernel_ms and len(enc_kernel_ms[0]) >= 7 and args.restart_interval == 0 else None)
         dk = float(np.mean([k[1] for k in dec_kernel_ms])) if dec_kernel_ms else 0.0
@@ -326,12 +327,24 @@ def main():
         # algorithmic bytes: every pixel byte and every .jls byte touched once by a pass over the batch
         alg_bytes = frames_n * (raw_bytes + jls_bytes)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        try:  # HBM bytes per frame of the dominant kernel measured with rocprofv3 PMC in its own run (profiles/README.md)
-            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+        # HBM bytes and instruction counts of the dominant kernel come from rocprofv3 PMC passes of their own (separate runs:
+        # profiles/README.md); they are used only when they were taken for THIS kernel instantiation and batch size
+        traffic, traffic_source, issue = None, None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_dominant_kernel_pmc.json")) as f:
                 tj = json.load(f)
-            if tj.get("kernel") == dom_name:
+            if tj.get("kernel") == dom_name and int(tj.get("frames", -1)) == frames_n:
                 traffic = int(tj["hbm_bytes_per_frame"] * frames_n)
+                traffic_source = tj.get("source")
+            if tj.get("kernel") == dom_name and dom_ms > 0:
+                # instruction-issue roofline: a SIMD issues at most one vector instruction per 4 cycles (MI355X_MICROARCH.md):
+                # 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s
+                valu = float(tj["valu_wave_instructions_per_sample"]) * frames_n * pixels
+                peak = 1024 * 2.4e9 / 4
+                issue = {"bound": "valu_issue", "achieved": round(valu / (dom_ms * 1e-3) / 1e9, 2), "peak": round(peak / 1e9, 1),
+                         "unit": "G wave-instructions/s", "frac": round(valu / (dom_ms * 1e-3) / peak, 4),
+                         "valu_wave_instructions_per_sample": tj["valu_wave_instructions_per_sample"],
+                         "source": tj.get("instruction_source")}
         except (OSError, ValueError, KeyError):
             pass
         line = {
@@ -362,17 +375,29 @@ def main():
             "encode_stage_ms": dict(zip(["analyze", "partition", "chains", "pack", "stuff"],
                                         [round(float(v), 3) for v in np.mean([k[2:7] for k in enc_kernel_ms], axis=0)]))
             if enc_kernel_ms and len(enc_kernel_ms[0]) >= 7 else None,
-            "encode_stage_note": "HIP-event time per stage summed over the passes of the batch; `stuff` runs on a side stream "
-                                 "under the next pass's first stages, so the five figures add up to more than encode_ms",
+            "encode_stage_note": "HIP-event time per stage summed over the passes of the batch (tile pipeline: analyze_tiles | "
+                                 "plan_chains + sort_tiles | walk_jobs + settle_chains, the run chain beside them | pack_tiles | "
+                                 "stuffing); `stuff` runs on a side stream under the next pass's first stages, so the five figures "
+                                 "add up to more than encode_ms",
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_source": "rocprofv3 PMC run committed under profiles/ (not collected in this run)" if traffic else None,
+                         "traffic_source": traffic_source,
                          "kernel_ms_per_launch": round(dom_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "issue_roofline": issue,
         }
         if not args.no_extras and args.restart_interval == 0:
             line.update(extras(lib, batch, torch, frames, streams, out, enc, dev, mpix, pitch))
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        # ---- context, never `value`: SURVEY 8(d)'s methodology (host buffer in -> host buffer out) and the whole host CPU
+        if "host_abi" in line:
+            h = line["host_abi"]
+            line["value_host_abi"] = {"value": round(1.0 / (1.0 / h["encode_mpix_s"] + 1.0 / h["decode_mpix_s"]), 1), "unit": "MPixels/s",
+                                      "frames": h["frames"], "what": "encode + decode round trip with the PCIe copies inside the clock"}
+        if "batch_sweep" in line and "cpu_baseline" in line:
+            allc = line["cpu_baseline"]["all_cores"]["value"]
+            line["vs_cpu_all_cores"] = {str(b["frames"]): round(1.0 / (1.0 / b["encode_mpix_s"] + 1.0 / b["decode_mpix_s"]) / allc, 2)
+                                        for b in line["batch_sweep"] if b["frames"] >= 256}
         print(json.dumps(line), flush=True)
 
     if use_dist:

@@ -19,6 +19,19 @@ class CodecParams(C.Structure):  # charls_amd_codec_params (include/charls_amd.h
                 ("encoding_options", C.c_uint32), ("restart_interval", C.c_uint32)]
 
 
+class DeviceShard(C.Structure):  # charls_amd_device_shard
+    _fields_ = [("device", C.c_int32), ("frame_count", C.c_uint32), ("d_frames", C.c_void_p), ("d_streams", C.c_void_p),
+                ("hip_stream", C.c_void_p)]
+
+
+class Gather(C.Structure):  # charls_amd_gather
+    _fields_ = [("root_shard", C.c_uint32), ("d_gathered", C.c_void_p), ("capacity_bytes", C.c_size_t),
+                ("offsets", C.POINTER(C.c_uint64)), ("total_bytes", C.POINTER(C.c_uint64)), ("transport", C.c_int32)]
+
+
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER_COPIES = 0, 1, 2
+
+
 def _bind(lib):
     l = lib.lib
     if getattr(l, "_batch_bound", False):
@@ -41,6 +54,13 @@ def _bind(lib):
     l.charls_amd_release_work_areas.restype = C.c_int32
     l.charls_amd_work_area_bytes.argtypes = []
     l.charls_amd_work_area_bytes.restype = C.c_uint64
+    l.charls_amd_encode_batch_devices.argtypes = [C.POINTER(CodecParams), C.c_uint32, C.POINTER(DeviceShard), C.c_size_t,
+                                                  C.c_uint32, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
+                                                  C.POINTER(Gather)]
+    l.charls_amd_encode_batch_devices.restype = C.c_int32
+    l.charls_amd_decode_batch_devices.argtypes = [C.c_uint32, C.POINTER(DeviceShard), C.c_size_t, C.POINTER(C.c_uint64),
+                                                  C.c_size_t, C.c_uint32, C.POINTER(CodecParams), C.POINTER(C.c_int32)]
+    l.charls_amd_decode_batch_devices.restype = C.c_int32
     l._batch_bound = True
     return l
 
@@ -142,6 +162,63 @@ def set_encode_engine(engine: int, lib=None):
 
 
 # ---- multi-GPU: frames are the sharding unit; the only exchange is the final bitstream gather -------------
+
+def encode_batch_devices(frame_shards, stream_shards, *, bits_per_sample=8, gather_to=None, transport=TRANSPORT_AUTO, lib=None):
+    """One process, several GPUs (charls_amd_encode_batch_devices): frame_shards[s] / stream_shards[s] are contiguous device
+    tensors of shard s on ITS device -- (F_s, H, W) single-component frames and (F_s, pitch) uint8 slots, same H, W and
+    pitch everywhere.  gather_to = (root shard index, uint8 device tensor on the root's device): the streams of all shards
+    are brought together there, back to back in frame order.  Returns (sizes, errcs, offsets or None, total or None)."""
+    lib = lib or capi.load_product()
+    l = _bind(lib)
+    n = len(frame_shards)
+    height, width = frame_shards[0].shape[-2], frame_shards[0].shape[-1]
+    frame_pitch = frame_shards[0][0].numel() * frame_shards[0].element_size() if frame_shards[0].shape[0] else height * width
+    pitch = stream_shards[0].shape[1]
+    shards = (DeviceShard * n)()
+    total = 0
+    for s in range(n):
+        f, st = frame_shards[s], stream_shards[s]
+        assert f.is_cuda and f.is_contiguous() and st.is_contiguous() and st.shape[1] == pitch and st.device == f.device
+        shards[s] = DeviceShard(f.device.index or 0, f.shape[0], f.data_ptr(), st.data_ptr(), None)
+        total += f.shape[0]
+    p = CodecParams(capi.FrameInfo(width, height, bits_per_sample, 1), 0, 0, 0, capi.PcParameters(0, 0, 0, 0, 0), 0, 0)
+    sizes = np.zeros(total, dtype=np.uint64)
+    errcs = np.zeros(total, dtype=np.int32)
+    offsets = total_bytes = None
+    g = None
+    if gather_to is not None:
+        root, buf = gather_to
+        offsets = np.zeros(total, dtype=np.uint64)
+        total_bytes = C.c_uint64(0)
+        g = Gather(root, buf.data_ptr(), buf.numel(), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), C.pointer(total_bytes), transport)
+    rc = l.charls_amd_encode_batch_devices(C.byref(p), n, shards, frame_pitch, 0, pitch, sizes.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                           errcs.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(g) if g is not None else None)
+    if rc != 0:
+        raise capi.JpegLSError(rc, "charls_amd_encode_batch_devices")
+    return sizes, errcs, offsets, (int(total_bytes.value) if total_bytes is not None else None)
+
+
+def decode_batch_devices(stream_shards, sizes, out_shards, *, lib=None):
+    """charls_amd_decode_batch_devices: shard s decodes stream_shards[s] (F_s, pitch) into out_shards[s] on its device."""
+    lib = lib or capi.load_product()
+    l = _bind(lib)
+    n = len(stream_shards)
+    shards = (DeviceShard * n)()
+    total = 0
+    for s in range(n):
+        st, o = stream_shards[s], out_shards[s]
+        shards[s] = DeviceShard(st.device.index or 0, st.shape[0], o.data_ptr(), st.data_ptr(), None)
+        total += st.shape[0]
+    sizes = np.ascontiguousarray(sizes, dtype=np.uint64)
+    errcs = np.zeros(total, dtype=np.int32)
+    p = CodecParams()
+    frame_pitch = out_shards[0][0].numel() * out_shards[0].element_size()
+    rc = l.charls_amd_decode_batch_devices(n, shards, stream_shards[0].shape[1], sizes.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                           frame_pitch, 0, C.byref(p), errcs.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise capi.JpegLSError(rc, "charls_amd_decode_batch_devices")
+    return p, errcs
+
 
 def shard_range(total: int, rank: int, world: int):
     """Contiguous block of frame indices owned by `rank` (sizes differ by at most one)."""

@@ -31,6 +31,7 @@ SOURCES = [
     "host/decoder_api.cpp",
     "host/misc_api.cpp",
     "host/batch_api.cpp",
+    "host/multi_device.cpp",
 ]
 
 
@@ -127,7 +128,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sys.stderr.write(f"scratch check: {len(table)} kernels, none with a private segment\n")
     for out, soname in ((OUT, "libcharls_amd.so"), (OUT_ALIAS, "libcharls.so.3")):
         link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out, "-Wl,-soname," + soname,
-                "-Wl,--no-undefined", "-Wl,--version-script=" + VERSION_SCRIPT]
+                "-Wl,--no-undefined", "-Wl,--version-script=" + VERSION_SCRIPT, "-ldl"]
         subprocess.check_call(link)
     dev_link = os.path.join(OUT_DIR, "libcharls.so")  # what -lcharls resolves at link time
     if os.path.lexists(dev_link):

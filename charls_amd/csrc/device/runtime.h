@@ -41,6 +41,7 @@ public:
 private:
     void* ptr_{};
     size_t cap_{};
+    int device_{-1}; // the device the memory lives on
 };
 
 // Pinned host allocation (descriptor upload / result download without staging copies).

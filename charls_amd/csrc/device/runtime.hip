@@ -62,12 +62,17 @@ void require_device()
 
 void* DeviceBuffer::ensure(size_t bytes)
 {
-    if (bytes <= cap_ && ptr_)
+    int device = 0;
+    hip_check(hipGetDevice(&device));
+    // (memory of another device is of no use to the kernels this thread is about to launch: a thread that moved on to
+    // another device starts over there)
+    if (bytes <= cap_ && ptr_ && device == device_)
         return ptr_;
     release();
     const size_t want = bytes < 256 ? 256 : bytes;
     hip_check(hipMalloc(&ptr_, want));
     cap_ = want;
+    device_ = device;
     return ptr_;
 }
 
@@ -532,6 +537,31 @@ struct StageTimer
     }
 };
 
+// Events of a call, destroyed with it (also when a HIP error is raised half-way through a pass).
+struct EventList
+{
+    std::vector<hipEvent_t> events;
+    explicit EventList(size_t n = 0) { grow(n); }
+    EventList(const EventList&) = delete;
+    EventList& operator=(const EventList&) = delete;
+    ~EventList()
+    {
+        for (hipEvent_t e : events)
+            (void)hipEventDestroy(e);
+    }
+    void grow(size_t n)
+    {
+        events.reserve(n);
+        while (events.size() < n)
+        {
+            hipEvent_t e{};
+            hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            events.push_back(e);
+        }
+    }
+    hipEvent_t operator[](size_t i) const { return events[i]; }
+};
+
 size_t align_up(size_t v, size_t a)
 {
     return (v + a - 1) / a * a;
@@ -909,7 +939,7 @@ struct TileLayout
         // run-interruption contexts (a test frame has 55 000 run events, 2 300 of them of the rarer type)
         const char* env_run_job = std::getenv("CHARLS_AMD_RUN_JOB_EVENTS");
         const char* env_run_warm = std::getenv("CHARLS_AMD_RUN_WARM_EVENTS");
-        run_job_events = env_run_job ? static_cast<uint32_t>(std::max(8, std::atoi(env_run_job)) / 8 * 8) : 2048u;
+        run_job_events = env_run_job ? static_cast<uint32_t>(std::max(32, std::atoi(env_run_job)) / 32 * 32) : 2048u;
         run_warm_events = env_run_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_warm))) : 2048u;
         const char* env_run_long = std::getenv("CHARLS_AMD_RUN_LONG_WARM_EVENTS");
         run_long_warm_events = env_run_long ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_long))) : 32768u;
@@ -955,7 +985,9 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         resident = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, budget / per_scan)));
     }
     uint8_t* arena = nullptr;
-    for (;;)
+    // a configured limit that does not even cover ONE work area is honoured: the one-wavefront-per-scan kernel needs none
+    const bool over_limit = g_workspace_limit.load() != 0 && budget < per_scan;
+    for (; !over_limit;)
     {
         arena = static_cast<uint8_t*>(try_ensure(pipeline_arena(), per_scan * resident));
         if (arena != nullptr || resident == 1)
@@ -977,27 +1009,16 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     // As in run_pipeline: the stuffing stage of a pass runs on a side stream under the next pass's stages A - C.
     const bool overlap_stuffing = passes > 1;
     hipStream_t stuff_stream = stream;
-    std::vector<hipEvent_t> packed, stuffed;
+    EventList packed, stuffed;
+    pipeline_lanes().ensure();
     if (overlap_stuffing)
     {
-        pipeline_lanes().ensure();
         stuff_stream = pipeline_lanes().streams[0];
-        packed.resize(passes);
-        stuffed.resize(passes);
-        for (uint32_t pass = 0; pass < passes; ++pass)
-        {
-            hip_check(hipEventCreateWithFlags(&packed[pass], hipEventDisableTiming));
-            hip_check(hipEventCreateWithFlags(&stuffed[pass], hipEventDisableTiming));
-        }
+        packed.grow(passes);
+        stuffed.grow(passes);
     }
-    pipeline_lanes().ensure();
     hipStream_t runs_stream = pipeline_lanes().streams[1];
-    std::vector<hipEvent_t> sorted(passes), runs_coded(passes);
-    for (uint32_t pass = 0; pass < passes; ++pass)
-    {
-        hip_check(hipEventCreateWithFlags(&sorted[pass], hipEventDisableTiming));
-        hip_check(hipEventCreateWithFlags(&runs_coded[pass], hipEventDisableTiming));
-    }
+    EventList sorted(passes), runs_coded(passes);
     static const bool attributes_set = [] {
         // (the sort stage asks for more than the 64 KB of LDS a kernel gets by default)
         const int lds = 160 * 1024;
@@ -1144,14 +1165,6 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     for (int i = 0; i < 5; ++i)
         tm.values[2 + i] = stage_ms[i];
     tm.count = 7;
-    for (hipEvent_t e : packed)
-        (void)hipEventDestroy(e);
-    for (hipEvent_t e : stuffed)
-        (void)hipEventDestroy(e);
-    for (hipEvent_t e : sorted)
-        (void)hipEventDestroy(e);
-    for (hipEvent_t e : runs_coded)
-        (void)hipEventDestroy(e);
 }
 
 } // namespace

@@ -59,7 +59,7 @@ constexpr uint32_t kTileLines = 16;        // lines of a tile at most
 constexpr uint32_t kSegments = 16;         // pieces of lines that the wavefronts of a tile workgroup work on, at most
 constexpr uint32_t kThreads = 512;         // workgroup of analyze_tiles / sort_tiles
 constexpr uint32_t kWaves = kThreads / 64;
-constexpr uint32_t kPackThreads = 256;     // workgroup of pack_tiles
+constexpr uint32_t kPackThreads = 512;     // workgroup of pack_tiles (16 consecutive samples per thread at most)
 constexpr uint16_t kNoLocalSlot = 0xFFFF;
 constexpr uint32_t kChainPad = 16;         // chains start on multiples of 16 records (one 64-byte line)
 constexpr uint32_t kSlack = kChains * kChainPad + 64; // spare records behind rec / code: padding + read-ahead of the walkers
@@ -1070,30 +1070,44 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
         run_index_packed = (run_index_packed & ~(0xFFu << shift)) | ((uint32_t)run_index << shift);
         return word;
     };
-    // The events are read eight at a time, the next eight requested before the current ones are coded.  Chains start on
-    // 64-byte boundaries and are followed by kSlack records, so whole groups can be read; `from` is a multiple of 8.
+    // The events are read a group at a time, the next group requested before the current one is coded: eight events, or
+    // thirty-two where only one bit of most records is looked at (little work per event: the requests have to be further
+    // ahead).  Chains start on 64-byte boundaries and are followed by kSlack records, so whole groups can be read; `from` is
+    // the start of a job, a multiple of the group size.
+    constexpr uint32_t kQuads = kOnly >= 0 ? 8 : 2; // 16-byte quads per group
     const JLS_GLOBAL_AS u32x4* runs4 = (const JLS_GLOBAL_AS u32x4*)runs;
     JLS_GLOBAL_AS u32x4* code4 = (JLS_GLOBAL_AS u32x4*)run_code;
-    uint32_t g = from / 8;
-    u32x4 nv[2] = {runs4[g * 2], runs4[g * 2 + 1]};
-    for (; g < to / 8; ++g)
+    for (; from % (kQuads * 4) != 0 && from < to; ++from) // (jobs smaller than a group: the CPU tests)
     {
-        const u32x4 cv[2] = {nv[0], nv[1]};
-        nv[0] = runs4[g * 2 + 2];
-        nv[1] = runs4[g * 2 + 3];
-        u32x4 o[2];
+        const uint32_t word = one(runs[from]);
+        if (kStore)
+            run_code[from] = word;
+    }
+    uint32_t g = from / (kQuads * 4);
+    u32x4 nv[kQuads];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+    for (uint32_t q = 0; q < kQuads; ++q)
+        nv[q] = runs4[g * kQuads + q];
+    for (; g < to / (kQuads * 4); ++g)
+    {
+        u32x4 cv[kQuads], o[kQuads];
+#pragma unroll
+        for (uint32_t q = 0; q < kQuads; ++q)
+        {
+            cv[q] = nv[q];
+            nv[q] = runs4[(g + 1) * kQuads + q];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kQuads; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                o[h][j] = one(cv[h][j]);
+                o[q][j] = one(cv[q][j]);
         if (kStore)
-        {
-            code4[g * 2] = o[0];
-            code4[g * 2 + 1] = o[1];
-        }
+#pragma unroll
+            for (uint32_t q = 0; q < kQuads; ++q)
+                code4[g * kQuads + q] = o[q];
     }
-    for (uint32_t e = g * 8; e < to; ++e)
+    for (uint32_t e = g * kQuads * 4; e < to; ++e)
     {
         const uint32_t word = one(runs[e]);
         if (kStore)
@@ -1393,7 +1407,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
 
     // ---- bits of this thread's samples.  The slots of a thread are 16-byte groups of the staged slot map (eight samples
     // each), read once and kept in registers for both passes.
-    constexpr int kGroups = (int)(kMaxTileSamples / kPackThreads / 8); // 4 groups = 32 samples at most
+    constexpr int kGroups = (int)(kMaxTileSamples / kPackThreads / 8); // 16 samples at most
     uint4 mine[kGroups];
 #pragma unroll
     for (int q = 0; q < kGroups; ++q)

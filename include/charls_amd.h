@@ -334,6 +334,57 @@ CHARLS_AMD_API charls_jpegls_errc charls_amd_decode_batch_device(uint32_t frame_
                                                                  uint32_t stride, charls_amd_codec_params* params_out,
                                                                  charls_jpegls_errc* errcs, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Part 2b -- several GPUs from one process (frames are the sharding unit; no exchange while coding; the only
+ * collective is the hand-over of the finished bitstreams).  The frames of a batch are dealt to shards; shard s lives on
+ * device shards[s].device with its frames and its stream slots in that device's memory, at the pitches given to the call.
+ * A worker thread per shard binds to the device and runs charls_amd_encode_batch_device / _decode_batch_device on the
+ * shard; sizes / errcs are HOST arrays over all frames in shard order (shard 0's frames first).  Every frame gets exactly
+ * the bytes and the errc of part 1, whatever the number of shards.
+ *
+ * encode, gather != NULL: after coding, every shard's streams are brought together, back to back and in frame order, in
+ * gather->d_gathered on the device of shard gather->root_shard; offsets[f] is where frame f starts (frames that failed
+ * take no room), *total_bytes the end.  The sizes are exchanged first (a prefix sum over host values here), then every
+ * other shard sends each stream -- exactly sizes[f] bytes -- to its place: with RCCL (ncclSend / ncclRecv pairs in groups,
+ * point to point over xGMI; librccl.so is opened at run time) or with peer copies (hipMemcpyPeerAsync).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct charls_amd_device_shard
+{
+    int32_t device;       /* HIP device ordinal */
+    uint32_t frame_count; /* frames of this shard (may be 0) */
+    const void* d_frames; /* encode: source frames; decode: destination frames (written) */
+    void* d_streams;      /* encode: destination slots; decode: source slots */
+    void* hip_stream;     /* a hipStream_t of that device, or NULL */
+} charls_amd_device_shard;
+
+typedef enum charls_amd_transport
+{
+    CHARLS_AMD_TRANSPORT_AUTO = 0,       /* RCCL when it can be loaded and the shards sit on distinct devices, else peer copies */
+    CHARLS_AMD_TRANSPORT_RCCL = 1,       /* fail when RCCL is not usable */
+    CHARLS_AMD_TRANSPORT_PEER_COPIES = 2
+} charls_amd_transport;
+
+typedef struct charls_amd_gather
+{
+    uint32_t root_shard;
+    void* d_gathered;      /* on the root shard's device */
+    size_t capacity_bytes;
+    uint64_t* offsets;     /* HOST, one per frame */
+    uint64_t* total_bytes; /* HOST, may be NULL */
+    charls_amd_transport transport;
+} charls_amd_gather;
+
+CHARLS_AMD_API charls_jpegls_errc charls_amd_encode_batch_devices(const charls_amd_codec_params* params,
+                                                                  uint32_t shard_count, const charls_amd_device_shard* shards,
+                                                                  size_t frame_pitch_bytes, uint32_t stride,
+                                                                  size_t stream_pitch_bytes, uint64_t* sizes,
+                                                                  charls_jpegls_errc* errcs, const charls_amd_gather* gather);
+
+CHARLS_AMD_API charls_jpegls_errc charls_amd_decode_batch_devices(uint32_t shard_count, const charls_amd_device_shard* shards,
+                                                                  size_t stream_pitch_bytes, const uint64_t* sizes,
+                                                                  size_t frame_pitch_bytes, uint32_t stride,
+                                                                  charls_amd_codec_params* params_out, charls_jpegls_errc* errcs);
+
 /* Extension: restart intervals on the encoder of part 1.  `lines` rows per interval (0 = none, the default) are coded
  * independently -- by different wavefronts at the same time -- and separated by RSTm markers; a DRI segment announces
  * the interval.  The reference's encoder has no equivalent (its output never contains restart markers); its decoder
@@ -346,9 +397,10 @@ CHARLS_AMD_API charls_jpegls_errc charls_amd_jpegls_encoder_set_restart_interval
  * kernel, 2 = force the parallel pipeline (returns invalid_argument when the scan is not eligible). Process-wide. */
 CHARLS_AMD_API charls_jpegls_errc charls_amd_set_encode_engine(int32_t engine);
 
-/* HBM kept by the library for its own work areas (the lossless encoder's per-scan work area of 21 B per sample, the
- * private buffers of restart intervals).  They belong to the calling thread, grow on demand and stay allocated between
- * calls.  The limit is process-wide: 0 (the default) = a quarter of the device's memory, and never more than what is
+/* HBM kept by the library for its own work areas (the lossless encoder's per-scan work area of 10 B per sample plus the
+ * unstuffed stream, the private buffers of restart intervals).  They belong to the calling thread and to the device that
+ * was current when they were made (a thread that moves to another device gets new ones there), grow on demand and stay
+ * allocated between calls.  The limit is process-wide: 0 (the default) = a quarter of the device's memory, and never more than what is
  * free minus 8 GiB.  A batch larger than the limit allows is coded in several passes; when not even one work area can be
  * allocated the encoder falls back to its one-wavefront-per-scan kernel, which needs none.  The host-pointer encoder /
  * decoder of part 1 release work areas above 1 GiB before they return. */
