@@ -172,7 +172,7 @@ def encode_batch_devices(frame_shards, stream_shards, *, bits_per_sample=8, gath
     l = _bind(lib)
     n = len(frame_shards)
     height, width = frame_shards[0].shape[-2], frame_shards[0].shape[-1]
-    frame_pitch = frame_shards[0][0].numel() * frame_shards[0].element_size() if frame_shards[0].shape[0] else height * width
+    frame_pitch = int(np.prod(frame_shards[0].shape[1:])) * frame_shards[0].element_size()
     pitch = stream_shards[0].shape[1]
     shards = (DeviceShard * n)()
     total = 0
@@ -212,7 +212,7 @@ def decode_batch_devices(stream_shards, sizes, out_shards, *, lib=None):
     sizes = np.ascontiguousarray(sizes, dtype=np.uint64)
     errcs = np.zeros(total, dtype=np.int32)
     p = CodecParams()
-    frame_pitch = out_shards[0][0].numel() * out_shards[0].element_size()
+    frame_pitch = int(np.prod(out_shards[0].shape[1:])) * out_shards[0].element_size()
     rc = l.charls_amd_decode_batch_devices(n, shards, stream_shards[0].shape[1], sizes.ctypes.data_as(C.POINTER(C.c_uint64)),
                                            frame_pitch, 0, C.byref(p), errcs.ctypes.data_as(C.POINTER(C.c_int32)))
     if rc != 0:

@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--json", action="store_true", help="print one JSON line with the numbers as well")
     args = ap.parse_args()
     c = CONFIGS[args.config]
+    if args.abi == "batch":
+        import torch  # noqa: F401  (before the library: torch brings its own HIP runtime, and the first one loaded serves both)
     lib = capi.CharLSLibrary(os.path.abspath(args.library)) if args.library else capi.load_product()
     if args.abi == "host":
         result = host_abi(lib, c, args.loop)
