@@ -204,13 +204,22 @@ JLS_DEV void stage_lines(const ScanDesc& d, const TileGeometry& g, S* rows)
       // most 16 KB: eight words per thread)
         const uint32_t words_per_line = bytes / 4, total = lines * words_per_line;
         constexpr int kMost = (kMaxTileSamples * 2 / 4 + kThreads - 1) / kThreads;
+        // word i of the staging area = word (i % words_per_line) of line i / words_per_line; a thread's words are kThreads
+        // apart, so line and word advance by constants (one division per thread, not one per word)
+        const uint32_t step_lines = kThreads / words_per_line, step_words = kThreads % words_per_line;
+        uint32_t line = threadIdx.x / words_per_line, word = threadIdx.x % words_per_line;
         uint32_t held[kMost];
 #pragma unroll
         for (int j = 0; j < kMost; ++j)
         {
-            const uint32_t i = threadIdx.x + (uint32_t)j * kThreads;
-            const uint32_t line = i / words_per_line, word = i - line * words_per_line;
-            held[j] = i < total ? reinterpret_cast<const uint32_t*>(from + (size_t)line * d.pixel_stride)[word] : 0u;
+            held[j] = line < lines ? reinterpret_cast<const uint32_t*>(from + (size_t)line * d.pixel_stride)[word] : 0u;
+            line += step_lines;
+            word += step_words;
+            if (word >= words_per_line)
+            {
+                word -= words_per_line;
+                ++line;
+            }
         }
 #pragma unroll
         for (int j = 0; j < kMost; ++j)
@@ -221,8 +230,8 @@ JLS_DEV void stage_lines(const ScanDesc& d, const TileGeometry& g, S* rows)
         }
         for (uint32_t i = threadIdx.x + kMost * kThreads; i < total; i += kThreads) // (tiles of many short lines of wide samples)
         {
-            const uint32_t line = i / words_per_line, word = i - line * words_per_line;
-            reinterpret_cast<uint32_t*>(to)[i] = reinterpret_cast<const uint32_t*>(from + (size_t)line * d.pixel_stride)[word];
+            const uint32_t l2 = i / words_per_line, w2 = i - l2 * words_per_line;
+            reinterpret_cast<uint32_t*>(to)[i] = reinterpret_cast<const uint32_t*>(from + (size_t)l2 * d.pixel_stride)[w2];
         }
     }
     else
@@ -525,13 +534,15 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     uint32_t* s_global = s_count + kChains + 1;           // first global slot of the tile's piece
     uint32_t* s_tmp = s_global + kChains + 1;             // kWaves words (+ padding to 16 words)
     uint32_t* s_same = s_tmp + 16;                        // [kWaves][kChains + 1] lanes of a chunk per chain, see P2; zero between uses
-    uint32_t* s_stage = s_same + kWaves * (kChains + 1);
+    uint32_t* s_rowbase = s_same + kWaves * (kChains + 1); // [kChains + 1] first row of the chain's piece (P3)
+    uint16_t* s_rowchain = reinterpret_cast<uint16_t*>(s_rowbase + kChains + 1); // [kMaxTileSamples / 64 + kChains + 1] (1008 B)
+    uint32_t* s_stage = s_rowbase + kChains + 1 + 252;
     const int mask = (1 << d.bits_per_sample) - 1;
     const Samples<S, ILV> sample{d, s_rows, g.first_line, mask};
     const uint16_t* key_tile = w.keyinv + (size_t)g.first_line * width;
 
     stage_lines<S, ILV>(d, g, s_rows);
-    for (uint32_t i = threadIdx.x; i < kSegments * (uint32_t)kChains; i += kThreads)
+    for (uint32_t i = threadIdx.x; i < g.segments * (uint32_t)kChains; i += kThreads)
         s_segoff[i] = 0;
     for (uint32_t i = threadIdx.x; i < kWaves * ((uint32_t)kChains + 1); i += kThreads)
         s_same[i] = 0;
@@ -601,6 +612,27 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
                     s_segoff[sgm * kChains + c] = running;
                     running += m;
                 }
+            }
+        }
+        // the pieces cut into rows of 64 records for the way out (P3): row q belongs to chain s_rowchain[q]; the interruption
+        // chain has no records
+        uint32_t rows[2], row_base[2];
+        for (int half = 0; half < 2; ++half)
+        {
+            const uint32_t c = threadIdx.x + (uint32_t)half * kThreads;
+            rows[half] = row_base[half] = c < (uint32_t)kChains && c != (uint32_t)kInterruptChain ? (n[half] + 63) / 64 : 0u;
+        }
+        block_exclusive_scan(row_base[0], row_base[1], s_tmp);
+        for (int half = 0; half < 2; ++half)
+        {
+            const uint32_t c = threadIdx.x + (uint32_t)half * kThreads;
+            if (c < (uint32_t)kChains)
+            {
+                s_rowbase[c] = row_base[half];
+                for (uint32_t j = 0; j < rows[half]; ++j)
+                    s_rowchain[row_base[half] + j] = (uint16_t)c;
+                if (c == (uint32_t)kChains - 1)
+                    s_rowbase[kChains] = row_base[half] + rows[half];
             }
         }
         if (threadIdx.x >= kThreads - g.tile_lines)
@@ -729,30 +761,25 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     }
     __syncthreads();
     // ---- P3: pieces out (the interruption chain has no records)
-    for (uint32_t c0 = wave; c0 < (uint32_t)kChains; c0 += kWaves * 4)
-    { // four pieces at a time: their LDS reads overlap
-        uint32_t n[4], from[4], to[4];
+    const uint32_t total_rows = s_rowbase[kChains];
+    for (uint32_t q0 = (uint32_t)wave * 4; q0 < total_rows; q0 += kWaves * 4)
+    { // four rows at a time: their LDS reads overlap
+        uint32_t to[4], held[4];
+        bool live[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
         {
-            const uint32_t c = c0 + (uint32_t)j * kWaves;
-            const bool live = c < (uint32_t)kChains && c != (uint32_t)kInterruptChain;
-            n[j] = live ? s_count[c] : 0u;
-            from[j] = live ? s_tileoff[c] : 0u;
-            to[j] = live ? s_global[c] : 0u;
+            const uint32_t q = q0 + (uint32_t)j;
+            const uint32_t c = q < total_rows ? s_rowchain[q] : 0u;
+            const uint32_t i = (q - s_rowbase[c]) * 64 + (uint32_t)lane;
+            live[j] = q < total_rows && i < s_count[c];
+            to[j] = s_global[c] + i;
+            held[j] = live[j] ? s_stage[s_tileoff[c] + i] : 0u;
         }
-        uint32_t first[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            first[j] = (uint32_t)lane < n[j] ? s_stage[from[j] + lane] : 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-        {
-            if ((uint32_t)lane < n[j])
-                w.rec[to[j] + lane] = first[j];
-            for (uint32_t i = lane + 64; i < n[j]; i += 64)
-                w.rec[to[j] + i] = s_stage[from[j] + i];
-        }
+            if (live[j])
+                w.rec[to[j]] = held[j];
     }
 }
 
@@ -1545,7 +1572,7 @@ inline size_t analyze_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_
 inline size_t sort_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t sample_bytes, int interleave_mode)
 {
     return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode) + (size_t)kSegments * kChains * 4 +
-           3 * ((size_t)kChains + 1) * 4 + 16 * 4 + (size_t)kWaves * (kChains + 1) * 4 + (size_t)lines_per_tile * width * 4;
+           4 * ((size_t)kChains + 1) * 4 + 16 * 4 + (size_t)kWaves * (kChains + 1) * 4 + 252 * 4 + (size_t)lines_per_tile * width * 4;
 }
 inline size_t pack_lds_bytes(uint32_t width, uint32_t lines_per_tile)
 {
