@@ -1,7 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): the bench line, the rocprofv3 kernel statistics of the same command and the PMC
-# passes that DESIGN.md / bench.py quote.  Everything lands in gpurun_out/final/; tools/summarise_profiles.py turns it
-# into the files committed under profiles/.
+# passes that DESIGN.md / bench.py quote.  Everything lands in gpurun_out/<dir>/; tools/summarise_profiles.py turns it
+# into the files committed under profiles/.  Round 3: the HBM traffic of the encoder is taken at 64 frames (all kernels of
+# the tile pipeline), traffic and instruction counts of the dominant kernel -- decode_scans_group<uchar, 8, 1> -- with the
+# bench's own 4096 frames (decode is one launch: the counters are per launch).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/${1:-final}
@@ -13,7 +15,9 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -
 rm -f $out/stats/*/bench_kernel_trace.csv $out/stats/bench_kernel_trace.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc_$c.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc4096_$c -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc4096_$c.log 2>&1
 done
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_inst -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc_inst.log 2>&1
+CHARLS_AMD_DECODE_GROUP=8 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $out/pmc_inst_g8 -o p -- python bench.py --frames 512 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc_inst_g8.log 2>&1
 find $out -name "*kernel_trace.csv" -size +8M -delete
-du -sh $out; find $out -type f | head -30
+du -sh $out; find $out -type f | head -40

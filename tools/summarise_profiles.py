@@ -23,7 +23,10 @@ def counters(sub):
     """kernel -> counter -> (sum, launches)"""
     acc = defaultdict(lambda: defaultdict(float))
     launches = defaultdict(set)
-    with open(os.path.join(SRC, sub, "p_counter_collection.csv"), newline="") as f:
+    path = os.path.join(SRC, sub, "p_counter_collection.csv")
+    if not os.path.exists(path):
+        return acc, {}
+    with open(path, newline="") as f:
         for row in csv.DictReader(f):
             k = short(row["Kernel_Name"])
             if not k.startswith("jls::"):
@@ -65,13 +68,46 @@ def main():
             b = (2 * fetch[k]["FETCH_SIZE"] + write[k]["WRITE_SIZE"]) * 1024 / PMC_FRAMES
             per_kernel[k] = b
             f.write(f"{k},{lf[k]},{fetch[k]['FETCH_SIZE']:.1f},{write[k]['WRITE_SIZE']:.1f},{b:.0f}\n")
+        encoder = sum(b for k, b in per_kernel.items() if "tile::" in k or "stuff" in k or "place_" in k)
+        f.write(f"# encoder (tile pipeline + stuffing + container kernels), sum: {encoder:.0f} bytes per frame\n")
+    # ---- the dominant kernel with the bench's own number of frames: traffic and instruction counts per launch
     dom = bench["roofline"]["kernel"]
-    match = [k for k in per_kernel if dom.split("+")[0] in k]
-    with open(os.path.join(DST, f"{TAG}_traffic.json"), "w") as f:
-        json.dump({"kernel": dom, "hbm_bytes_per_frame": per_kernel[match[0]] if match else None,
-                   "source": f"profiles/{TAG}_pmc_traffic_frames{PMC_FRAMES}.csv",
-                   "note": f"(2*FETCH_SIZE + WRITE_SIZE) * 1024 / {PMC_FRAMES} frames; FETCH_SIZE doubled per the guide's gfx950 correction"},
-                  f, indent=1)
+    frames = bench["config"]["frames_per_gpu"]
+    fetch_big, lb = counters("pmc4096_FETCH_SIZE")
+    write_big, _ = counters("pmc4096_WRITE_SIZE")
+    inst8, l8 = counters("pmc_inst_g8")
+    dom_pmc = {"kernel": dom, "frames": frames}
+    big = [k for k in fetch_big if dom in k and "<unsigned char, 8, 1>" in k and k in write_big]
+    fetch_g8, lg = counters("pmc_g8_FETCH_SIZE")
+    write_g8, _ = counters("pmc_g8_WRITE_SIZE")
+    small = [k for k in fetch_g8 if dom in k and "<unsigned char, 8, 1>" in k and k in write_g8]
+    if big:
+        k = big[0]
+        per_launch = (2 * fetch_big[k]["FETCH_SIZE"] + write_big[k]["WRITE_SIZE"]) * 1024 / max(1, lb[k])
+        dom_pmc.update({"instantiation": k, "hbm_bytes_per_frame": per_launch / frames, "launches_seen": lb[k],
+                        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py --steps 1 --warmup 0` "
+                                  f"({frames} frames), (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch, profiles/{TAG}_dominant_kernel_pmc.json"})
+    if small:
+        k = small[0]
+        per_frame = (2 * fetch_g8[k]["FETCH_SIZE"] + write_g8[k]["WRITE_SIZE"]) * 1024 / max(1, lg[k]) / PMC_FRAMES
+        dom_pmc["hbm_bytes_per_frame_at_64_frames"] = per_frame
+        if not big:  # the 4096-frame PMC pass did not survive: the same instantiation with 64 frames stands in, and says so
+            dom_pmc.update({"instantiation": k, "hbm_bytes_per_frame": per_frame, "frames": frames, "measured_with_frames": PMC_FRAMES,
+                            "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `CHARLS_AMD_DECODE_GROUP=8 python bench.py --frames "
+                                      f"{PMC_FRAMES} --steps 1 --warmup 0` (the bench's instantiation, eight scans per wavefront, with "
+                                      f"{PMC_FRAMES} frames: the PMC pass with {frames} frames crashed in rocprofv3), per frame"})
+    g8 = [k for k in inst8 if dom in k and "<unsigned char, 8, 1>" in k]
+    if g8:
+        k = g8[0]
+        samples = PMC_FRAMES * 4096 * 4096 * max(1, l8[k])
+        dom_pmc.update({"valu_wave_instructions_per_sample": round(inst8[k]["SQ_INSTS_VALU"] / samples, 3),
+                        "salu_wave_instructions_per_sample": round(inst8[k]["SQ_INSTS_SALU"] / samples, 3),
+                        "lds_wave_instructions_per_sample": round(inst8[k]["SQ_INSTS_LDS"] / samples, 3),
+                        "instruction_source": "rocprofv3 --pmc SQ_INSTS_* of `CHARLS_AMD_DECODE_GROUP=8 python bench.py --frames 64 --steps 1 "
+                                              "--warmup 0` (eight scans per wavefront, as in the 4096-frame launch; per-sample counts do "
+                                              "not depend on the number of wavefronts)"})
+    with open(os.path.join(DST, f"{TAG}_dominant_kernel_pmc.json"), "w") as f:
+        json.dump(dom_pmc, f, indent=1)
         f.write("\n")
 
     # ---- instruction mix of the decoder
@@ -84,9 +120,9 @@ def main():
         for k in sorted(inst):
             c = inst[k]
             f.write(f"{k} launches={li[k]} " + " ".join(f"{n}={v:.4g}" for n, v in sorted(c.items())) + "\n")
-            if c.get("SQ_INSTS_VALU") and ("decode_scans" in k or "bias_chains" in k or "code_events" in k):
-                f.write(f"    per sample: VALU {c['SQ_INSTS_VALU']/samples:.1f}  SALU {c['SQ_INSTS_SALU']/samples:.1f}  "
-                        f"LDS {c['SQ_INSTS_LDS']/samples:.2f}  wave-cycles(x4) {4*c['SQ_WAVE_CYCLES']/samples:.0f}\n")
+            if c.get("SQ_INSTS_VALU") and li.get(k):
+                f.write(f"    per sample: VALU {c['SQ_INSTS_VALU']/samples:.2f}  SALU {c['SQ_INSTS_SALU']/samples:.2f}  "
+                        f"LDS {c['SQ_INSTS_LDS']/samples:.3f}  wave-cycles(x4) {4*c['SQ_WAVE_CYCLES']/samples:.1f}\n")
     print("profiles written for", TAG, "value", bench["value"])
 
 
