@@ -1025,6 +1025,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         const int lds = 160 * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::analyze_tiles<uint8_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::analyze_tiles<uint16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::pack_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1127,7 +1128,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
         hipLaunchKernelGGL(tile::clear_pack_state, dim3(64, n), dim3(256), 0, s, d_works,
                            static_cast<uint32_t>(lay.off_raw + lay.raw_bytes - lay.off_bbase));
-        hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::kPackThreads), tile::pack_lds_bytes(proto.width, lay.lines_per_tile), s,
+        hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::kPackThreads), tile::pack_lds_bytes(proto.width, lay.lines_per_tile, proto.bits_per_sample), s,
                            descs, d_works);
         t.mark();
         if (overlap_stuffing)

@@ -857,84 +857,125 @@ JLS_DEV uint32_t chain_of_job(const uint32_t* job_first, uint32_t job)
 }
 
 // C1: grid (ceil(max_jobs / 64), scans) x 64; max_jobs = samples / job_events + kChains.
+//
+// Memory: a lane walks its own job, 64 bytes (16 records) per round, and the 64 jobs of a wavefront lie tens of KB apart.
+// Fetched by the lanes themselves that is 64 requests of 16 bytes per instruction, each a quarter of a 64-byte segment --
+// the code words went out the same way, and the stage moved twice the bytes it had to (PMC, round 3).  So the wavefront
+// fetches and stores TOGETHER: four neighbouring lanes cover one job's 64 bytes (16 jobs per instruction, whole segments),
+// and a 5 KB table in LDS turns "16 bytes of 16 jobs" into "64 bytes of my job" and back.  The next round's records are
+// requested before the current round is coded.
 template <typename S>
 __global__ void __launch_bounds__(64) walk_jobs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
+    constexpr uint32_t kRow = 20; // words from one lane's 16 words to the next lane's (80 bytes: 16-byte aligned, banks spread)
     __shared__ uint32_t s_first[kChains + 1];
+    __shared__ uint64_t s_in[64], s_out[64];       // where the lane's first round of records / code words is
+    __shared__ uint32_t s_rounds[64], s_quiet[64]; // rounds of the lane; rounds of warm-up before its first stored one
+    __shared__ __attribute__((aligned(16))) uint32_t s_swap[64 * kRow];
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const Traits t = make_traits(d);
     const uint32_t jobs = w.job_first[kChains];
     if (blockIdx.x * 64u >= jobs)
         return;
-    for (int c = threadIdx.x; c <= kChains; c += 64)
+    const int lane = threadIdx.x;
+    for (int c = lane; c <= kChains; c += 64)
         s_first[c] = w.job_first[c];
     __syncthreads();
-    const uint32_t job = blockIdx.x * 64u + threadIdx.x;
-    if (job >= jobs)
-        return;
-    const uint32_t chain = chain_of_job(s_first, job);
-    const uint32_t n = w.chain_total[chain];
-    const uint32_t start = (job - s_first[chain]) * w.job_events; // multiple of 16
+    const uint32_t job = blockIdx.x * 64u + (uint32_t)lane;
+    const bool live = job < jobs;
+    const uint32_t chain = live ? chain_of_job(s_first, job) : 1u;
+    const uint32_t n = live ? w.chain_total[chain] : 0u;
+    const uint32_t start = live ? (job - s_first[chain]) * w.job_events : 0u; // multiple of 16
     const uint32_t end = start + w.job_events < n ? start + w.job_events : n;
     const uint32_t warm = start > w.warm_events ? (start - w.warm_events) & ~15u : 0u;
-    const JLS_GLOBAL_AS u32x4* in = (const JLS_GLOBAL_AS u32x4*)(w.rec + w.chain_base[chain]);
-    JLS_GLOBAL_AS u32x4* out = (JLS_GLOBAL_AS u32x4*)(w.code + w.chain_base[chain]);
-
-    Chain s{initial_a(t), 0, 0, chain_n_before(warm, (uint32_t)t.reset), 0};
-    // ---- warm-up: the state forgets where it started (no output)
-    uint32_t g = warm / 16;
-    u32x4 next[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        next[j] = in[g * 4 + j];
-    for (; g < start / 16; ++g)
+    const uint32_t* in = w.rec + w.chain_base[chain];
+    uint32_t* out = w.code + w.chain_base[chain];
+    const uint32_t rounds = end / 16 - warm / 16, quiet = start / 16 - warm / 16;
+    s_in[lane] = (uint64_t)reinterpret_cast<uintptr_t>(in + (warm & ~15u));
+    s_out[lane] = (uint64_t)reinterpret_cast<uintptr_t>(out + (warm & ~15u));
+    s_rounds[lane] = rounds;
+    s_quiet[lane] = quiet;
+    __syncthreads();
+    uint32_t most = rounds;
+    for (int delta = 32; delta > 0; delta >>= 1)
     {
-        u32x4 cur[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-        {
-            cur[j] = next[j];
-            next[j] = in[(g + 1) * 4 + j]; // behind the last chain: kSlack
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                (void)code_event<S>(s, cur[j][e], t);
+        const uint32_t other = __shfl_xor(most, delta);
+        most = other > most ? other : most;
     }
-    s.bad = 0;
-    JobState st;
-    st.in_a = s.a;
-    st.in_b = s.b;
-    st.in_c = s.c;
-    // ---- the job's own events, 16 at a time
-    for (; g < end / 16; ++g)
+    // the four (job, quarter) pairs this lane moves for the wavefront
+    const uint32_t part = (uint32_t)lane & 3u;
+    uint64_t f_in[4], f_out[4];
+    uint32_t f_rounds[4], f_quiet[4], f_row[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
     {
+        const uint32_t j = (uint32_t)q * 16 + ((uint32_t)lane >> 2);
+        f_in[q] = s_in[j] + part * 16;
+        f_out[q] = s_out[j] + part * 16;
+        f_rounds[q] = s_rounds[j];
+        f_quiet[q] = s_quiet[j];
+        f_row[q] = j * kRow + part * 4;
+    }
+    auto fetch = [&](uint32_t r, u32x4 (&v)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            v[q] = r < f_rounds[q] ? *reinterpret_cast<const JLS_GLOBAL_AS u32x4*>((uintptr_t)(f_in[q] + (uint64_t)r * 64)) : u32x4{0, 0, 0, 0};
+    };
+    Chain s{initial_a(t), 0, 0, chain_n_before(warm, (uint32_t)t.reset), 0};
+    JobState st{};
+    bool started = false; // the warm-up is over: the state at the job's first event has been noted
+    auto note_start = [&] {
+        s.bad = 0;
+        st.in_a = s.a;
+        st.in_b = s.b;
+        st.in_c = s.c;
+        started = true;
+    };
+    u32x4 coming[4];
+    fetch(0, coming);
+    for (uint32_t r = 0; r < most; ++r)
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<u32x4*>(&s_swap[f_row[q]]) = coming[q];
+        JLS_LOCKSTEP();
         u32x4 cur[4], o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
+            cur[j] = *reinterpret_cast<const u32x4*>(&s_swap[(uint32_t)lane * kRow + (uint32_t)j * 4]);
+        JLS_LOCKSTEP();
+        fetch(r + 1, coming);
+        if (r == quiet && !started)
+            note_start();
+        if (r < rounds)
         {
-            cur[j] = next[j];
-            next[j] = in[(g + 1) * 4 + j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[j][e] = code_event<S>(s, cur[j][e], t);
         }
+        if (__any(r >= quiet && r < rounds))
+        { // (uniform) some lane has code words to store
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<u32x4*>(&s_swap[(uint32_t)lane * kRow + (uint32_t)j * 4]) = o[j];
+            JLS_LOCKSTEP();
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                o[j][e] = code_event<S>(s, cur[j][e], t);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            out[g * 4 + j] = o[j];
+            for (int q = 0; q < 4; ++q)
+                if (r >= f_quiet[q] && r < f_rounds[q])
+                    *reinterpret_cast<JLS_GLOBAL_AS u32x4*>((uintptr_t)(f_out[q] + (uint64_t)r * 64)) = *reinterpret_cast<const u32x4*>(&s_swap[f_row[q]]);
+            JLS_LOCKSTEP();
+        }
     }
+    if (!live)
+        return;
+    if (!started)
+        note_start();
     // ---- the last, partial group of a chain (its tail is the chain's padding)
-    if ((end & 15u) != 0)
-    {
-        const JLS_GLOBAL_AS uint32_t* in1 = (const JLS_GLOBAL_AS uint32_t*)in;
-        JLS_GLOBAL_AS uint32_t* out1 = (JLS_GLOBAL_AS uint32_t*)out;
-        for (uint32_t i = end & ~15u; i < end; ++i)
-            out1[i] = code_event<S>(s, in1[i], t);
-    }
+    for (uint32_t i = end & ~15u; i < end; ++i)
+        out[i] = code_event<S>(s, in[i], t);
     st.out_a = s.a;
     st.out_b = s.b;
     st.out_c = s.c;
@@ -1312,6 +1353,14 @@ JLS_HOST_DEV uint32_t pack_inv_offset(uint32_t width, uint32_t lines_per_tile) /
     return (head + 15u) & ~15u;
 }
 
+// Words of the bit buffer of pack_tiles: a sample's code has at most LIMIT = 2 (bpp + max(8, bpp)) bits (a run-length code
+// longer than that stands for as many samples without a code of their own), plus the two shared boundary words.
+JLS_HOST_DEV uint32_t pack_bits_words(uint32_t width, uint32_t lines_per_tile, int32_t bits_per_sample)
+{
+    const uint32_t limit = 2u * (uint32_t)(bits_per_sample + (bits_per_sample > 8 ? bits_per_sample : 8));
+    return lines_per_tile * width * limit / 32 + 2;
+}
+
 JLS_DEV void expand_code(uint32_t word, uint64_t& bits, int& len)
 {
     if (word & kRunTag)
@@ -1500,52 +1549,96 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         }
     }
     __syncthreads();
-    if (sum == 0)
-        return;
-    const uint64_t bitpos = s_start + s_scan[threadIdx.x] - sum;
-    uint64_t word_at = bitpos >> 5;
-    const uint64_t first_word = word_at;
-    uint32_t pending = (uint32_t)(bitpos & 31); // the leading bits of the first word belong to the previous thread
-    uint64_t acc = 0;                           // bits [63 - pending, ...) downwards are ours
-    // n <= 32 bits of `part` behind what is pending; a full 32-bit word leaves at once
-    auto put = [&](uint32_t part, uint32_t n) {
-        acc |= (uint64_t)part << ((64u - pending - n) & 63u);
-        pending += n;
-        if (pending >= 32)
-        {
-            const uint32_t o = __builtin_bswap32((uint32_t)(acc >> 32));
-            if (word_at < w.raw_words)
+    // ---- the tile's bits are put together in LDS (over the slot map, which lives in registers by now) and leave as whole
+    // words, coalesced: only the first and the last word of a tile are shared with its neighbours and go out with an atomic
+    // OR.  (Every thread writing its two or three words straight to memory, boundary words with atomics, cost 48 MB of
+    // write traffic per 4096 x 4096 frame for 7 MB of stream.)
+    const uint64_t tile_start = s_start;
+    const uint32_t tile_bits = s_scan[kPackThreads - 1];
+    const uint32_t head = (uint32_t)(tile_start & 31);
+    const uint32_t tile_words = (head + tile_bits + 31) / 32;
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_inv);
+    const bool in_lds = tile_words <= pack_bits_words(d.width, w.lines_per_tile, d.bits_per_sample); // (always, by the bound on a code's length)
+    if (in_lds)
+    {
+        for (uint32_t i = threadIdx.x; i < tile_words; i += kPackThreads)
+            s_bits[i] = 0;
+    }
+    __syncthreads();
+    if (sum != 0)
+    {
+        const uint64_t bitpos = in_lds ? (uint64_t)head + s_scan[threadIdx.x] - sum : tile_start + s_scan[threadIdx.x] - sum;
+        uint64_t word_at = bitpos >> 5;
+        const uint64_t first_word = word_at;
+        uint32_t pending = (uint32_t)(bitpos & 31); // the leading bits of the first word belong to the previous thread
+        uint64_t acc = 0;                           // bits [63 - pending, ...) downwards are ours
+        // n <= 32 bits of `part` behind what is pending; a full 32-bit word leaves at once
+        auto put = [&](uint32_t part, uint32_t n) {
+            acc |= (uint64_t)part << ((64u - pending - n) & 63u);
+            pending += n;
+            if (pending >= 32)
             {
-                if (word_at == first_word)
-                    atomicOr(&w.raw[word_at], o); // shared with the previous thread's tail
-                else
-                    w.raw[word_at] = o; // entirely ours
+                const uint32_t o = (uint32_t)(acc >> 32);
+                if (in_lds)
+                {
+                    if (word_at == first_word)
+                        atomicOr(&s_bits[word_at], o); // shared with the previous thread's tail
+                    else
+                        s_bits[word_at] = o; // entirely ours
+                }
+                else if (word_at < w.raw_words)
+                {
+                    if (word_at == first_word)
+                        atomicOr(&w.raw[word_at], __builtin_bswap32(o));
+                    else
+                        w.raw[word_at] = __builtin_bswap32(o);
+                }
+                acc <<= 32;
+                pending -= 32;
+                ++word_at;
             }
-            acc <<= 32;
-            pending -= 32;
-            ++word_at;
-        }
-    };
+        };
 #pragma unroll
-    for (int q = 0; q < kGroups; ++q)
+        for (int q = 0; q < kGroups; ++q)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-        {
-            const uint32_t slot = slot_of(q, j);
-            if (slot == kNoLocalSlot)
-                continue;
-            uint64_t v;
-            int len;
-            expand_code(s_code[slot], v, len);
-            if (len > 32)
-            { // (codes of wide samples, long runs: rare)
-                put((uint32_t)(v >> 32), (uint32_t)len - 32u);
-                len = 32;
+            for (int j = 0; j < 8; ++j)
+            {
+                const uint32_t slot = slot_of(q, j);
+                if (slot == kNoLocalSlot)
+                    continue;
+                uint64_t v;
+                int len;
+                expand_code(s_code[slot], v, len);
+                if (len > 32)
+                { // (codes of wide samples, long runs: rare)
+                    put((uint32_t)(v >> 32), (uint32_t)len - 32u);
+                    len = 32;
+                }
+                put((uint32_t)v, (uint32_t)len);
             }
-            put((uint32_t)v, (uint32_t)len);
+        if (pending > 0)
+        { // tail shared with the next thread
+            if (in_lds)
+                atomicOr(&s_bits[word_at], (uint32_t)(acc >> 32));
+            else if (word_at < w.raw_words)
+                atomicOr(&w.raw[word_at], __builtin_bswap32((uint32_t)(acc >> 32)));
         }
-    if (pending > 0 && word_at < w.raw_words)
-        atomicOr(&w.raw[word_at], __builtin_bswap32((uint32_t)(acc >> 32))); // tail shared with the next thread
+    }
+    if (!in_lds)
+        return;
+    __syncthreads();
+    const uint64_t first_global = tile_start >> 5;
+    for (uint32_t i = threadIdx.x; i < tile_words; i += kPackThreads)
+    {
+        const uint64_t at = first_global + i;
+        if (at >= w.raw_words)
+            continue;
+        const uint32_t o = __builtin_bswap32(s_bits[i]);
+        if (i == 0 || i + 1 == tile_words)
+            atomicOr(&w.raw[at], o); // shared with the neighbouring tiles
+        else
+            w.raw[at] = o;
+    }
 }
 
 // Zeroes the look-back states and the raw bit stream of every scan of a pass (contiguous in a work area).
@@ -1574,10 +1667,11 @@ inline size_t sort_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t s
     return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode) + (size_t)kSegments * kChains * 4 +
            4 * ((size_t)kChains + 1) * 4 + 16 * 4 + (size_t)kWaves * (kChains + 1) * 4 + 252 * 4 + (size_t)lines_per_tile * width * 4;
 }
-inline size_t pack_lds_bytes(uint32_t width, uint32_t lines_per_tile)
+inline size_t pack_lds_bytes(uint32_t width, uint32_t lines_per_tile, int32_t bits_per_sample)
 {
     const uint32_t per_thread = ((lines_per_tile * width + kPackThreads - 1) / kPackThreads + 7u) & ~7u;
-    return (size_t)pack_inv_offset(width, lines_per_tile) + (size_t)kPackThreads * per_thread * 2;
+    const size_t slot_map = (size_t)kPackThreads * per_thread * 2, bit_buffer = (size_t)pack_bits_words(width, lines_per_tile, bits_per_sample) * 4;
+    return (size_t)pack_inv_offset(width, lines_per_tile) + (slot_map > bit_buffer ? slot_map : bit_buffer); // (the bits take the map's place)
 }
 // Lines per tile for lines of `width` samples: as many whole lines as fit `tile_samples` (8192 for samples of one byte,
 // 4096 for two: the sort stage keeps the lines, the keys and the sorted records of a tile in LDS), at most kTileLines.

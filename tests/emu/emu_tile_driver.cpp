@@ -103,7 +103,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         emu::launch(tile::walk_run_jobs<S, 0>, dim3((unsigned)((max_run_jobs * count + 63) / 64)), dim3(64), 0, descs, wk, (uint32_t)count);
         emu::launch(tile::settle_runs<S, 0>, dim3((count + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
     }
-    emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::kPackThreads), tile::pack_lds_bytes(p.width, lines_per_tile), descs, wk);
+    emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::kPackThreads), tile::pack_lds_bytes(p.width, lines_per_tile, p.bits_per_sample), descs, wk);
     const pipe::Work* sk = stuff.data();
     if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env == nullptr || std::atoi(env) != 0)
     {
