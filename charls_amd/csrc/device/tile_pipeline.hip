@@ -1379,7 +1379,6 @@ JLS_DEV void expand_code(uint32_t word, uint64_t& bits, int& len)
 __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
     JLS_DYNAMIC_LDS(smem);
-    __shared__ uint64_t s_start;
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const uint32_t tile = blockIdx.x;
@@ -1543,7 +1542,8 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         {
             if (b != 0)
                 store_relaxed(&w.blockbase[b], pipe::kBlockUpTo | (start + own));
-            s_start = start;
+            s_tmp[12] = (uint32_t)start; // (two words of the scan scratch: the kernel has no static LDS, its dynamic
+            s_tmp[13] = (uint32_t)(start >> 32); // region may then be as large as the CU's)
             if (b + 1 == tiles)
                 *w.total_bits = start + own;
         }
@@ -1553,7 +1553,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     // words, coalesced: only the first and the last word of a tile are shared with its neighbours and go out with an atomic
     // OR.  (Every thread writing its two or three words straight to memory, boundary words with atomics, cost 48 MB of
     // write traffic per 4096 x 4096 frame for 7 MB of stream.)
-    const uint64_t tile_start = s_start;
+    const uint64_t tile_start = (uint64_t)s_tmp[12] | ((uint64_t)s_tmp[13] << 32);
     const uint32_t tile_bits = s_scan[kPackThreads - 1];
     const uint32_t head = (uint32_t)(tile_start & 31);
     const uint32_t tile_words = (head + tile_bits + 31) / 32;
