@@ -962,7 +962,7 @@ struct TileLayout
         off_code = take((samples + tile::kSlack) * 4);
         off_jobs = take(max_jobs * sizeof(tile::JobState));
         off_runjobs = take(max_run_jobs * sizeof(tile::RunJob));
-        off_bbase = take(static_cast<size_t>(tiles) * 8);
+        off_bbase = take(align_up(static_cast<size_t>(tiles) * 12, 16)); // look-back states (8 B) and tile flags (4 B)
         off_raw = take(raw_bytes);
         off_bits = take(16);
         off_status = take(8);
@@ -1062,6 +1062,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             w.run_warm_events = lay.run_warm_events;
             w.run_long_warm_events = lay.run_long_warm_events;
             w.blockbase = reinterpret_cast<uint64_t*>(base + lay.off_bbase);
+            w.tile_done = reinterpret_cast<uint32_t*>(base + lay.off_bbase + static_cast<size_t>(lay.tiles) * 8);
             w.raw = reinterpret_cast<uint32_t*>(base + lay.off_raw);
             w.raw_words = lay.raw_bytes / 4;
             w.total_bits = reinterpret_cast<uint64_t*>(base + lay.off_bits) + copy; // (zeroed by plan_chains)
@@ -1126,8 +1127,8 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         t.mark();
         if (overlap_stuffing && pass > 0)
             hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
-        hipLaunchKernelGGL(tile::clear_pack_state, dim3(64, n), dim3(256), 0, s, d_works,
-                           static_cast<uint32_t>(lay.off_raw + lay.raw_bytes - lay.off_bbase));
+        hipLaunchKernelGGL(tile::clear_pack_state, dim3(1, n), dim3(256), 0, s, d_works,
+                           static_cast<uint32_t>(align_up(static_cast<size_t>(lay.tiles) * 12, 16)));
         hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::kPackThreads), tile::pack_lds_bytes(proto.width, lay.lines_per_tile, proto.bits_per_sample), s,
                            descs, d_works);
         t.mark();

@@ -85,7 +85,8 @@ struct Work
     uint32_t* code;        // [samples + kSlack] code words in chain order (run starts: interruption record until C3)
     JobState* jobs;        // [samples / job_events + kChains]
     struct RunJob* run_jobs; // [samples / run_job_events + 1] jobs of the run chain
-    uint64_t* blockbase;   // [tiles] look-back states of pack_tiles; followed by raw (cleared together)
+    uint64_t* blockbase;   // [tiles] look-back states of pack_tiles; followed by tile_done (cleared together)
+    uint32_t* tile_done;   // [tiles] pack_tiles: the tile's words are in memory
     uint32_t* raw;
     uint64_t raw_words;
     uint64_t* total_bits;
@@ -1550,28 +1551,26 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     }
     __syncthreads();
     // ---- the tile's bits are put together in LDS (over the slot map, which lives in registers by now) and leave as whole
-    // words, coalesced: only the first and the last word of a tile are shared with its neighbours and go out with an atomic
-    // OR.  (Every thread writing its two or three words straight to memory, boundary words with atomics, cost 48 MB of
-    // write traffic per 4096 x 4096 frame for 7 MB of stream.)
+    // words, coalesced.  Nothing of the raw stream is cleared beforehand: a tile stores every word it touches, zero padded,
+    // except its first one when that word starts in the tile before -- that one it completes with an atomic OR once the
+    // tile before has stored its words (tile_done, a flag per tile; tiles run in index order, so the wait is for a tile that
+    // was started earlier).  (Round 2 cleared the whole buffer, 17.8 MB per frame for 7.3 MB of stream, and every thread
+    // wrote its two or three words with atomics: 48 MB of write traffic.)
     const uint64_t tile_start = (uint64_t)s_tmp[12] | ((uint64_t)s_tmp[13] << 32);
     const uint32_t tile_bits = s_scan[kPackThreads - 1];
     const uint32_t head = (uint32_t)(tile_start & 31);
-    const uint32_t tile_words = (head + tile_bits + 31) / 32;
+    const uint32_t tile_words = tile_bits == 0 ? 0u : (head + tile_bits + 31) / 32; // (<= pack_bits_words: a code has at most LIMIT bits per sample it stands for)
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_inv);
-    const bool in_lds = tile_words <= pack_bits_words(d.width, w.lines_per_tile, d.bits_per_sample); // (always, by the bound on a code's length)
-    if (in_lds)
-    {
-        for (uint32_t i = threadIdx.x; i < tile_words; i += kPackThreads)
-            s_bits[i] = 0;
-    }
+    for (uint32_t i = threadIdx.x; i < tile_words; i += kPackThreads)
+        s_bits[i] = 0;
     __syncthreads();
     if (sum != 0)
     {
-        const uint64_t bitpos = in_lds ? (uint64_t)head + s_scan[threadIdx.x] - sum : tile_start + s_scan[threadIdx.x] - sum;
-        uint64_t word_at = bitpos >> 5;
-        const uint64_t first_word = word_at;
-        uint32_t pending = (uint32_t)(bitpos & 31); // the leading bits of the first word belong to the previous thread
-        uint64_t acc = 0;                           // bits [63 - pending, ...) downwards are ours
+        const uint32_t bitpos = head + s_scan[threadIdx.x] - sum;
+        uint32_t word_at = bitpos >> 5;
+        const uint32_t first_word = word_at;
+        uint32_t pending = bitpos & 31; // the leading bits of the first word belong to the previous thread
+        uint64_t acc = 0;               // bits [63 - pending, ...) downwards are ours
         // n <= 32 bits of `part` behind what is pending; a full 32-bit word leaves at once
         auto put = [&](uint32_t part, uint32_t n) {
             acc |= (uint64_t)part << ((64u - pending - n) & 63u);
@@ -1579,20 +1578,10 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
             if (pending >= 32)
             {
                 const uint32_t o = (uint32_t)(acc >> 32);
-                if (in_lds)
-                {
-                    if (word_at == first_word)
-                        atomicOr(&s_bits[word_at], o); // shared with the previous thread's tail
-                    else
-                        s_bits[word_at] = o; // entirely ours
-                }
-                else if (word_at < w.raw_words)
-                {
-                    if (word_at == first_word)
-                        atomicOr(&w.raw[word_at], __builtin_bswap32(o));
-                    else
-                        w.raw[word_at] = __builtin_bswap32(o);
-                }
+                if (word_at == first_word)
+                    atomicOr(&s_bits[word_at], o); // shared with the previous thread's tail
+                else
+                    s_bits[word_at] = o; // entirely ours
                 acc <<= 32;
                 pending -= 32;
                 ++word_at;
@@ -1617,31 +1606,42 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
                 put((uint32_t)v, (uint32_t)len);
             }
         if (pending > 0)
-        { // tail shared with the next thread
-            if (in_lds)
-                atomicOr(&s_bits[word_at], (uint32_t)(acc >> 32));
-            else if (word_at < w.raw_words)
-                atomicOr(&w.raw[word_at], __builtin_bswap32((uint32_t)(acc >> 32)));
-        }
+            atomicOr(&s_bits[word_at], (uint32_t)(acc >> 32)); // tail shared with the next thread
     }
-    if (!in_lds)
-        return;
     __syncthreads();
     const uint64_t first_global = tile_start >> 5;
+    const bool shared_first = head != 0; // the first word of this tile's range starts in the tile before
     for (uint32_t i = threadIdx.x; i < tile_words; i += kPackThreads)
     {
         const uint64_t at = first_global + i;
-        if (at >= w.raw_words)
+        if ((i == 0 && shared_first) || at >= w.raw_words)
             continue;
-        const uint32_t o = __builtin_bswap32(s_bits[i]);
-        if (i == 0 || i + 1 == tile_words)
-            atomicOr(&w.raw[at], o); // shared with the neighbouring tiles
-        else
-            w.raw[at] = o;
+        w.raw[at] = __builtin_bswap32(s_bits[i]);
+    }
+    if (tile + 1 == tiles && threadIdx.x < 4)
+    { // the stuffing stage reads a few bytes past the last bit: zeros
+        const uint64_t at = ((tile_start + tile_bits + 31) >> 5) + threadIdx.x;
+        if (at < w.raw_words)
+            w.raw[at] = 0;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        if (shared_first)
+        { // (tile 0 starts at bit 0)
+            while (__hip_atomic_load(&w.tile_done[tile - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            {
+            }
+            if (tile_words != 0 && first_global < w.raw_words)
+                atomicOr(&w.raw[first_global], __builtin_bswap32(s_bits[0]));
+            __threadfence();
+        }
+        __hip_atomic_store(&w.tile_done[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// Zeroes the look-back states and the raw bit stream of every scan of a pass (contiguous in a work area).
+// Zeroes the look-back states and the tile flags of every scan of a pass (contiguous in a work area).
 __global__ void __launch_bounds__(256) clear_pack_state(const Work* __restrict__ works, uint32_t bytes_per_scan)
 {
     uint4* at = reinterpret_cast<uint4*>(works[blockIdx.y].blockbase);

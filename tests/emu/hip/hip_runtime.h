@@ -220,6 +220,17 @@ inline T atomicExch(T* p, T v)
 {
     return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST);
 }
+#define __HIP_MEMORY_SCOPE_AGENT 0
+template <typename T>
+inline T __hip_atomic_load(const T* p, int order, int)
+{
+    return __atomic_load_n(p, order);
+}
+template <typename T, typename V>
+inline void __hip_atomic_store(T* p, V v, int order, int)
+{
+    __atomic_store_n(p, (T)v, order);
+}
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
