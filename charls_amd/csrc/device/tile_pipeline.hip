@@ -1628,6 +1628,12 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     __syncthreads();
     if (threadIdx.x == 0)
     {
+        // The flag says "the word the NEXT tile may share with me is in memory".  A tile that stored its last word itself
+        // raises it at once and only then waits for its predecessor (the waits of different tiles do not form a chain); a
+        // tile whose only word is the shared one passes the predecessor's word on and has to wait first.
+        const bool stored_last = tile_words >= 2 || (tile_words == 1 && !shared_first);
+        if (stored_last)
+            __hip_atomic_store(&w.tile_done[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (shared_first)
         { // (tile 0 starts at bit 0)
             while (__hip_atomic_load(&w.tile_done[tile - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0)
@@ -1635,9 +1641,12 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
             }
             if (tile_words != 0 && first_global < w.raw_words)
                 atomicOr(&w.raw[first_global], __builtin_bswap32(s_bits[0]));
-            __threadfence();
         }
-        __hip_atomic_store(&w.tile_done[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (!stored_last)
+        {
+            __threadfence();
+            __hip_atomic_store(&w.tile_done[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
