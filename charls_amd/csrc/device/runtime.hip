@@ -962,7 +962,7 @@ struct TileLayout
         off_code = take((samples + tile::kSlack) * 4);
         off_jobs = take(max_jobs * sizeof(tile::JobState));
         off_runjobs = take(max_run_jobs * sizeof(tile::RunJob));
-        off_bbase = take(align_up(static_cast<size_t>(tiles) * 12, 16)); // look-back states (8 B) and tile flags (4 B)
+        off_bbase = take(static_cast<size_t>(tiles) * 16); // look-back states and tile tails, 8 B each
         off_raw = take(raw_bytes);
         off_bits = take(16);
         off_status = take(8);
@@ -1062,7 +1062,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             w.run_warm_events = lay.run_warm_events;
             w.run_long_warm_events = lay.run_long_warm_events;
             w.blockbase = reinterpret_cast<uint64_t*>(base + lay.off_bbase);
-            w.tile_done = reinterpret_cast<uint32_t*>(base + lay.off_bbase + static_cast<size_t>(lay.tiles) * 8);
+            w.tile_tail = reinterpret_cast<uint64_t*>(base + lay.off_bbase) + lay.tiles;
             w.raw = reinterpret_cast<uint32_t*>(base + lay.off_raw);
             w.raw_words = lay.raw_bytes / 4;
             w.total_bits = reinterpret_cast<uint64_t*>(base + lay.off_bits) + copy; // (zeroed by plan_chains)
@@ -1128,7 +1128,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         if (overlap_stuffing && pass > 0)
             hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
         hipLaunchKernelGGL(tile::clear_pack_state, dim3(1, n), dim3(256), 0, s, d_works,
-                           static_cast<uint32_t>(align_up(static_cast<size_t>(lay.tiles) * 12, 16)));
+                           static_cast<uint32_t>(static_cast<size_t>(lay.tiles) * 16));
         hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::kPackThreads), tile::pack_lds_bytes(proto.width, lay.lines_per_tile, proto.bits_per_sample), s,
                            descs, d_works);
         t.mark();

@@ -85,8 +85,8 @@ struct Work
     uint32_t* code;        // [samples + kSlack] code words in chain order (run starts: interruption record until C3)
     JobState* jobs;        // [samples / job_events + kChains]
     struct RunJob* run_jobs; // [samples / run_job_events + 1] jobs of the run chain
-    uint64_t* blockbase;   // [tiles] look-back states of pack_tiles; followed by tile_done (cleared together)
-    uint32_t* tile_done;   // [tiles] pack_tiles: the tile's words are in memory
+    uint64_t* blockbase;   // [tiles] look-back states of pack_tiles; followed by tile_tail (cleared together)
+    uint64_t* tile_tail;   // [tiles] pack_tiles: the bits of the tile's last, partial word | valid << 63
     uint32_t* raw;
     uint64_t raw_words;
     uint64_t* total_bits;
@@ -1551,17 +1551,19 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     }
     __syncthreads();
     // ---- the tile's bits are put together in LDS (over the slot map, which lives in registers by now) and leave as whole
-    // words, coalesced.  Nothing of the raw stream is cleared beforehand: a tile stores every word it touches, zero padded,
-    // except its first one when that word starts in the tile before -- that one it completes with an atomic OR once the
-    // tile before has stored its words (tile_done, a flag per tile; tiles run in index order, so the wait is for a tile that
-    // was started earlier).  (Round 2 cleared the whole buffer, 17.8 MB per frame for 7.3 MB of stream, and every thread
-    // wrote its two or three words with atomics: 48 MB of write traffic.)
+    // words, coalesced.  Nothing of the raw stream is cleared beforehand and no word is written twice: the last, partial
+    // word of a tile is not stored by that tile but PUBLISHED (tile_tail: the bits and a valid flag in one 64-bit word, like
+    // the look-back states -- the word carries everything, no fence), and the next tile, whose first bits complete it, ORs
+    // it into its own first word before storing that.  A tile publishes as soon as its bits are in LDS and only then waits
+    // for its predecessor (the waits do not form a chain, except through tiles of less than a word).  (Round 2 cleared the
+    // whole buffer, 17.8 MB per frame for 7.3 MB of stream, and every thread wrote its two or three words with atomics:
+    // 48 MB of write traffic.)
     const uint64_t tile_start = (uint64_t)s_tmp[12] | ((uint64_t)s_tmp[13] << 32);
     const uint32_t tile_bits = s_scan[kPackThreads - 1];
     const uint32_t head = (uint32_t)(tile_start & 31);
-    const uint32_t tile_words = tile_bits == 0 ? 0u : (head + tile_bits + 31) / 32; // (<= pack_bits_words: a code has at most LIMIT bits per sample it stands for)
+    const uint32_t tile_words = (head + tile_bits + 31) / 32; // (<= pack_bits_words: a code has at most LIMIT bits per sample it stands for)
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_inv);
-    for (uint32_t i = threadIdx.x; i < tile_words; i += kPackThreads)
+    for (uint32_t i = threadIdx.x; i < tile_words + 1; i += kPackThreads)
         s_bits[i] = 0;
     __syncthreads();
     if (sum != 0)
@@ -1609,48 +1611,46 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
             atomicOr(&s_bits[word_at], (uint32_t)(acc >> 32)); // tail shared with the next thread
     }
     __syncthreads();
+    const bool last_tile = tile + 1 == tiles;
+    const bool shared_first = head != 0;                                     // my first word starts in the tile before
+    const bool partial_last = ((head + tile_bits) & 31u) != 0 && !last_tile; // my last word is completed by the next tile
+    constexpr uint64_t kTailValid = 1ull << 63;
+    if (threadIdx.x == 0)
+    {
+        // (with no word of its own -- tile_words 0, or one word that neither starts nor ends here -- a tile passes on what its
+        // predecessor left, plus its own bits)
+        const bool own_tail = tile_words >= 2 || !shared_first;
+        if (own_tail)
+            store_relaxed(&w.tile_tail[tile], kTailValid | (partial_last ? s_bits[tile_words - 1] : 0u));
+        if (shared_first)
+        { // (tile 0 starts at bit 0)
+            uint64_t before;
+            do
+                before = load_relaxed(&w.tile_tail[tile - 1]);
+            while ((before & kTailValid) == 0);
+            s_bits[0] |= (uint32_t)before;
+        }
+        if (!own_tail)
+            store_relaxed(&w.tile_tail[tile], kTailValid | (partial_last ? s_bits[0] : 0u));
+    }
+    __syncthreads();
     const uint64_t first_global = tile_start >> 5;
-    const bool shared_first = head != 0; // the first word of this tile's range starts in the tile before
-    for (uint32_t i = threadIdx.x; i < tile_words; i += kPackThreads)
+    const uint32_t stored_words = partial_last ? tile_words - 1 : tile_words;
+    for (uint32_t i = threadIdx.x; i < stored_words; i += kPackThreads)
     {
         const uint64_t at = first_global + i;
-        if ((i == 0 && shared_first) || at >= w.raw_words)
-            continue;
-        w.raw[at] = __builtin_bswap32(s_bits[i]);
+        if (at < w.raw_words)
+            w.raw[at] = __builtin_bswap32(s_bits[i]);
     }
-    if (tile + 1 == tiles && threadIdx.x < 4)
+    if (last_tile && threadIdx.x < 4)
     { // the stuffing stage reads a few bytes past the last bit: zeros
-        const uint64_t at = ((tile_start + tile_bits + 31) >> 5) + threadIdx.x;
+        const uint64_t at = first_global + tile_words + threadIdx.x;
         if (at < w.raw_words)
             w.raw[at] = 0;
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        // The flag says "the word the NEXT tile may share with me is in memory".  A tile that stored its last word itself
-        // raises it at once and only then waits for its predecessor (the waits of different tiles do not form a chain); a
-        // tile whose only word is the shared one passes the predecessor's word on and has to wait first.
-        const bool stored_last = tile_words >= 2 || (tile_words == 1 && !shared_first);
-        if (stored_last)
-            __hip_atomic_store(&w.tile_done[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        if (shared_first)
-        { // (tile 0 starts at bit 0)
-            while (__hip_atomic_load(&w.tile_done[tile - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0)
-            {
-            }
-            if (tile_words != 0 && first_global < w.raw_words)
-                atomicOr(&w.raw[first_global], __builtin_bswap32(s_bits[0]));
-        }
-        if (!stored_last)
-        {
-            __threadfence();
-            __hip_atomic_store(&w.tile_done[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
 }
 
-// Zeroes the look-back states and the tile flags of every scan of a pass (contiguous in a work area).
+// Zeroes the look-back states and the tile tails of every scan of a pass (contiguous in a work area).
 __global__ void __launch_bounds__(256) clear_pack_state(const Work* __restrict__ works, uint32_t bytes_per_scan)
 {
     uint4* at = reinterpret_cast<uint4*>(works[blockIdx.y].blockbase);

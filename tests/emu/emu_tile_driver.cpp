@@ -60,9 +60,9 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         w.run_job_events = run_job_events;
         w.run_warm_events = run_warm_events;
         w.run_long_warm_events = run_long_warm_events;
-        uint8_t* pack_state = (uint8_t*)zalloc((size_t)tiles * 12 + 16);
+        uint8_t* pack_state = (uint8_t*)zalloc((size_t)tiles * 16 + 16);
         w.blockbase = (uint64_t*)pack_state;
-        w.tile_done = (uint32_t*)(pack_state + (size_t)tiles * 8);
+        w.tile_tail = w.blockbase + tiles;
         w.raw = (uint32_t*)galloc(raw_bytes); // (not cleared by the product either)
         w.raw_words = raw_bytes / 4;
         w.total_bits = (uint64_t*)galloc(8);
