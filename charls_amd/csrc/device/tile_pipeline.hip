@@ -64,6 +64,7 @@ constexpr uint16_t kNoLocalSlot = 0xFFFF;
 constexpr uint32_t kChainPad = 16;         // chains start on multiples of 16 records (one 64-byte line)
 constexpr uint32_t kSlack = kChains * kChainPad + 64; // spare records behind rec / code: padding + read-ahead of the walkers
 constexpr uint32_t kPlanGroups = 16;       // plan_chains sums the tiles of a scan in this many groups
+#define JLS_HOST_DEV_EARLY __host__ __device__ inline
 constexpr uint32_t kRunTag = 1u << 31;     // code word of a run-length code: ones : 6 | tail length : 5 | tail : 20
 
 // State of a job at its first event (after the warm-up) and behind its last one (N is a function of the event index);
@@ -245,20 +246,25 @@ JLS_DEV void stage_lines(const ScanDesc& d, const TileGeometry& g, S* rows)
         }
 }
 
+JLS_HOST_DEV_EARLY uint32_t sort_segments(uint32_t lines_per_tile) // segments of a full tile (tile_geometry)
+{
+    return lines_per_tile >= kWaves ? lines_per_tile : lines_per_tile * (kWaves / lines_per_tile);
+}
+
 // LDS carve-up shared by analyze_tiles and sort_tiles (byte offsets; every region 16-byte aligned).
 struct TileLds
 {
     uint32_t rows, keys, masks, table, end;
 };
 template <typename S, int ILV>
-JLS_DEV TileLds tile_lds(uint32_t width, uint32_t lines_per_tile)
+JLS_DEV TileLds tile_lds(uint32_t width, uint32_t lines_per_tile, bool with_keys)
 {
     auto up = [](uint32_t v) { return (v + 15u) & ~15u; };
     TileLds l;
     const uint32_t chunks = (width + 63) / 64;
     l.rows = 0;
     l.keys = up(ILV == 1 ? 0u : (lines_per_tile + 1) * width * (uint32_t)sizeof(S));
-    l.masks = l.keys + up(lines_per_tile * width * 2u);
+    l.masks = l.keys + (with_keys ? up(lines_per_tile * width * 2u) : 0u);
     l.table = l.masks + up(lines_per_tile * chunks * 16u);
     l.end = l.table;
     return l;
@@ -281,7 +287,7 @@ __global__ void __launch_bounds__(kThreads) analyze_tiles(const ScanDesc* __rest
     const uint32_t step = ILV == 1 ? pipe::line_step(d) : 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t width = g.width, chunks = g.chunks;
-    const TileLds lds = tile_lds<S, ILV>(width, w.lines_per_tile);
+    const TileLds lds = tile_lds<S, ILV>(width, w.lines_per_tile, true);
     S* s_rows = reinterpret_cast<S*>(smem + lds.rows);
     uint16_t* s_key = reinterpret_cast<uint16_t*>(smem + lds.keys);
     uint64_t* s_eq = reinterpret_cast<uint64_t*>(smem + lds.masks); // [line][chunk]
@@ -524,13 +530,12 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     const uint32_t step = ILV == 1 ? pipe::line_step(d) : 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t width = g.width, chunks = g.chunks;
-    const TileLds lds = tile_lds<S, ILV>(width, w.lines_per_tile);
+    const TileLds lds = tile_lds<S, ILV>(width, w.lines_per_tile, false);
     S* s_rows = reinterpret_cast<S*>(smem + lds.rows);
-    uint16_t* s_key = reinterpret_cast<uint16_t*>(smem + lds.keys);
     uint64_t* s_noev = reinterpret_cast<uint64_t*>(smem + lds.masks);                                // [line][chunk]
     uint32_t* s_lead = reinterpret_cast<uint32_t*>(s_noev + (size_t)w.lines_per_tile * chunks);       // [line][chunk + 1] (fits: 16 B per (line, chunk) reserved)
     uint32_t* s_segoff = reinterpret_cast<uint32_t*>(smem + lds.table);                               // [kSegments][kChains]
-    uint32_t* s_tileoff = s_segoff + kSegments * kChains; // first local slot of the chain
+    uint32_t* s_tileoff = s_segoff + sort_segments(w.lines_per_tile) * kChains; // first local slot of the chain
     uint32_t* s_count = s_tileoff + kChains + 1;          // events of the chain in this tile
     uint32_t* s_global = s_count + kChains + 1;           // first global slot of the tile's piece
     uint32_t* s_tmp = s_global + kChains + 1;             // kWaves words (+ padding to 16 words)
@@ -571,12 +576,8 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
                 {
                     const uint32_t x = k * 64 + lane;
                     const uint16_t key = held[j];
-                    if (x < width)
-                    {
-                        s_key[r * width + x] = key;
-                        if (key != kNoEvent)
-                            atomicAdd(&s_segoff[sgm * kChains + (key & 0x1FF)], 1u);
-                    }
+                    if (x < width && key != kNoEvent)
+                        atomicAdd(&s_segoff[sgm * kChains + (key & 0x1FF)], 1u);
                     const unsigned long long m = __ballot(x < width && key == kNoEvent);
                     if (lane == 0)
                         s_noev[r * chunks + k] = m;
@@ -660,10 +661,16 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
         const uint32_t y = g.first_line + r;
         const uint32_t k0 = piece * g.chunks_per_piece;
         const uint32_t k1 = k0 + g.chunks_per_piece < chunks ? k0 + g.chunks_per_piece : chunks;
-        const uint16_t* keys = s_key + r * width;
         uint32_t* segoff = s_segoff + sgm * kChains;
         uint32_t* same_of = s_same + (uint32_t)wave * (kChains + 1);
-        uint16_t* inv_row = w.keyinv + (size_t)y * width;
+        uint16_t* inv_row = w.keyinv + (size_t)y * width; // the key of a sample is read here and its slot written in its place
+        // (the keys are not kept in LDS -- 16 KB that decide between one and two workgroups per CU: they are read again,
+        // two chunks ahead of their use)
+        auto key_at = [&](uint32_t k) -> uint16_t {
+            const uint32_t x = k * 64 + lane;
+            return k < k1 && x < width ? inv_row[x] : kNoEvent;
+        };
+        uint16_t key_1 = key_at(k0), key_2 = key_at(k0 + 1);
         const S* cur = s_rows + (r + 1) * width; // (planar scans: the line in LDS, the line above it `width` samples before)
         const int edge_a = y >= step ? sample(y - step, 0) : 0;
         const int edge_c = y >= 2 * step ? (ILV == 1 || r >= 1 ? sample(y - 2 * step, 0) : pipe::load_sample<S, ILV>(d, y - 2, 0, mask)) : 0;
@@ -673,7 +680,9 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
         {
             const uint32_t x = k * 64 + lane;
             const bool inside = x < width;
-            const uint16_t key = inside ? keys[x] : kNoEvent;
+            const uint16_t key = key_1;
+            key_1 = key_2;
+            key_2 = key_at(k + 2);
             const bool has = key != kNoEvent;
             const uint32_t chain = key & 0x1FFu;
             if (has && !upper)
@@ -1660,20 +1669,20 @@ __global__ void __launch_bounds__(256) clear_pack_state(const Work* __restrict__
 }
 
 // LDS bytes of the tile kernels for lines of `width` samples of `sample_bytes` bytes, `lines_per_tile` lines per tile.
-inline size_t tile_common_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t sample_bytes, int interleave_mode)
+inline size_t tile_common_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t sample_bytes, int interleave_mode, bool with_keys)
 {
     auto up = [](size_t v) { return (v + 15) & ~size_t{15}; };
     const size_t chunks = (width + 63) / 64;
-    return up(interleave_mode == 1 ? 0 : (size_t)(lines_per_tile + 1) * width * sample_bytes) + up((size_t)lines_per_tile * width * 2) +
-           up((size_t)lines_per_tile * chunks * 16);
+    return up(interleave_mode == 1 ? 0 : (size_t)(lines_per_tile + 1) * width * sample_bytes) +
+           (with_keys ? up((size_t)lines_per_tile * width * 2) : 0) + up((size_t)lines_per_tile * chunks * 16);
 }
 inline size_t analyze_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t sample_bytes, int interleave_mode)
 {
-    return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode) + ((size_t)kChains + 1) * 4 + pipe::kGradientTable;
+    return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode, true) + ((size_t)kChains + 1) * 4 + pipe::kGradientTable;
 }
 inline size_t sort_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t sample_bytes, int interleave_mode)
 {
-    return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode) + (size_t)kSegments * kChains * 4 +
+    return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode, false) + (size_t)sort_segments(lines_per_tile) * kChains * 4 +
            4 * ((size_t)kChains + 1) * 4 + 16 * 4 + (size_t)kWaves * (kChains + 1) * 4 + 252 * 4 + (size_t)lines_per_tile * width * 4;
 }
 inline size_t pack_lds_bytes(uint32_t width, uint32_t lines_per_tile, int32_t bits_per_sample)
