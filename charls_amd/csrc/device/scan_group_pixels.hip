@@ -131,7 +131,9 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
             records[q] = fresh;
         if (sub < 2)
             run_ctx[sub] = RunCtx{sub, initial_a(t), 1, 0};
-        for (int q = lane; q <= 2 * cap; q += 64)
+        // (the host checks the thresholds of ONE scan of the launch: a scan with T3 beyond the table that leads its wavefront
+        // must not write past the table's region -- it and its neighbours go to the exact decoder, see `usable`)
+        for (int q = lane; q <= 2 * cap && q < (int)L::kLutBytes; q += 64)
             lut[q] = (unsigned char)(quantize(t_first, q - cap) + 4);
         for (uint32_t q = sub; q < 2 * NL * line_bytes / (uint32_t)sizeof(S); q += G)
             line_a[q] = 0;
@@ -153,7 +155,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
     JLS_LOCKSTEP();
 
     enum : int { kLineStart = 0, kInLine, kDrain, kDone };
-    const bool usable = own_table && lds_address(smem) == 0; // (see lds_load)
+    const bool usable = own_table && (!kWide || t_first.t3 <= kMaxTableT3) && lds_address(smem) == 0; // (see lds_load)
     int phase = !live || !usable ? kDone : (d.height == 0 ? kDrain : kLineStart);
     bool retry = live && !usable;
     uint32_t p = 0; // consumed dense bits

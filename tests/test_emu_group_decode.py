@@ -136,6 +136,32 @@ def test_group_decoder_leaves_other_thresholds_to_the_exact_decoder():
             assert (res[f].errc, res[f].flags) == (0, 4), f
 
 
+def test_group_decoder_wide_thresholds_first_in_the_wavefront_do_not_overrun_the_table():
+    """the host checks the thresholds of ONE scan of a launch; a 16-bit scan whose T3 is beyond the shared
+    gradient table (2 x 1023 + 2 bytes) and that happens to lead its wavefront must neither fill the table past its
+    region (the context records of the first scan follow it) nor decode on it: every scan of the wavefront reports
+    kFastRetry or decodes correctly, and nothing is corrupted."""
+    L = emu_bind.lib()
+    w, h = 40, 10
+    keep, outs, descs, imgs = [], [], [], []
+    presets = [(65535, 30, 900, 5000, 64), None, None]
+    for f, preset in enumerate(presets):
+        img = synth.frame_numpy(w, h, seed=f + 13, bits=16, kind="mixed")
+        jls = ob.encode(img, width=w, height=h, bits_per_sample=16, preset=preset)
+        cont = jls_container.parse(jls)
+        pc = jls_container.validated_pc(cont.pc, 16, 0)
+        pix = np.zeros(w * h * 2, dtype=np.uint8)
+        descs.append(emu_bind.make_desc(w, h, 1, 0, 16, 0, 0, pc, 0, pix, w * 2, _stream_copy(jls, cont.scans[0].data_start), keep))
+        outs.append(pix)
+        imgs.append(img)
+    res = _launch(L, descs, 16)  # four scans per wavefront: the wide-threshold scan leads
+    for f in range(len(presets)):
+        assert res[f].errc == 0 and res[f].flags in (0, 4), f
+        if res[f].flags == 0:
+            assert outs[f].tobytes() == imgs[f].tobytes(), f
+    assert res[0].flags == 4
+
+
 @pytest.mark.parametrize("name", ["fuzzy-input-bad-run-mode-golomb-code.jls", "fuzzy_input_golomb_16.jls",
                                   "fuzzy-input-no-valid-bits-at-the-end.jls", "no_start_byte_after_encoded_scan.jls"])
 def test_group_decoder_defers_on_corrupt_streams(name):
