@@ -20,6 +20,9 @@ ap.add_argument("--bits", type=int, default=8)
 ap.add_argument("--groups", default="0,16")
 ap.add_argument("--sizes", default="64,256,1024,4096")
 ap.add_argument("--repeat", type=int, default=1)
+ap.add_argument("--distinct", type=int, default=0,
+                help="synthesise only this many distinct frames and repeat them (few torch kernels: rocprofv3 --pmc crashes in "
+                     "torch's synthesis kernels when thousands of them run under it)")
 args = ap.parse_args()
 
 import glob
@@ -61,7 +64,12 @@ class ClockSampler:
 lib = capi.load_product()
 dev = torch.device("cuda:0")
 t0 = time.perf_counter()
-frames = synth.frames_torch(args.frames, args.width, args.height, seed0=2, bits=args.bits, device=dev)
+if args.distinct and args.distinct < args.frames:
+    base = synth.frames_torch(args.distinct, args.width, args.height, seed0=2, bits=args.bits, device=dev)
+    frames = base.repeat((args.frames + args.distinct - 1) // args.distinct, 1, 1)[:args.frames].contiguous()
+    del base
+else:
+    frames = synth.frames_torch(args.frames, args.width, args.height, seed0=2, bits=args.bits, device=dev)
 torch.cuda.synchronize()
 out = torch.empty_like(frames)
 batch.set_workspace_limit(64 << 30, lib)
