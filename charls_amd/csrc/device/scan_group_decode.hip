@@ -289,7 +289,8 @@ JLS_DEV LaneMask leader_lanes()
 JLS_DEV LaneMask exec_narrow(LaneMask lanes)
 {
     LaneMask before;
-    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1" : "=&s"(before) : "s"(lanes) : "memory");
+    // (s_mov: nothing else changes -- an s_and would also write SCC, which the compiler may be keeping a loop condition in)
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1" : "=&s"(before) : "s"(lanes) : "memory");
     return before;
 }
 JLS_DEV void exec_restore(LaneMask before)
@@ -688,20 +689,23 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 p = p_kept;
             ok_flag = lane_of(ok_m) ? 1 : 0;
             exec_restore(everyone);
-            // the state of a scan, back to all lanes of its group
-            p = from_leader<G>(p, lane);
-            w0 = from_leader<G>(w0, lane);
+            // the state of a scan, back to all lanes of its group.  (`opaque` is a volatile asm, like the two EXEC changes: the
+            // compiler keeps their order, so the shuffles -- which it would otherwise hoist above the restore, where only
+            // the leaders take part in them -- stay behind it.)
+            auto back = [&](uint32_t v) -> uint32_t { return from_leader<G>(opaque(v), lane); };
+            p = back(p);
+            w0 = back(w0);
             if (kWide)
-                w1 = from_leader<G>(w1, lane);
-            q1 = (int)from_leader<G>((uint32_t)q1, lane);
-            t9 = (int)from_leader<G>((uint32_t)t9, lane);
-            a = (int)from_leader<G>((uint32_t)a, lane);
-            i = from_leader<G>(i, lane);
+                w1 = back(w1);
+            q1 = (int)back((uint32_t)q1);
+            t9 = (int)back((uint32_t)t9);
+            a = (int)back((uint32_t)a);
+            i = back(i);
             if (kWide)
-                a_seen = from_leader<G>(a_seen, lane);
-            retry = from_leader<G>((uint32_t)retry, lane) != 0;
-            qsu = (int)from_leader<G>((uint32_t)qsu, lane);
-            ok_flag = (int)from_leader<G>((uint32_t)ok_flag, lane);
+                a_seen = back(a_seen);
+            retry = back((uint32_t)retry) != 0;
+            qsu = (int)back((uint32_t)qsu);
+            ok_flag = (int)back((uint32_t)ok_flag);
             ok_m = lanes_where(ok_flag != 0);
         }
         // what stopped a scan that is still inside its line: Q = 0 is run mode, anything else an unusual code
