@@ -274,45 +274,6 @@ JLS_DEV int take_unary(const uint32_t* ring, uint32_t& p, int most)
     }
 }
 
-// One lane per group of G: lane 0 of every group.
-template <int G>
-JLS_DEV LaneMask leader_lanes()
-{
-    LaneMask m = 0;
-    for (int l = 0; l < 64; l += G)
-        m |= 1ull << l;
-    return m;
-}
-// EXEC narrowed to `lanes` (returns what it was) and restored.  The CPU harness keeps all lanes running: they compute the
-// same values, which is what the code between the two calls relies on anyway.
-#ifndef JLS_EMULATED
-JLS_DEV LaneMask exec_narrow(LaneMask lanes)
-{
-    LaneMask before;
-    // (s_mov: nothing else changes -- an s_and would also write SCC, which the compiler may be keeping a loop condition in)
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1" : "=&s"(before) : "s"(lanes) : "memory");
-    return before;
-}
-JLS_DEV void exec_restore(LaneMask before)
-{
-    asm volatile("s_mov_b64 exec, %0" : : "s"(before) : "memory");
-}
-#else
-JLS_DEV LaneMask exec_narrow(LaneMask)
-{
-    return ~0ull;
-}
-JLS_DEV void exec_restore(LaneMask)
-{
-}
-#endif
-// The value the first lane of the caller's group holds.
-template <int G>
-JLS_DEV uint32_t from_leader(uint32_t v, int lane)
-{
-    return (uint32_t)__shfl((int)v, lane & ~(G - 1));
-}
-
 } // namespace grp
 
 // Dynamic LDS: (64 / G) * grp::region_bytes<S>(width).  `count` scans, 64 / G of them per workgroup of one wavefront.
@@ -511,14 +472,6 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             // a line (finished or waiting for their marker: their contexts and line are dead) run along on their own dead
             // state without advancing.
             const uint32_t p_kept = p;
-            // POWER.  All G lanes of a group hold the same scan state, and the step loop used to run on all of them: 64 lanes
-            // switching for 64 / G scans.  With every SIMD busy that is enough to pull the chip's clock down (PMC, round 3: the
-            // same wavefront-cycles per step at 2 and at 4 wavefronts per CU, 30 % more time: 2.3 -> 1.8 GHz).  The loop and
-            // the bookkeeping behind it therefore run on ONE lane per scan (EXEC is narrowed by hand; everything in between is
-            // per-lane arithmetic, LDS accesses that all lanes of a group made to the same address anyway, and ballots, which
-            // only ever see active lanes); the other lanes get the state back afterwards.
-            const LaneMask leaders = leader_lanes<G>();
-            const LaneMask in_line_leaders = in_line_m & leaders;
             S* lp = in_line ? line + i - 1 : line + width + 2; // slot of the previous step's sample
             const uint32_t lp_step = in_line ? 1u : 0u;
             Record* where = records + 365;      // the previous step's context record (an unused slot at first)
@@ -540,8 +493,6 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 w0 <<= 8;
             }
             uint32_t k_seen = 0, mm_seen = 0, a_seen_now = 0;
-            int ok_flag = 0;
-            const LaneMask everyone = exec_narrow(leaders);
             do
             {
                 // -- bookkeeping of the previous step, part 1: registers (Ra was set when the sample was decoded)
@@ -642,7 +593,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 q1n = (int)opaque((uint32_t)q1n);
                 k_seen |= (uint32_t)k; // of every lane: a lane that cannot decode still looked at a real context
                 // one exit (the compiler unifies loop exits anyway): a one-hot counter that an event clears
-                ticker = tick(ticker, in_line_leaders, ok_m);
+                ticker = tick(ticker, in_line_m, ok_m);
             } while (ticker != 0);
             // the bookkeeping owed to the lanes whose last step decoded a sample
             bool owed_last;
@@ -687,26 +638,6 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             }
             else
                 p = p_kept;
-            ok_flag = lane_of(ok_m) ? 1 : 0;
-            exec_restore(everyone);
-            // the state of a scan, back to all lanes of its group.  (`opaque` is a volatile asm, like the two EXEC changes: the
-            // compiler keeps their order, so the shuffles -- which it would otherwise hoist above the restore, where only
-            // the leaders take part in them -- stay behind it.)
-            auto back = [&](uint32_t v) -> uint32_t { return from_leader<G>(opaque(v), lane); };
-            p = back(p);
-            w0 = back(w0);
-            if (kWide)
-                w1 = back(w1);
-            q1 = (int)back((uint32_t)q1);
-            t9 = (int)back((uint32_t)t9);
-            a = (int)back((uint32_t)a);
-            i = back(i);
-            if (kWide)
-                a_seen = back(a_seen);
-            retry = back((uint32_t)retry) != 0;
-            qsu = (int)back((uint32_t)qsu);
-            ok_flag = (int)back((uint32_t)ok_flag);
-            ok_m = lanes_where(ok_flag != 0);
         }
         // what stopped a scan that is still inside its line: Q = 0 is run mode, anything else an unusual code
         const int qs = qsu - 364;
