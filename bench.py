@@ -202,6 +202,9 @@ def main():
                     help="NOT the headline: code every N lines as a restart interval (this library's encoder extension; "
                          "the reference's encoder cannot emit restart markers, so the streams are no longer the "
                          "reference's bytes, only decodable by it)")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="profiling aid, never for the bench line: synthesise only this many distinct frames and repeat them "
+                         "(rocprofv3 --pmc crashes inside torch's per-frame synthesis kernels when thousands of them run under it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip batch_sweep / single_frame_ms / host_abi")
     ap.add_argument("--selftest-exchange", action="store_true", help="launcher + exchange on fabricated streams (no codec)")
@@ -254,7 +257,12 @@ def main():
 
     frames_n = args.frames
     seed0 = 2 + rank * 100003  # rank 0 frame 0 == golden cfg2_full
-    frames = synth.frames_torch(frames_n, WIDTH, HEIGHT, seed0=seed0, bits=BITS, device=dev)
+    if args.distinct and args.distinct < frames_n:
+        base = synth.frames_torch(args.distinct, WIDTH, HEIGHT, seed0=seed0, bits=BITS, device=dev)
+        frames = base.repeat((frames_n + args.distinct - 1) // args.distinct, 1, 1)[:frames_n].contiguous()
+        del base
+    else:
+        frames = synth.frames_torch(frames_n, WIDTH, HEIGHT, seed0=seed0, bits=BITS, device=dev)
     pitch = (batch.estimated_destination_size(WIDTH, HEIGHT, BITS, 1) + 255) & ~255
     streams = torch.empty((frames_n, pitch), dtype=torch.uint8, device=dev)
     out = torch.empty_like(frames)
@@ -360,7 +368,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic (seeded gradient + noise frames, charls_amd/synth.py)",
+            "data": "synthetic (seeded gradient + noise frames, charls_amd/synth.py)" +
+                    (f"; PROFILING RUN: {args.distinct} distinct frames repeated" if args.distinct else ""),
             "config": {"workload": "BASELINE configs[1]: 4096x4096 8-bit gray lossless, batch of independent frames",
                        "frames_per_gpu": frames_n, "jls_bytes_per_frame": int(jls_bytes),
                        "sharding": (f"frames over {world} rank(s), bitstreams sent to rank 0 over "

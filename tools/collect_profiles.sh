@@ -23,6 +23,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex "jls" --output-format csv -d $out/pmc_inst -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc_inst.log 2>&1
 CHARLS_AMD_DECODE_GROUP=8 timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex "decode_scans" --output-format csv -d $out/pmc_inst_g8 -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc_inst_g8.log 2>&1
+# the dominant kernel with the bench's own 4096 frames: 64 distinct frames repeated, so that torch's synthesis is a few kernels
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "decode_scans" --output-format csv -d $out/pmc4096_$c -o p -- python bench.py --distinct 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc4096_$c.log 2>&1
+done
 # one frame: where single-frame latency goes
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/one -o one -- python bench.py --frames 1 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/one.json 2> $out/one.log
 find $out -name "*kernel_trace.csv" -size +8M -delete
