@@ -85,8 +85,10 @@ def main():
         k = big[0]
         per_launch = (2 * fetch_big[k]["FETCH_SIZE"] + write_big[k]["WRITE_SIZE"]) * 1024 / max(1, lb[k])
         dom_pmc.update({"instantiation": k, "hbm_bytes_per_frame": per_launch / frames, "launches_seen": lb[k],
-                        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py --steps 1 --warmup 0` "
-                                  f"({frames} frames), (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch, profiles/{TAG}_dominant_kernel_pmc.json"})
+                        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py --distinct 64 --steps 1 --warmup 0` "
+                                  f"({frames} frames in flight, 64 distinct ones repeated: rocprofv3 --pmc does not survive torch "
+                                  f"synthesising {frames} frames one by one), (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch, "
+                                  f"profiles/{TAG}_dominant_kernel_pmc.json"})
     if small:
         k = small[0]
         per_frame = (2 * fetch_g8[k]["FETCH_SIZE"] + write_g8[k]["WRITE_SIZE"]) * 1024 / max(1, lg[k]) / PMC_FRAMES
