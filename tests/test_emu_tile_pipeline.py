@@ -59,13 +59,13 @@ def test_tile_pipeline_matches_reference_scan_bytes(c):
         assert data == jls[scan.data_start:scan.data_end]
 
 
-@pytest.mark.parametrize("job,warm", [(16, 0), (16, 16), (64, 32), (64, 1024), (1024, 1024)])
+@pytest.mark.parametrize("job,warm", [(16, 0), (64, 32), (1024, 1024)])
 @pytest.mark.parametrize("kind,bits,w,h,seed", [("mixed", 8, 130, 11, 1), ("zero", 8, 130, 9, 2), ("hard", 12, 65, 9, 4),
                                                 ("mixed", 16, 129, 7, 5), ("mixed", 8, 1, 50, 7), ("noise", 16, 40, 12, 9),
                                                 ("gradient", 8, 300, 40, 3), ("noise", 8, 96, 20, 11)])
 def test_tile_pipeline_batch_of_seeded_frames(kind, bits, w, h, seed, job, warm):
     """Several frames in one launch, every job / warm-up setting: each frame equals the oracle."""
-    frames = [synth.frame_numpy(w, h, seed=seed * 10 + f, bits=bits, kind=kind) for f in range(3)]
+    frames = [synth.frame_numpy(w, h, seed=seed * 10 + f, bits=bits, kind=kind) for f in range(2)]
     pc = jls_container.validated_pc((0,) * 5, bits, 0)
     got = _encode_planes(frames, w, h, bits, pc, w * h * 4 + 1024, job=job, warm=warm)
     for img, (errc, flags, data) in zip(frames, got):

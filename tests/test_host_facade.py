@@ -146,3 +146,20 @@ def test_restart_interval_setter_is_additive_and_checked(lib):
     finally:
         L.charls_jpegls_encoder_destroy.argtypes = [C.c_void_p]
         L.charls_jpegls_encoder_destroy(enc)
+
+
+def test_every_symbol_the_header_declares_is_exported():
+    """include/charls_amd.h is the boundary: every function it declares (the 48 of the reference and the additive
+    charls_amd_* entry points) must be an exported symbol of the library -- loads and look-ups only, no compute."""
+    import ctypes
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "include", "charls_amd.h")) as f:
+        text = f.read()
+    declared = set(re.findall(r"CHARLS_AMD_API\s+[\w\s\*]+?\b(charls_\w+)\s*\(", text))
+    assert len(declared) >= 48 + 11, sorted(declared)
+    assert {"charls_amd_encode_batch_device", "charls_amd_decode_batch_device", "charls_amd_encode_batch_devices",
+            "charls_amd_decode_batch_devices"} <= declared
+    lib = ctypes.CDLL(os.path.join(root, "charls_amd", "lib", "libcharls_amd.so"))
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, missing
