@@ -186,11 +186,12 @@ size_t group_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
 }
 
 // Lanes per scan of the speed path (scan_group_decode.hip) for a launch of `count` scans; 0 = the one-scan-per-wavefront
-// kernel (scan_fast_decode.hip).  What a scan costs per sample does not depend on how many scans share its wavefront, but
-// wavefronts that share a CU slow each other down (four of them by a third: they queue at the LDS), so the scans are packed
-// as densely as it takes to give every CU at most one wavefront -- and no denser, because the lanes of a scan share its
-// bulk work (un-stuffing, row stores) and every event of one scan (run mode, end of line) stalls the others of its
-// wavefront: measured on 4096 frames of 4096 x 4096, 8 lanes per scan decode in 4.84 s, 16 in 5.48 s, 4 in 5.86 s.
+// kernel (scan_fast_decode.hip).  A wavefront stops for every event of every one of its scans (run mode, end of line,
+// refill), so the fewer scans share a wavefront the less a sample costs: 3.45 s for the 16.8 M samples of a 4096 x 4096 frame
+// with 2 scans per wavefront, 3.65 s with 4, 4.14 s with 8 (profiles/r03_decode_sweep_lanes_per_scan.txt).  Against that, the
+// chip clocks down once more than two of a CU's four SIMDs run this kernel (2.3 -> 1.8 GHz with all four busy, and not on
+// every run: 4096 frames with 4 scans per wavefront took 3.94 s in one sweep and 5.01 s in the next), so the scans are packed
+// as densely as it takes to stay at two wavefronts per CU, and no denser.
 // CHARLS_AMD_DECODE_GROUP overrides (0, 4, 8, 16, 32).
 int decode_group_lanes(const ScanDesc& d, uint32_t count)
 {
@@ -216,7 +217,7 @@ int decode_group_lanes(const ScanDesc& d, uint32_t count)
         if (group_lds_bytes(d, per_wave) > kGroupDecodeLds)
             break;
         best = lanes;
-        if ((count + per_wave - 1) / per_wave <= cus)
+        if ((count + per_wave - 1) / per_wave <= 2 * cus)
             break;
     }
     return best;

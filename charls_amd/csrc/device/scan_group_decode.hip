@@ -148,38 +148,19 @@ JLS_DEV void put_bits(uint32_t* ring, uint32_t p, uint32_t v, int n)
 // Un-stuffs G x 16 coded bytes of every scan whose lanes pass `want` (JPEG-LS stuffing is byte aligned in the coded
 // stream: the byte after a 0xFF carries 7 payload bits; a 0xFF followed by a byte >= 0x80 is a marker).  Called by all
 // 64 lanes; the shuffles only ever read lanes of the caller's own group.
+//
+// Two renderings.  Inside a scan -- every wanted lane's 16 bytes and the byte behind them are coded bytes that have a
+// predecessor, and no 0xFF is followed by a byte >= 0x80 -- a lane's bytes are ONE 128-bit number in the ring's bit order
+// from which the stuffed bits are deleted (one byte in 256 is followed by one; the wavefront loops as often as its busiest
+// lane has them, once or twice) and which then goes to the ring as five words.  The first bytes of a misaligned stream,
+// the bytes around its end and anything that looks like a marker take the byte-by-byte rendering (refill_bytewise).
 template <int G>
-JLS_DEV void refill(Producer& s, uint32_t* ring, bool want, int lane, int sub)
+JLS_DEV void refill_bytewise(Producer& s, uint32_t* ring, bool want, int lane, int sub, uint64_t u0, const uint4& raw,
+                             uint32_t next_first, uint32_t before)
 {
     constexpr uint32_t kChunk = G * 16;
-    // 1) clear the words this refill may touch (everything after the word holding `produced`)
-    if (want)
-    {
-        const uint32_t first = (s.produced + 31) >> 5;
-        for (uint32_t j = sub; j < kChunk / 4 + 2; j += G)
-        {
-            const uint32_t q = (first + j) & (kRingWords - 1);
-            ring[q] = 0;
-            if (q < 2)
-                ring[kRingWords + q] = 0;
-        }
-    }
-    JLS_LOCKSTEP();
-    // 2) every lane takes 16 coded bytes
-    const uint64_t u0 = s.u_next + (uint64_t)sub * 16;
-    uint4 raw = make_uint4(0, 0, 0, 0);
-    uint32_t next_first = 0; // coded byte following this lane's 16 (for the marker test of its last byte)
-    if (want && u0 < s.u_end)
-    {
-        raw = *reinterpret_cast<const uint4*>(s.gbase + u0);
-        if (u0 + 16 < s.u_end)
-            next_first = s.gbase[u0 + 16];
-    }
     const uint32_t words[4] = {raw.x, raw.y, raw.z, raw.w};
     const uint32_t last = words[3] >> 24;
-    uint32_t before = __shfl_up(last, 1);
-    if (sub == 0)
-        before = s.prev_byte;
     int nbits[16];
     uint32_t bytes[16];
     int marker_at = 16;
@@ -247,6 +228,122 @@ JLS_DEV void refill(Producer& s, uint32_t* ring, bool want, int lane, int sub)
             s.u_marker = s.u_next + (uint64_t)first_marker * 16 + (uint64_t)marker_j;
             s.ended = true;
         }
+        s.u_next += kChunk;
+        if (s.u_next >= s.u_end)
+            s.ended = true;
+    }
+}
+
+// Bits 7, 15, 23, 31: the bytes of w that are 0xFF (exact: no carries between the bytes).
+JLS_DEV uint32_t ff_bytes(uint32_t w)
+{
+    const uint32_t v = ~w;
+    return ~((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) | 0x7F7F7F7Fu);
+}
+
+template <int G>
+JLS_DEV void refill(Producer& s, uint32_t* ring, bool want, int lane, int sub)
+{
+    constexpr uint32_t kChunk = G * 16;
+    // 1) clear the words this refill may touch (everything after the word holding `produced`)
+    if (want)
+    {
+        const uint32_t first = (s.produced + 31) >> 5;
+        for (uint32_t j = sub; j < kChunk / 4 + 2; j += G)
+        {
+            const uint32_t q = (first + j) & (kRingWords - 1);
+            ring[q] = 0;
+            if (q < 2)
+                ring[kRingWords + q] = 0;
+        }
+    }
+    JLS_LOCKSTEP();
+    // 2) every lane takes 16 coded bytes
+    const uint64_t u0 = s.u_next + (uint64_t)sub * 16;
+    uint4 raw = make_uint4(0, 0, 0, 0);
+    uint32_t next_first = 0; // coded byte following this lane's 16 (for the marker test of its last byte)
+    if (want && u0 < s.u_end)
+    {
+        raw = *reinterpret_cast<const uint4*>(s.gbase + u0);
+        if (u0 + 16 < s.u_end)
+            next_first = s.gbase[u0 + 16];
+    }
+    const uint32_t last = raw.w >> 24;
+    uint32_t before = __shfl_up(last, 1);
+    if (sub == 0)
+        before = s.prev_byte; // (0 ahead of the first coded byte)
+    // 0xFF bytes, and bytes with their first bit set, as bits 7, 15, 23, 31 of their words
+    const uint32_t z0 = ff_bytes(raw.x), z1 = ff_bytes(raw.y), z2 = ff_bytes(raw.z), z3 = ff_bytes(raw.w);
+    const uint32_t marker_like = (((z0 << 8) & raw.x) | (((z1 << 8) | (z0 >> 24)) & raw.y) | (((z2 << 8) | (z1 >> 24)) & raw.z) |
+                                  (((z3 << 8) | (z2 >> 24)) & raw.w) | ((z3 >> 24) & next_first)) & 0x80808080u;
+    const bool inside = u0 >= s.u_begin && u0 + 17 <= s.u_end;
+    if (!__all(!want || (inside && marker_like == 0)))
+    {
+        JLS_PATH(11); // refills byte by byte
+        refill_bytewise<G>(s, ring, want, lane, sub, u0, raw, next_first, before);
+        return;
+    }
+    // 3) the lane's bytes in the ring's bit order (the first bit of the stream is bit 0)
+    uint32_t d0 = __builtin_bswap32(bit_reverse(raw.x)), d1 = __builtin_bswap32(bit_reverse(raw.y));
+    uint32_t d2 = __builtin_bswap32(bit_reverse(raw.z)), d3 = __builtin_bswap32(bit_reverse(raw.w));
+    // the stuffed bits: the first bit (bit 8 t of the number) of every byte t that follows a 0xFF
+    uint32_t f0 = (((z0 << 8) | (before == 0xFFu ? 0x80u : 0u))) >> 7, f1 = ((z1 << 8) | (z0 >> 24)) >> 7;
+    uint32_t f2 = ((z2 << 8) | (z1 >> 24)) >> 7, f3 = ((z3 << 8) | (z2 >> 24)) >> 7;
+    const int total = want ? 128 - (__popc(f0) + __popc(f1) + __popc(f2) + __popc(f3)) : 0;
+    if (!want)
+        f0 = f1 = f2 = f3 = 0;
+    while (__any((f0 | f1 | f2 | f3) != 0))
+    { // delete the last of them: what lies above it moves down one bit
+        JLS_PATH(12); // trips of the refill's delete loop
+        if ((f0 | f1 | f2 | f3) != 0)
+        {
+            const int at = f3 ? 3 : (f2 ? 2 : (f1 ? 1 : 0));
+            const uint32_t fw = f3 ? f3 : (f2 ? f2 : (f1 ? f1 : f0));
+            const uint32_t bit = 31u - leading_zeros(fw);
+            const uint32_t below = (1u << bit) - 1u;
+            const uint32_t e0 = (d0 >> 1) | (d1 << 31), e1 = (d1 >> 1) | (d2 << 31), e2 = (d2 >> 1) | (d3 << 31), e3 = d3 >> 1;
+            d0 = at == 0 ? (d0 & below) | (e0 & ~below) : d0;
+            d1 = at == 1 ? (d1 & below) | (e1 & ~below) : (at < 1 ? e1 : d1);
+            d2 = at == 2 ? (d2 & below) | (e2 & ~below) : (at < 2 ? e2 : d2);
+            d3 = at == 3 ? (d3 & below) | (e3 & ~below) : e3;
+            f0 = at == 0 ? f0 & below : f0;
+            f1 = at == 1 ? f1 & below : f1;
+            f2 = at == 2 ? f2 & below : f2;
+            f3 = at == 3 ? f3 & below : f3;
+        }
+    }
+    // 4) exclusive prefix sum of the group's bit counts, then the number goes to the ring as five words
+    int inc = total;
+    for (int delta = 1; delta < G; delta <<= 1)
+    {
+        const int up = __shfl_up(inc, delta);
+        if (sub >= delta)
+            inc += up;
+    }
+    const int group_base = lane - sub;
+    if (want)
+    {
+        const uint32_t p = s.produced + (uint32_t)(inc - total);
+        const uint32_t o = p & 31u;
+        const uint32_t q = p >> 5;
+        const uint32_t c[5] = {d0 << o, (uint32_t)((((uint64_t)d1 << 32) | d0) << o >> 32), (uint32_t)((((uint64_t)d2 << 32) | d1) << o >> 32),
+                               (uint32_t)((((uint64_t)d3 << 32) | d2) << o >> 32), (uint32_t)(((uint64_t)d3 << o) >> 32)};
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+        {
+            const uint32_t qj = (q + (uint32_t)j) & (kRingWords - 1);
+            atomicOr(&ring[qj], c[j]);
+            if (qj < 2)
+                atomicOr(&ring[kRingWords + qj], c[j]);
+        }
+    }
+    const int chunk_bits = __shfl(inc, group_base + G - 1);
+    const uint32_t chunk_last = __shfl(last, group_base + G - 1);
+    JLS_LOCKSTEP();
+    if (want)
+    {
+        s.produced += (uint32_t)chunk_bits;
+        s.prev_byte = chunk_last;
         s.u_next += kChunk;
         if (s.u_next >= s.u_end)
             s.ended = true;
@@ -407,6 +504,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
 
     for (;;)
     {
+        JLS_PATH(0); // rounds
         // ---- producer: keep kMarginBits ahead of the consumer; scans that finished their samples look for the marker
         {
             const uint32_t ahead = src.produced - p;
@@ -415,6 +513,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             if (__any(need))
             {
                 const bool want = busy && ahead <= kRingBits - G * 128u - 128u;
+                JLS_PATH(1); // refills
                 refill<G>(src, ring, want, lane, sub);
                 continue;
             }
@@ -424,6 +523,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             const bool starting = phase == kLineStart;
             if (__any(starting))
             {
+                JLS_PATH(2); // line starts
                 if (NL > 1 && starting)
                 {
                     line = line0 + (uint32_t)comp * line_stride;
@@ -452,13 +552,23 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
         const LaneMask in_line_m = lanes_where(in_line);
         LaneMask ok_m = ~0ull; // lanes whose last step decoded a sample
         int qsu = 364;         // Q + 364 of the last step
+        // what the last step of a lane that could not decode its sample had in its registers (the run handler starts from it)
+        uint32_t win_stopped = 0, t_next_stopped = 0;
+        int q1n_stopped = 0;
         if (in_line_m != 0)
         {
             // no scan may step past the end of its line: the wavefront takes as many steps as the shortest rest allows
             const uint32_t rest_of_line = width + 1 - i;
             uint32_t steps = kStepsPerCheck;
-            while (lanes_where(in_line && rest_of_line < steps) != 0)
-                --steps;
+            for (;;)
+            { // (one trip per scan that is close to the end of its line, at most)
+                const LaneMask closer = lanes_where(in_line && rest_of_line < steps);
+                if (closer == 0)
+                    break;
+                JLS_PATH(4); // trips of the step-count loop
+                steps = value_of_lowest_lane(closer, rest_of_line);
+            }
+            JLS_PATH(3); // step loops
             uint64_t ticker = 1ull << (steps - 1); // one-hot step counter, 1 <= steps <= kStepsPerCheck
             // lanes outside their line never pass the `u < limit` test below
             const uint32_t limit_v = opaque(in_line ? limit_m : 0u);
@@ -493,8 +603,10 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 w0 <<= 8;
             }
             uint32_t k_seen = 0, mm_seen = 0, a_seen_now = 0;
+            uint32_t win_now;
             do
             {
+                JLS_PATH(5); // steps
                 // -- bookkeeping of the previous step, part 1: registers (Ra was set when the sample was decoded)
                 p += t_adv;
                 if (kWide)
@@ -527,6 +639,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 }
                 JLS_SCHEDULE_FENCE(); // the arithmetic above covers the latency of the four reads
                 const uint32_t win = (uint32_t)(ring_words >> (p & 31)); // the next 32 bits of the stream
+                win_now = win;
                 // -- the chain: Ra -> Q3 -> context -> k -> code -> Errval -> sample
                 qsu = mad24(t9, 9, q3); // Q + 364 (the three gradients come with + 4 each)
                 t9 = mad24(q1n, 9, q1); // T of the next sample (a lane that cannot decode this one rebuilds its T and Q1)
@@ -595,6 +708,9 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 // one exit (the compiler unifies loop exits anyway): a one-hot counter that an event clears
                 ticker = tick(ticker, in_line_m, ok_m);
             } while (ticker != 0);
+            win_stopped = win_now;
+            t_next_stopped = t_next;
+            q1n_stopped = q1n;
             // the bookkeeping owed to the lanes whose last step decoded a sample
             bool owed_last;
             int ra_stopped;
@@ -646,17 +762,99 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
         const bool slow = stopped && qs != 0 && !retry;
 
         // ---- run mode: reference src/scan_decoder_impl.hpp:264-337, src/scan_decoder_core.hpp:72-100
+        // Three run events in four are a run of length 0 -- the single bit 0 (and J zero bits) -- followed by its interruption
+        // sample, and everything such an event needs is in the registers its lane left the step loop with: the bit window
+        // (the lane consumed nothing in its last step), Rb = the sample above the interruption sample, and the window of the
+        // previous line, which slides on by one sample exactly as a regular step would slide it.  What is left to fetch is
+        // the run context (both are read, ahead of knowing which) and one gradient for the next sample.  The general handler
+        // below takes every other case, and all of them when the codes of one lane do not fit its window.
+        bool empty_runs = false;
         if (__any(in_run))
         {
+            const RunCtx ctx0 = run_ctx[0], ctx1 = run_ctx[1];
+            const int j = run_j(run_index);
+            const uint32_t w2 = j >= 31 ? 0u : win_stopped >> (1 + j); // the bits behind the run-length code
+            const uint32_t avail = 31u - (uint32_t)j;
+            const int b_at = rb_of(); // prev[i]
+            const int which = a == b_at ? 1 : 0;
+            RunCtx ctx = which ? ctx1 : ctx0;
+            const uint32_t goal = (uint32_t)ctx.a + (uint32_t)(ctx.n >> 1) * (uint32_t)ctx.ritype;
+            int k = 0;
+            if (goal > (uint32_t)ctx.n)
+            {
+                k = (int)leading_zeros((uint32_t)ctx.n) - (int)leading_zeros(goal);
+                k += (((uint64_t)(uint32_t)ctx.n << k) < goal) ? 1 : 0;
+            }
+            const uint32_t zeros = lowest_one(w2);
+            const int escape_from = t.limit - j - 1 - t.qbpp - 1;
+            const int tail_bits = (int)zeros < escape_from ? k : t.qbpp;
+            const uint32_t code_bits = zeros + 1u + (uint32_t)tail_bits;
+            const bool fits = (win_stopped & 1u) == 0 && field(win_stopped >> 1, j) == 0 && k <= 24 && zeros < 32u && code_bits <= avail &&
+                              i <= width;
+            empty_runs = __all(!in_run || fits);
+            if (empty_runs)
+            {
+                JLS_PATH(13); // run handlers with nothing but runs of length 0
+                const uint32_t tail = field(w2 >> ((zeros + 1u) & 31u), tail_bits);
+                const int em = (int)zeros < escape_from ? ((int)zeros << k) + (int)tail : (int)tail + 1;
+                const int e = run_error_value(ctx, em + ctx.ritype, k);
+                run_update(ctx, e, em, t.reset);
+                const int x = which ? ((a + e) & t.maxval) : ((b_at + e * ((b_at - a) < 0 ? -1 : 1)) & t.maxval);
+                // Q2 of the next sample: its Rb is this one's Rd, its Rc this one's Rb
+                const int q2n = quantised(rd_of() - b_at);
+                JLS_LOCKSTEP();
+                if (in_run)
+                {
+                    run_ctx[which] = ctx;
+                    line[i] = (S)x;
+                    a = x;
+                    if (run_index > 0)
+                        --run_index;
+                    ++i;
+                    p += 1u + (uint32_t)j + code_bits;
+                    if (kWide)
+                    {
+                        w0 = (w0 >> 16) | (w1 << 16);
+                        w1 = (w1 >> 16) | (t_next_stopped << 16);
+                    }
+                    else
+                        w0 = (w0 >> 8) | (t_next_stopped << 24);
+                    q1 = q1n_stopped;
+                    t9 = 9 * q1 + q2n;
+                }
+                JLS_LOCKSTEP();
+            }
+        }
+        if (!empty_runs && __any(in_run))
+        {
+            JLS_PATH(6); // run handler
             const uint32_t remaining = width - (i - 1);
             uint32_t run = 0;
-            bool counting = in_run;
+            // A run event stops all scans of the wavefront, so what it costs is paid 64 / G times per run: the run-length code
+            // (a few ones, a zero, J bits) comes out of ONE 32-bit window of the ring, bit by bit in a register.
+            uint32_t window = peek32(ring, p);
+            uint32_t used = 0;
+            // (most run-length codes are the single zero bit of a run shorter than its first block: no trip at all then)
+            bool counting = in_run && (window & 1u) != 0;
+            if (in_run && !counting)
+            {
+                window >>= 1;
+                used = 1;
+            }
             while (__any(counting))
             {
-                const uint32_t bit = peek32(ring, p) & 1u;
+                JLS_PATH(7); // bits of run-length codes
                 if (counting)
                 {
-                    ++p;
+                    if (used == 32)
+                    { // (a code longer than the window)
+                        p += 32;
+                        used = 0;
+                        window = peek32(ring, p);
+                    }
+                    const uint32_t bit = window & 1u;
+                    window >>= 1;
+                    ++used;
                     if (bit)
                     {
                         const uint32_t block = 1u << run_j(run_index);
@@ -674,7 +872,18 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             bool interrupted = in_run && run != remaining;
             if (interrupted)
             {
-                run += take_bits(ring, p, run_j(run_index));
+                const int j = run_j(run_index);
+                if (used + (uint32_t)j <= 32)
+                {
+                    run += field(window, j);
+                    used += (uint32_t)j;
+                }
+                else
+                {
+                    p += used;
+                    used = 0;
+                    run += take_bits(ring, p, j);
+                }
                 if (run > remaining)
                 {
                     retry = true;
@@ -682,11 +891,14 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                     run = 0;
                 }
             }
+            if (in_run)
+                p += used;
             JLS_LOCKSTEP();
             {
                 uint32_t r = (uint32_t)sub;
                 while (__any(in_run && r < run))
                 {
+                    JLS_PATH(8); // trips of the run fill
                     if (in_run && r < run)
                         line[i + r] = (S)a;
                     r += G;
@@ -700,9 +912,48 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             int x = 0;
             if (interrupted)
             {
-                const int k = run_k(ctx);
+                // k = min{k : N << k >= A + (N >> 1) RItype} (src/run_mode_context.hpp:34-62) from the leading zeros
+                const uint32_t goal = (uint32_t)ctx.a + (uint32_t)(ctx.n >> 1) * (uint32_t)ctx.ritype;
+                int k = 0;
+                if (goal > (uint32_t)ctx.n)
+                {
+                    k = (int)leading_zeros((uint32_t)ctx.n) - (int)leading_zeros(goal);
+                    k += (((uint64_t)(uint32_t)ctx.n << k) < goal) ? 1 : 0;
+                }
                 const int limit = t.limit - run_j(run_index) - 1;
-                const int u = k > 24 ? -1 : take_unary(ring, p, 47); // anything longer: let the exact decoder classify it
+                // prefix and remainder out of one window where they fit (they do unless the code is an unusual one)
+                const uint32_t w2 = peek32(ring, p);
+                const uint32_t zeros = lowest_one(w2); // 0xFFFFFFFF: no one bit in the window
+                int u = -1;
+                int em = 0;
+                if (k <= 24 && zeros < 32u)
+                {
+                    u = (int)zeros;
+                    const int tail_bits = u < limit - t.qbpp - 1 ? k : t.qbpp;
+                    uint32_t tail;
+                    if (zeros + 1u + (uint32_t)tail_bits <= 32u)
+                    {
+                        tail = field(zeros == 31u ? 0u : w2 >> (zeros + 1u), tail_bits);
+                        p += zeros + 1u + (uint32_t)tail_bits;
+                    }
+                    else
+                    {
+                        p += zeros + 1u;
+                        tail = take_bits(ring, p, tail_bits);
+                    }
+                    em = u < limit - t.qbpp - 1 ? (u << k) + (int)tail : (int)tail + 1;
+                }
+                else if (k <= 24)
+                { // a prefix of 32 zeros or more: the general reader (anything beyond 47: let the exact decoder classify it)
+                    u = take_unary(ring, p, 47);
+                    if (u >= 0)
+                    {
+                        if (u < limit - t.qbpp - 1)
+                            em = (u << k) + (int)take_bits(ring, p, k);
+                        else
+                            em = (int)take_bits(ring, p, t.qbpp) + 1;
+                    }
+                }
                 if (u < 0)
                 {
                     retry = true;
@@ -710,11 +961,6 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 }
                 else
                 {
-                    int em;
-                    if (u < limit - t.qbpp - 1)
-                        em = (u << k) + (int)take_bits(ring, p, k);
-                    else
-                        em = (int)take_bits(ring, p, t.qbpp) + 1;
                     const int e = run_error_value(ctx, em + ctx.ritype, k);
                     run_update(ctx, e, em, t.reset);
                     x = which ? ((a + e) & t.maxval) : ((b_at + e * ((b_at - a) < 0 ? -1 : 1)) & t.maxval);
@@ -740,6 +986,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
         // ---- one regular-mode sample with every case the step loop leaves out (escape codes, long prefixes)
         if (__any(slow))
         {
+            JLS_PATH(9); // unusual codes
             const int rc = rc_of(), rb = rb_of();
             const int s = qs >> 31;
             const int idx = (qs ^ s) - s;
@@ -796,6 +1043,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             const bool ending = phase == kInLine && i > width;
             if (__any(ending))
             {
+                JLS_PATH(10); // line ends
                 uint8_t* row = d.pixels + (size_t)y * d.pixel_stride;
                 const S* samples = line + 1;
                 const uint32_t row_bytes = width * (uint32_t)sizeof(S);

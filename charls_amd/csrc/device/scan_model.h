@@ -23,6 +23,17 @@ namespace jls {
 #define JLS_LOCKSTEP_STORES() ((void)0)
 #endif
 
+// Path counters of the CPU test harness (tools/decode_path_profile.py: how often a wavefront takes each path of a kernel,
+// to be priced with the instruction counts of the compiled code).  Nothing in the product build.
+#ifdef JLS_PATH_PROFILE
+extern "C" unsigned long long jls_path_counts[32];
+#define JLS_PATH(n) do { if (threadIdx.x == 0) ++jls_path_counts[n]; } while (0)
+#define JLS_PATH_ADD(n, v) do { if (threadIdx.x == 0) jls_path_counts[n] += (unsigned long long)(v); } while (0)
+#else
+#define JLS_PATH(n) ((void)0)
+#define JLS_PATH_ADD(n, v) ((void)0)
+#endif
+
 // Pointers that are loaded from a descriptor in memory are "generic" to the compiler, which then emits flat_* memory
 // instructions; those tick both wait counters and force conservative s_waitcnt 0.  Declaring them global lets the
 // compiler use global_* instructions and count outstanding loads exactly.  (Empty in the CPU test harness.)
@@ -141,6 +152,10 @@ JLS_DEV bool lane_of(LaneMask m)
 {
     return __builtin_amdgcn_inverse_ballot_w64(m);
 }
+JLS_DEV uint32_t value_of_lowest_lane(LaneMask m, uint32_t v) // v of the first lane of m (m != 0): s_ff1, v_readlane
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_ctzll(m));
+}
 JLS_DEV int mad24(int a, int b, int c)
 {
     int r;
@@ -243,6 +258,10 @@ JLS_DEV LaneMask lanes_where(bool p)
 JLS_DEV bool lane_of(LaneMask m)
 {
     return ((m >> emu::lane_id()) & 1ull) != 0;
+}
+JLS_DEV uint32_t value_of_lowest_lane(LaneMask m, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_ctzll(m));
 }
 JLS_DEV int mad24(int a, int b, int c)
 {

@@ -55,6 +55,13 @@ def tile_lib():
     return _libs["tile"]
 
 
+def profile_lib():
+    """scan_group_decode.hip with its path counters on (tools/decode_path_profile.py)."""
+    if "profile" not in _libs:
+        _libs["profile"] = _build_and_load("emu_profile_driver.cpp", os.path.join(ROOT, "tests", "_emu_build", "libjls_emu_profile.so"))
+    return _libs["profile"]
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -23,7 +23,10 @@ ap.add_argument("--repeat", type=int, default=1)
 ap.add_argument("--distinct", type=int, default=0,
                 help="synthesise only this many distinct frames and repeat them (few torch kernels: rocprofv3 --pmc crashes in "
                      "torch's synthesis kernels when thousands of them run under it)")
+ap.add_argument("--lib", default=None, help="another build of the product library (A/B runs of kernel variants)")
 args = ap.parse_args()
+if args.lib:
+    capi.PRODUCT_LIB = os.path.abspath(args.lib)
 
 import glob
 import threading
