@@ -42,6 +42,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "lossless_pipeline.hip"
 
 namespace jls {
@@ -1695,7 +1698,9 @@ inline size_t pack_lds_bytes(uint32_t width, uint32_t lines_per_tile, int32_t bi
 // 4096 for two: the sort stage keeps the lines, the keys and the sorted records of a tile in LDS), at most kTileLines.
 inline uint32_t lines_per_tile_for(uint32_t width, uint32_t sample_bytes)
 {
-    const uint32_t tile_samples = sample_bytes == 1 ? kMaxTileSamples : kMaxTileSamples / 2;
+    uint32_t tile_samples = sample_bytes == 1 ? kMaxTileSamples : kMaxTileSamples / 2;
+    if (const char* env = std::getenv("CHARLS_AMD_TILE_SAMPLES")) // (smaller tiles: more workgroups per CU; for measurements)
+        tile_samples = std::min<uint32_t>(tile_samples, std::max(64, std::atoi(env)));
     const uint32_t n = tile_samples / width;
     return n < 1 ? 1 : (n > kTileLines ? kTileLines : n);
 }
