@@ -84,6 +84,16 @@ struct Record
     uint32_t ncb;
 };
 
+JLS_DEV Record load_record(uint32_t address) // a record by its LDS address
+{
+    const uint64_t both = lds_load<uint64_t>(address);
+    return Record{(uint32_t)both, (uint32_t)(both >> 32)};
+}
+JLS_DEV void store_record(uint32_t address, const Record& r)
+{
+    lds_store<uint64_t>(address, ((uint64_t)r.ncb << 32) | r.a);
+}
+
 // The dense bit ring is LSB first: stream bit j is bit (j & 31) of word (j >> 5), so that the next 32 bits of the stream are
 // one funnel shift (v_alignbit_b32) of two neighbouring words, the unary prefix is a count of TRAILING zeros, and a
 // k-bit field of the stream (whose first bit is the most significant) is the bit-reversed low end of the window.
@@ -653,11 +663,11 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 const int sgn = qsu < 364 ? -1 : 1;
                 const int idx = (int)abs_difference((uint32_t)qsu, 364u);
                 JLS_LOCKSTEP();
-                lds_store<Record>(where, updated); // bookkeeping, part 3: the stores
+                store_record(where, updated); // bookkeeping, part 3: the stores
                 lp[-1] = (S)a;
                 JLS_LOCKSTEP();
                 where = records_at + ((uint32_t)idx << 3); // idx 0 (run mode) reads a valid, unused record
-                const Record rec = lds_load<Record>(where);
+                const Record rec = load_record(where);
                 const uint32_t u = lowest_one(win); // length of the unary prefix; 0xFFFFFFFF for an all-zero window
                 const uint32_t u1 = u + 1u; // the window beyond the prefix: u1 = 32 only with k = 0, where no field is read
                 const uint32_t beyond = bit_reverse(win >> (u1 & 31u));
@@ -732,7 +742,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 ra_stopped = (int)lp[-1]; // Ra of a lane whose last step did not decode: stored by that step
                 if (owed)
                 {
-                    lds_store<Record>(where, Record{(uint32_t)ctx.a, ((uint32_t)ctx.b << 16) | pack_bytes((uint32_t)ctx.c, (uint32_t)ctx.n)});
+                    store_record(where, Record{(uint32_t)ctx.a, ((uint32_t)ctx.b << 16) | pack_bytes((uint32_t)ctx.c, (uint32_t)ctx.n)});
                     lp[0] = (S)a;
                     p += t_adv;
                     if (kWide)
