@@ -84,16 +84,6 @@ struct Record
     uint32_t ncb;
 };
 
-JLS_DEV Record load_record(uint32_t address) // a record by its LDS address
-{
-    const uint64_t both = lds_load<uint64_t>(address);
-    return Record{(uint32_t)both, (uint32_t)(both >> 32)};
-}
-JLS_DEV void store_record(uint32_t address, const Record& r)
-{
-    lds_store<uint64_t>(address, ((uint64_t)r.ncb << 32) | r.a);
-}
-
 // The dense bit ring is LSB first: stream bit j is bit (j & 31) of word (j >> 5), so that the next 32 bits of the stream are
 // one funnel shift (v_alignbit_b32) of two neighbouring words, the unary prefix is a count of TRAILING zeros, and a
 // k-bit field of the stream (whose first bit is the most significant) is the bit-reversed low end of the window.
@@ -512,15 +502,10 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
         t9 = 9 * q1 + quantised((int)rb - rc);
     };
 
-    // Most rounds end with every scan of the wavefront in the middle of a line, its bits in the ring and nothing to
-    // hand back: ONE test after the event handlers then takes the place of the tests at the bottom and at the top of the
-    // round (end of line, end of scan, refill, start of line), which each cost a few instructions per round and scan event.
-    bool quiet = false;
     for (;;)
     {
         JLS_PATH(0); // rounds
         // ---- producer: keep kMarginBits ahead of the consumer; scans that finished their samples look for the marker
-        if (!quiet)
         {
             const uint32_t ahead = src.produced - p;
             const bool busy = phase != kDone && !src.ended;
@@ -534,7 +519,6 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             }
         }
         // ---- first sample of a line: reference src/scan_codec.hpp:189-195, src/scan_decoder_impl.hpp:62-129
-        if (!quiet)
         {
             const bool starting = phase == kLineStart;
             if (__any(starting))
@@ -600,8 +584,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             const uint32_t p_kept = p;
             S* lp = in_line ? line + i - 1 : line + width + 2; // slot of the previous step's sample
             const uint32_t lp_step = in_line ? 1u : 0u;
-            const uint32_t records_at = opaque(lds_address(records));
-            uint32_t where = records_at + 365u * 8u; // LDS address of the previous step's context record (an unused slot at first)
+            Record* where = records + 365;      // the previous step's context record (an unused slot at first)
             // what the previous step leaves for its context update: A + |Errval|, N, B + Errval (all three already halved
             // when N had reached RESET) and the record's other word, for C
             int u_a = 0, u_n1 = 2, u_tb = 0; // u_n1 = N + 1
@@ -663,11 +646,11 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 const int sgn = qsu < 364 ? -1 : 1;
                 const int idx = (int)abs_difference((uint32_t)qsu, 364u);
                 JLS_LOCKSTEP();
-                store_record(where, updated); // bookkeeping, part 3: the stores
+                *where = updated;      // bookkeeping, part 3: the stores
                 lp[-1] = (S)a;
                 JLS_LOCKSTEP();
-                where = records_at + ((uint32_t)idx << 3); // idx 0 (run mode) reads a valid, unused record
-                const Record rec = load_record(where);
+                where = records + idx; // idx 0 (run mode) reads a valid, unused record
+                const Record rec = *where;
                 const uint32_t u = lowest_one(win); // length of the unary prefix; 0xFFFFFFFF for an all-zero window
                 const uint32_t u1 = u + 1u; // the window beyond the prefix: u1 = 32 only with k = 0, where no field is read
                 const uint32_t beyond = bit_reverse(win >> (u1 & 31u));
@@ -742,7 +725,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                 ra_stopped = (int)lp[-1]; // Ra of a lane whose last step did not decode: stored by that step
                 if (owed)
                 {
-                    store_record(where, Record{(uint32_t)ctx.a, ((uint32_t)ctx.b << 16) | pack_bytes((uint32_t)ctx.c, (uint32_t)ctx.n)});
+                    *where = Record{(uint32_t)ctx.a, ((uint32_t)ctx.b << 16) | pack_bytes((uint32_t)ctx.c, (uint32_t)ctx.n)};
                     lp[0] = (S)a;
                     p += t_adv;
                     if (kWide)
@@ -754,8 +737,8 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
                     else
                         w0 = (w0 >> 8) | (t_next << 24);
                     ++lp;
+                    q1 = q1n;
                 }
-                q1 = q1n; // (a lane that stopped gets its Q1 from the handler that takes its sample)
                 JLS_LOCKSTEP();
             }
             if (in_line)
@@ -1051,12 +1034,6 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
 
         if (kWide && a_seen >= (1u << 24))
             retry = true;
-        quiet = __all(phase == kInLine && i <= width && !retry && (src.ended || src.produced - p >= kMarginBits));
-        if (quiet)
-        {
-            JLS_PATH(14); // quiet rounds
-            continue;
-        }
         if (retry)
             phase = kDone;
 

@@ -20,7 +20,7 @@ from test_emu_serial_kernels import _stream_copy  # noqa: E402
 
 NAMES = ["rounds", "refills", "line starts", "step loops", "trips of the step-count loop", "steps", "general run handler",
          "run-length code bits", "trips of the run fill", "unusual codes", "line ends", "refills byte by byte",
-         "trips of the refill's delete loop", "fast handler of empty runs", "quiet rounds"]
+         "trips of the refill's delete loop", "fast handler of empty runs"]
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--width", type=int, default=4096)
