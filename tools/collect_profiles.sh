@@ -19,7 +19,6 @@ rm -f $out/stats/*/bench_kernel_trace.csv $out/stats/bench_kernel_trace.csv
 # depend on the number of wavefronts)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 240 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "jls" --output-format csv -d $out/pmc_$c -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc_$c.log 2>&1
-  CHARLS_AMD_DECODE_GROUP=8 timeout 240 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "decode_scans" --output-format csv -d $out/pmc_g8_$c -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc_g8_$c.log 2>&1
 done
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex "jls" --output-format csv -d $out/pmc_inst -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc_inst.log 2>&1
 CHARLS_AMD_DECODE_GROUP=8 timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex "decode_scans" --output-format csv -d $out/pmc_inst_g8 -o p -- python bench.py --frames 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc_inst_g8.log 2>&1
@@ -29,5 +28,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # one frame: where single-frame latency goes
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/one -o one -- python bench.py --frames 1 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/one.json 2> $out/one.log
+# the other BASELINE configurations (parity cases, not bench lines)
+timeout 200 python tools/measure_configs.py --only 2,3,5a,5c > $out/other_configs.txt 2>&1
 find $out -name "*kernel_trace.csv" -size +8M -delete
 du -sh $out; find $out -type f | head -40
