@@ -5,6 +5,7 @@
 
 #include "../device/runtime.h"
 #include "common.h"
+#include "scan_engine.h"
 
 using namespace jls;
 
@@ -160,6 +161,7 @@ charls_jpegls_errc charls_amd_set_workspace_limit(uint64_t bytes)
 charls_jpegls_errc charls_amd_release_work_areas(void)
 {
     dev::release_work_areas();
+    release_idle_engine_resources(); // the device buffers, streams and staging areas that handles share (scan_engine.h)
     return CHARLS_JPEGLS_ERRC_SUCCESS;
 }
 

@@ -4,6 +4,8 @@
 // pointer out.  There is no CPU implementation behind it: without a usable GPU every call raises
 // CHARLS_AMD_ERRC_DEVICE_UNAVAILABLE.
 #pragma once
+#include <memory>
+
 #include "../device/runtime.h"
 #include "common.h"
 
@@ -20,6 +22,30 @@ struct ScanSpec
     charls_jpegls_pc_parameters pc; // validated
     uint32_t restart_interval;
 };
+
+// What a handle needs on the device: a stream, the device copies of pixels and coded bytes, descriptors, a pinned
+// staging area.  The reference's callers create an encoder or decoder per image (cli/benchmark.cpp does, inside its
+// clock); creating and destroying these per handle cost more than coding a 4096 x 4096 frame (hipStreamCreate, five
+// hipMalloc, hipHostMalloc and their frees), so handles take a set from a process-wide pool and give it back
+// (scan_engine.cpp: acquire_resources / release_resources; a few sets of bounded size stay idle).
+struct EngineResources
+{
+    hipStream_t stream{};
+    int device{-1};
+    dev::DeviceBuffer pixels, bits, scratch, desc, result;
+    dev::PinnedBuffer staging;
+    EngineResources() = default;
+    EngineResources(const EngineResources&) = delete;
+    EngineResources& operator=(const EngineResources&) = delete;
+    ~EngineResources();
+    size_t device_bytes() const noexcept
+    {
+        return pixels.capacity() + bits.capacity() + scratch.capacity() + desc.capacity() + result.capacity();
+    }
+};
+
+// Frees the idle sets of the pool (charls_amd_release_work_areas calls it).
+void release_idle_engine_resources() noexcept;
 
 class ScanEngine
 {
@@ -59,10 +85,7 @@ private:
     ScanResult run(const ScanDesc& desc, bool decode);
     void run_many(const ScanDesc* descs, uint32_t count, bool decode, ScanResult* results);
 
-    hipStream_t stream_{};
-    bool have_stream_{};
-    dev::DeviceBuffer pixels_, bits_, scratch_, desc_, result_;
-    dev::PinnedBuffer staging_;
+    std::unique_ptr<EngineResources> r_; // from the pool at the first device call, back to it with the handle
     size_t pixel_bytes_{}, stream_bytes_{}, plane_capacity_{};
 };
 

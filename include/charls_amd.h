@@ -403,7 +403,10 @@ CHARLS_AMD_API charls_jpegls_errc charls_amd_set_encode_engine(int32_t engine);
  * allocated between calls.  The limit is process-wide: 0 (the default) = a quarter of the device's memory, and never more than what is
  * free minus 8 GiB.  A batch larger than the limit allows is coded in several passes; when not even one work area can be
  * allocated the encoder falls back to its one-wavefront-per-scan kernel, which needs none.  The host-pointer encoder /
- * decoder of part 1 release work areas above 1 GiB before they return. */
+ * decoder of part 1 release work areas above 1 GiB before they return.  Their handles share a small process-wide pool of
+ * device buffers, streams and pinned staging areas (at most 4 idle sets of at most 512 MiB each: callers create a handle per
+ * image, and creating these per handle costs more than coding a frame); charls_amd_release_work_areas frees the idle ones
+ * too. */
 CHARLS_AMD_API charls_jpegls_errc charls_amd_set_workspace_limit(uint64_t bytes);
 CHARLS_AMD_API charls_jpegls_errc charls_amd_release_work_areas(void); /* the calling thread's */
 CHARLS_AMD_API uint64_t charls_amd_work_area_bytes(void);              /* the calling thread's, currently allocated */
