@@ -1,0 +1,76 @@
+"""Which paths of scan_group_decode.hip a decode takes (CPU harness with the kernel's path counters on, tests/emu/
+emu_profile_driver.cpp): the rewritten refill and the register-only run handler must be the paths that run on ordinary
+streams, with the byte-by-byte refill and the general handler left for what they are kept for.  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import common
+import emu_bind
+import jls_container
+import oracle_bind as ob
+from charls_amd import synth
+from test_emu_serial_kernels import _stream_copy
+
+ROUNDS, REFILLS, STEPS, GENERAL_RUNS, BYTEWISE, DELETE_TRIPS, EMPTY_RUNS = 0, 1, 5, 6, 11, 12, 13
+
+
+def _decode(frames, width, height, group):
+    L = emu_bind.profile_lib()
+    keep, outs, descs = [], [], []
+    for img in frames:
+        jls = ob.encode(img, width=width, height=height, bits_per_sample=8)
+        cont = jls_container.parse(jls)
+        pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+        pix = np.zeros(width * height, dtype=np.uint8)
+        descs.append(emu_bind.make_desc(width, height, 1, 0, 8, 0, 0, pc, 0, pix, width, _stream_copy(jls, cont.scans[0].data_start), keep))
+        outs.append(pix)
+    n = len(descs)
+    arr = (emu_bind.ScanDesc * n)(*descs)
+    res = (emu_bind.ScanResult * n)()
+    counts = (C.c_ulonglong * 32)()
+    assert L.emu_profile_decode_group(arr, res, n, group, counts) == 0
+    for r, o, img in zip(res, outs, frames):
+        assert (r.errc, r.flags) == (0, 0)
+        assert o.tobytes() == np.ascontiguousarray(img).tobytes()
+    return list(counts)
+
+
+@pytest.mark.parametrize("group", [8, 16, 32])
+def test_noise_streams_are_unstuffed_by_the_128_bit_refill(group):
+    """Noise compresses to nothing: long streams with a 0xFF in every 256 bytes.  Apart from the first bytes of a misaligned
+    stream and the bytes around its end every refill is the 128-bit one, and it deletes stuffed bits."""
+    w, h = 384, 24
+    frames = [synth.frame_numpy(w, h, seed=300 + f, bits=8, kind="noise") for f in range(64 // group)]
+    c = _decode(frames, w, h, group)
+    assert c[REFILLS] >= 4
+    assert c[DELETE_TRIPS] > 0, "no stuffed bit met the 128-bit refill: the test frames are too small"
+    assert c[BYTEWISE] <= 4, "the byte-by-byte refill is for the ends of a stream"
+    assert c[BYTEWISE] < c[REFILLS]
+
+
+def test_empty_runs_take_the_register_only_handler():
+    """The bench's frames: most run events are runs of length 0, and those do not enter the general handler."""
+    w, h = 1024, 6
+    frames = [synth.frame_numpy(w, h, seed=1000 + f, bits=8, kind="gradient") for f in range(8)]
+    c = _decode(frames, w, h, 8)
+    assert c[STEPS] > 0 and c[ROUNDS] > 0
+    assert c[EMPTY_RUNS] > c[GENERAL_RUNS] > 0
+
+
+def test_flat_frames_never_take_it():
+    """All zero (the value a frame's surroundings have): every line is one run to its end, nothing is interrupted."""
+    w, h = 200, 9
+    c = _decode([np.zeros((h, w), dtype=np.uint8) for _ in range(2)], w, h, 32)
+    assert c[EMPTY_RUNS] == 0 and c[GENERAL_RUNS] > 0
+
+
+def test_the_path_profile_tool_runs():
+    out = subprocess.run([sys.executable, os.path.join(common.ROOT, "tools", "decode_path_profile.py"), "--width", "256", "--lines", "4",
+                          "--group", "16"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "fast handler of empty runs" in out.stdout and "refills" in out.stdout
