@@ -13,10 +13,13 @@
 //     line, an empty bit ring) raises an event, the wavefront leaves the step loop, and the event is handled once, out
 //     of line, under the predicate of the groups that raised it;
 //   * the G lanes of a group share the bulk work of their scan: un-stuffing 16 coded bytes per lane into the dense
-//     bit ring (as in scan_fast_decode.hip), run fills, and the 16-byte row stores of every finished line;
+//     bit ring, run fills, and the 16-byte row stores of every finished line;
+//   * what all scans of the wavefront wait for is written for instruction count as well: a refill handles a lane's 16
+//     bytes as one 128-bit number (refill), a run of length 0 and its interruption sample -- three run events in four --
+//     come out of the registers the lane left the step loop with (the handler in front of the general one);
 //   * LDS per scan: 365 context records (8 B), two run contexts, a 1 KB dense bit ring and ONE line of samples = 8.1 KB
-//     for 4096 8-bit samples; with the gradient table the scans of a wavefront share, 33 KB per wavefront at G = 16: four
-//     wavefronts per CU, one per SIMD.
+//     for 4096 8-bit samples; with the gradient table the scans of a wavefront share, 33 KB per wavefront at G = 16, 76 KB
+//     at G = 8 (two wavefronts per CU: the launch rule of runtime.hip: decode_group_lanes).
 //
 // Like scan_fast_decode.hip this is not a restatement of the reference's bit reader: a result is accepted only when the
 // scan ends cleanly (all samples decoded inside the entropy-coded segment, zero padding, marker next); everything else
