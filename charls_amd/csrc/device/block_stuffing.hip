@@ -9,12 +9,18 @@
 // owns the output bytes that start inside it, and what it needs from its predecessors is only the state in which it is
 // entered: the offset (0..7) of its first byte from its first bit, and whether that byte is a 7-bit one -- 16 states:
 //
-//   survey   one LANE per chunk walks its chunk from each of the 16 entry states (between two 0xFF bytes the walk is a
-//            search for an all-ones byte at a fixed bit phase, 64 bits at a time) and records, per state, how many output
-//            bytes the chunk owns and in which state it hands over;
-//   resolve  one wavefront per scan composes the chunks' tables from chunk 0 (state 0) on -- a table look-up per chunk out
-//            of LDS -- and leaves every chunk its entry state and the index of its first output byte;
+//   survey   one LANE per (chunk, entry state) walks the chunk from that state (between two 0xFF bytes the walk is a
+//            search for an all-ones byte at a fixed bit phase, 64 bits at a time) and records how many output bytes the
+//            chunk owns and in which state it hands over;
+//   resolve  one workgroup per scan composes the chunks' tables from chunk 0 (state 0) on: every lane composes the
+//            tables of a run of chunks into one map (entry state -> exit state, owned bytes), one lane walks the 256 maps,
+//            every lane walks its chunks again from the state it is really entered in and leaves every chunk its entry
+//            state and the index of its first output byte;
 //   emit     one lane per chunk walks once more, from its real entry state, and stores its bytes.
+//
+// (Until the end of round 3 the survey was one lane per chunk -- sixteen walks in a row -- and the composition one lane per
+// scan: 0.68 + 0.53 ms of the 6 ms ONE 4096 x 4096 frame takes through the host-pointer ABI, on 111 wavefronts and on one
+// lane.)
 //
 // Output and result words are those of stuff_scan (a trailing 0xFF is followed by 0x00, the last partial byte is zero
 // padded, flags bit 1 when the capacity is within 3 bytes of the size).  The default form of stage E since round 3
@@ -31,7 +37,7 @@ namespace pipe {
 constexpr uint32_t kStuffChunk = 1024;             // raw bytes per chunk
 constexpr uint32_t kStuffChunkBits = kStuffChunk * 8;
 constexpr uint32_t kStuffStates = 16;              // offset of the first byte (0..7) | 8 when it is a 7-bit byte
-constexpr uint32_t kStuffTile = 256;               // chunks whose tables the resolve step holds in LDS at a time
+constexpr uint32_t kStuffResolveThreads = 256;     // lanes of the resolve step: each composes ceil(chunks / 256) tables
 
 // Words per chunk in Work::stuff_tables: kStuffStates table entries (owned bytes | exit state << 16), then the entry state
 // and the first output byte index (two words) as resolve leaves them.
@@ -92,36 +98,41 @@ JLS_DEV uint32_t walk_chunk(const uint8_t* raw, uint64_t& from, uint32_t& width,
     return count;
 }
 
-// grid (ceil(chunks / 64), scans) x 64 lanes.
+// Workgroups (of 64 lanes) of the survey of a raw stream of at most `raw_bytes` bytes: one lane per (chunk, entry state).
+__host__ __device__ constexpr uint32_t stuff_survey_blocks(uint64_t raw_bytes)
+{
+    return (uint32_t)(((raw_bytes / kStuffChunk + 1) * kStuffStates + 63) / 64);
+}
+
+// grid (stuff_survey_blocks, scans) x 64 lanes.
 __global__ void __launch_bounds__(64) stuff_survey(const Work* __restrict__ works)
 {
     const Work w = works[blockIdx.y];
     const uint64_t total_bits = *w.total_bits;
     const uint32_t chunks = (uint32_t)((total_bits + kStuffChunkBits - 1) / kStuffChunkBits);
-    const uint32_t chunk = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t item = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t chunk = item / kStuffStates, state = item % kStuffStates;
     if (chunk >= chunks || (uint64_t)(total_bits + 7) / 8 > (uint64_t)w.raw_words * 4)
         return;
     const uint8_t* raw = reinterpret_cast<const uint8_t*>(w.raw);
     const uint64_t begin = (uint64_t)chunk * kStuffChunkBits;
     const uint64_t end = begin + kStuffChunkBits < total_bits ? begin + kStuffChunkBits : total_bits;
-    uint32_t* table = w.stuff_tables + (size_t)chunk * kStuffWords;
-    for (uint32_t state = 0; state < kStuffStates; ++state)
-    {
-        uint64_t r = begin + (state & 7u);
-        uint32_t wd = (state & 8u) ? 7u : 8u;
-        bool last_ff;
-        const uint32_t count = walk_chunk<false>(raw, r, wd, end, last_ff, [](uint32_t, uint32_t) {});
-        const uint32_t exit_state = (uint32_t)((r - (begin + kStuffChunkBits)) & 7u) | (wd == 7 ? 8u : 0u);
-        table[state] = count | (exit_state << 16);
-    }
+    uint64_t r = begin + (state & 7u);
+    uint32_t wd = (state & 8u) ? 7u : 8u;
+    bool last_ff;
+    const uint32_t count = walk_chunk<false>(raw, r, wd, end, last_ff, [](uint32_t, uint32_t) {});
+    const uint32_t exit_state = (uint32_t)((r - (begin + kStuffChunkBits)) & 7u) | (wd == 7 ? 8u : 0u);
+    w.stuff_tables[(size_t)chunk * kStuffWords + state] = count | (exit_state << 16);
 }
 
-// grid (scans) x 64 lanes.
-__global__ void __launch_bounds__(64) stuff_resolve(const Work* __restrict__ works)
+// grid (scans) x kStuffResolveThreads lanes.
+__global__ void __launch_bounds__(kStuffResolveThreads) stuff_resolve(const Work* __restrict__ works)
 {
-    __shared__ uint32_t s_table[kStuffTile * kStuffStates];
-    __shared__ uint32_t s_entry[kStuffTile];
-    __shared__ uint32_t s_first[kStuffTile * 2];
+    __shared__ uint32_t s_row[kStuffResolveThreads * kStuffStates];   // the table of the chunk a lane is at
+    __shared__ uint32_t s_count[kStuffResolveThreads * kStuffStates]; // bytes a lane's chunks own, by the state they are entered in
+    __shared__ uint64_t s_exit[kStuffResolveThreads];                 // ... and the state they hand over in, four bits per entry state
+    __shared__ uint32_t s_entry[kStuffResolveThreads];                // the state a lane's chunks are really entered in
+    __shared__ uint64_t s_first[kStuffResolveThreads];                // output bytes before them
     const Work w = works[blockIdx.x];
     const uint64_t total_bits = *w.total_bits;
     // Nothing was surveyed for a scan that is invalid or whose raw stream did not fit its buffer (write_raw_bits clamps
@@ -129,34 +140,86 @@ __global__ void __launch_bounds__(64) stuff_resolve(const Work* __restrict__ wor
     if ((*w.status & kStatusInvalid) != 0 || (uint64_t)(total_bits + 7) / 8 > (uint64_t)w.raw_words * 4)
         return;
     const uint32_t chunks = (uint32_t)((total_bits + kStuffChunkBits - 1) / kStuffChunkBits);
-    const int lane = threadIdx.x;
-    uint32_t state = 0;  // the first byte of the stream starts at bit 0 and is an 8-bit one
-    uint64_t index = 0;  // output bytes before the chunk
-    for (uint32_t c0 = 0; c0 < chunks; c0 += kStuffTile)
+    const uint32_t lane = threadIdx.x;
+    const uint32_t per_lane = (chunks + kStuffResolveThreads - 1) / kStuffResolveThreads;
+    const uint32_t from = lane * per_lane < chunks ? lane * per_lane : chunks;
+    const uint32_t to = from + per_lane < chunks ? from + per_lane : chunks;
+    uint32_t* row = s_row + lane * kStuffStates; // (a lane's own slot: a table is looked up by state, which registers cannot be)
+    const u32x4* tables = reinterpret_cast<const u32x4*>(w.stuff_tables); // kStuffWords words = five quads per chunk
+    u32x4* row4 = reinterpret_cast<u32x4*>(row);
+    constexpr uint32_t kQuads = kStuffWords / 4;
+    // 1) the chunks of the lane as ONE map: exits = state after them, counts = bytes they own, for each of the 16 entry states
+    uint64_t exits = 0xFEDCBA9876543210ull;
+    uint32_t counts[kStuffStates];
+#pragma unroll
+    for (uint32_t st = 0; st < kStuffStates; ++st)
+        counts[st] = 0;
+    u32x4 ahead[4];
+    if (from < to)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            ahead[q] = tables[(size_t)from * kQuads + q];
+    for (uint32_t c = from; c < to; ++c)
     {
-        const uint32_t n = chunks - c0 < kStuffTile ? chunks - c0 : kStuffTile;
-        for (uint32_t k = lane; k < n * kStuffStates; k += 64)
-            s_table[k] = w.stuff_tables[(size_t)(c0 + k / kStuffStates) * kStuffWords + k % kStuffStates];
-        __syncthreads();
-        if (lane == 0)
-            for (uint32_t c = 0; c < n; ++c)
-            {
-                s_entry[c] = state;
-                s_first[2 * c] = (uint32_t)index;
-                s_first[2 * c + 1] = (uint32_t)(index >> 32);
-                const uint32_t t = s_table[c * kStuffStates + state];
-                index += t & 0xFFFFu;
-                state = t >> 16;
-            }
-        __syncthreads();
-        for (uint32_t c = lane; c < n; c += 64)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            row4[q] = ahead[q];
+        if (c + 1 < to)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                ahead[q] = tables[(size_t)(c + 1) * kQuads + q];
+        uint64_t next = 0;
+#pragma unroll
+        for (uint32_t st = 0; st < kStuffStates; ++st)
         {
-            uint32_t* out = w.stuff_tables + (size_t)(c0 + c) * kStuffWords + kStuffStates;
-            out[0] = s_entry[c];
-            out[1] = s_first[2 * c];
-            out[2] = s_first[2 * c + 1];
+            const uint32_t t = row[(uint32_t)(exits >> (4 * st)) & 15u];
+            counts[st] += t & 0xFFFFu;
+            next |= (uint64_t)(t >> 16) << (4 * st);
         }
-        __syncthreads();
+        exits = next;
+    }
+    s_exit[lane] = exits;
+#pragma unroll
+    for (uint32_t st = 0; st < kStuffStates; ++st)
+        s_count[lane * kStuffStates + st] = counts[st];
+    __syncthreads();
+    // 2) one lane walks the maps: the first byte of the stream starts at bit 0 and is an 8-bit one
+    if (lane == 0)
+    {
+        uint32_t state = 0;
+        uint64_t index = 0;
+        for (uint32_t l = 0; l < kStuffResolveThreads; ++l)
+        {
+            s_entry[l] = state;
+            s_first[l] = index;
+            index += s_count[l * kStuffStates + state];
+            state = (uint32_t)(s_exit[l] >> (4 * state)) & 15u;
+        }
+    }
+    __syncthreads();
+    // 3) every lane walks its chunks again, from the state they are really entered in
+    uint32_t state = s_entry[lane];
+    uint64_t index = s_first[lane];
+    if (from < to)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            ahead[q] = tables[(size_t)from * kQuads + q];
+    for (uint32_t c = from; c < to; ++c)
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            row4[q] = ahead[q];
+        if (c + 1 < to)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                ahead[q] = tables[(size_t)(c + 1) * kQuads + q];
+        uint32_t* out = w.stuff_tables + (size_t)c * kStuffWords + kStuffStates;
+        out[0] = state;
+        out[1] = (uint32_t)index;
+        out[2] = (uint32_t)(index >> 32);
+        const uint32_t t = row[state];
+        index += t & 0xFFFFu;
+        state = t >> 16;
     }
 }
 

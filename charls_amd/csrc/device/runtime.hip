@@ -846,8 +846,9 @@ void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_result
         if (block_stuffing_enabled() && n <= kBlockStuffingScans)
         {
             const uint32_t chunk_waves = static_cast<uint32_t>((lay.raw_bytes / pipe::kStuffChunk + 1 + 63) / 64);
-            hipLaunchKernelGGL(pipe::stuff_survey, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, d_works);
-            hipLaunchKernelGGL(pipe::stuff_resolve, dim3(n), dim3(64), 0, stuff_stream, d_works);
+            const uint32_t survey_blocks = pipe::stuff_survey_blocks(lay.raw_bytes);
+            hipLaunchKernelGGL(pipe::stuff_survey, dim3(survey_blocks, n), dim3(64), 0, stuff_stream, d_works);
+            hipLaunchKernelGGL(pipe::stuff_resolve, dim3(n), dim3(pipe::kStuffResolveThreads), 0, stuff_stream, d_works);
             hipLaunchKernelGGL(pipe::stuff_emit, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, descs, d_works, d_results + first);
         }
         else
@@ -1144,8 +1145,9 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         if (block_stuffing_enabled() && n <= kBlockStuffingScans)
         {
             const uint32_t chunk_waves = static_cast<uint32_t>((lay.raw_bytes / pipe::kStuffChunk + 1 + 63) / 64);
-            hipLaunchKernelGGL(pipe::stuff_survey, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, d_stuff);
-            hipLaunchKernelGGL(pipe::stuff_resolve, dim3(n), dim3(64), 0, stuff_stream, d_stuff);
+            const uint32_t survey_blocks = pipe::stuff_survey_blocks(lay.raw_bytes);
+            hipLaunchKernelGGL(pipe::stuff_survey, dim3(survey_blocks, n), dim3(64), 0, stuff_stream, d_stuff);
+            hipLaunchKernelGGL(pipe::stuff_resolve, dim3(n), dim3(pipe::kStuffResolveThreads), 0, stuff_stream, d_stuff);
             hipLaunchKernelGGL(pipe::stuff_emit, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, descs, d_stuff, d_results + first);
         }
         else

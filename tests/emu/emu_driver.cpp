@@ -132,8 +132,9 @@ static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, i
         for (int i = 0; i < count; ++i)
             most = std::max(most, (size_t)works[i].raw_words * 4);
         const unsigned chunk_waves = (unsigned)((most / pipe::kStuffChunk + 1 + 63) / 64);
-        emu::launch(pipe::stuff_survey, dim3(chunk_waves, count), dim3(64), 0, wk);
-        emu::launch(pipe::stuff_resolve, dim3(count), dim3(64), 0, wk);
+        const unsigned survey_blocks = pipe::stuff_survey_blocks(most);
+        emu::launch(pipe::stuff_survey, dim3(survey_blocks, count), dim3(64), 0, wk);
+        emu::launch(pipe::stuff_resolve, dim3(count), dim3(pipe::kStuffResolveThreads), 0, wk);
         emu::launch(pipe::stuff_emit, dim3(chunk_waves, count), dim3(64), 0, descs, wk, results);
     }
     else
@@ -188,8 +189,9 @@ void emu_stuff_raw(const uint8_t* raw, uint64_t total_bits, uint64_t raw_bytes, 
     if (blocks)
     {
         const unsigned chunk_waves = (unsigned)((raw_bytes / pipe::kStuffChunk + 1 + 63) / 64);
-        emu::launch(pipe::stuff_survey, dim3(chunk_waves, 1), dim3(64), 0, (const pipe::Work*)&w);
-        emu::launch(pipe::stuff_resolve, dim3(1), dim3(64), 0, (const pipe::Work*)&w);
+        const unsigned survey_blocks = pipe::stuff_survey_blocks(raw_bytes);
+        emu::launch(pipe::stuff_survey, dim3(survey_blocks, 1), dim3(64), 0, (const pipe::Work*)&w);
+        emu::launch(pipe::stuff_resolve, dim3(1), dim3(pipe::kStuffResolveThreads), 0, (const pipe::Work*)&w);
         emu::launch(pipe::stuff_emit, dim3(chunk_waves, 1), dim3(64), 0, (const ScanDesc*)&d, (const pipe::Work*)&w, result);
     }
     else

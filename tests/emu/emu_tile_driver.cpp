@@ -112,8 +112,9 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         for (int i = 0; i < count; ++i)
             most = std::max(most, (size_t)works[i].raw_words * 4);
         const unsigned chunk_waves = (unsigned)((most / pipe::kStuffChunk + 1 + 63) / 64);
-        emu::launch(pipe::stuff_survey, dim3(chunk_waves, count), dim3(64), 0, sk);
-        emu::launch(pipe::stuff_resolve, dim3(count), dim3(64), 0, sk);
+        const unsigned survey_blocks = pipe::stuff_survey_blocks(most);
+        emu::launch(pipe::stuff_survey, dim3(survey_blocks, count), dim3(64), 0, sk);
+        emu::launch(pipe::stuff_resolve, dim3(count), dim3(pipe::kStuffResolveThreads), 0, sk);
         emu::launch(pipe::stuff_emit, dim3(chunk_waves, count), dim3(64), 0, descs, sk, results);
     }
     else

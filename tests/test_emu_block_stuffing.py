@@ -54,6 +54,11 @@ def _streams():
     bits = np.ones(40000, dtype=np.uint8)
     bits[rng.integers(0, 40000, size=400)] = 0
     cases.append((np.packbits(bits).tobytes(), 40000 - 3))
+    # more chunks than the resolve step has lanes: every lane composes the tables of several chunks into one map, and with
+    # a 0xFF in every second or third byte the maps do not collapse to one exit state
+    for n, p_one in [(600000, 0.9), (270001, 0.97)]:
+        bits = (rng.random(n * 8) < p_one).astype(np.uint8)
+        cases.append((np.packbits(bits).tobytes(), n * 8 - int(rng.integers(0, 8))))
     return cases
 
 
