@@ -27,6 +27,7 @@ import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -270,14 +271,37 @@ def main():
 
     enc_ms, dec_ms, enc_kernel_ms, dec_kernel_ms = [], [], [], []
 
+    # The streams are final when the encoder returns: their hand-over to rank 0 starts right away, on a side stream and a
+    # thread of its own, and runs UNDER the decoder (which keeps half of the SIMDs and none of the xGMI links busy); the step
+    # ends when both are through.  (Round 3 ran it after the decoder: 7 x 30 GB landing on rank 0 behind 5.5 s of coding.)
+    gather_stream = torch.cuda.Stream(device=dev) if (use_dist and backend == "nccl") else None
+
+    def hand_over(enc, failure):
+        try:
+            if gather_stream is not None:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(gather_stream):
+                    batch.gather_streams(enc.streams, enc.sizes, dst=0, sink=lambda r, first, part, sz: None)
+                gather_stream.synchronize()
+            else:
+                batch.gather_streams(enc.streams, enc.sizes, dst=0, sink=lambda r, first, part, sz: None)
+        except BaseException as e:  # noqa: BLE001 -- re-raised by the step
+            failure.append(e)
+
     def step(timed: bool):
         t0 = time.perf_counter()
         enc = batch.encode_batch(frames, bits_per_sample=BITS, streams=streams, restart_interval=args.restart_interval, lib=lib)
         t1 = time.perf_counter()
+        failure, mover = [], None
+        if use_dist:
+            mover = threading.Thread(target=hand_over, args=(enc, failure), name="bitstream-gather")
+            mover.start()
         _, errcs, dec_t = batch.decode_batch(enc.streams, enc.sizes, out, lib=lib)
         t2 = time.perf_counter()
-        if use_dist:
-            batch.gather_streams(enc.streams, enc.sizes, dst=0, sink=lambda r, first, part, sz: None)
+        if mover is not None:
+            mover.join()
+            if failure:
+                raise failure[0]
         if timed:
             enc_ms.append((t1 - t0) * 1e3)
             dec_ms.append((t2 - t1) * 1e3)
@@ -345,10 +369,11 @@ def main():
                 traffic = int(tj["hbm_bytes_per_frame"] * frames_n)
                 traffic_source = tj.get("source")
             if tj.get("kernel") == dom_name and dom_ms > 0:
-                # instruction-issue roofline: a SIMD issues at most one vector instruction per 4 cycles (MI355X_MICROARCH.md):
-                # 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s
+                # instruction-issue roofline: the SIMDs of CDNA4 are 32 lanes wide, a wave64 vector instruction issues over TWO
+                # cycles (MI355X_MICROARCH.md, "Wave scheduling"): 1024 SIMDs x 2.4 GHz / 2 = 1228.8 G wave-instructions/s.
+                # (Round 3 divided by 4 -- the GCN figure -- and reported twice the fraction.)
                 valu = float(tj["valu_wave_instructions_per_sample"]) * frames_n * pixels
-                peak = 1024 * 2.4e9 / 4
+                peak = 1024 * 2.4e9 / 2
                 issue = {"bound": "valu_issue", "achieved": round(valu / (dom_ms * 1e-3) / 1e9, 2), "peak": round(peak / 1e9, 1),
                          "unit": "G wave-instructions/s", "frac": round(valu / (dom_ms * 1e-3) / peak, 4),
                          "valu_wave_instructions_per_sample": tj["valu_wave_instructions_per_sample"],
@@ -373,7 +398,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 4096x4096 8-bit gray lossless, batch of independent frames",
                        "frames_per_gpu": frames_n, "jls_bytes_per_frame": int(jls_bytes),
                        "sharding": (f"frames over {world} rank(s), bitstreams sent to rank 0 over "
-                                    f"{dist.get_backend() if use_dist else 'nccl'} inside the timed region") if world > 1 else "1 GPU",
+                                    f"{dist.get_backend() if use_dist else 'nccl'} inside the timed region, under the decoder") if world > 1 else "1 GPU",
                        "ranks_seen_by_backend": dist.get_world_size() if use_dist else 1,
                        "engine": args.engine, "restart_interval": args.restart_interval},
             "bit_exact_vs_reference": bit_exact,

@@ -138,4 +138,8 @@ struct Timings
 };
 Timings& last_timings() noexcept;
 
+// Process-wide totals of what the speculative stages of the lossless encoder did (tile_pipeline.hip, tile::Counter):
+// regular-chain jobs, how many of them were walked again by the settling lane, the same two for the run chain.
+void speculation_counters(uint64_t out[4]) noexcept;
+
 } // namespace jls::dev

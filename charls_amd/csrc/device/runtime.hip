@@ -124,6 +124,15 @@ Timings& last_timings() noexcept
     return t;
 }
 
+namespace {
+std::atomic<uint64_t> g_speculation[4]{};
+}
+void speculation_counters(uint64_t out[4]) noexcept
+{
+    for (int i = 0; i < 4; ++i)
+        out[i] = g_speculation[i].load();
+}
+
 void launch_encode_serial(const ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
 {
     if (count == 0)
@@ -668,19 +677,31 @@ struct PipelineLanes
 {
     hipStream_t streams[kMaxPipelineLanes]{};
     bool created = false;
-    ~PipelineLanes()
+    int device = -1; // streams belong to a device: a thread that moved on to another one gets new streams there
+    ~PipelineLanes() { destroy(); }
+    void destroy() noexcept
     {
-        if (created)
-            for (hipStream_t s : streams)
-                (void)hipStreamDestroy(s);
+        if (!created)
+            return;
+        int current = 0;
+        const bool switched = hipGetDevice(&current) == hipSuccess && current != device && hipSetDevice(device) == hipSuccess;
+        for (hipStream_t s : streams)
+            (void)hipStreamDestroy(s);
+        if (switched)
+            (void)hipSetDevice(current);
+        created = false;
     }
     void ensure()
     {
-        if (created)
+        int current = 0;
+        hip_check(hipGetDevice(&current));
+        if (created && current == device)
             return;
+        destroy();
         for (hipStream_t& s : streams)
             hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         created = true;
+        device = current;
     }
 };
 PipelineLanes& pipeline_lanes()
@@ -973,6 +994,32 @@ struct TileLayout
     }
 };
 
+// The tile kernels ask for more dynamic LDS than a kernel gets by default.  Function attributes are per DEVICE: they are set
+// once for every device this process launches the kernels on.
+void ensure_tile_attributes()
+{
+    static std::mutex guard;
+    static uint64_t done[4] = {0, 0, 0, 0}; // bitmap of devices
+    int device = 0;
+    hip_check(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(guard);
+    if (device >= 0 && device < 256 && (done[device >> 6] >> (device & 63) & 1u) != 0)
+        return;
+    const int lds = 160 * 1024;
+    auto set = [&](const void* kernel) { hip_check(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); };
+    set(reinterpret_cast<const void*>(tile::analyze_tiles<uint8_t, 0>));
+    set(reinterpret_cast<const void*>(tile::analyze_tiles<uint16_t, 0>));
+    set(reinterpret_cast<const void*>(tile::pack_tiles));
+    set(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 0>));
+    set(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 1>));
+    set(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 0>));
+    set(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 1>));
+    if (device >= 0 && device < 256)
+        done[device >> 6] |= uint64_t{1} << (device & 63);
+}
+
+constexpr size_t kCounterBytes = 256; // tile::kCounters words behind the work areas of a call
+
 template <typename S>
 void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
 {
@@ -992,7 +1039,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     const bool over_limit = g_workspace_limit.load() != 0 && budget < per_scan;
     for (; !over_limit;)
     {
-        arena = static_cast<uint8_t*>(try_ensure(pipeline_arena(), per_scan * resident));
+        arena = static_cast<uint8_t*>(try_ensure(pipeline_arena(), per_scan * resident + kCounterBytes));
         if (arena != nullptr || resident == 1)
             break;
         resident = (resident + 1) / 2;
@@ -1005,6 +1052,9 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     }
     const uint32_t passes = (count + resident - 1) / resident;
     const uint32_t per_pass = (count + passes - 1) / passes; // passes of equal size (a short last pass fills the chip badly)
+    // what the speculative stages did (tile::Counter), summed over the scans and passes of this call
+    auto* d_counters = reinterpret_cast<uint32_t*>(arena + per_scan * resident);
+    hip_check(hipMemsetAsync(d_counters, 0, kCounterBytes, stream));
     std::vector<std::vector<tile::Work>> works(passes);
     std::vector<std::vector<pipe::Work>> stuff_works(passes);
     std::vector<StageTimer> timers;
@@ -1022,19 +1072,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     }
     hipStream_t runs_stream = pipeline_lanes().streams[1];
     EventList sorted(passes), runs_coded(passes);
-    static const bool attributes_set = [] {
-        // (the sort stage asks for more than the 64 KB of LDS a kernel gets by default)
-        const int lds = 160 * 1024;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::analyze_tiles<uint8_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::analyze_tiles<uint16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::pack_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        return true;
-    }();
-    (void)attributes_set;
+    ensure_tile_attributes();
 
     for (uint32_t pass = 0; pass < passes; ++pass)
     {
@@ -1069,6 +1107,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             w.raw_words = lay.raw_bytes / 4;
             w.total_bits = reinterpret_cast<uint64_t*>(base + lay.off_bits) + copy; // (zeroed by plan_chains)
             w.status = reinterpret_cast<uint32_t*>(base + lay.off_status) + copy;
+            w.counters = d_counters;
             w.lines_per_tile = lay.lines_per_tile;
             w.tiles = lay.tiles;
             w.job_events = lay.job_events;
@@ -1159,7 +1198,11 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     }
     if (overlap_stuffing)
         hip_check(hipStreamWaitEvent(stream, stuffed[passes - 1], 0));
+    uint32_t counters[tile::kCounters] = {};
+    hip_check(hipMemcpyAsync(counters, d_counters, sizeof counters, hipMemcpyDeviceToHost, stream));
     hip_check(hipStreamSynchronize(stream)); // the host copies of the work descriptors and the timers go out of scope
+    for (uint32_t i = 0; i < tile::kCounters; ++i)
+        g_speculation[i].fetch_add(counters[i]);
     Timings& tm = last_timings();
     double stage_ms[5] = {0, 0, 0, 0, 0};
     for (StageTimer& t : timers)

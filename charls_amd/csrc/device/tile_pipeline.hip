@@ -70,6 +70,17 @@ constexpr uint32_t kPlanGroups = 16;       // plan_chains sums the tiles of a sc
 #define JLS_HOST_DEV_EARLY __host__ __device__ inline
 constexpr uint32_t kRunTag = 1u << 31;     // code word of a run-length code: ones : 6 | tail length : 5 | tail : 20
 
+// What the speculative stages did in a call (charls_amd_speculation_counters): jobs of the regular chains / of the run chain,
+// and how many of them the settling lane had to walk again because their predecessor did not end in the state they assumed.
+enum Counter : uint32_t
+{
+    kCountJobs = 0,
+    kCountJobsRewalked = 1,
+    kCountRunJobs = 2,
+    kCountRunJobsRewalked = 3,
+    kCounters = 4
+};
+
 // State of a job at its first event (after the warm-up) and behind its last one (N is a function of the event index);
 // bad: an event of the job would make the reference raise invalid_data.
 struct JobState
@@ -95,6 +106,7 @@ struct Work
     uint64_t raw_words;
     uint64_t* total_bits;
     uint32_t* status;
+    uint32_t* counters;    // [kCounters] of the CALL (shared by its scans): what the speculation did, see Counter
     // the launch's geometry (all scans of a launch share width, sample type and interleave mode; a scan may have FEWER
     // lines than the launch was sized for -- the last restart interval of a frame -- and then has fewer tiles)
     uint32_t lines_per_tile, tiles, job_events, warm_events;
@@ -1017,7 +1029,7 @@ __global__ void __launch_bounds__(64) settle_chains(const ScanDesc* __restrict__
     const uint32_t n = w.chain_total[chain];
     const uint32_t* in = w.rec + w.chain_base[chain];
     uint32_t* out = w.code + w.chain_base[chain];
-    uint32_t bad = 0;
+    uint32_t bad = 0, rewalked = 0;
     JobState prev = w.jobs[j0];
     bad |= prev.bad;
     for (uint32_t j = j0 + 1; j < j1; ++j)
@@ -1025,6 +1037,7 @@ __global__ void __launch_bounds__(64) settle_chains(const ScanDesc* __restrict__
         JobState cur = w.jobs[j];
         if (cur.in_a != prev.out_a || cur.in_b != prev.out_b || cur.in_c != prev.out_c)
         { // walk the job again from the state its predecessor really ended in
+            ++rewalked;
             const uint32_t start = (j - j0) * w.job_events;
             const uint32_t end = start + w.job_events < n ? start + w.job_events : n;
             Chain s{prev.out_a, prev.out_b, prev.out_c, chain_n_before(start, (uint32_t)t.reset), 0};
@@ -1040,6 +1053,9 @@ __global__ void __launch_bounds__(64) settle_chains(const ScanDesc* __restrict__
     }
     if (bad)
         atomicOr(w.status, kStatusInvalid);
+    atomicAdd(&w.counters[kCountJobs], j1 - j0);
+    if (rewalked)
+        atomicAdd(&w.counters[kCountJobsRewalked], rewalked);
 }
 
 // C3: the run chain.  RUNindex, the two run-interruption contexts and the slot counter of the interruption samples are a
@@ -1334,17 +1350,22 @@ __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ d
     const uint32_t n = w.chain_total[0];
     const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
     if (jobs < 2)
+    {
+        atomicAdd(&w.counters[kCountRunJobs], jobs);
         return;
+    }
     const uint32_t* runs = w.rec + w.chain_base[0];
     uint32_t* run_code = w.code + w.chain_base[0];
     uint32_t* int_code = w.code + w.chain_base[kInterruptChain];
     RunState prev = w.run_jobs[0].out;
+    uint32_t rewalked = 0;
     for (uint32_t j = 1; j < jobs; ++j)
     {
         const RunJob cur = w.run_jobs[j];
         RunState out = cur.out;
         if (!same_state(cur.in, prev))
         { // code the job again from the state its predecessor really ended in
+            ++rewalked;
             out = prev;
             const uint32_t from = j * w.run_job_events;
             const uint32_t to = from + w.run_job_events < n ? from + w.run_job_events : n;
@@ -1352,6 +1373,9 @@ __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ d
         }
         prev = out;
     }
+    atomicAdd(&w.counters[kCountRunJobs], jobs);
+    if (rewalked)
+        atomicAdd(&w.counters[kCountRunJobsRewalked], rewalked);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -170,6 +170,16 @@ uint64_t charls_amd_work_area_bytes(void)
     return dev::work_area_bytes();
 }
 
+int32_t charls_amd_speculation_counters(uint64_t* out, int32_t capacity)
+{
+    uint64_t v[4];
+    dev::speculation_counters(v);
+    int32_t n = 0;
+    for (; out != nullptr && n < capacity && n < 4; ++n)
+        out[n] = v[n];
+    return n;
+}
+
 int32_t charls_amd_last_timings(double* out, int32_t capacity)
 {
     const dev::Timings& t = dev::last_timings();

@@ -1,11 +1,17 @@
-// multi_device.cpp -- charls_amd_encode_batch_devices / charls_amd_decode_batch_devices (charls_amd.h part 2b).
+// multi_device.cpp -- several GPUs from one process (charls_amd.h part 2b): charls_amd_devices_* and the two
+// charls_amd_*_batch_devices entry points that run on the process-wide default context.
 //
 // frames are the sharding unit, there is no exchange while coding, and the only collective is the hand-over
-// of the finished bitstreams to one device.  One process drives several GPUs: a worker thread per shard binds to the
-// shard's device, owns its HIP stream and its work areas (they belong to the calling thread and remember their device),
-// and runs the single-device batch call of batch_api.cpp on the shard's frames.  The reference has no counterpart; the
-// seam is the same one as everywhere else in this library (`encode_scan` / `decode_scan` per scan,
-// src/charls_jpegls_encoder.cpp:285-296, src/charls_jpegls_decoder.cpp:186-189).
+// of the finished bitstreams to one device.  One process drives several GPUs through a CONTEXT (charls_amd_devices) that
+// lives across calls and owns
+//   * a worker thread per (device, shard ordinal on that device), bound to its device for life: the encoder's work areas
+//     belong to the thread that made them (runtime.hip), so a worker that stays keeps its areas -- the second call
+//     allocates nothing (giving ~90 GB back to the driver and asking for it again took seconds per call when every call
+//     started its own threads);
+//   * the RCCL communicator over the devices of the last gathered call and a stream per device for the exchange
+//     (ncclCommInitAll costs hundreds of milliseconds: it runs when the device list changes, not per call).
+// The reference has no counterpart; the seam is the same one as everywhere else in this library (`encode_scan` /
+// `decode_scan` per scan, src/charls_jpegls_encoder.cpp:285-296, src/charls_jpegls_decoder.cpp:186-189).
 //
 // Gather (encode only, optional): sizes are exchanged first (they are host values of this process already: the
 // all-gather of SURVEY 8e is a prefix sum here), then every non-root shard sends each of its streams -- exactly
@@ -17,7 +23,12 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -87,30 +98,206 @@ void check_shards(uint32_t shard_count, const charls_amd_device_shard* shards)
     }
 }
 
-// Runs `work(shard)` for every shard on a thread of its own, bound to the shard's device; the first error wins.
-template <typename Work>
-charls_jpegls_errc on_every_shard(uint32_t shard_count, const charls_amd_device_shard* shards, Work work)
+// A thread bound to one device for as long as the context lives.  Its thread-local work areas (the encoder's arena, the
+// interval buffers) stay allocated between tasks.
+class Worker
 {
-    std::atomic<int32_t> first_error{CHARLS_JPEGLS_ERRC_SUCCESS};
-    auto body = [&](uint32_t s) {
-        charls_jpegls_errc e = CHARLS_JPEGLS_ERRC_SUCCESS;
-        if (hipSetDevice(shards[s].device) != hipSuccess)
-            e = CHARLS_AMD_ERRC_DEVICE_UNAVAILABLE;
-        else
-            e = work(s);
-        int32_t expected = CHARLS_JPEGLS_ERRC_SUCCESS;
-        if (e != CHARLS_JPEGLS_ERRC_SUCCESS)
-            first_error.compare_exchange_strong(expected, static_cast<int32_t>(e));
-        // the work areas of this thread die with it: give the memory back while the device is still current
-        (void)charls_amd_release_work_areas();
-    };
-    std::vector<std::thread> workers;
-    workers.reserve(shard_count);
+public:
+    explicit Worker(int device) : device_(device), thread_([this] { loop(); }) {}
+    Worker(const Worker&) = delete;
+    Worker& operator=(const Worker&) = delete;
+    ~Worker()
+    {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (thread_.joinable())
+            thread_.join();
+    }
+    void submit(std::function<charls_jpegls_errc()> task)
+    {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            task_ = std::move(task);
+            pending_ = true;
+            done_ = false;
+        }
+        cv_.notify_all();
+    }
+    charls_jpegls_errc wait()
+    {
+        std::unique_lock<std::mutex> lock(m_);
+        cv_.wait(lock, [this] { return done_; });
+        return result_;
+    }
+
+private:
+    void loop()
+    {
+        const bool bound = hipSetDevice(device_) == hipSuccess;
+        for (;;)
+        {
+            std::function<charls_jpegls_errc()> task;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                cv_.wait(lock, [this] { return pending_ || stop_; });
+                if (!pending_)
+                    break; // (stop)
+                task = std::move(task_);
+                pending_ = false;
+            }
+            charls_jpegls_errc r = CHARLS_AMD_ERRC_DEVICE_UNAVAILABLE;
+            if (bound)
+            {
+                try
+                {
+                    r = task();
+                }
+                catch (...)
+                {
+                    r = current_exception_to_errc();
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                result_ = r;
+                done_ = true;
+            }
+            cv_.notify_all();
+        }
+        // this thread's work areas die with it: give the memory back while the device is still current (the thread's OWN
+        // areas -- not the process-wide pool of the host-pointer handles)
+        if (bound)
+            dev::release_work_areas();
+    }
+
+    int device_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<charls_jpegls_errc()> task_;
+    bool pending_ = false, done_ = true, stop_ = false;
+    charls_jpegls_errc result_ = CHARLS_JPEGLS_ERRC_SUCCESS;
+    std::thread thread_; // (last: it starts in the constructor)
+};
+
+} // namespace
+
+// The context: workers and the exchange's communicator, kept across calls.  One call at a time per context.
+struct charls_amd_devices
+{
+    std::mutex call;
+    std::map<std::pair<int, uint32_t>, std::unique_ptr<Worker>> workers; // (device, ordinal among the shards of that device)
+    std::vector<int> comm_devices; // devices of the cached communicator, in shard order
+    std::vector<Rccl::Comm> comms;
+    std::vector<hipStream_t> comm_streams;
+
+    Worker& worker(int device, uint32_t ordinal)
+    {
+        std::unique_ptr<Worker>& w = workers[{device, ordinal}];
+        if (!w)
+            w = std::make_unique<Worker>(device);
+        return *w;
+    }
+
+    void drop_communicator() noexcept
+    {
+        int current = 0;
+        (void)hipGetDevice(&current);
+        for (size_t s = 0; s < comm_devices.size(); ++s)
+        {
+            if (s < comm_streams.size() && comm_streams[s] != nullptr)
+            {
+                (void)hipSetDevice(comm_devices[s]);
+                (void)hipStreamDestroy(comm_streams[s]);
+            }
+            if (s < comms.size() && comms[s] != nullptr)
+                (void)rccl().comm_destroy(comms[s]);
+        }
+        comm_devices.clear();
+        comms.clear();
+        comm_streams.clear();
+        (void)hipSetDevice(current);
+    }
+
+    // Communicator and exchange streams over `devices` (shard order): made when the device list changes.
+    void ensure_communicator(const std::vector<int>& devices)
+    {
+        if (devices == comm_devices && !comms.empty())
+            return;
+        drop_communicator();
+        const Rccl& api = rccl();
+        std::vector<Rccl::Comm> made(devices.size(), nullptr);
+        if (api.comm_init_all(made.data(), static_cast<int>(devices.size()), devices.data()) != 0)
+        {
+            for (Rccl::Comm c : made)
+                if (c != nullptr)
+                    (void)api.comm_destroy(c);
+            raise(CHARLS_AMD_ERRC_DEVICE_FAILURE);
+        }
+        comm_devices = devices;
+        comms = made;
+        comm_streams.assign(devices.size(), nullptr);
+        for (size_t s = 0; s < devices.size(); ++s)
+            if (hipSetDevice(devices[s]) != hipSuccess || hipStreamCreateWithFlags(&comm_streams[s], hipStreamNonBlocking) != hipSuccess)
+            {
+                drop_communicator();
+                raise(CHARLS_AMD_ERRC_DEVICE_FAILURE);
+            }
+    }
+
+    ~charls_amd_devices()
+    {
+        drop_communicator();
+        workers.clear(); // joins the threads; each frees its work areas on its way out
+    }
+};
+
+namespace {
+
+// The context behind charls_amd_encode_batch_devices / charls_amd_decode_batch_devices and behind a NULL context argument.
+// Never destroyed by the runtime (worker threads must not outlive-or-race the HIP runtime's own teardown at exit);
+// charls_amd_devices_destroy(NULL) releases what it holds.
+std::mutex g_default_guard;
+charls_amd_devices* g_default = nullptr;
+
+charls_amd_devices& context_or_default(charls_amd_devices* ctx)
+{
+    if (ctx != nullptr)
+        return *ctx;
+    std::lock_guard<std::mutex> lock(g_default_guard);
+    if (g_default == nullptr)
+        g_default = new charls_amd_devices;
+    return *g_default;
+}
+
+// Runs `work(shard)` for every shard on the context's worker of the shard's device; the first error wins.
+template <typename Work>
+charls_jpegls_errc on_every_shard(charls_amd_devices& ctx, uint32_t shard_count, const charls_amd_device_shard* shards, Work work)
+{
+    std::vector<Worker*> used(shard_count, nullptr);
+    std::map<int, uint32_t> seen; // shards per device so far
     for (uint32_t s = 0; s < shard_count; ++s)
-        workers.emplace_back(body, s);
-    for (std::thread& t : workers)
-        t.join();
-    return static_cast<charls_jpegls_errc>(first_error.load());
+        used[s] = &ctx.worker(shards[s].device, seen[shards[s].device]++); // (may throw bad_alloc / system_error: nothing submitted yet)
+    uint32_t submitted = 0;
+    charls_jpegls_errc first_error = CHARLS_JPEGLS_ERRC_SUCCESS;
+    try
+    {
+        for (; submitted < shard_count; ++submitted)
+            used[submitted]->submit([&work, s = submitted]() -> charls_jpegls_errc { return work(s); });
+    }
+    catch (...)
+    { // (a task could not be handed over: the ones that were are still waited for -- they refer to this frame's locals)
+        first_error = current_exception_to_errc();
+    }
+    for (uint32_t s = 0; s < submitted; ++s)
+    {
+        const charls_jpegls_errc e = used[s]->wait();
+        if (first_error == CHARLS_JPEGLS_ERRC_SUCCESS)
+            first_error = e;
+    }
+    return first_error;
 }
 
 struct StreamGuard
@@ -124,10 +311,80 @@ struct StreamGuard
 
 } // namespace
 
-extern "C" charls_jpegls_errc charls_amd_encode_batch_devices(const charls_amd_codec_params* params, uint32_t shard_count,
-                                                              const charls_amd_device_shard* shards, size_t frame_pitch_bytes,
-                                                              uint32_t stride, size_t stream_pitch_bytes, uint64_t* sizes,
-                                                              charls_jpegls_errc* errcs, const charls_amd_gather* gather)
+// ---- the context API -------------------------------------------------------------------------------------------------
+
+extern "C" charls_amd_devices* charls_amd_devices_create(void)
+{
+    try
+    {
+        return new charls_amd_devices;
+    }
+    catch (...)
+    {
+        return nullptr;
+    }
+}
+
+extern "C" void charls_amd_devices_destroy(charls_amd_devices* context)
+{
+    if (context != nullptr)
+    {
+        delete context;
+        return;
+    }
+    // NULL: what the default context holds (its threads, their work areas, the communicator)
+    charls_amd_devices* d = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_default_guard);
+        d = g_default;
+        g_default = nullptr;
+    }
+    delete d;
+}
+
+extern "C" uint64_t charls_amd_devices_work_area_bytes(charls_amd_devices* context)
+try
+{
+    charls_amd_devices& ctx = context_or_default(context);
+    std::lock_guard<std::mutex> lock(ctx.call);
+    std::atomic<uint64_t> total{0};
+    for (auto& entry : ctx.workers)
+        entry.second->submit([&total]() -> charls_jpegls_errc {
+            total.fetch_add(dev::work_area_bytes());
+            return CHARLS_JPEGLS_ERRC_SUCCESS;
+        });
+    for (auto& entry : ctx.workers)
+        (void)entry.second->wait();
+    return total.load();
+}
+catch (...)
+{
+    return 0;
+}
+
+extern "C" charls_jpegls_errc charls_amd_devices_release_work_areas(charls_amd_devices* context)
+try
+{
+    charls_amd_devices& ctx = context_or_default(context);
+    std::lock_guard<std::mutex> lock(ctx.call);
+    for (auto& entry : ctx.workers)
+        entry.second->submit([]() -> charls_jpegls_errc {
+            dev::release_work_areas();
+            return CHARLS_JPEGLS_ERRC_SUCCESS;
+        });
+    for (auto& entry : ctx.workers)
+        (void)entry.second->wait();
+    return CHARLS_JPEGLS_ERRC_SUCCESS;
+}
+catch (...)
+{
+    return current_exception_to_errc();
+}
+
+extern "C" charls_jpegls_errc charls_amd_devices_encode_batch(charls_amd_devices* context, const charls_amd_codec_params* params,
+                                                              uint32_t shard_count, const charls_amd_device_shard* shards,
+                                                              size_t frame_pitch_bytes, uint32_t stride, size_t stream_pitch_bytes,
+                                                              uint64_t* sizes, charls_jpegls_errc* errcs, const charls_amd_gather* gather)
 try
 {
     check_pointer(params);
@@ -135,13 +392,15 @@ try
     check_pointer(errcs);
     dev::require_device();
     check_shards(shard_count, shards);
+    charls_amd_devices& ctx = context_or_default(context);
+    std::lock_guard<std::mutex> lock(ctx.call);
     std::vector<uint64_t> first(shard_count + 1, 0);
     for (uint32_t s = 0; s < shard_count; ++s)
         first[s + 1] = first[s] + shards[s].frame_count;
     int caller_device = 0;
     (void)hipGetDevice(&caller_device);
 
-    const charls_jpegls_errc coded = on_every_shard(shard_count, shards, [&](uint32_t s) -> charls_jpegls_errc {
+    const charls_jpegls_errc coded = on_every_shard(ctx, shard_count, shards, [&](uint32_t s) -> charls_jpegls_errc {
         const charls_amd_device_shard& sh = shards[s];
         if (sh.frame_count == 0)
             return CHARLS_JPEGLS_ERRC_SUCCESS;
@@ -149,7 +408,6 @@ try
         return charls_amd_encode_batch_device(params, sh.frame_count, sh.d_frames, frame_pitch_bytes, stride, sh.d_streams,
                                               stream_pitch_bytes, sizes + first[s], errcs + first[s], stream);
     });
-    (void)hipSetDevice(caller_device);
     if (coded != CHARLS_JPEGLS_ERRC_SUCCESS || gather == nullptr)
         return coded;
 
@@ -179,6 +437,11 @@ try
     if (gather->transport == CHARLS_AMD_TRANSPORT_RCCL && !use_rccl)
         raise(CHARLS_AMD_ERRC_DEVICE_FAILURE); // RCCL was asked for and is not usable here
 
+    struct RestoreDevice
+    {
+        int device;
+        ~RestoreDevice() { (void)hipSetDevice(device); }
+    } restore{caller_device};
     // the root's own streams: copies on its device
     hip_check(hipSetDevice(root_device));
     {
@@ -194,15 +457,10 @@ try
             std::vector<int> devices(shard_count);
             for (uint32_t s = 0; s < shard_count; ++s)
                 devices[s] = shards[s].device;
-            std::vector<Rccl::Comm> comms(shard_count, nullptr);
-            if (api.comm_init_all(comms.data(), static_cast<int>(shard_count), devices.data()) != 0)
-                raise(CHARLS_AMD_ERRC_DEVICE_FAILURE);
-            std::vector<hipStream_t> streams(shard_count, nullptr);
+            ctx.ensure_communicator(devices);
+            const std::vector<Rccl::Comm>& comms = ctx.comms;
+            const std::vector<hipStream_t>& streams = ctx.comm_streams;
             bool failed = false;
-            for (uint32_t s = 0; s < shard_count && !failed; ++s)
-            {
-                failed = hipSetDevice(devices[s]) != hipSuccess || hipStreamCreateWithFlags(&streams[s], hipStreamNonBlocking) != hipSuccess;
-            }
             // one grouped send / receive pair per frame, in rounds of 64 frames per peer (point-to-point over xGMI)
             constexpr uint64_t kRound = 64;
             for (uint64_t r0 = 0; !failed; r0 += kRound)
@@ -233,18 +491,15 @@ try
             }
             for (uint32_t s = 0; s < shard_count; ++s)
             {
-                if (streams[s] != nullptr)
-                {
-                    (void)hipSetDevice(devices[s]);
-                    failed = hipStreamSynchronize(streams[s]) != hipSuccess || failed;
-                    (void)hipStreamDestroy(streams[s]);
-                }
-                if (comms[s] != nullptr)
-                    (void)api.comm_destroy(comms[s]);
+                (void)hipSetDevice(devices[s]);
+                failed = hipStreamSynchronize(streams[s]) != hipSuccess || failed;
             }
             (void)hipSetDevice(root_device);
             if (failed)
+            {
+                ctx.drop_communicator(); // (its state after a failed group is unknown: the next call starts a new one)
                 raise(CHARLS_AMD_ERRC_DEVICE_FAILURE);
+            }
         }
         else
         {
@@ -261,7 +516,6 @@ try
         }
         hip_check(hipStreamSynchronize(own.s));
     }
-    (void)hipSetDevice(caller_device);
     if (gather->total_bytes != nullptr)
         *gather->total_bytes = at;
     return CHARLS_JPEGLS_ERRC_SUCCESS;
@@ -271,9 +525,9 @@ catch (...)
     return current_exception_to_errc();
 }
 
-extern "C" charls_jpegls_errc charls_amd_decode_batch_devices(uint32_t shard_count, const charls_amd_device_shard* shards,
-                                                              size_t stream_pitch_bytes, const uint64_t* sizes,
-                                                              size_t frame_pitch_bytes, uint32_t stride,
+extern "C" charls_jpegls_errc charls_amd_devices_decode_batch(charls_amd_devices* context, uint32_t shard_count,
+                                                              const charls_amd_device_shard* shards, size_t stream_pitch_bytes,
+                                                              const uint64_t* sizes, size_t frame_pitch_bytes, uint32_t stride,
                                                               charls_amd_codec_params* params_out, charls_jpegls_errc* errcs)
 try
 {
@@ -281,13 +535,13 @@ try
     check_pointer(errcs);
     dev::require_device();
     check_shards(shard_count, shards);
+    charls_amd_devices& ctx = context_or_default(context);
+    std::lock_guard<std::mutex> lock(ctx.call);
     std::vector<uint64_t> first(shard_count + 1, 0);
     for (uint32_t s = 0; s < shard_count; ++s)
         first[s + 1] = first[s] + shards[s].frame_count;
-    int caller_device = 0;
-    (void)hipGetDevice(&caller_device);
     std::vector<charls_amd_codec_params> found(shard_count);
-    const charls_jpegls_errc coded = on_every_shard(shard_count, shards, [&](uint32_t s) -> charls_jpegls_errc {
+    const charls_jpegls_errc coded = on_every_shard(ctx, shard_count, shards, [&](uint32_t s) -> charls_jpegls_errc {
         const charls_amd_device_shard& sh = shards[s];
         if (sh.frame_count == 0)
             return CHARLS_JPEGLS_ERRC_SUCCESS;
@@ -296,7 +550,6 @@ try
                                               const_cast<void*>(sh.d_frames), frame_pitch_bytes, stride, &found[s], errcs + first[s],
                                               static_cast<hipStream_t>(sh.hip_stream));
     });
-    (void)hipSetDevice(caller_device);
     if (params_out != nullptr)
         for (uint32_t s = 0; s < shard_count; ++s)
             if (shards[s].frame_count != 0)
@@ -309,4 +562,23 @@ try
 catch (...)
 {
     return current_exception_to_errc();
+}
+
+// ---- the same two calls on the process-wide default context
+extern "C" charls_jpegls_errc charls_amd_encode_batch_devices(const charls_amd_codec_params* params, uint32_t shard_count,
+                                                              const charls_amd_device_shard* shards, size_t frame_pitch_bytes,
+                                                              uint32_t stride, size_t stream_pitch_bytes, uint64_t* sizes,
+                                                              charls_jpegls_errc* errcs, const charls_amd_gather* gather)
+{
+    return charls_amd_devices_encode_batch(nullptr, params, shard_count, shards, frame_pitch_bytes, stride, stream_pitch_bytes, sizes,
+                                           errcs, gather);
+}
+
+extern "C" charls_jpegls_errc charls_amd_decode_batch_devices(uint32_t shard_count, const charls_amd_device_shard* shards,
+                                                              size_t stream_pitch_bytes, const uint64_t* sizes,
+                                                              size_t frame_pitch_bytes, uint32_t stride,
+                                                              charls_amd_codec_params* params_out, charls_jpegls_errc* errcs)
+{
+    return charls_amd_devices_decode_batch(nullptr, shard_count, shards, stream_pitch_bytes, sizes, frame_pitch_bytes, stride, params_out,
+                                           errcs);
 }

@@ -338,8 +338,8 @@ CHARLS_AMD_API charls_jpegls_errc charls_amd_decode_batch_device(uint32_t frame_
  * Part 2b -- several GPUs from one process (frames are the sharding unit; no exchange while coding; the only
  * collective is the hand-over of the finished bitstreams).  The frames of a batch are dealt to shards; shard s lives on
  * device shards[s].device with its frames and its stream slots in that device's memory, at the pitches given to the call.
- * A worker thread per shard binds to the device and runs charls_amd_encode_batch_device / _decode_batch_device on the
- * shard; sizes / errcs are HOST arrays over all frames in shard order (shard 0's frames first).  Every frame gets exactly
+ * A worker thread per shard, bound to the shard's device, runs charls_amd_encode_batch_device / _decode_batch_device on the
+ * shard (the threads belong to a context that lives across calls, see charls_amd_devices below); sizes / errcs are HOST arrays over all frames in shard order (shard 0's frames first).  Every frame gets exactly
  * the bytes and the errc of part 1, whatever the number of shards.
  *
  * encode, gather != NULL: after coding, every shard's streams are brought together, back to back and in frame order, in
@@ -385,6 +385,28 @@ CHARLS_AMD_API charls_jpegls_errc charls_amd_decode_batch_devices(uint32_t shard
                                                                   size_t frame_pitch_bytes, uint32_t stride,
                                                                   charls_amd_codec_params* params_out, charls_jpegls_errc* errcs);
 
+/* The context behind the two calls above.  It lives across calls and owns a worker thread per (device, shard ordinal on
+ * that device), bound to its device for life -- the encoder's work areas belong to the thread that made them, so a second
+ * call of the same shape allocates nothing -- and the RCCL communicator and exchange streams of the last gathered call
+ * (re-made only when the list of devices changes).  One call at a time per context; different contexts are independent.
+ * charls_amd_encode_batch_devices / charls_amd_decode_batch_devices run on a process-wide default context, which is also
+ * what a NULL `context` argument means below; charls_amd_devices_destroy(NULL) releases everything the default context
+ * holds (its threads end, their work areas are freed, the communicator is destroyed). */
+typedef struct charls_amd_devices charls_amd_devices;
+CHARLS_AMD_API charls_amd_devices* charls_amd_devices_create(void); /* NULL when out of memory */
+CHARLS_AMD_API void charls_amd_devices_destroy(charls_amd_devices* context);
+CHARLS_AMD_API charls_jpegls_errc charls_amd_devices_encode_batch(charls_amd_devices* context, const charls_amd_codec_params* params,
+                                                                  uint32_t shard_count, const charls_amd_device_shard* shards,
+                                                                  size_t frame_pitch_bytes, uint32_t stride,
+                                                                  size_t stream_pitch_bytes, uint64_t* sizes,
+                                                                  charls_jpegls_errc* errcs, const charls_amd_gather* gather);
+CHARLS_AMD_API charls_jpegls_errc charls_amd_devices_decode_batch(charls_amd_devices* context, uint32_t shard_count,
+                                                                  const charls_amd_device_shard* shards, size_t stream_pitch_bytes,
+                                                                  const uint64_t* sizes, size_t frame_pitch_bytes, uint32_t stride,
+                                                                  charls_amd_codec_params* params_out, charls_jpegls_errc* errcs);
+CHARLS_AMD_API uint64_t charls_amd_devices_work_area_bytes(charls_amd_devices* context); /* HBM held by the context's workers */
+CHARLS_AMD_API charls_jpegls_errc charls_amd_devices_release_work_areas(charls_amd_devices* context); /* (the threads stay) */
+
 /* Extension: restart intervals on the encoder of part 1.  `lines` rows per interval (0 = none, the default) are coded
  * independently -- by different wavefronts at the same time -- and separated by RSTm markers; a DRI segment announces
  * the interval.  The reference's encoder has no equivalent (its output never contains restart markers); its decoder
@@ -414,6 +436,14 @@ CHARLS_AMD_API uint64_t charls_amd_work_area_bytes(void);              /* the ca
 /* Milliseconds of GPU time (hipEvent) the last batch call on this thread spent in its kernels, by stage:
  * out[0] total, out[1] dominant kernel, out[2..7] stage breakdown. Returns the number of values. */
 CHARLS_AMD_API int32_t charls_amd_last_timings(double* out, int32_t capacity);
+
+/* The lossless encoder codes the chain of every context in JOBS that start from a guessed state and are checked against
+ * their predecessors afterwards; a job whose guess was wrong is coded again from the true state, so the bytes
+ * never depend on the guesses -- only the time does.  Process-wide totals since the library was loaded:
+ * out[0] jobs of the regular chains, out[1] how many of them were coded again, out[2] / out[3] the same for the run
+ * chain.  Frames whose jobs are mostly coded again (full-range noise) encode at the speed of one lane per chain: a caller
+ * can tell from these counters.  Returns the number of values written (4 at most). */
+CHARLS_AMD_API int32_t charls_amd_speculation_counters(uint64_t* out, int32_t capacity);
 
 /* 0 when a gfx950 device is usable, otherwise CHARLS_AMD_ERRC_DEVICE_UNAVAILABLE. */
 CHARLS_AMD_API charls_jpegls_errc charls_amd_device_status(void);

@@ -15,6 +15,8 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 #include <cstring>
 #include <vector>
 
+static uint32_t g_counters[jls::tile::kCounters]; // of the last emu_encode_tile_pipeline call
+
 // The tile pipeline (tile_pipeline.hip), kernel by kernel, in the order and with the launch geometry runtime.hip uses.
 // job_events / warm_events as given: the tests use small values so that small images have many jobs, and warm-ups too
 // short to converge so that settle_chains has to walk jobs again.
@@ -44,6 +46,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         allocs.push_back(q);
         return q;
     };
+    std::memset(g_counters, 0, sizeof g_counters);
     for (int i = 0; i < count; ++i)
     {
         tile::Work& w = works[i];
@@ -67,6 +70,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         w.raw_words = raw_bytes / 4;
         w.total_bits = (uint64_t*)galloc(8);
         w.status = (uint32_t*)galloc(4);
+        w.counters = g_counters;
         w.lines_per_tile = lines_per_tile;
         w.tiles = tiles;
         w.job_events = job_events;
@@ -132,6 +136,12 @@ void emu_encode_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         emu_tile_pipeline<uint16_t>(descs, results, count, job_events, warm_events, run_job_events, run_warm_events, run_long_warm_events);
     else
         emu_tile_pipeline<uint8_t>(descs, results, count, job_events, warm_events, run_job_events, run_warm_events, run_long_warm_events);
+}
+
+void emu_tile_counters(uint32_t* out)
+{
+    for (uint32_t i = 0; i < jls::tile::kCounters; ++i)
+        out[i] = g_counters[i];
 }
 
 size_t emu_sizeof_scan_desc() { return sizeof(jls::ScanDesc); }

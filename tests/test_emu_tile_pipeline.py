@@ -289,3 +289,22 @@ def test_tile_pipeline_run_chain_in_jobs(run_job, run_warm, run_long):
     pc16 = jls_container.validated_pc((0,) * 5, 16, 0)
     (errc, flags, data), = _encode_planes([wide], w, h, 16, pc16, w * h * 4 + 1024, runs=(run_job, run_warm, run_long))
     assert errc == 0 and data == _scan_bytes(ob.encode(wide, width=w, height=h, bits_per_sample=16))
+
+
+def test_tile_pipeline_counts_the_jobs_it_had_to_walk_again():
+    """The counters behind charls_amd_speculation_counters: with no warm-up every job guesses the initial state, so jobs are
+    walked again; with a warm-up longer than the chains nothing is."""
+    import ctypes as C
+    L = emu_bind.tile_lib()
+    img = synth.frame_numpy(300, 40, seed=3, kind="gradient")
+    pc = jls_container.validated_pc((0,) * 5, 8, 0)
+    want = _scan_bytes(ob.encode(img, width=300, height=40))
+    out = (C.c_uint32 * 4)()
+    (errc, flags, data), = _encode_planes([img], 300, 40, 8, pc, 300 * 40 * 2 + 1024, job=16, warm=0, runs=(32, 0, 0))
+    assert errc == 0 and data == want
+    L.emu_tile_counters(out)
+    assert out[0] > 100 and out[1] > 10 and out[2] >= 1
+    (errc, flags, data), = _encode_planes([img], 300, 40, 8, pc, 300 * 40 * 2 + 1024, job=1024, warm=1 << 20, runs=(2048, 2048, 32768))
+    assert errc == 0 and data == want
+    L.emu_tile_counters(out)
+    assert out[0] > 0 and out[1] == 0 and out[3] == 0
