@@ -931,24 +931,26 @@ bool tile_pipeline_enabled()
 
 bool tile_pipeline_eligible(const ScanDesc& d)
 {
-    return tile_pipeline_enabled() && d.interleave_mode != 2 &&
-           d.width <= (d.bits_per_sample > 8 ? tile::kMaxTileSamples / 2 : tile::kMaxTileSamples);
+    // (pixel mode takes sample-interleaved scans and lines of any width; what stays out: nothing the pipeline is eligible for)
+    return tile_pipeline_enabled();
 }
 
 // Work area of one scan: 10 B per sample (key / slot 2, record 4, code 4), the (tiles + 1) x 367 piece table, the job
 // states and the unstuffed stream.
 struct TileLayout
 {
+    tile::TilePlan plan;
     size_t samples, lines, raw_bytes, max_jobs, max_run_jobs;
     uint32_t lines_per_tile, tiles, job_events, warm_events, run_job_events, run_warm_events, run_long_warm_events;
     size_t off_keyinv, off_seg, off_total, off_base, off_jobfirst, off_rec, off_code, off_jobs, off_runjobs, off_bbase, off_raw,
         off_bits, off_status, off_stuff, bytes;
     TileLayout(const ScanDesc& d, size_t capacity_hint, uint32_t count)
     {
-        lines = static_cast<size_t>(d.height) * (d.interleave_mode == 1 ? static_cast<size_t>(d.components) : 1);
-        samples = static_cast<size_t>(d.width) * lines;
-        lines_per_tile = tile::lines_per_tile_for(d.width, d.bits_per_sample > 8 ? 2u : 1u);
-        tiles = static_cast<uint32_t>((lines + lines_per_tile - 1) / lines_per_tile);
+        plan = tile::plan_tiles(d);
+        lines = plan.lines;
+        samples = static_cast<size_t>(plan.samples);
+        lines_per_tile = plan.lines_per_tile;
+        tiles = plan.tiles;
         // Jobs: every job pays warm_events of warm-up, so long jobs are cheaper; but ONE frame needs thousands of lanes to
         // fill the chip.  Aim at a quarter of a million lanes per launch, between 1024 and 8192 events per job.
         const char* env_job = std::getenv("CHARLS_AMD_JOB_EVENTS");
@@ -968,7 +970,7 @@ struct TileLayout
         const char* env_run_long = std::getenv("CHARLS_AMD_RUN_LONG_WARM_EVENTS");
         run_long_warm_events = env_run_long ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_long))) : 32768u;
         max_run_jobs = samples / run_job_events + 1;
-        const size_t worst = worst_case_scan_bytes(d.width, static_cast<uint32_t>(lines), 1, d.bits_per_sample);
+        const size_t worst = worst_case_scan_bytes(plan.line_samples, static_cast<uint32_t>(lines), 1, d.bits_per_sample);
         raw_bytes = align_up((capacity_hint < worst ? capacity_hint : worst) + 64, 16);
         size_t o = 0;
         auto take = [&](size_t n) {
@@ -1014,6 +1016,10 @@ void ensure_tile_attributes()
     set(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 1>));
     set(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 0>));
     set(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 1>));
+    set(reinterpret_cast<const void*>(tile::analyze_pixel_tiles<uint8_t>));
+    set(reinterpret_cast<const void*>(tile::analyze_pixel_tiles<uint16_t>));
+    set(reinterpret_cast<const void*>(tile::sort_pixel_tiles<uint8_t>));
+    set(reinterpret_cast<const void*>(tile::sort_pixel_tiles<uint16_t>));
     if (device >= 0 && device < 256)
         done[device >> 6] |= uint64_t{1} << (device & 63);
 }
@@ -1112,6 +1118,9 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             w.tiles = lay.tiles;
             w.job_events = lay.job_events;
             w.warm_events = lay.warm_events;
+            w.segs_per_line = lay.plan.segs_per_line;
+            w.seg_pixels = lay.plan.seg_pixels;
+            w.tile_capacity = lay.plan.tile_capacity;
             pipe::Work& sw = stuff_works[pass][i];
             std::memset(&sw, 0, sizeof sw);
             sw.raw = w.raw;
@@ -1125,18 +1134,26 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
 
         const ScanDesc* descs = d_descs + first;
         const uint32_t tiles_grid = 8 * ((lay.tiles + 7) / 8);
-        const size_t lds_a = tile::analyze_lds_bytes(proto.width, lay.lines_per_tile, sizeof(S), proto.interleave_mode);
-        const size_t lds_b = tile::sort_lds_bytes(proto.width, lay.lines_per_tile, sizeof(S), proto.interleave_mode);
+        const tile::TilePlan& plan = lay.plan;
+        const bool pixel_mode = plan.mode == 2;
+        const size_t lds_a = pixel_mode ? tile::analyze_pixel_lds_bytes(plan.lines_per_tile, plan.max_pixels, plan.nc, sizeof(S), plan.tile_capacity)
+                                        : tile::analyze_lds_bytes(proto.width, lay.lines_per_tile, sizeof(S), proto.interleave_mode);
+        const size_t lds_b = pixel_mode ? tile::sort_pixel_lds_bytes(plan.lines_per_tile, plan.max_pixels, plan.nc, sizeof(S), plan.tile_capacity)
+                                        : tile::sort_lds_bytes(proto.width, lay.lines_per_tile, sizeof(S), proto.interleave_mode);
         timers.emplace_back(s);
         StageTimer& t = timers.back();
         t.mark();
-        if (proto.interleave_mode == 1)
+        if (pixel_mode)
+            hipLaunchKernelGGL((tile::analyze_pixel_tiles<S>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_a, s, descs, d_works);
+        else if (proto.interleave_mode == 1)
             hipLaunchKernelGGL((tile::analyze_tiles<S, 1>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_a, s, descs, d_works);
         else
             hipLaunchKernelGGL((tile::analyze_tiles<S, 0>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_a, s, descs, d_works);
         t.mark();
         hipLaunchKernelGGL(tile::plan_chains, dim3(n), dim3(1024), 0, s, descs, d_works);
-        if (proto.interleave_mode == 1)
+        if (pixel_mode)
+            hipLaunchKernelGGL((tile::sort_pixel_tiles<S>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_b, s, descs, d_works);
+        else if (proto.interleave_mode == 1)
             hipLaunchKernelGGL((tile::sort_tiles<S, 1>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_b, s, descs, d_works);
         else
             hipLaunchKernelGGL((tile::sort_tiles<S, 0>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_b, s, descs, d_works);
@@ -1148,18 +1165,29 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         {
             const uint32_t run_jobs = static_cast<uint32_t>(lay.max_run_jobs);
             const dim3 lanes((static_cast<uint64_t>(run_jobs) * n + 63) / 64);
-            hipLaunchKernelGGL((tile::count_runs<S>), dim3(std::min<uint32_t>(run_jobs, 32), n), dim3(64), 0, runs_stream, d_works);
-            hipLaunchKernelGGL(tile::scan_runs, dim3(n), dim3(64), 0, runs_stream, d_works);
-            if (proto.interleave_mode == 1)
-            {
-                hipLaunchKernelGGL((tile::walk_run_jobs<S, 1>), lanes, dim3(64), 0, runs_stream, descs, d_works, n);
-                hipLaunchKernelGGL((tile::settle_runs<S, 1>), dim3((n + 63) / 64), dim3(64), 0, runs_stream, descs, d_works, n);
-            }
+            const dim3 count_grid(std::min<uint32_t>(run_jobs, 32), n), settle_grid((n + 63) / 64);
+            if (pixel_mode)
+                hipLaunchKernelGGL((tile::count_runs<S, 1>), count_grid, dim3(64), 0, runs_stream, d_works, plan.nc);
             else
-            {
-                hipLaunchKernelGGL((tile::walk_run_jobs<S, 0>), lanes, dim3(64), 0, runs_stream, descs, d_works, n);
-                hipLaunchKernelGGL((tile::settle_runs<S, 0>), dim3((n + 63) / 64), dim3(64), 0, runs_stream, descs, d_works, n);
-            }
+                hipLaunchKernelGGL((tile::count_runs<S, 0>), count_grid, dim3(64), 0, runs_stream, d_works, 1u);
+            hipLaunchKernelGGL(tile::scan_runs, dim3(n), dim3(64), 0, runs_stream, d_works);
+#define JLS_RUN_CHAIN(ILV, FMT)                                                                                          \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        hipLaunchKernelGGL((tile::walk_run_jobs<S, ILV, FMT>), lanes, dim3(64), 0, runs_stream, descs, d_works, n);      \
+        hipLaunchKernelGGL((tile::settle_runs<S, ILV, FMT>), settle_grid, dim3(64), 0, runs_stream, descs, d_works, n);  \
+    } while (0)
+            if (!pixel_mode && proto.interleave_mode == 1)
+                JLS_RUN_CHAIN(1, 0);
+            else if (!pixel_mode)
+                JLS_RUN_CHAIN(0, 0);
+            else if (proto.interleave_mode == 2)
+                JLS_RUN_CHAIN(2, 1);
+            else if (proto.interleave_mode == 1)
+                JLS_RUN_CHAIN(1, 1);
+            else
+                JLS_RUN_CHAIN(0, 1);
+#undef JLS_RUN_CHAIN
         }
         hip_check(hipEventRecord(runs_coded[pass], runs_stream));
         hipLaunchKernelGGL((tile::walk_jobs<S>), dim3(static_cast<uint32_t>((lay.max_jobs + 63) / 64), n), dim3(64), 0, s, descs, d_works);
@@ -1170,7 +1198,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
         hipLaunchKernelGGL(tile::clear_pack_state, dim3(1, n), dim3(256), 0, s, d_works,
                            static_cast<uint32_t>(static_cast<size_t>(lay.tiles) * 16));
-        hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::kPackThreads), tile::pack_lds_bytes(proto.width, lay.lines_per_tile, proto.bits_per_sample), s,
+        hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::kPackThreads), tile::pack_lds_bytes(lay.plan.tile_capacity, proto.bits_per_sample), s,
                            descs, d_works);
         t.mark();
         if (overlap_stuffing)
@@ -1230,7 +1258,7 @@ bool pipeline_eligible(const ScanDesc& d) noexcept
     if (!planar && !interleaved)
         return false;
     const uint64_t samples = static_cast<uint64_t>(d.width) * d.height * static_cast<uint64_t>(d.components);
-    if (samples >= (uint64_t{1} << 31) || d.width > 65536)
+    if (samples >= (uint64_t{1} << 31))
         return false;
     if (d.reset == 0 && samples >= (uint64_t{1} << 23))
         return false; // N never halves (RESET = 256 m through the reference's uint8): it would outgrow the 24-bit multiplies of the chain stage

@@ -111,6 +111,9 @@ struct Work
     // lines than the launch was sized for -- the last restart interval of a frame -- and then has fewer tiles)
     uint32_t lines_per_tile, tiles, job_events, warm_events;
     uint32_t run_job_events, run_warm_events, run_long_warm_events; // (run_job_events: a multiple of 8)
+    // lines that do not fit a tile are cut into segs_per_line tiles of seg_pixels pixels (a multiple of 64; the last one
+    // shorter), lines_per_tile is then 1; otherwise segs_per_line = 1.  tile_capacity: samples of a tile at most.
+    uint32_t segs_per_line, seg_pixels, tile_capacity;
 };
 
 JLS_DEV uint32_t tile_of_block(uint32_t block, uint32_t tiles) // XCD-aware: workgroup b runs on XCD b % 8; each XCD gets a band of tiles
@@ -126,7 +129,39 @@ JLS_DEV uint32_t scan_lines(const ScanDesc& d)
 }
 JLS_DEV uint32_t scan_tiles(const ScanDesc& d, const Work& w) // tiles of THIS scan (<= w.tiles)
 {
-    return (scan_lines(d) + w.lines_per_tile - 1) / w.lines_per_tile;
+    return (scan_lines(d) + w.lines_per_tile - 1) / w.lines_per_tile * w.segs_per_line;
+}
+// Samples per pixel of a coded line: the components of a sample-interleaved scan are coded pixel by pixel, component by
+// component (src/scan_encoder_impl.hpp:147-246), so its "line" is width * components samples long.
+JLS_DEV uint32_t samples_per_pixel(const ScanDesc& d)
+{
+    return d.interleave_mode == 2 ? (uint32_t)d.components : 1u;
+}
+// The samples of a tile in raster order of the scan: [first, first + count).
+struct TileSpan
+{
+    uint64_t first;
+    uint32_t count;
+};
+JLS_DEV TileSpan tile_span(const ScanDesc& d, const Work& w, uint32_t tile)
+{
+    const uint32_t nc = samples_per_pixel(d), line_samples = d.width * nc, lines = scan_lines(d);
+    TileSpan s;
+    if (w.segs_per_line == 1)
+    {
+        const uint32_t first_line = tile * w.lines_per_tile;
+        const uint32_t tile_lines = lines - first_line < w.lines_per_tile ? lines - first_line : w.lines_per_tile;
+        s.first = (uint64_t)first_line * line_samples;
+        s.count = tile_lines * line_samples;
+    }
+    else
+    {
+        const uint32_t line = tile / w.segs_per_line, px0 = (tile % w.segs_per_line) * w.seg_pixels;
+        const uint32_t pixels = d.width - px0 < w.seg_pixels ? d.width - px0 : w.seg_pixels;
+        s.first = (uint64_t)line * line_samples + (uint64_t)px0 * nc;
+        s.count = pixels * nc;
+    }
+    return s;
 }
 
 // How the wavefronts of a tile workgroup share a tile: every line is cut into `pieces` runs of chunks (64 samples), a
@@ -808,6 +843,12 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     }
 }
 
+} // namespace tile
+} // namespace jls
+#include "tile_pixel_mode.hip"
+namespace jls {
+namespace tile {
+
 // ---------------------------------------------------------------------------------------------------------------
 // C: the regular-mode recurrence, src/scan_encoder_core.hpp:40-103 + src/regular_mode_context.hpp:45-136, one event.
 struct Chain
@@ -1097,14 +1138,90 @@ JLS_DEV uint32_t run_word(int ones, int tail_len, uint32_t tail)
 // interruption sample to the next slot of chain kInterruptChain: its events are these samples, in this order).
 // kOnly = 0 / 1: only the interruptions of that type are looked at, and only their context moves (the long warm-up of the
 // rarer context, see walk_run_jobs); -1: everything.
-template <typename S, int ILV, bool kStore, int kOnly = -1>
+// FMT = 1: the records of pixel mode (RunRecord2): error value and type of an interruption sample with a slot of its own are
+// the record of that slot (int_rec, in the order of the slots); a sample-interleaved scan (ILV = 2) codes the `nc`
+// components of an interruption pixel one after the other on run context 0 (src/scan_encoder_impl.hpp:277-302).
+template <typename S, int ILV, bool kStore, int kOnly = -1, int FMT = 0>
 JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code, uint32_t* int_code, uint32_t from, uint32_t to,
-                       RunState& s, uint32_t type0, uint32_t type1, uint32_t own_slot)
+                       RunState& s, uint32_t type0, uint32_t type1, uint32_t own_slot, const uint32_t* int_rec = nullptr, uint32_t nc = 1)
 {
     RunCtx rc0{0, s.a0, chain_n_before(type0, (uint32_t)t.reset), s.nn0};
     RunCtx rc1{1, s.a1, chain_n_before(type1, (uint32_t)t.reset), s.nn1};
     uint32_t run_index_packed = s.index;
     auto one = [&](uint32_t v) -> uint32_t {
+        if (FMT == 1)
+        {
+            const bool eol = RunRecord2::is_end_of_line(v), zero = RunRecord2::is_zero_run(v);
+            if (kOnly >= 0)
+            { // (single-component lines only: the context of one interruption type alone)
+                if (!eol)
+                {
+                    const uint32_t mine = own_slot;
+                    own_slot += zero ? 0u : 1u;
+                    if (RunRecord2::which(v) == kOnly)
+                    {
+                        RunCtx& ctx = kOnly ? rc1 : rc0;
+                        const int err = RunRecord2::err(zero ? v : int_rec[mine]);
+                        const int k = run_k(ctx);
+                        const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - run_map(ctx, err, k);
+                        run_update(ctx, err, em, t.reset);
+                    }
+                }
+                return 0u;
+            }
+            uint32_t run = RunRecord2::run(v);
+            const uint32_t shift = ILV == 1 ? RunRecord2::component(v) * 8u : 0u;
+            int run_index = (int)((run_index_packed >> shift) & 0xFFu);
+            int ones = 0;
+            while (run >= (1u << run_j(run_index)))
+            {
+                ++ones;
+                run -= 1u << run_j(run_index);
+                if (run_index < 31)
+                    ++run_index;
+            }
+            uint32_t word;
+            if (eol)
+            {
+                if (run != 0)
+                    ++ones;
+                word = run_word(ones, 0, 0);
+            }
+            else
+            {
+                const int jb = run_j(run_index);
+                word = run_word(ones, jb + 1, run);
+                for (uint32_t c = 0; c < (ILV == 2 ? nc : 1u); ++c)
+                {
+                    const bool shares = zero && c == 0; // the run's own sample: both codes in one word
+                    const uint32_t ir = shares ? v : int_rec[own_slot];
+                    const int which = ILV == 2 ? 0 : RunRecord2::which(v);
+                    const int err = RunRecord2::err(ir);
+                    RunCtx ctx = which ? rc1 : rc0;
+                    const int k = run_k(ctx);
+                    const int map = run_map(ctx, err, k);
+                    const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - map;
+                    const pipe::CodeWord cw = pipe::golomb_word(t, k, em, t.limit - jb - 1);
+                    run_update(ctx, err, em, t.reset);
+                    if (which)
+                        rc1 = ctx;
+                    else
+                        rc0 = ctx;
+                    if (shares) // J + 1 zero bits, then the interruption code (<= LIMIT bits in all)
+                        word = ((uint32_t)(jb + 1 + cw.len) << 24) | (uint32_t)cw.bits;
+                    else
+                    {
+                        if (kStore)
+                            int_code[own_slot] = ((uint32_t)cw.len << 24) | (uint32_t)cw.bits;
+                        ++own_slot;
+                    }
+                }
+                if (run_index > 0)
+                    --run_index;
+            }
+            run_index_packed = (run_index_packed & ~(0xFFu << shift)) | ((uint32_t)run_index << shift);
+            return word;
+        }
         if (kOnly >= 0)
         { // the context of one type alone: it depends on the error values of its own interruptions and on nothing else
             if (!RunRecord<S>::is_end_of_line(v) && RunRecord<S>::which(v) == kOnly)
@@ -1218,8 +1335,8 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
 }
 
 // grid (up to 32, scans) x 64: a wavefront counts the events of a job (and of every gridDim.x-th job after it).
-template <typename S>
-__global__ void __launch_bounds__(64) count_runs(const Work* __restrict__ works)
+template <typename S, int FMT = 0>
+__global__ void __launch_bounds__(64) count_runs(const Work* __restrict__ works, uint32_t nc)
 {
     const Work w = works[blockIdx.y];
     const uint32_t n = w.chain_total[0];
@@ -1232,6 +1349,15 @@ __global__ void __launch_bounds__(64) count_runs(const Work* __restrict__ works)
         for (uint32_t e = from + threadIdx.x; e < to; e += 64)
         {
             const uint32_t v = runs[e];
+            if (FMT == 1)
+            { // pixel mode; the `nc` components of an interruption pixel of a sample-interleaved scan all code on context 0
+                const bool interrupted = !RunRecord2::is_end_of_line(v), zero = RunRecord2::is_zero_run(v);
+                const int which = RunRecord2::which(v);
+                type0 += interrupted ? (nc > 1 ? nc : (which == 0 ? 1u : 0u)) : 0u;
+                type1 += interrupted && nc == 1 && which != 0;
+                own += interrupted ? (zero ? nc - 1 : nc) : 0u;
+                continue;
+            }
             const bool interrupted = !RunRecord<S>::is_end_of_line(v);
             type0 += interrupted && RunRecord<S>::which(v) == 0;
             type1 += interrupted && RunRecord<S>::which(v) != 0;
@@ -1291,7 +1417,7 @@ __global__ void __launch_bounds__(64) scan_runs(const Work* __restrict__ works)
 }
 
 // grid (ceil(max_run_jobs * scans / 64)) x 64: one lane per (job, scan), lanes of a wavefront = the same job of different scans.
-template <typename S, int ILV>
+template <typename S, int ILV, int FMT = 0>
 __global__ void __launch_bounds__(64) walk_run_jobs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
 {
     const uint32_t tid = blockIdx.x * 64u + threadIdx.x;
@@ -1307,15 +1433,17 @@ __global__ void __launch_bounds__(64) walk_run_jobs(const ScanDesc* __restrict__
     const uint32_t* runs = w.rec + w.chain_base[0];
     uint32_t* run_code = w.code + w.chain_base[0];
     uint32_t* int_code = w.code + w.chain_base[kInterruptChain];
+    const uint32_t* int_rec = w.rec + w.chain_base[kInterruptChain]; // (pixel mode)
+    const uint32_t nc = samples_per_pixel(d);
     // The warm-ups start at job boundaries (that is where the counts are known).  RUNindex and the context of the more
     // frequent interruption type forget within run_warm_events run events; the context of the rarer type (4 % of the
     // interruptions of a test frame) needs as many of ITS OWN events, so it alone is warmed up over run_long_warm_events
-    // before that -- a walk that looks at one bit of every other record.
+    // before that -- a walk that looks at one bit of every other record.  (A sample-interleaved scan has one type only.)
     const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
     const RunJob last = w.run_jobs[jobs - 1]; // (counts before the last job: good enough to tell which type is the rarer one)
     const bool rare1 = last.type1 < last.type0;
     const uint32_t warm_jobs = (w.run_warm_events + w.run_job_events - 1) / w.run_job_events;
-    const uint32_t long_jobs = warm_jobs + (w.run_long_warm_events + w.run_job_events - 1) / w.run_job_events;
+    const uint32_t long_jobs = warm_jobs + (ILV == 2 ? 0u : (w.run_long_warm_events + w.run_job_events - 1) / w.run_job_events);
     const uint32_t warm_job = job > warm_jobs ? job - warm_jobs : 0u;
     const uint32_t long_job = job > long_jobs ? job - long_jobs : 0u;
     RunState s{0, initial_a(t), 0, initial_a(t), 0};
@@ -1325,20 +1453,20 @@ __global__ void __launch_bounds__(64) walk_run_jobs(const ScanDesc* __restrict__
     {
         const RunJob far = w.run_jobs[long_job];
         if (rare1)
-            walk_runs<S, ILV, false, 1>(t, runs, run_code, int_code, long_job * w.run_job_events, warm_job * w.run_job_events, s, before.type0, far.type1, 0);
+            walk_runs<S, ILV, false, 1, FMT>(t, runs, run_code, int_code, long_job * w.run_job_events, warm_job * w.run_job_events, s, before.type0, far.type1, far.own_slot, int_rec, nc);
         else
-            walk_runs<S, ILV, false, 0>(t, runs, run_code, int_code, long_job * w.run_job_events, warm_job * w.run_job_events, s, far.type0, before.type1, 0);
+            walk_runs<S, ILV, false, 0, FMT>(t, runs, run_code, int_code, long_job * w.run_job_events, warm_job * w.run_job_events, s, far.type0, before.type1, far.own_slot, int_rec, nc);
     }
     if (warm_job < job)
-        walk_runs<S, ILV, false>(t, runs, run_code, int_code, warm_job * w.run_job_events, from, s, before.type0, before.type1, before.own_slot);
+        walk_runs<S, ILV, false, -1, FMT>(t, runs, run_code, int_code, warm_job * w.run_job_events, from, s, before.type0, before.type1, before.own_slot, int_rec, nc);
     mine.in = s;
-    walk_runs<S, ILV, true>(t, runs, run_code, int_code, from, to, s, mine.type0, mine.type1, mine.own_slot);
+    walk_runs<S, ILV, true, -1, FMT>(t, runs, run_code, int_code, from, to, s, mine.type0, mine.type1, mine.own_slot, int_rec, nc);
     mine.out = s;
     w.run_jobs[job] = mine;
 }
 
 // grid (ceil(scans / 64)) x 64: one lane per scan checks its jobs' boundaries.
-template <typename S, int ILV>
+template <typename S, int ILV, int FMT = 0>
 __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
 {
     const uint32_t frame = blockIdx.x * 64u + threadIdx.x;
@@ -1357,6 +1485,8 @@ __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ d
     const uint32_t* runs = w.rec + w.chain_base[0];
     uint32_t* run_code = w.code + w.chain_base[0];
     uint32_t* int_code = w.code + w.chain_base[kInterruptChain];
+    const uint32_t* int_rec = w.rec + w.chain_base[kInterruptChain];
+    const uint32_t nc = samples_per_pixel(d);
     RunState prev = w.run_jobs[0].out;
     uint32_t rewalked = 0;
     for (uint32_t j = 1; j < jobs; ++j)
@@ -1369,7 +1499,7 @@ __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ d
             out = prev;
             const uint32_t from = j * w.run_job_events;
             const uint32_t to = from + w.run_job_events < n ? from + w.run_job_events : n;
-            walk_runs<S, ILV, true>(t, runs, run_code, int_code, from, to, out, cur.type0, cur.type1, cur.own_slot);
+            walk_runs<S, ILV, true, -1, FMT>(t, runs, run_code, int_code, from, to, out, cur.type0, cur.type1, cur.own_slot, int_rec, nc);
         }
         prev = out;
     }
@@ -1383,19 +1513,19 @@ __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ d
 // LDS: codes[tile] u32 | tileoff / count / global [kChains + 1] each | scan[256] | tmp
 #define JLS_HOST_DEV __host__ __device__ inline
 // LDS of pack_tiles: where the staged slot map starts (behind the code words, the piece tables and the row table)
-JLS_HOST_DEV uint32_t pack_inv_offset(uint32_t width, uint32_t lines_per_tile) // 16-byte aligned
+JLS_HOST_DEV uint32_t pack_inv_offset(uint32_t tile_capacity) // 16-byte aligned
 {
-    const uint32_t head = lines_per_tile * width * 4 + 4 * ((uint32_t)kChains + 1) * 4 + kPackThreads * 4 + 16 * 4 +
-                          (lines_per_tile * width / 64 + (uint32_t)kChains + 8) * 2;
+    const uint32_t head = tile_capacity * 4 + 4 * ((uint32_t)kChains + 1) * 4 + kPackThreads * 4 + 16 * 4 +
+                          (tile_capacity / 64 + (uint32_t)kChains + 8) * 2;
     return (head + 15u) & ~15u;
 }
 
 // Words of the bit buffer of pack_tiles: a sample's code has at most LIMIT = 2 (bpp + max(8, bpp)) bits (a run-length code
 // longer than that stands for as many samples without a code of their own), plus the two shared boundary words.
-JLS_HOST_DEV uint32_t pack_bits_words(uint32_t width, uint32_t lines_per_tile, int32_t bits_per_sample)
+JLS_HOST_DEV uint32_t pack_bits_words(uint32_t tile_capacity, int32_t bits_per_sample)
 {
     const uint32_t limit = 2u * (uint32_t)(bits_per_sample + (bits_per_sample > 8 ? bits_per_sample : 8));
-    return lines_per_tile * width * limit / 32 + 2;
+    return tile_capacity * limit / 32 + 2;
 }
 
 JLS_DEV void expand_code(uint32_t word, uint64_t& bits, int& len)
@@ -1422,7 +1552,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     const uint32_t tiles = scan_tiles(d, w);
     if (tile >= tiles)
         return;
-    const uint32_t tile_capacity = w.lines_per_tile * d.width;
+    const uint32_t tile_capacity = w.tile_capacity;
     const uint32_t per_thread = ((tile_capacity + kPackThreads - 1) / kPackThreads + 7u) & ~7u; // consecutive samples of a thread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr uint32_t kPackWaves = kPackThreads / 64;
@@ -1434,12 +1564,10 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     uint32_t* s_tmp = s_scan + kPackThreads;   // one word per wavefront (16 reserved)
     uint32_t* s_rowbase = s_tmp + 16;          // [kChains + 1] first row of the chain's piece
     uint16_t* s_rowchain = reinterpret_cast<uint16_t*>(s_rowbase + kChains + 1); // [tile / 64 + kChains + 8]
-    uint16_t* s_inv = reinterpret_cast<uint16_t*>(smem + pack_inv_offset(d.width, w.lines_per_tile)); // [kPackThreads * per_thread] slot map of the tile
-    const uint32_t lines = scan_lines(d);
-    const uint32_t first_line = tile * w.lines_per_tile;
-    const uint32_t tile_lines = lines - first_line < w.lines_per_tile ? lines - first_line : w.lines_per_tile;
-    const uint32_t tile_samples = tile_lines * d.width;
-    const uint16_t* inv = w.keyinv + (size_t)first_line * d.width;
+    uint16_t* s_inv = reinterpret_cast<uint16_t*>(smem + pack_inv_offset(tile_capacity)); // [kPackThreads * per_thread] slot map of the tile
+    const TileSpan span = tile_span(d, w, tile);
+    const uint32_t tile_samples = span.count;
+    const uint16_t* inv = w.keyinv + span.first;
 
     // the slot map of the tile: coalesced into LDS (a thread's 32 consecutive slots straight from memory were 32 requests
     // of one cache line each per wavefront instruction)
@@ -1712,22 +1840,59 @@ inline size_t sort_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t s
     return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode, false) + (size_t)sort_segments(lines_per_tile) * kChains * 4 +
            4 * ((size_t)kChains + 1) * 4 + 16 * 4 + (size_t)kWaves * (kChains + 1) * 4 + 252 * 4 + (size_t)lines_per_tile * width * 4;
 }
-inline size_t pack_lds_bytes(uint32_t width, uint32_t lines_per_tile, int32_t bits_per_sample)
+inline size_t pack_lds_bytes(uint32_t tile_capacity, int32_t bits_per_sample)
 {
-    const uint32_t per_thread = ((lines_per_tile * width + kPackThreads - 1) / kPackThreads + 7u) & ~7u;
-    const size_t slot_map = (size_t)kPackThreads * per_thread * 2, bit_buffer = (size_t)pack_bits_words(width, lines_per_tile, bits_per_sample) * 4;
-    return (size_t)pack_inv_offset(width, lines_per_tile) + (slot_map > bit_buffer ? slot_map : bit_buffer); // (the bits take the map's place)
+    const uint32_t per_thread = ((tile_capacity + kPackThreads - 1) / kPackThreads + 7u) & ~7u;
+    const size_t slot_map = (size_t)kPackThreads * per_thread * 2, bit_buffer = (size_t)pack_bits_words(tile_capacity, bits_per_sample) * 4;
+    return (size_t)pack_inv_offset(tile_capacity) + (slot_map > bit_buffer ? slot_map : bit_buffer); // (the bits take the map's place)
 }
-// Lines per tile for lines of `width` samples: as many whole lines as fit `tile_samples` (8192 for samples of one byte,
-// 4096 for two: the sort stage keeps the lines, the keys and the sorted records of a tile in LDS), at most kTileLines.
-inline uint32_t lines_per_tile_for(uint32_t width, uint32_t sample_bytes)
+// How a scan is cut into tiles.  A tile holds up to `cap` samples (8192 of one byte, 4096 of two: the sort stage keeps the
+// lines, the sorted records and its tables of a tile in LDS; CHARLS_AMD_TILE_SAMPLES lowers it -- more workgroups per CU for
+// measurements, segment tiles on small images for tests).  Lines that fit: as many whole lines as fit, at most kTileLines.
+// Lines that do not: every line is cut into segs_per_line segments of seg_pixels pixels (a multiple of 64, the last one
+// shorter).  mode: 0 = planar whole lines (analyze_tiles<S, 0>), 1 = line-interleaved whole lines (<S, 1>), 2 = pixel mode
+// (tile_pixel_mode.hip: sample-interleaved scans, and any scan whose lines do not fit a tile; CHARLS_AMD_PIXEL_MODE=1 sends
+// every scan there -- for tests).
+struct TilePlan
 {
-    uint32_t tile_samples = sample_bytes == 1 ? kMaxTileSamples : kMaxTileSamples / 2;
-    if (const char* env = std::getenv("CHARLS_AMD_TILE_SAMPLES")) // (smaller tiles: more workgroups per CU; for measurements)
-        tile_samples = std::min<uint32_t>(tile_samples, std::max(64, std::atoi(env)));
-    const uint32_t n = tile_samples / width;
-    return n < 1 ? 1 : (n > kTileLines ? kTileLines : n);
+    uint32_t mode, nc, lines, line_samples, lines_per_tile, segs_per_line, seg_pixels, tiles, tile_capacity, max_pixels;
+    uint64_t samples;
+};
+inline TilePlan plan_tiles(const ScanDesc& d)
+{
+    TilePlan p{};
+    const uint32_t sample_bytes = d.bits_per_sample > 8 ? 2u : 1u;
+    uint32_t cap = sample_bytes == 1 ? kMaxTileSamples : kMaxTileSamples / 2;
+    if (const char* env = std::getenv("CHARLS_AMD_TILE_SAMPLES"))
+        cap = std::min<uint32_t>(cap, (uint32_t)std::max(64, std::atoi(env)));
+    const char* force = std::getenv("CHARLS_AMD_PIXEL_MODE");
+    const bool force_pixel_mode = force != nullptr && std::atoi(force) != 0;
+    p.nc = d.interleave_mode == 2 ? (uint32_t)d.components : 1u;
+    p.lines = d.height * (d.interleave_mode == 1 ? (uint32_t)d.components : 1u);
+    p.line_samples = d.width * p.nc;
+    p.samples = (uint64_t)p.line_samples * p.lines;
+    if (p.line_samples <= cap && !(force_pixel_mode && d.interleave_mode == 1))
+    { // (a line-interleaved scan in pixel mode keeps ONE line above the tile: segments of single lines only)
+        const uint32_t n = cap / p.line_samples;
+        p.lines_per_tile = n < 1 ? 1 : (n > kTileLines ? kTileLines : n);
+        p.segs_per_line = 1;
+        p.seg_pixels = d.width;
+        p.tile_capacity = p.lines_per_tile * p.line_samples;
+        p.mode = d.interleave_mode == 2 || force_pixel_mode ? 2u : (uint32_t)d.interleave_mode;
+    }
+    else
+    {
+        p.lines_per_tile = 1;
+        const uint32_t fit = std::min(cap, p.line_samples) / p.nc / 64 * 64;
+        const uint32_t max_px = fit < 64 ? 64 : fit;
+        p.segs_per_line = (d.width + max_px - 1) / max_px;
+        p.seg_pixels = ((d.width + p.segs_per_line - 1) / p.segs_per_line + 63) / 64 * 64;
+        p.tile_capacity = p.seg_pixels * p.nc;
+        p.mode = 2;
+    }
+    p.tiles = (p.lines + p.lines_per_tile - 1) / p.lines_per_tile * p.segs_per_line;
+    p.max_pixels = p.segs_per_line == 1 ? d.width : p.seg_pixels;
+    return p;
 }
-
 } // namespace tile
 } // namespace jls

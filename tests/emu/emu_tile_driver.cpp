@@ -26,10 +26,10 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
 {
     using namespace jls;
     const ScanDesc& p = descs[0];
-    const size_t lines = (size_t)p.height * (size_t)(p.interleave_mode == 1 ? p.components : 1);
-    const size_t samples = (size_t)p.width * lines;
-    const uint32_t lines_per_tile = tile::lines_per_tile_for(p.width, (uint32_t)sizeof(S));
-    const uint32_t tiles = (uint32_t)((lines + lines_per_tile - 1) / lines_per_tile);
+    const tile::TilePlan plan = tile::plan_tiles(p);
+    const size_t samples = (size_t)plan.samples;
+    const uint32_t lines_per_tile = plan.lines_per_tile;
+    const uint32_t tiles = plan.tiles;
     const size_t max_jobs = samples / job_events + pipe::kChains;
     const size_t max_run_jobs = samples / run_job_events + 1;
     std::vector<tile::Work> works(count);
@@ -75,6 +75,9 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         w.tiles = tiles;
         w.job_events = job_events;
         w.warm_events = warm_events;
+        w.segs_per_line = plan.segs_per_line;
+        w.seg_pixels = plan.seg_pixels;
+        w.tile_capacity = plan.tile_capacity;
         pipe::Work& sw = stuff[i];
         std::memset(&sw, 0, sizeof sw);
         sw.raw = w.raw;
@@ -85,30 +88,50 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     }
     const tile::Work* wk = works.data();
     const unsigned tiles_grid = 8 * ((tiles + 7) / 8);
-    if (p.interleave_mode == 1)
-        emu::launch(tile::analyze_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::analyze_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode), descs, wk);
+    const bool pixel_mode = plan.mode == 2;
+    const size_t lds_a = pixel_mode ? tile::analyze_pixel_lds_bytes(plan.lines_per_tile, plan.max_pixels, plan.nc, (uint32_t)sizeof(S), plan.tile_capacity)
+                                    : tile::analyze_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode);
+    const size_t lds_b = pixel_mode ? tile::sort_pixel_lds_bytes(plan.lines_per_tile, plan.max_pixels, plan.nc, (uint32_t)sizeof(S), plan.tile_capacity)
+                                    : tile::sort_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode);
+    if (pixel_mode)
+        emu::launch(tile::analyze_pixel_tiles<S>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_a, descs, wk);
+    else if (p.interleave_mode == 1)
+        emu::launch(tile::analyze_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_a, descs, wk);
     else
-        emu::launch(tile::analyze_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::analyze_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode), descs, wk);
+        emu::launch(tile::analyze_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_a, descs, wk);
     emu::launch(tile::plan_chains, dim3(count), dim3(1024), 0, descs, wk);
-    if (p.interleave_mode == 1)
-        emu::launch(tile::sort_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::sort_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode), descs, wk);
+    if (pixel_mode)
+        emu::launch(tile::sort_pixel_tiles<S>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_b, descs, wk);
+    else if (p.interleave_mode == 1)
+        emu::launch(tile::sort_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_b, descs, wk);
     else
-        emu::launch(tile::sort_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), tile::sort_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode), descs, wk);
+        emu::launch(tile::sort_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_b, descs, wk);
     emu::launch(tile::walk_jobs<S>, dim3((unsigned)((max_jobs + 63) / 64), count), dim3(64), 0, descs, wk);
     emu::launch(tile::settle_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
-    emu::launch(tile::count_runs<S>, dim3((unsigned)std::min<size_t>(max_run_jobs, 32), count), dim3(64), 0, wk);
-    emu::launch(tile::scan_runs, dim3(count), dim3(64), 0, wk);
-    if (p.interleave_mode == 1)
-    {
-        emu::launch(tile::walk_run_jobs<S, 1>, dim3((unsigned)((max_run_jobs * count + 63) / 64)), dim3(64), 0, descs, wk, (uint32_t)count);
-        emu::launch(tile::settle_runs<S, 1>, dim3((count + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
-    }
+    const dim3 count_grid((unsigned)std::min<size_t>(max_run_jobs, 32), count), lanes((unsigned)((max_run_jobs * count + 63) / 64)), settle_grid((count + 63) / 64);
+    if (pixel_mode)
+        emu::launch(tile::count_runs<S, 1>, count_grid, dim3(64), 0, wk, plan.nc);
     else
-    {
-        emu::launch(tile::walk_run_jobs<S, 0>, dim3((unsigned)((max_run_jobs * count + 63) / 64)), dim3(64), 0, descs, wk, (uint32_t)count);
-        emu::launch(tile::settle_runs<S, 0>, dim3((count + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
-    }
-    emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::kPackThreads), tile::pack_lds_bytes(p.width, lines_per_tile, p.bits_per_sample), descs, wk);
+        emu::launch(tile::count_runs<S, 0>, count_grid, dim3(64), 0, wk, 1u);
+    emu::launch(tile::scan_runs, dim3(count), dim3(64), 0, wk);
+#define EMU_RUN_CHAIN(ILV, FMT)                                                                                  \
+    do                                                                                                           \
+    {                                                                                                            \
+        emu::launch(tile::walk_run_jobs<S, ILV, FMT>, lanes, dim3(64), 0, descs, wk, (uint32_t)count);          \
+        emu::launch(tile::settle_runs<S, ILV, FMT>, settle_grid, dim3(64), 0, descs, wk, (uint32_t)count);       \
+    } while (0)
+    if (!pixel_mode && p.interleave_mode == 1)
+        EMU_RUN_CHAIN(1, 0);
+    else if (!pixel_mode)
+        EMU_RUN_CHAIN(0, 0);
+    else if (p.interleave_mode == 2)
+        EMU_RUN_CHAIN(2, 1);
+    else if (p.interleave_mode == 1)
+        EMU_RUN_CHAIN(1, 1);
+    else
+        EMU_RUN_CHAIN(0, 1);
+#undef EMU_RUN_CHAIN
+    emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::kPackThreads), tile::pack_lds_bytes(plan.tile_capacity, p.bits_per_sample), descs, wk);
     const pipe::Work* sk = stuff.data();
     if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env == nullptr || std::atoi(env) != 0)
     {

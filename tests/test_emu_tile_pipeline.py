@@ -308,3 +308,113 @@ def test_tile_pipeline_counts_the_jobs_it_had_to_walk_again():
     assert errc == 0 and data == want
     L.emu_tile_counters(out)
     assert out[0] > 0 and out[1] == 0 and out[3] == 0
+
+
+# ---- pixel mode (tile_pixel_mode.hip): sample-interleaved scans, and lines cut into segment tiles ---------------------
+
+def _encode_scan(img, width, height, comps, ilv, bits, ct=0, capacity=None, job=64, warm=32, runs=RUN_JOBS):
+    """One scan of any interleave mode through the emulated tile pipeline; returns (errc, flags, bytes)."""
+    L = emu_bind.tile_lib()
+    keep = []
+    pc = jls_container.validated_pc((0,) * 5, bits, 0)
+    pix = np.frombuffer(np.ascontiguousarray(img).tobytes(), dtype=np.uint8).copy()
+    nbytes = 1 if bits <= 8 else 2
+    stride = width * nbytes * (comps if ilv != 0 else 1)
+    out = np.zeros(capacity or (width * height * comps * nbytes * 2 + 1024), dtype=np.uint8)
+    desc = emu_bind.make_desc(width, height, comps, ilv, bits, 0, ct, pc, 0, pix, stride, out, keep)
+    arr = (emu_bind.ScanDesc * 1)(desc)
+    res = (emu_bind.ScanResult * 1)()
+    L.emu_encode_tile_pipeline(arr, res, 1, job, warm, runs[0], runs[1], runs[2])
+    return res[0].errc, res[0].flags, out[:res[0].bytes].tobytes()
+
+
+def _rgb(w, h, seed, bits=8, comps=3, kind="mixed", flat=0.0):
+    img = synth.frame_numpy(w, h, seed=seed, bits=bits, components=comps, kind=kind, interleaved=True)
+    if flat:
+        rng = np.random.default_rng(seed)
+        # flat patches common to ALL components: run mode of a sample-interleaved scan needs every component to match
+        for _ in range(int(flat * h)):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            n = int(rng.integers(2, max(3, w // 2)))
+            img[y, x:x + n, :] = img[y, x, :]
+            if y + 1 < h:
+                img[y + 1, x:x + n, :] = img[y, x, :]
+    return img
+
+
+@pytest.mark.parametrize("comps,bits,ct,w,h,kind", [(3, 8, 0, 130, 11, "mixed"), (3, 8, 1, 67, 19, "mixed"), (3, 8, 2, 200, 9, "hard"),
+                                                     (3, 8, 3, 64, 33, "gradient"), (2, 8, 0, 129, 7, "mixed"), (4, 8, 0, 65, 12, "mixed"),
+                                                     (3, 16, 0, 70, 9, "mixed"), (3, 16, 1, 66, 8, "hard"), (3, 12, 0, 90, 10, "mixed"),
+                                                     (3, 8, 0, 1, 20, "mixed"), (3, 8, 0, 50, 1, "mixed"), (3, 8, 0, 96, 14, "zero"),
+                                                     (4, 16, 0, 33, 6, "noise"), (3, 5, 0, 40, 10, "noise")])
+@pytest.mark.parametrize("cap", [None, "256"])
+def test_pixel_mode_sample_interleaved_matches_oracle(monkeypatch, comps, bits, ct, w, h, kind, cap):
+    """ILV_SAMPLE scans, whole-line tiles and (cap = 256 samples per tile) lines cut into segment tiles."""
+    if cap:
+        monkeypatch.setenv("CHARLS_AMD_TILE_SAMPLES", cap)
+    img = _rgb(w, h, seed=w + h + comps, bits=bits, comps=comps, kind=kind, flat=0.5)
+    kw = dict(width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=2, color_transformation=ct)
+    want = _scan_bytes(ob.encode(img, **kw))
+    errc, flags, data = _encode_scan(img, w, h, comps, 2, bits, ct)
+    assert errc == 0 and data == want
+
+
+@pytest.mark.parametrize("job,warm,runs", [(16, 0, (32, 0, 0)), (64, 32, RUN_JOBS), (1024, 1024, (2048, 2048, 32768))])
+@pytest.mark.parametrize("cap", [None, "192"])
+def test_pixel_mode_speculation_settings(monkeypatch, job, warm, runs, cap):
+    if cap:
+        monkeypatch.setenv("CHARLS_AMD_TILE_SAMPLES", cap)
+    w, h = 150, 40
+    img = _rgb(w, h, seed=5, flat=1.5)
+    kw = dict(width=w, height=h, component_count=3, interleave_mode=2)
+    errc, flags, data = _encode_scan(img, w, h, 3, 2, 8, job=job, warm=warm, runs=runs)
+    assert errc == 0 and data == _scan_bytes(ob.encode(img, **kw))
+
+
+def test_pixel_mode_long_runs_across_segments(monkeypatch):
+    """Runs that leave their segment tile (their length is counted on from the keys of the tiles that follow), runs that end
+    with the line, a flat image (every tile looks back to the start of its line for its run state)."""
+    monkeypatch.setenv("CHARLS_AMD_TILE_SAMPLES", "192")
+    w, h = 700, 6
+    img = np.zeros((h, w, 3), dtype=np.uint8)
+    img[1, 100:, :] = (9, 9, 200)
+    img[2, ::7, 1] = 3
+    img[3, 300:650, :] = (1, 2, 3)
+    img[4, 5:, 0] = 77
+    kw = dict(width=w, height=h, component_count=3, interleave_mode=2)
+    errc, flags, data = _encode_scan(img, w, h, 3, 2, 8)
+    assert errc == 0 and data == _scan_bytes(ob.encode(img, **kw))
+    flat = np.full((4, 1000, 3), 41, dtype=np.uint8)
+    errc, flags, data = _encode_scan(flat, 1000, 4, 3, 2, 8)
+    assert errc == 0 and data == _scan_bytes(ob.encode(flat, width=1000, height=4, component_count=3, interleave_mode=2))
+
+
+@pytest.mark.parametrize("bits,w,h,kind,cap", [(8, 700, 9, "mixed", "256"), (8, 1000, 5, "zero", "128"), (16, 300, 8, "mixed", "64"),
+                                               (12, 513, 7, "hard", "192"), (8, 9000, 2, "mixed", None), (16, 5000, 2, "mixed", None),
+                                               (8, 130, 11, "mixed", "PIXEL")])
+def test_pixel_mode_wide_planar_lines(monkeypatch, bits, w, h, kind, cap):
+    """Single-component lines wider than a tile (cut into segment tiles; two run-interruption contexts), and -- PIXEL -- an
+    ordinary scan sent through pixel mode with whole-line tiles."""
+    if cap == "PIXEL":
+        monkeypatch.setenv("CHARLS_AMD_PIXEL_MODE", "1")
+    elif cap:
+        monkeypatch.setenv("CHARLS_AMD_TILE_SAMPLES", cap)
+    img = synth.frame_numpy(w, h, seed=w, bits=bits, kind=kind)
+    if kind == "mixed":
+        img[h // 2, w // 3:] = img[h // 2, w // 3]  # a run to the end of the line, across segments
+        img[h - 1, 10:w - 10] = img[h - 1, 10]
+    errc, flags, data = _encode_scan(img, w, h, 1, 0, bits)
+    assert errc == 0 and data == _scan_bytes(ob.encode(img, width=w, height=h, bits_per_sample=bits))
+
+
+@pytest.mark.parametrize("bits,ct,cap", [(8, 0, "128"), (8, 1, "256"), (16, 2, "64"), (8, 0, "PIXEL")])
+def test_pixel_mode_wide_line_interleaved(monkeypatch, bits, ct, cap):
+    if cap == "PIXEL":
+        monkeypatch.setenv("CHARLS_AMD_PIXEL_MODE", "1")
+    else:
+        monkeypatch.setenv("CHARLS_AMD_TILE_SAMPLES", cap)
+    w, h = 333, 7
+    img = _rgb(w, h, seed=bits + ct, bits=bits, flat=1.0)
+    kw = dict(width=w, height=h, bits_per_sample=bits, component_count=3, interleave_mode=1, color_transformation=ct)
+    errc, flags, data = _encode_scan(img, w, h, 3, 1, bits, ct)
+    assert errc == 0 and data == _scan_bytes(ob.encode(img, **kw))
