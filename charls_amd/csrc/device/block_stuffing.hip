@@ -3,7 +3,7 @@
 //
 // JPEG-LS stuffing (a byte that follows 0xFF carries 7 bits, src/scan_encoder.hpp:103-180) is sequential only through the
 // position at which every output byte STARTS in the raw bit stream: byte i starts at r_i, takes w_i bits (8, or 7 behind a
-// 0xFF byte) and the next one starts at r_i + w_i.  stuff_scan (lossless_pipeline.hip) walks that chain with one wavefront
+// 0xFF byte) and the next one starts at r_i + w_i.  stuff_scan (pipeline_common.hip) walks that chain with one wavefront
 // per scan: 27 ms for the 7 MB of a 4096 x 4096 frame -- a quarter of the time ONE frame takes to encode, and the reason the
 // stage of a pass has to hide under the next pass.  Here the raw stream is cut into chunks of kStuffChunk bytes; a chunk
 // owns the output bytes that start inside it, and what it needs from its predecessors is only the state in which it is
@@ -29,7 +29,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "lossless_pipeline.hip"
+#include "pipeline_common.hip"
 
 namespace jls {
 namespace pipe {

@@ -102,7 +102,7 @@ void launch_decode(const ScanDesc& proto, const ScanDesc* d_descs, ScanResult* d
 
 // Encoder dispatch.  All `count` scans share the geometry / coding mode of `proto` (HOST copy of one of them; its
 // stream_capacity is an upper bound of every scan's capacity).  Lossless single-component scans go through the
-// parallel pipeline (lossless_pipeline.hip) unless the engine is forced to serial; everything else, and the rare scan
+// parallel pipeline (tile_pipeline.hip) unless the engine is forced to serial; everything else, and the rare scan
 // whose destination is within 3 bytes of its output size, runs the exact one-wavefront-per-scan kernel.
 bool pipeline_eligible(const ScanDesc& proto) noexcept;
 void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream);

@@ -11,7 +11,7 @@
 #include "scan_serial.hip"
 #include "container_kernels.hip"
 #include "scan_wave_decode.hip"
-#include "lossless_pipeline.hip"
+#include "pipeline_common.hip"
 #include "block_stuffing.hip"
 #include "tile_pipeline.hip"
 #include "scan_fast_decode.hip"
@@ -590,48 +590,6 @@ bool block_stuffing_enabled()
 constexpr uint32_t kBlockStuffingScans = 8; // scans per pass up to which stage E runs in its block-parallel form (it is for latency: every chunk is
                                             // walked from 16 entry states, 2.7 GB of L2 misses per frame when 64 frames do it at once)
 
-// Bytes of work area one scan needs (21 B per sample + per-line histograms + the unstuffed stream).
-struct PipeLayout
-{
-    size_t samples, lines, blocks, raw_bytes;
-    size_t off_key, off_val, off_hist, off_total, off_base, off_sval, off_spos, off_inv, off_len, off_code, off_bbase,
-        off_raw, off_bits, off_status, off_stuff, bytes;
-    PipeLayout(const ScanDesc& d, size_t capacity_hint)
-    {
-        const int32_t comps = d.interleave_mode != 0 ? d.components : 1;
-        lines = static_cast<size_t>(d.height) * (d.interleave_mode == 1 ? static_cast<size_t>(d.components) : 1);
-        samples = static_cast<size_t>(d.width) * d.height * static_cast<size_t>(comps);
-        blocks = (samples + pipe::kPackBlock - 1) / pipe::kPackBlock;
-        const size_t worst = worst_case_scan_bytes(d.width, d.height, comps, d.bits_per_sample);
-        raw_bytes = align_up((capacity_hint < worst ? capacity_hint : worst) + 64, 16);
-        size_t o = 0;
-        auto take = [&](size_t n) {
-            const size_t at = o;
-            o = align_up(o + n, 256);
-            return at;
-        };
-        // key (2 B) + val (4 B) are dead once the events are scattered; the 8-byte codes written by stage C re-use them
-        const size_t val_at = align_up(samples * 2, 256);
-        off_code = take(std::max((samples + pipe::kChainSlack) * 8, val_at + samples * 4));
-        off_key = off_code;
-        off_val = off_code + val_at;
-        off_hist = take(lines * pipe::kChains * 4);
-        off_total = take(pipe::kChains * 4);
-        off_base = take(pipe::kChains * 4);
-        off_sval = take((samples + pipe::kChainSlack) * 4);
-        off_spos = take((samples + pipe::kChainSlack) * 4);
-        off_inv = take(samples * 4);
-        off_len = take(samples + pipe::kChainSlack);
-        off_bbase = take(blocks * 8);
-        off_raw = take(raw_bytes);
-        off_bits = take(16);  // total_bits and status in two copies: the stuffing of one pass runs under the next pass
-        off_status = take(8);
-        // the tables of block_stuffing.hip (1.3 MB of 376) only when that form of stage E is switched on
-        off_stuff = take(block_stuffing_enabled() ? (raw_bytes / pipe::kStuffChunk + 1) * pipe::kStuffWords * 4 : 0);
-        bytes = o;
-    }
-};
-
 DeviceBuffer& pipeline_arena()
 {
     static thread_local DeviceBuffer arena;
@@ -670,9 +628,9 @@ void* try_ensure(DeviceBuffer& buffer, size_t bytes) noexcept
     }
 }
 
-// Side streams of the pipeline (per thread, created once): passes of a batch that does not fit the work area at once are
-// dealt round-robin to up to kMaxPipelineLanes lanes, each with its own slice of the arena and its own HIP stream.
-constexpr int kMaxPipelineLanes = 3;
+// Side streams of the pipeline (per thread and device): the stuffing stage of a pass runs on one of them under the next pass's
+// first stages, the run chain on another under the walkers of the regular chains.
+constexpr int kMaxPipelineLanes = 2;
 struct PipelineLanes
 {
     hipStream_t streams[kMaxPipelineLanes]{};
@@ -710,230 +668,8 @@ PipelineLanes& pipeline_lanes()
     return lanes;
 }
 
-// Why lanes: the chain stage (bias_chains) is as long as the longest context chain of a frame whatever the number of
-// frames in the pass -- 58 ms for ONE 4096 x 4096 test frame, about 95 ms in a pass of 228 -- and keeps only a few hundred
-// wavefronts busy, while the other stages are bandwidth-shaped and fill the chip.  Passes that follow each other on ONE
-// stream pay that latency in full, once per pass; independent passes on different streams could run one pass's chain
-// stage under the other passes' wide stages (the arena is shared out between the lanes: smaller passes, more of them).
-// Measured (4096 frames, profiles/r02_encode_lanes.txt): 5.04 / 4.73 / 4.85 s with 1 / 2 / 3 lanes on one box, 5.09 /
-// 5.15 / 5.08 s on another -- the chain and stuffing stages, which live on memory latency, slow down under the other
-// lanes' traffic by about what the overlap wins.  One lane is the default; CHARLS_AMD_ENCODE_LANES = 2 or 3 selects more.
-template <typename S>
-void run_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
-{
-    const PipeLayout lay(proto, proto.stream_capacity);
-    const size_t budget = arena_budget(pipeline_arena().capacity());
-    const size_t per_scan = lay.bytes + 2 * sizeof(pipe::Work); // (two copies of the descriptors, see overlap_stuffing)
-    uint32_t resident = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(count, budget / per_scan))); // scans in the arena
-    uint8_t* arena = nullptr;
-    for (;;)
-    { // less HBM than the budget promised (fragmentation, another process): fewer scans at a time
-        arena = static_cast<uint8_t*>(try_ensure(pipeline_arena(), per_scan * resident));
-        if (arena != nullptr || resident == 1)
-            break;
-        resident = (resident + 1) / 2;
-    }
-    if (arena == nullptr)
-    { // not even one work area: the one-wavefront-per-scan kernel needs none
-        launch_encode_serial(d_descs, d_results, count, stream);
-        last_timings().count = 2;
-        return;
-    }
-    int lanes = 1;
-    if (count > resident)
-    { // several passes: overlap them
-        const char* env = std::getenv("CHARLS_AMD_ENCODE_LANES");
-        lanes = env ? std::atoi(env) : 1;
-        lanes = std::max(1, std::min({lanes, kMaxPipelineLanes, static_cast<int>(resident)}));
-    }
-    const uint32_t per_pass = resident / static_cast<uint32_t>(lanes); // scans of one pass = one lane's slice of the arena
-    const size_t lane_bytes = per_scan * per_pass;
-    const uint32_t passes = (count + per_pass - 1) / per_pass;
-    hipStream_t lane_stream[kMaxPipelineLanes] = {stream, stream, stream};
-    hipEvent_t fork{}, join[kMaxPipelineLanes]{};
-    if (lanes > 1)
-    {
-        pipeline_lanes().ensure();
-        hip_check(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-        hip_check(hipEventRecord(fork, stream)); // everything the caller queued (descriptors, scan headers) comes first
-        for (int l = 0; l < lanes; ++l)
-        {
-            lane_stream[l] = pipeline_lanes().streams[l];
-            hip_check(hipStreamWaitEvent(lane_stream[l], fork, 0));
-        }
-    }
-    std::vector<std::vector<pipe::Work>> works(passes); // one host copy per pass: the uploads are asynchronous
-    std::vector<StageTimer> timers;
-    timers.reserve(passes);
-    // The last stage (stuff_scan: one wavefront per scan walking 7 MB, 29 ms for a pass of 228 frames that leaves three
-    // quarters of the SIMDs idle) needs nothing of the arena but the raw bits, the two result words and the descriptors,
-    // and the next pass touches none of them before ITS pack stage: it runs on a side stream under the next pass's
-    // analyze / partition / chain stages (descriptors, total_bits and status alternate between two copies).
-    const bool overlap_stuffing = lanes == 1 && passes > 1;
-    hipStream_t stuff_stream = stream;
-    std::vector<hipEvent_t> packed, stuffed;
-    if (overlap_stuffing)
-    {
-        pipeline_lanes().ensure();
-        stuff_stream = pipeline_lanes().streams[0];
-        packed.resize(passes);
-        stuffed.resize(passes);
-        for (uint32_t pass = 0; pass < passes; ++pass)
-        {
-            hip_check(hipEventCreateWithFlags(&packed[pass], hipEventDisableTiming));
-            hip_check(hipEventCreateWithFlags(&stuffed[pass], hipEventDisableTiming));
-        }
-    }
-
-    for (uint32_t pass = 0; pass < passes; ++pass)
-    {
-        const uint32_t first = pass * per_pass;
-        const uint32_t n = std::min(per_pass, count - first);
-        const int lane = static_cast<int>(pass % static_cast<uint32_t>(lanes));
-        hipStream_t s = lane_stream[lane];
-        uint8_t* slice = arena + lane_bytes * static_cast<size_t>(lane);
-        const size_t copy = pass & 1u;
-        auto* d_works = reinterpret_cast<pipe::Work*>(slice + lay.bytes * per_pass) + copy * per_pass;
-        works[pass].resize(n);
-        for (uint32_t i = 0; i < n; ++i)
-        {
-            uint8_t* base = slice + lay.bytes * i;
-            pipe::Work& w = works[pass][i];
-            w.key = reinterpret_cast<uint16_t*>(base + lay.off_key);
-            w.val = reinterpret_cast<uint32_t*>(base + lay.off_val);
-            w.hist = reinterpret_cast<uint32_t*>(base + lay.off_hist);
-            w.chain_total = reinterpret_cast<uint32_t*>(base + lay.off_total);
-            w.chain_base = reinterpret_cast<uint32_t*>(base + lay.off_base);
-            w.sval = reinterpret_cast<uint32_t*>(base + lay.off_sval);
-            w.spos = reinterpret_cast<uint32_t*>(base + lay.off_spos);
-            w.inv = reinterpret_cast<uint32_t*>(base + lay.off_inv);
-            w.len = base + lay.off_len;
-            w.code = reinterpret_cast<uint64_t*>(base + lay.off_code);
-            w.blockbase = reinterpret_cast<uint64_t*>(base + lay.off_bbase);
-            w.raw = reinterpret_cast<uint32_t*>(base + lay.off_raw);
-            w.raw_words = lay.raw_bytes / 4;
-            w.total_bits = reinterpret_cast<uint64_t*>(base + lay.off_bits) + copy; // (zeroed by chain_offsets)
-            w.status = reinterpret_cast<uint32_t*>(base + lay.off_status) + copy;
-            w.stuff_tables = reinterpret_cast<uint32_t*>(base + lay.off_stuff);
-        }
-        hip_check(hipMemcpyAsync(d_works, works[pass].data(), sizeof(pipe::Work) * n, hipMemcpyHostToDevice, s));
-
-        const ScanDesc* descs = d_descs + first;
-        const uint32_t chunks = (proto.width + 63) / 64;
-        const size_t lds_a = static_cast<size_t>(chunks) * 20 + pipe::kChains * 4 + pipe::kGradientTable;
-        const uint32_t blocks = static_cast<uint32_t>(lay.blocks);
-        const uint32_t rows_grid = 8 * ((static_cast<uint32_t>(lay.lines) + 7) / 8); // analyze_pixels idles the surplus
-        timers.emplace_back(s);
-        StageTimer& t = timers.back();
-        t.mark();
-        if (proto.interleave_mode == 2)
-            hipLaunchKernelGGL((pipe::analyze_pixels<S>), dim3(rows_grid, n), dim3(64), lds_a, s, descs, d_works);
-        else if (proto.interleave_mode == 1)
-            hipLaunchKernelGGL((pipe::analyze_rows<S, 1>), dim3(rows_grid, n), dim3(64), lds_a, s, descs, d_works);
-        else
-            hipLaunchKernelGGL((pipe::analyze_rows<S, 0>), dim3(rows_grid, n), dim3(64), lds_a, s, descs, d_works);
-        t.mark();
-        hipLaunchKernelGGL(pipe::chain_offsets, dim3(n), dim3(384), 0, s, descs, d_works);
-        hipLaunchKernelGGL(pipe::scatter_events, dim3(rows_grid, n), dim3(64), 0, s, descs, d_works);
-        t.mark();
-        const dim3 chains_grid((n * pipe::kChains + 63) / 64);
-        if (proto.interleave_mode == 2)
-            hipLaunchKernelGGL((pipe::bias_chains<S, 2>), chains_grid, dim3(64), 0, s, descs, d_works, n);
-        else if (proto.interleave_mode == 1)
-        {
-            hipLaunchKernelGGL((pipe::prepare_run_events<S, 1>), dim3(64, n), dim3(256), 0, s, descs, d_works);
-            hipLaunchKernelGGL((pipe::bias_chains<S, 1>), chains_grid, dim3(64), 0, s, descs, d_works, n);
-        }
-        else
-        {
-            hipLaunchKernelGGL((pipe::prepare_run_events<S, 0>), dim3(64, n), dim3(256), 0, s, descs, d_works);
-            hipLaunchKernelGGL((pipe::bias_chains<S, 0>), chains_grid, dim3(64), 0, s, descs, d_works, n);
-        }
-        hipLaunchKernelGGL(pipe::code_events, dim3(pipe::kRegularChains, n), dim3(64), 0, s, descs, d_works);
-        t.mark();
-        if (overlap_stuffing && pass > 0)
-            hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
-        // look-back states and raw bits start at zero (one region per work area; both multiples of 16 bytes)
-        hipLaunchKernelGGL(pipe::clear_pack_state, dim3(64, n), dim3(256), 0, s, d_works,
-                           static_cast<uint32_t>(lay.off_raw + lay.raw_bytes - lay.off_bbase));
-        hipLaunchKernelGGL(pipe::write_raw_bits, dim3(blocks, n), dim3(256), 0, s, descs, d_works);
-        t.mark();
-        if (overlap_stuffing)
-        {
-            hip_check(hipEventRecord(packed[pass], s));
-            hip_check(hipStreamWaitEvent(stuff_stream, packed[pass], 0));
-        }
-        t.mark_on(stuff_stream);
-        if (block_stuffing_enabled() && n <= kBlockStuffingScans)
-        {
-            const uint32_t chunk_waves = static_cast<uint32_t>((lay.raw_bytes / pipe::kStuffChunk + 1 + 63) / 64);
-            const uint32_t survey_blocks = pipe::stuff_survey_blocks(lay.raw_bytes);
-            hipLaunchKernelGGL(pipe::stuff_survey, dim3(survey_blocks, n), dim3(64), 0, stuff_stream, d_works);
-            hipLaunchKernelGGL(pipe::stuff_resolve, dim3(n), dim3(pipe::kStuffResolveThreads), 0, stuff_stream, d_works);
-            hipLaunchKernelGGL(pipe::stuff_emit, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, descs, d_works, d_results + first);
-        }
-        else
-            hipLaunchKernelGGL(pipe::stuff_scan, dim3(n), dim3(64), 0, stuff_stream, descs, d_works, d_results + first);
-        t.mark_on(stuff_stream);
-        if (overlap_stuffing)
-            hip_check(hipEventRecord(stuffed[pass], stuff_stream));
-        hip_check(hipGetLastError());
-    }
-    if (overlap_stuffing)
-        hip_check(hipStreamWaitEvent(stream, stuffed[passes - 1], 0));
-    if (lanes > 1)
-    { // the caller's stream continues when every lane is through
-        for (int l = 0; l < lanes; ++l)
-        {
-            hip_check(hipEventCreateWithFlags(&join[l], hipEventDisableTiming));
-            hip_check(hipEventRecord(join[l], lane_stream[l]));
-            hip_check(hipStreamWaitEvent(stream, join[l], 0));
-        }
-    }
-    hip_check(hipStreamSynchronize(stream)); // the host copies of the work descriptors and the timers go out of scope
-    // values[2..6]: analyze, partition, chains, pack, stuff (ms), summed over the passes -- with several lanes the passes
-    // overlap, so the sum exceeds the wall time (values[0], taken by the batch API around the whole call)
-    Timings& tm = last_timings();
-    double stage_ms[5] = {0, 0, 0, 0, 0};
-    for (StageTimer& t : timers)
-    {
-        for (int i = 0; i < 4; ++i)
-            stage_ms[i] += t.between(i, i + 1);
-        stage_ms[4] += t.between(5, 6); // on the stuffing stream: overlapped with the next pass when it is a side stream
-    }
-    for (int i = 0; i < 5; ++i)
-        tm.values[2 + i] = stage_ms[i];
-    tm.count = 7;
-    if (lanes > 1)
-    {
-        (void)hipEventDestroy(fork);
-        for (int l = 0; l < lanes; ++l)
-            (void)hipEventDestroy(join[l]);
-    }
-    for (hipEvent_t e : packed)
-        (void)hipEventDestroy(e);
-    for (hipEvent_t e : stuffed)
-        (void)hipEventDestroy(e);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Tile pipeline (tile_pipeline.hip): planar and line-interleaved lossless scans whose lines fit a tile.
-
-// CHARLS_AMD_TILE_PIPELINE=0 keeps such scans on the round-2 pipeline (for A/B measurements).
-bool tile_pipeline_enabled()
-{
-    static const bool enabled = [] {
-        const char* env = std::getenv("CHARLS_AMD_TILE_PIPELINE");
-        return env == nullptr || std::atoi(env) != 0;
-    }();
-    return enabled;
-}
-
-bool tile_pipeline_eligible(const ScanDesc& d)
-{
-    // (pixel mode takes sample-interleaved scans and lines of any width; what stays out: nothing the pipeline is eligible for)
-    return tile_pipeline_enabled();
-}
+// Tile pipeline (tile_pipeline.hip, tile_pixel_mode.hip): every lossless scan the pipeline is eligible for.
 
 // Work area of one scan: 10 B per sample (key / slot 2, record 4, code 4), the (tiles + 1) x 367 piece table, the job
 // states and the unstuffed stream.
@@ -1372,17 +1108,10 @@ void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_resul
             launch_encode_serial(d_descs, d_results, count, stream);
         return;
     }
-    if (tile_pipeline_eligible(proto))
-    {
-        if (proto.bits_per_sample > 8)
-            run_tile_pipeline<uint16_t>(proto, d_descs, d_results, count, stream);
-        else
-            run_tile_pipeline<uint8_t>(proto, d_descs, d_results, count, stream);
-    }
-    else if (proto.bits_per_sample > 8)
-        run_pipeline<uint16_t>(proto, d_descs, d_results, count, stream);
+    if (proto.bits_per_sample > 8)
+        run_tile_pipeline<uint16_t>(proto, d_descs, d_results, count, stream);
     else
-        run_pipeline<uint8_t>(proto, d_descs, d_results, count, stream);
+        run_tile_pipeline<uint8_t>(proto, d_descs, d_results, count, stream);
     // Scans whose destination is within 3 bytes of their size: the reference's verdict depends on its flush history
     // (src/scan_encoder.hpp:117-120), so those few are re-coded by the kernel that restates that history.
     std::vector<ScanResult> results(count);

@@ -230,15 +230,15 @@ __global__ void __launch_bounds__(64) encode_pixels_group(const ScanDesc* __rest
     const Traits t_first = make_traits(d_first);
     const bool own_table = t.t1 == t_first.t1 && t.t2 == t_first.t2 && t.t3 == t_first.t3 && t.bpp == t_first.bpp &&
                            t.near == t_first.near;
+    const int cap = kWide ? t_first.t3 : 255; // the table covers -cap .. cap
     {
         const Record fresh{(uint32_t)initial_a(t), 1u};
         for (int q = sub; q < 366; q += G)
             records[q] = fresh;
         if (sub < 2)
             run_ctx[sub] = RunCtx{sub, initial_a(t), 1, 0};
-        if (!kWide)
-            for (int q = lane; q <= 510; q += 64)
-                lut[q] = (unsigned char)(quantize(t_first, q - 255) + 4);
+        for (int q = lane; q <= 2 * cap && q < (int)Layout<S>::kLutBytes; q += 64)
+            lut[q] = (unsigned char)(quantize(t_first, q - cap) + 4);
         for (uint32_t q = sub; q < 2 * NL * line_samples; q += G)
             line_a[q] = 0;
     }
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(64) encode_pixels_group(const ScanDesc* __rest
 #pragma unroll
     for (int c = 0; c < NL; ++c)
         run_index_of[c] = 0;
-    const bool quick = !kWide && __all(!live || own_table) && lds_address(smem) == 0; // (see lds_load)
+    const bool quick = (!kWide || t_first.t3 <= kMaxTableT3) && __all(!live || own_table) && lds_address(smem) == 0; // (see lds_load)
 
     // staged bytes -> destination, by the lanes of the group (everything written so far, or whole 256-byte pieces)
     auto drain = [&](bool wanted, bool everything) __attribute__((always_inline)) {
@@ -545,7 +545,6 @@ __global__ void __launch_bounds__(64) encode_pixels_group(const ScanDesc* __rest
         }
         // ---- pixels
         bool stepped = false; // the pixel loop ran: the lanes it stopped at take ONE general step
-        if constexpr (!kWide)
         {
             const bool active = quick && phase == kInLine && bw.err == kOk; // i <= width: the end of a line is handled at once
             const LaneMask active_m = lanes_where(active);
@@ -570,7 +569,10 @@ __global__ void __launch_bounds__(64) encode_pixels_group(const ScanDesc* __rest
                 int qsu[NC], q1[NC], ra[NC], rb[NC], rc[NC], xs[NC];
                 Record rec[NC];
                 auto index_of = [&](int q) -> uint32_t { return abs_difference((uint32_t)q, 364u); };
-                auto gradient = [&](int diff) -> int { return (int)lds_load<unsigned char>((uint32_t)(diff + 255)); }; // the table is at LDS address 0
+                // the table is at LDS address 0: -255 .. 255 for 8-bit samples, -T3 .. T3 (differences clamped) for wider ones
+                auto gradient = [&](int diff) -> int {
+                    return (int)lds_load<unsigned char>((uint32_t)((kWide ? med3(diff, -cap, cap) : diff) + cap));
+                };
                 auto record_at = [&](uint32_t idx) -> Record {
                     const uint32_t at = records_address + (idx << 3);
                     return Record{lds_load<uint32_t>(at), lds_load<uint32_t>(at + 4)};

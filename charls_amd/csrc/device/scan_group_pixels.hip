@@ -172,8 +172,9 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
         run_index_of[c] = 0;
     const uint32_t line_samples = line_bytes / (uint32_t)sizeof(S);
     const uint32_t margin_bits = (uint32_t)(kPixelStepsPerCheck + 1) * NC * (uint32_t)t.limit + 320u;
-    // the pixel loop takes scans of 8-bit samples (the scans of a wavefront share NEAR: it is part of their gradient table)
-    const bool quick = !kWide;
+    // the pixel loop takes every scan whose gradient table is the wavefront's (the scans of a wavefront share NEAR: it is part
+    // of the table; `usable` above)
+    const bool quick = true;
 
     auto quantised = [&](int diff) -> int { // quantised gradient + 4: 0 .. 8
         if (kWide)
@@ -297,7 +298,6 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
         // ---- pixels
         bool in_run = false;
         bool stepped = false; // the pixel loop ran: the lanes it stopped at take ONE general step
-        if constexpr (!kWide)
         {
             const bool active = quick && phase == kInLine && !retry; // i <= width: the end of a line is handled at once
             const LaneMask active_m = lanes_where(active);
@@ -325,7 +325,11 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                 int qsu[NC], q1[NC], ra[NC], rb[NC], rc[NC];
                 Record rec[NC];
                 auto index_of = [&](int q) -> uint32_t { return abs_difference((uint32_t)q, 364u); };
-                auto gradient = [&](int diff) -> int { return (int)lds_load<unsigned char>((uint32_t)(diff + 255)); }; // the table is at LDS address 0
+                // the table is at LDS address 0: -255 .. 255 for 8-bit samples, -T3 .. T3 (differences clamped: one more
+                // instruction) for wider ones
+                auto gradient = [&](int diff) -> int {
+                    return (int)lds_load<unsigned char>((uint32_t)((kWide ? med3(diff, -cap, cap) : diff) + cap));
+                };
                 auto record_at = [&](uint32_t idx) -> Record {
                     const uint32_t at = records_address + (idx << 3);
                     return Record{lds_load<uint32_t>(at), lds_load<uint32_t>(at + 4)};
@@ -395,6 +399,8 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                         const int k_raw = ((int)(float_bits(r.a) - float_bits((uint32_t)n)) + 0x7FFFFF) >> 23;
                         const int k = k_raw < 0 ? 0 : k_raw;
                         const int mm = (int)((u << k) | (uint32_t)(((uint64_t)beyond << k) >> 32));
+                        if (kWide) // the code has to lie inside the 32-bit window (8-bit samples: u < 23 and k <= 9)
+                            ok_m &= lanes_where(u1 + (uint32_t)k <= 32u);
                         const int half = mm >> 1;
                         const int odd = kNearLoop ? (mm & 1) : ((mm ^ (((k - 1) & (2 * bb + n - 1)) >> 31)) & 1);
                         const int e = half ^ -odd;
@@ -483,7 +489,7 @@ __global__ void __launch_bounds__(64) decode_pixels_group(const ScanDesc* __rest
                 } while (ticker != 0);
                 // the reference raises invalid_data for k >= 16; valid streams of 8-bit samples keep k <= 9 and the mapped
                 // error below RANGE (anything else is left to the exact decoder as a whole)
-                if (active && (k_seen >= 10u || (mm_seen >> t.qbpp) != 0u))
+                if (active && (k_seen >= (kWide ? 16u : 10u) || (mm_seen >> t.qbpp) != 0u))
                     retry = true;
                 // one general step for the lanes the loop stopped at
                 const bool stopped = active && !lane_of(ok_m) && !retry;

@@ -11,7 +11,7 @@
 //     mode, bit stuffing (src/scan_encoder_impl.hpp:109-302, src/scan_decoder_impl.hpp:132-337),
 //   * the 365 regular + 2 run-interruption contexts live in LDS (5.9 KB per wavefront).
 //
-// The lossless single-component encoder has a far more parallel formulation (lossless_pipeline.hip); this file is the
+// The lossless single-component encoder has a far more parallel formulation (tile_pipeline.hip); this file is the
 // general path and the decoder.  Results are bit-exact with the reference, including the error codes of appendix D.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,7 +1,8 @@
 // tile_pipeline.hip -- round-3 parallel JPEG-LS encoder for lossless single-component and line-interleaved scans.
 //
-// Same idea as lossless_pipeline.hip (in lossless mode everything except the adaptive statistics is a pure function of
-// the image, reference src/scan_encoder_impl.hpp:109-144), rebuilt around two observations:
+// In lossless mode everything except the adaptive statistics is a pure function of the image (reference
+// src/scan_encoder_impl.hpp:109-144).  The pipeline is built around two observations (round 2 had the same idea as a
+// line-by-line scatter with one lane per chain; it is gone):
 //
 //  1. HBM traffic.  The round-2 pipeline moved 1.48 GB per 4096 x 4096 frame (61 x the algorithmic bytes): 6 B/sample of
 //     analysis results written and read back, 4-byte records scattered line by line to ~30 chains per 64 samples (every
@@ -23,7 +24,7 @@
 //     true state by the settling lane, so the result is exact in every case and only the time depends on the data.
 //     One walker computes k, the error correction and the Golomb word as well: bias_chains + code_events became one pass.
 //
-// Stages (planar scan; ILV_LINE: "coded lines", see lossless_pipeline.hip):
+// Stages (planar scan; ILV_LINE: "coded lines", see pipeline_common.hip):
 //   A  analyze_tiles   one workgroup per tile, one wavefront per line at a time: chain id + sign of every sample (key,
 //                      2 B), run-mode segmentation as a carry chain over ballot masks, events per (tile, chain)
 //   B1 plan_chains     per scan: exclusive prefix over tiles per chain -> where each tile's piece of each chain goes;
@@ -45,7 +46,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "lossless_pipeline.hip"
+#include "pipeline_common.hip"
 
 namespace jls {
 namespace tile {
@@ -888,7 +889,7 @@ JLS_DEV uint32_t code_event(Chain& s, uint32_t rec, const Traits& t)
     k = k > 15 ? 15 : k;
     const int corr = k == 0 ? ((2 * s.b + s.n - 1) >> 31) : 0;
     const pipe::CodeWord cw = pipe::golomb_word(t, k, map_error(corr ^ err), t.limit);
-    // A.12 / A.13 in the median form of lossless_pipeline.hip
+    // A.12 / A.13 in median form
     s.a += err < 0 ? -err : err;
     s.bad |= (uint32_t)(s.a >= (1 << 24));
     int tb = s.b + err;

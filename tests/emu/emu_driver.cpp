@@ -7,13 +7,14 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 } // namespace emu
 
 #include "../../charls_amd/csrc/device/scan_serial.hip"
-#include "../../charls_amd/csrc/device/lossless_pipeline.hip"
+#include "../../charls_amd/csrc/device/pipeline_common.hip"
 #include "../../charls_amd/csrc/device/block_stuffing.hip"
 #include "../../charls_amd/csrc/device/scan_fast_decode.hip"
 #include "../../charls_amd/csrc/device/scan_group_decode.hip"
 #include "../../charls_amd/csrc/device/scan_group_pixels.hip"
 #include "../../charls_amd/csrc/device/scan_group_encode.hip"
 #include "../../charls_amd/csrc/device/restart_intervals.hip"
+#include "emu_tile_pipeline.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -55,103 +56,7 @@ int emu_decode_scans_wave(const jls::ScanDesc* descs, jls::ScanResult* results, 
 
 } // extern "C"
 
-// The lossless pipeline, kernel by kernel, in the order and with the launch geometry runtime.hip uses.
-template <typename S>
-static void emu_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count)
-{
-    using namespace jls;
-    const ScanDesc& p = descs[0];
-    const size_t samples = (size_t)p.width * p.height * (size_t)(p.interleave_mode != 0 ? p.components : 1);
-    const size_t lines = (size_t)p.height * (size_t)(p.interleave_mode == 1 ? p.components : 1);
-    const size_t blocks = (samples + pipe::kPackBlock - 1) / pipe::kPackBlock;
-    std::vector<pipe::Work> works(count);
-    std::vector<void*> allocs;
-    auto zalloc = [&](size_t bytes) {
-        void* q = std::calloc(bytes + 64, 1);
-        allocs.push_back(q);
-        return q;
-    };
-    // work areas the product does not clear are filled with garbage here (the arena is reused from pass to pass)
-    auto galloc = [&](size_t bytes) {
-        void* q = std::malloc(bytes + 64);
-        std::memset(q, 0xA5, bytes + 64);
-        allocs.push_back(q);
-        return q;
-    };
-    for (int i = 0; i < count; ++i)
-    {
-        pipe::Work& w = works[i];
-        const size_t raw_bytes = ((size_t)descs[i].stream_capacity + 64 + 15) / 16 * 16;
-        w.code = (uint64_t*)galloc((samples + pipe::kChainSlack) * 8 + 512);  // stage C re-uses the storage of key/val, as in runtime.hip
-        w.key = (uint16_t*)w.code;
-        w.val = (uint32_t*)((unsigned char*)w.code + ((samples * 2 + 255) / 256) * 256);
-        w.hist = (uint32_t*)zalloc(lines * pipe::kChains * 4);
-        w.chain_total = (uint32_t*)zalloc(pipe::kChains * 4);
-        w.chain_base = (uint32_t*)zalloc(pipe::kChains * 4);
-        w.sval = (uint32_t*)galloc((samples + pipe::kChainSlack) * 4);
-        w.spos = (uint32_t*)galloc((samples + pipe::kChainSlack) * 4);
-        w.inv = (uint32_t*)galloc(samples * 4);
-        w.len = (uint8_t*)galloc(samples + pipe::kChainSlack);
-        w.blockbase = (uint64_t*)zalloc(blocks * 8);
-        w.raw = (uint32_t*)zalloc(raw_bytes);
-        w.raw_words = raw_bytes / 4;
-        w.total_bits = (uint64_t*)zalloc(8);
-        w.status = (uint32_t*)zalloc(4);
-        w.stuff_tables = (uint32_t*)galloc((raw_bytes / pipe::kStuffChunk + 2) * pipe::kStuffWords * 4);
-    }
-    const uint32_t chunks = (p.width + 63) / 64;
-    const size_t lds_a = (size_t)chunks * 20 + pipe::kChains * 4 + pipe::kGradientTable;
-    const pipe::Work* wk = works.data();
-    const unsigned rows_grid = 8 * (((unsigned)lines + 7) / 8);
-    if (p.interleave_mode == 2)
-        emu::launch(pipe::analyze_pixels<S>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
-    else if (p.interleave_mode == 1)
-        emu::launch(pipe::analyze_rows<S, 1>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
-    else
-        emu::launch(pipe::analyze_rows<S, 0>, dim3(rows_grid, count), dim3(64), lds_a, descs, wk);
-    emu::launch(pipe::chain_offsets, dim3(count), dim3(384), 0, descs, wk);
-    emu::launch(pipe::scatter_events, dim3(rows_grid, count), dim3(64), 0, descs, wk);
-    const dim3 chains_grid((count * pipe::kChains + 63) / 64);
-    if (p.interleave_mode == 2)
-        emu::launch(pipe::bias_chains<S, 2>, chains_grid, dim3(64), 0, descs, wk, (uint32_t)count);
-    else if (p.interleave_mode == 1)
-    {
-        emu::launch(pipe::prepare_run_events<S, 1>, dim3(2, count), dim3(256), 0, descs, wk);
-        emu::launch(pipe::bias_chains<S, 1>, chains_grid, dim3(64), 0, descs, wk, (uint32_t)count);
-    }
-    else
-    {
-        emu::launch(pipe::prepare_run_events<S, 0>, dim3(2, count), dim3(256), 0, descs, wk);
-        emu::launch(pipe::bias_chains<S, 0>, chains_grid, dim3(64), 0, descs, wk, (uint32_t)count);
-    }
-    emu::launch(pipe::code_events, dim3(pipe::kRegularChains, count), dim3(64), 0, descs, wk);
-    emu::launch(pipe::write_raw_bits, dim3((unsigned)blocks, count), dim3(256), 0, descs, wk);
-    if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env == nullptr || std::atoi(env) != 0)
-    { // the block-parallel form of the stage (block_stuffing.hip), grids as in runtime.hip
-        size_t most = 0;
-        for (int i = 0; i < count; ++i)
-            most = std::max(most, (size_t)works[i].raw_words * 4);
-        const unsigned chunk_waves = (unsigned)((most / pipe::kStuffChunk + 1 + 63) / 64);
-        const unsigned survey_blocks = pipe::stuff_survey_blocks(most);
-        emu::launch(pipe::stuff_survey, dim3(survey_blocks, count), dim3(64), 0, wk);
-        emu::launch(pipe::stuff_resolve, dim3(count), dim3(pipe::kStuffResolveThreads), 0, wk);
-        emu::launch(pipe::stuff_emit, dim3(chunk_waves, count), dim3(64), 0, descs, wk, results);
-    }
-    else
-        emu::launch(pipe::stuff_scan, dim3(count), dim3(64), 0, descs, wk, results);
-    for (void* q : allocs)
-        std::free(q);
-}
-
 extern "C" {
-
-void emu_encode_pipeline(const jls::ScanDesc* descs, jls::ScanResult* results, int count)
-{
-    if (descs[0].bits_per_sample > 8)
-        emu_pipeline<uint16_t>(descs, results, count);
-    else
-        emu_pipeline<uint8_t>(descs, results, count);
-}
 
 int emu_decode_scans_fast(const jls::ScanDesc* descs, jls::ScanResult* results, int count)
 {
@@ -397,7 +302,12 @@ void emu_encode_with_restart_intervals(const jls::ScanDesc* parents, jls::ScanRe
                 capacity, (uint16_t*)nullptr, (uint64_t)0, subs.data());
     // the last interval of a scan may be shorter: the pipeline takes its geometry per scan, as in the product
     for (size_t i = 0; i < subs_n; ++i)
-        emu_encode_pipeline(&subs[i], &sub_results[i], 1);
+    {
+        if (subs[i].bits_per_sample > 8)
+            emu_tile_pipeline<uint16_t>(&subs[i], &sub_results[i], 1, 256, 128, 2048, 2048, 32768);
+        else
+            emu_tile_pipeline<uint8_t>(&subs[i], &sub_results[i], 1, 256, 128, 2048, 2048, 32768);
+    }
     emu_join_intervals(parents, subs.data(), intervals, sub_results.data(), offsets.data(), results, count);
 }
 

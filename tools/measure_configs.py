@@ -49,11 +49,11 @@ args = ap.parse_args()
 only = set(args.only.split(","))
 
 
-def rgb_frames(count, size, seed0):
-    """(count, size, size, 3) uint8: synth.frame_numpy's interleaved layout (plane k of frame f uses seed seed0 + f + 7919 k)."""
-    out = torch.empty((count, size, size, 3), dtype=torch.uint8, device=dev)
+def rgb_frames(count, size, seed0, bits=8):
+    """(count, size, size, 3) uint8 / int16: synth.frame_numpy's interleaved layout (plane k of frame f uses seed seed0 + f + 7919 k)."""
+    out = torch.empty((count, size, size, 3), dtype=torch.uint8 if bits <= 8 else torch.int16, device=dev)
     for k in range(3):
-        out[..., k] = synth.frames_torch(count, size, size, seed0=seed0 + 7919 * k, bits=8, device=dev)
+        out[..., k] = synth.frames_torch(count, size, size, seed0=seed0 + 7919 * k, bits=bits, device=dev)
     return out
 
 
@@ -91,6 +91,19 @@ if "5d" in only:
     rgb = rgb_frames(args.rgb_frames, 4096, 5)
     run("config 4 line-interleaved near-lossless (5d): 4096x4096 RGB ILV_LINE NEAR=2", rgb, bits=8, comps=3, ilv=1, near=2)
     del rgb
+    torch.cuda.empty_cache()
+    batch.release_work_areas(lib)
+if "5e" in only:
+    rgb = rgb_frames(max(1, args.rgb_frames // 2), 4096, 5, bits=16)
+    run("4096x4096 RGB 16-bit ILV_SAMPLE lossless (5e)", rgb, bits=16, comps=3, ilv=2)
+    run("4096x4096 RGB 16-bit ILV_SAMPLE NEAR=2 (5f)", rgb, bits=16, comps=3, ilv=2, near=2)
+    del rgb
+    torch.cuda.empty_cache()
+    batch.release_work_areas(lib)
+if "6w" in only:
+    f = synth.frames_torch(512, 4096, 4096, seed0=4, bits=16, device=dev)
+    run("near-lossless 16-bit gray (6w): 4096x4096 16-bit gray NEAR=2", f, bits=16, near=2)
+    del f
     torch.cuda.empty_cache()
     batch.release_work_areas(lib)
 if "5b" in only:
