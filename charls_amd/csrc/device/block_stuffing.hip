@@ -43,12 +43,15 @@ constexpr uint32_t kStuffResolveThreads = 256;     // lanes of the resolve step:
 // and the first output byte index (two words) as resolve leaves them.
 constexpr uint32_t kStuffWords = kStuffStates + 4;
 
+struct __attribute__((packed)) UnalignedU64
+{
+    uint64_t v;
+};
 JLS_DEV uint64_t raw_bits_at(const uint8_t* raw, uint64_t bit) // the 64 raw bits from `bit` on, first bit most significant
 {
     const uint8_t* p = raw + (bit >> 3);
-    uint64_t v = 0;
-    for (int i = 0; i < 8; ++i)
-        v = (v << 8) | p[i];
+    // (one load of eight bytes at any address -- gfx950 takes unaligned global loads -- instead of eight of one byte)
+    const uint64_t v = __builtin_bswap64(reinterpret_cast<const UnalignedU64*>(p)->v);
     const uint32_t s = (uint32_t)(bit & 7u);
     return s == 0 ? v : (v << s) | ((uint64_t)p[8] >> (8 - s));
 }

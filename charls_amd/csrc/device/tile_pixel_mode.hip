@@ -108,8 +108,10 @@ JLS_DEV void load_coded_pixel(const ScanDesc& d, uint32_t line, uint32_t x, int 
 // Rows of the staging area: row 0 = the line above the tile's first line, rows 1.. = the tile's lines; slot j of a row =
 // pixel px0 - 1 + j.  Margins: left of pixel 0 sits pixel 0 of the line above (cur[0] = prev[1], src/scan_codec.hpp:189-195),
 // right of the last pixel of a line that pixel again (prev[w + 1] = prev[w]); lines above the scan are zeros.
+//
+// Pixel by pixel (line-interleaved scans: the staged line holds ONE component of the pixels in memory).
 template <typename S>
-JLS_DEV void stage_pixel_rows(const ScanDesc& d, const PixelTile& g, S* rows, int mask)
+JLS_DEV void stage_pixel_rows_generic(const ScanDesc& d, const PixelTile& g, S* rows, int mask)
 {
     const uint32_t total = (g.tile_lines + 1) * g.slots;
     for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
@@ -130,6 +132,110 @@ JLS_DEV void stage_pixel_rows(const ScanDesc& d, const PixelTile& g, S* rows, in
         S* to = rows + (size_t)i * g.nc;
         for (uint32_t c = 0; c < g.nc; ++c)
             to[c] = (S)(c == 0 ? px[0] : c == 1 ? px[1] : c == 2 ? px[2] : px[3]);
+    }
+}
+
+struct __attribute__((packed)) UnalignedU32
+{
+    uint32_t v;
+};
+
+// Planar and sample-interleaved scans: the pixels of a staged row are the bytes of the source row, so they come as whole
+// words (gfx950 takes a 4-byte global load at any address; the LDS side is kept aligned: up to three bytes at either end
+// of a row go one by one), masked to the sample precision on the way; a colour transform then runs over the staged pixels
+// in place, and the margins that are not neighbours in memory (the edges of the scan) are filled pixel by pixel.  Every
+// sample is loaded once and transformed once, where the stages read it five times.
+template <typename S>
+JLS_DEV void stage_pixel_rows(const ScanDesc& d, const PixelTile& g, S* rows, int mask)
+{
+    if (d.interleave_mode == 1)
+    {
+        stage_pixel_rows_generic<S>(d, g, rows, mask);
+        return;
+    }
+    const uint32_t pb = g.nc * (uint32_t)sizeof(S), row_bytes = g.slots * pb;
+    uint8_t* lds = reinterpret_cast<uint8_t*>(rows); // (16-byte aligned)
+    const uint32_t a = g.px0 > 0 ? g.px0 - 1 : 0; // first and last pixel that are copied
+    const uint32_t b = g.px0 + g.pixels < d.width ? g.px0 + g.pixels : d.width - 1;
+    const uint32_t first_slot = a + 1 - g.px0;
+    const uint32_t n = (b - a + 1) * pb; // bytes of a row that are copied
+    const uint32_t mask_word = sizeof(S) == 1 ? (uint32_t)mask * 0x01010101u : (uint32_t)mask * 0x00010001u;
+    const uint32_t R = g.tile_lines + 1;
+    const uint32_t max_words = n / 4 + 1;
+    auto row_at = [&](uint32_t row, uint32_t& lead, uint32_t& words) -> uint32_t { // offset of the copied bytes in LDS
+        const uint32_t at = row * row_bytes + first_slot * pb;
+        lead = (4u - (at & 3u)) & 3u;
+        lead = lead < n ? lead : n;
+        words = (n - lead) / 4;
+        return at;
+    };
+    for (uint32_t i = threadIdx.x; i < R * max_words; i += blockDim.x)
+    {
+        const uint32_t row = i / max_words, wi = i - row * max_words;
+        uint32_t lead, words;
+        const uint32_t at = row_at(row, lead, words);
+        if (wi < words)
+        {
+            uint32_t v = 0;
+            if (g.first_line + row >= 1)
+            {
+                const uint8_t* from = d.pixels + (size_t)(g.first_line + row - 1) * d.pixel_stride + (size_t)a * pb + lead + 4 * wi;
+                v = reinterpret_cast<const UnalignedU32*>(from)->v & mask_word;
+            }
+            *reinterpret_cast<uint32_t*>(lds + at + lead + 4 * wi) = v;
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < R * 8; i += blockDim.x)
+    { // the bytes before the first and behind the last whole word of a row
+        const uint32_t row = i / 8, j = i % 8;
+        uint32_t lead, words;
+        const uint32_t at = row_at(row, lead, words);
+        const uint32_t tail = n - lead - 4 * words;
+        const bool head = j < 4;
+        const uint32_t o = head ? j : lead + 4 * words + (j - 4);
+        if (head ? j < lead : (j - 4) < tail)
+        {
+            uint32_t v = 0;
+            if (g.first_line + row >= 1)
+            {
+                const uint32_t byte_mask = sizeof(S) == 1 ? (uint32_t)mask : ((o & 1u) ? (uint32_t)mask >> 8 : (uint32_t)mask & 0xFFu);
+                v = (uint32_t)(d.pixels + (size_t)(g.first_line + row - 1) * d.pixel_stride + (size_t)a * pb)[o] & byte_mask;
+            }
+            lds[at + o] = (uint8_t)v;
+        }
+    }
+    if (d.color_transformation != 0)
+    { // (three components of 8 or 16 bits, src/color_transform.hpp:26-117; every pixel belongs to one thread)
+        __syncthreads();
+        const uint32_t per_row = b - a + 1;
+        for (uint32_t i = threadIdx.x; i < R * per_row; i += blockDim.x)
+        {
+            const uint32_t row = i / per_row, k = i - row * per_row;
+            if (g.first_line + row < 1)
+                continue;
+            S* px = reinterpret_cast<S*>(lds + row * row_bytes + (first_slot + k) * pb);
+            unsigned t[3];
+            hp_forward(d.color_transformation, sizeof(S) == 2, (int)px[0], (int)px[1], (int)px[2], t);
+            px[0] = (S)t[0];
+            px[1] = (S)t[1];
+            px[2] = (S)t[2];
+        }
+    }
+    if (threadIdx.x < 2 * R)
+    { // the margins at the edges of the scan
+        const uint32_t row = threadIdx.x / 2;
+        const bool right = (threadIdx.x & 1u) != 0;
+        const int64_t line = (int64_t)g.first_line + row - 1;
+        if (right ? g.px0 + g.pixels == d.width : g.px0 == 0)
+        {
+            const int64_t from_line = right ? line : line - 1;
+            int px[4] = {0, 0, 0, 0};
+            if (from_line >= 0)
+                load_coded_pixel<S>(d, (uint32_t)from_line, right ? d.width - 1 : 0u, mask, px);
+            S* to = reinterpret_cast<S*>(lds + row * row_bytes + (right ? g.slots - 1 : 0u) * pb);
+            for (uint32_t c = 0; c < g.nc; ++c)
+                to[c] = (S)(c == 0 ? px[0] : c == 1 ? px[1] : c == 2 ? px[2] : px[3]);
+        }
     }
 }
 

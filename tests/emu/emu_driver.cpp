@@ -9,6 +9,7 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 #include "../../charls_amd/csrc/device/scan_serial.hip"
 #include "../../charls_amd/csrc/device/pipeline_common.hip"
 #include "../../charls_amd/csrc/device/block_stuffing.hip"
+#include "../../charls_amd/csrc/device/speculative_stuffing.hip"
 #include "../../charls_amd/csrc/device/scan_fast_decode.hip"
 #include "../../charls_amd/csrc/device/scan_group_decode.hip"
 #include "../../charls_amd/csrc/device/scan_group_pixels.hip"
@@ -81,7 +82,9 @@ void emu_stuff_raw(const uint8_t* raw, uint64_t total_bits, uint64_t raw_bytes, 
     std::memcpy(words.data(), raw, (size_t)raw_bytes);
     uint64_t bits = total_bits;
     uint32_t status = 0;
-    std::vector<uint32_t> tables((size_t)(raw_bytes / pipe::kStuffChunk + 2) * pipe::kStuffWords, 0xA5A5A5A5u);
+    const pipe::SpecGeometry spec = pipe::stuff_spec_geometry();
+    std::vector<uint32_t> tables(std::max((size_t)(raw_bytes / pipe::kStuffChunk + 2) * pipe::kStuffWords,
+                                          pipe::stuff_spec_table_words(raw_bytes, spec.chunk_bytes)), 0xA5A5A5A5u);
     pipe::Work w{};
     w.raw = words.data();
     w.raw_words = (uint32_t)(raw_bytes / 4);
@@ -91,7 +94,14 @@ void emu_stuff_raw(const uint8_t* raw, uint64_t total_bits, uint64_t raw_bytes, 
     ScanDesc d{};
     d.stream = out;
     d.stream_capacity = capacity;
-    if (blocks)
+    if (blocks == 2)
+    { // the speculative form (speculative_stuffing.hip), grids as in runtime.hip
+        const unsigned waves = (unsigned)((raw_bytes / spec.chunk_bytes + 1 + 63) / 64);
+        emu::launch(pipe::stuff_spec_survey, dim3(waves, 1), dim3(64), 0, (const pipe::Work*)&w, spec.chunk_bytes, spec.warm_bytes);
+        emu::launch(pipe::stuff_spec_resolve, dim3(1), dim3(64), 0, (const pipe::Work*)&w, spec.chunk_bytes);
+        emu::launch(pipe::stuff_spec_emit, dim3(waves, 1), dim3(64), 0, (const ScanDesc*)&d, (const pipe::Work*)&w, result, spec.chunk_bytes);
+    }
+    else if (blocks)
     {
         const unsigned chunk_waves = (unsigned)((raw_bytes / pipe::kStuffChunk + 1 + 63) / 64);
         const unsigned survey_blocks = pipe::stuff_survey_blocks(raw_bytes);

@@ -5,6 +5,7 @@
 
 #include "../../charls_amd/csrc/device/tile_pipeline.hip"
 #include "../../charls_amd/csrc/device/block_stuffing.hip"
+#include "../../charls_amd/csrc/device/speculative_stuffing.hip"
 
 #include <algorithm>
 #include <cstdlib>
@@ -80,7 +81,8 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         sw.raw_words = w.raw_words;
         sw.total_bits = w.total_bits;
         sw.status = w.status;
-        sw.stuff_tables = (uint32_t*)galloc((raw_bytes / pipe::kStuffChunk + 2) * pipe::kStuffWords * 4);
+        sw.stuff_tables = (uint32_t*)galloc(std::max((raw_bytes / pipe::kStuffChunk + 2) * pipe::kStuffWords,
+                                                     pipe::stuff_spec_table_words(raw_bytes, pipe::stuff_spec_geometry().chunk_bytes)) * 4);
     }
     const tile::Work* wk = works.data();
     const unsigned tiles_grid = 8 * ((tiles + 7) / 8);
@@ -129,7 +131,18 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
 #undef EMU_RUN_CHAIN
     emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::kPackThreads), tile::pack_lds_bytes(plan.tile_capacity, p.bits_per_sample), descs, wk);
     const pipe::Work* sk = stuff.data();
-    if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env == nullptr || std::atoi(env) != 0)
+    if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env != nullptr && std::atoi(env) == 2)
+    { // the speculative form (CHARLS_AMD_BLOCK_STUFFING=2 is a switch of this harness only: the product picks by batch size)
+        const pipe::SpecGeometry spec = pipe::stuff_spec_geometry();
+        size_t most = 0;
+        for (int i = 0; i < count; ++i)
+            most = std::max(most, (size_t)works[i].raw_words * 4);
+        const unsigned waves = (unsigned)((most / spec.chunk_bytes + 1 + 63) / 64);
+        emu::launch(pipe::stuff_spec_survey, dim3(waves, count), dim3(64), 0, sk, spec.chunk_bytes, spec.warm_bytes);
+        emu::launch(pipe::stuff_spec_resolve, dim3(count), dim3(64), 0, sk, spec.chunk_bytes);
+        emu::launch(pipe::stuff_spec_emit, dim3(waves, count), dim3(64), 0, descs, sk, results, spec.chunk_bytes);
+    }
+    else if (env == nullptr || std::atoi(env) != 0)
     {
         size_t most = 0;
         for (int i = 0; i < count; ++i)

@@ -1,5 +1,6 @@
-"""Stage E of the encoder pipeline in its two forms (stuff_scan, and the block-parallel survey / resolve / emit of
-block_stuffing.hip) on raw bit streams of every shape, against a bit-by-bit restatement of JPEG-LS stuffing
+"""Stage E of the encoder pipeline in its three forms (stuff_scan; the block-parallel survey / resolve / emit of
+block_stuffing.hip; the speculative form of speculative_stuffing.hip, with chunks and warm-ups small enough that guesses fail
+and scans are given up) on raw bit streams of every shape, against a bit-by-bit restatement of JPEG-LS stuffing
 (reference src/scan_encoder.hpp:103-180: a byte that follows 0xFF carries seven bits; a final 0xFF is followed by 0x00)."""
 import ctypes as C
 
@@ -29,7 +30,8 @@ def _reference(raw: bytes, total_bits: int) -> bytes:
     return bytes(out)
 
 
-def _run(L, raw: bytes, total_bits: int, capacity: int, blocks: bool):
+def _run(L, raw: bytes, total_bits: int, capacity: int, blocks):
+    """blocks: False / 0 = stuff_scan, True / 1 = block form, 2 = speculative form."""
     raw_bytes = (len(raw) + 64 + 15) // 16 * 16
     buf = np.zeros(raw_bytes, dtype=np.uint8)
     buf[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)
@@ -39,7 +41,7 @@ def _run(L, raw: bytes, total_bits: int, capacity: int, blocks: bool):
     out = np.full(capacity + 16, 0xEE, dtype=np.uint8)
     res = emu_bind.ScanResult()
     L.emu_stuff_raw(buf.ctypes.data_as(C.c_void_p), C.c_uint64(total_bits), C.c_uint64(raw_bytes), out.ctypes.data_as(C.c_void_p),
-                    C.c_uint64(capacity), C.c_int(1 if blocks else 0), C.byref(res))
+                    C.c_uint64(capacity), C.c_int(int(blocks)), C.byref(res))
     assert (out[capacity:] == 0xEE).all(), "wrote behind the destination"
     return res.errc, res.flags, res.bytes, out[:min(capacity, res.bytes)].tobytes()
 
@@ -62,20 +64,33 @@ def _streams():
     return cases
 
 
+SPEC = [None, ("64", "0"), ("64", "64"), ("256", "2048"), ("1024", "512")]  # (chunk, warm-up) of the speculative form
+
+
+def _spec(monkeypatch, geometry):
+    if geometry is None:
+        monkeypatch.delenv("CHARLS_AMD_SPEC_CHUNK", raising=False)
+        monkeypatch.delenv("CHARLS_AMD_SPEC_WARM", raising=False)
+    else:
+        monkeypatch.setenv("CHARLS_AMD_SPEC_CHUNK", geometry[0])
+        monkeypatch.setenv("CHARLS_AMD_SPEC_WARM", geometry[1])
+
+
 @pytest.mark.parametrize("index", range(len(_streams())))
-def test_both_forms_equal_the_bitwise_rule(index):
+def test_all_forms_equal_the_bitwise_rule(index, monkeypatch):
     L = emu_bind.lib()
     raw, total_bits = _streams()[index]
     want = _reference(raw, total_bits)
-    for blocks in (False, True):
+    for blocks, geometry in [(0, None), (1, None)] + [(2, g) for g in SPEC]:
+        _spec(monkeypatch, geometry)
         errc, flags, size, data = _run(L, raw, total_bits, len(want) + 100, blocks)
-        assert (errc, size) == (0, len(want)), (blocks, errc, size, len(want))
-        assert data == want, blocks
+        assert (errc, size) == (0, len(want)), (blocks, geometry, errc, size, len(want))
+        assert data == want, (blocks, geometry)
         assert flags == 0
 
 
 @pytest.mark.parametrize("index", [3, 8, 9, 12])
-def test_capacity_verdicts_agree(index):
+def test_capacity_verdicts_agree(index, monkeypatch):
     """Too small, exact, and the three-byte zone in which the host re-runs the exact kernel (flags bit 1)."""
     L = emu_bind.lib()
     raw, total_bits = _streams()[index]
@@ -83,16 +98,32 @@ def test_capacity_verdicts_agree(index):
     for capacity in [0, 1, len(want) - 1, len(want), len(want) + 1, len(want) + 3, len(want) + 4]:
         if capacity < 0:
             continue
-        a = _run(L, raw, total_bits, capacity, False)
-        b = _run(L, raw, total_bits, capacity, True)
-        assert a[:3] == b[:3], (capacity, a[:3], b[:3])
-        assert a[3] == b[3] == want[:min(capacity, len(want))], capacity
+        a = _run(L, raw, total_bits, capacity, 0)
+        for blocks, geometry in [(1, None), (2, None), (2, ("64", "64")), (2, ("256", "2048"))]:
+            _spec(monkeypatch, geometry)
+            b = _run(L, raw, total_bits, capacity, blocks)
+            assert a[:3] == b[:3], (capacity, blocks, geometry, a[:3], b[:3])
+            assert a[3] == b[3] == want[:min(capacity, len(want))], (capacity, blocks, geometry)
 
 
-def test_pipeline_through_the_block_form(monkeypatch):
-    """The whole encoder pipeline with stage E in its block-parallel form (the switch runtime.hip reads as well)."""
-    import test_emu_pipeline as P
-    monkeypatch.setenv("CHARLS_AMD_BLOCK_STUFFING", "1")
-    P.test_pipeline_batch_of_seeded_frames("mixed", 8, 130, 11, 1)
-    P.test_pipeline_batch_of_seeded_frames("noise", 16, 40, 12, 9)
-    P.test_pipeline_destination_too_small_and_knife_edge()
+def test_tile_pipeline_through_every_form(monkeypatch):
+    """The whole encoder pipeline with stage E in each of its forms (CHARLS_AMD_BLOCK_STUFFING: 0, 1, and -- a switch of the
+    harness -- 2 for the speculative form, here with 64-byte chunks)."""
+    import test_emu_tile_pipeline as P
+    monkeypatch.setenv("CHARLS_AMD_SPEC_CHUNK", "64")
+    monkeypatch.setenv("CHARLS_AMD_SPEC_WARM", "256")
+    for form in ("0", "1", "2"):
+        monkeypatch.setenv("CHARLS_AMD_BLOCK_STUFFING", form)
+        P.test_tile_pipeline_batch_of_seeded_frames("mixed", 8, 130, 11, 1, 64, 32)
+        P.test_tile_pipeline_batch_of_seeded_frames("noise", 16, 40, 12, 9, 64, 32)
+    monkeypatch.setenv("CHARLS_AMD_BLOCK_STUFFING", "2")
+    img = P.synth.frame_numpy(64, 64, seed=3, kind="mixed")
+    want = P.ob.encode(img, width=64, height=64)
+    n = len(P._scan_bytes(want))
+    pc = P.jls_container.validated_pc((0,) * 5, 8, 0)
+    (errc, flags, data), = P._encode_planes([img], 64, 64, 8, pc, n - 1)
+    assert errc == 3
+    (errc, flags, data), = P._encode_planes([img], 64, 64, 8, pc, n + 2)
+    assert errc == 0 and flags == 2
+    (errc, flags, data), = P._encode_planes([img], 64, 64, 8, pc, n + 4)
+    assert errc == 0 and flags == 0 and data == P._scan_bytes(want)

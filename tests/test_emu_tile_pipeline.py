@@ -418,3 +418,20 @@ def test_pixel_mode_wide_line_interleaved(monkeypatch, bits, ct, cap):
     kw = dict(width=w, height=h, bits_per_sample=bits, component_count=3, interleave_mode=1, color_transformation=ct)
     errc, flags, data = _encode_scan(img, w, h, 3, 1, bits, ct)
     assert errc == 0 and data == _scan_bytes(ob.encode(img, **kw))
+
+
+@pytest.mark.parametrize("comps,ilv,bits", [(3, 2, 12), (3, 2, 5), (1, 0, 10), (1, 0, 3)])
+def test_pixel_mode_masks_bits_above_the_sample_precision(monkeypatch, comps, ilv, bits):
+    """Source samples with garbage above bits_per_sample (src/copy_to_line_buffer.hpp masks them; test/jpegls_encoder_test.cpp:1577-1755)."""
+    monkeypatch.setenv("CHARLS_AMD_PIXEL_MODE", "1")
+    monkeypatch.setenv("CHARLS_AMD_TILE_SAMPLES", "192")
+    w, h = 211, 9
+    rng = np.random.default_rng(bits)
+    clean = _rgb(w, h, seed=bits, bits=bits, comps=comps, flat=1.0) if comps > 1 else synth.frame_numpy(w, h, seed=bits, bits=bits, kind="mixed")
+    full = 8 if bits <= 8 else 16
+    dirty = (clean.astype(np.uint32) | (rng.integers(0, 1 << (full - bits), size=clean.shape).astype(np.uint32) << bits)).astype(clean.dtype)
+    kw = dict(width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=ilv)
+    want = ob.encode(dirty, **kw)
+    assert want == ob.encode(clean, **kw)
+    errc, flags, data = _encode_scan(dirty, w, h, comps, ilv, bits)
+    assert errc == 0 and data == _scan_bytes(want)
