@@ -86,6 +86,57 @@ __global__ void advance_cursor(FrameCursor* __restrict__ cursors, const ScanResu
     cursors[f] = c;
 }
 
+// The component scans of planar frames coded TOGETHER (one launch for all of them, into private buffers of `capacity` bytes:
+// scan r of frame f at private + (f * rounds + r) * capacity) are put where the reference's writer would have had them coded:
+// one workgroup per frame walks its scans in order -- SOS header (header_size bytes, the r-th of `headers`), then the scan's
+// bytes -- and stops at the first scan that failed or that leaves fewer than 4 bytes behind it: there the reference's verdict
+// depends on the capacity it passes to THAT scan (src/scan_encoder.hpp:117-120), so the frame is marked (redo[f] = 1) and
+// coded again scan by scan by the host.
+struct __attribute__((packed)) UnalignedWord
+{
+    uint32_t v;
+};
+__global__ void __launch_bounds__(256) place_plane_scans(uint8_t* __restrict__ slots, uint64_t slot_pitch, const uint8_t* __restrict__ headers,
+                                                         uint32_t header_size, uint32_t rounds, const uint8_t* __restrict__ private_streams,
+                                                         uint64_t capacity, const ScanResult* __restrict__ results,
+                                                         FrameCursor* __restrict__ cursors, uint32_t* __restrict__ redo)
+{
+    const uint32_t f = blockIdx.x;
+    FrameCursor c = cursors[f];
+    uint8_t* slot = slots + (uint64_t)f * slot_pitch;
+    bool again = false;
+    for (uint32_t r = 0; r < rounds && c.errc == kOk && !again; ++r)
+    {
+        if (c.offset + header_size > slot_pitch)
+        {
+            c.errc = kDestinationTooSmall;
+            break;
+        }
+        const ScanResult res = results[(uint64_t)f * rounds + r];
+        const uint64_t remaining = slot_pitch - c.offset - header_size;
+        if (res.errc != kOk || res.bytes + 4 > remaining)
+        { // (a scan that failed in its private buffer may still fail differently -- or not at all -- in place)
+            again = true;
+            break;
+        }
+        for (uint32_t i = threadIdx.x; i < header_size; i += blockDim.x)
+            slot[c.offset + i] = headers[(uint64_t)r * header_size + i];
+        const uint8_t* from = private_streams + ((uint64_t)f * rounds + r) * capacity;
+        uint8_t* to = slot + c.offset + header_size;
+        const uint64_t words = res.bytes / 4;
+        for (uint64_t i = threadIdx.x; i < words; i += blockDim.x)
+            reinterpret_cast<UnalignedWord*>(to)[i].v = reinterpret_cast<const UnalignedWord*>(from)[i].v;
+        for (uint64_t i = words * 4 + threadIdx.x; i < res.bytes; i += blockDim.x)
+            to[i] = from[i];
+        c.offset += header_size + res.bytes;
+    }
+    if (threadIdx.x == 0)
+    {
+        cursors[f] = c;
+        redo[f] = again ? 1u : 0u;
+    }
+}
+
 __global__ void place_epilogue(uint8_t* __restrict__ slots, uint64_t slot_pitch, FrameCursor* __restrict__ cursors,
                                uint32_t even_size, uint64_t* __restrict__ sizes, uint32_t* __restrict__ errcs,
                                uint32_t frames)

@@ -133,6 +133,8 @@ ScanDesc base_desc(const charls_frame_info& f, int32_t components, int32_t ilv, 
     return d;
 }
 
+thread_local bool t_force_rounds = false; // the batch encoder codes the component scans of planar frames one round per component
+
 } // namespace
 
 extern "C" charls_jpegls_errc charls_amd_encode_batch_device(const charls_amd_codec_params* params, uint32_t frame_count,
@@ -231,7 +233,69 @@ try
     dev::launch_place_prologue(slots, stream_pitch_bytes, d_blob.as<uint8_t>(), prologue_size,
                                d_cursors.as<dev::FrameCursorPod>(), frame_count, stream);
     size_t blob_offset = prologue_size;
-    for (uint32_t r = 0; r < rounds; ++r)
+    // ---- the component scans of planar frames TOGETHER (reference src/charls_jpegls_encoder.cpp:209-224 codes them in a plain
+    // loop; they share nothing): one launch over frames x components into private buffers, then every frame's scans are put in
+    // place behind their SOS headers (place_plane_scans).  Frames go in groups that keep the private buffers under 8 GiB.  A
+    // frame with a scan that failed or that ends within 4 bytes of its destination is coded again below, scan by scan with
+    // the reference's capacities -- its verdict depends on them there (src/scan_encoder.hpp:117-120).
+    std::vector<uint8_t> redo_frames; // 1 = code this frame in rounds (all of them when the scans are not coded together)
+    const bool equal_headers = [&] {
+        for (auto& h : sos)
+            if (h.size() != sos[0].size())
+                return false;
+        return true;
+    }();
+    if (rounds > 1 && p.restart_interval == 0 && equal_headers && !t_force_rounds && std::getenv("CHARLS_AMD_BATCH_ROUNDS") == nullptr)
+    {
+        const size_t worst = dev::worst_case_scan_bytes(f.width, f.height, 1, f.bits_per_sample);
+        const size_t capacity = (std::min(stream_pitch_bytes, worst) + 255) & ~size_t{255};
+        constexpr size_t kPrivateBudget = size_t{8} << 30;
+        const uint32_t group = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(frame_count, kPrivateBudget / (capacity * rounds))));
+        dev::DeviceBuffer d_private, d_plane_descs, d_plane_results, d_redo;
+        auto* priv = static_cast<uint8_t*>(d_private.ensure(capacity * rounds * group));
+        d_plane_descs.ensure(sizeof(ScanDesc) * rounds * group);
+        d_plane_results.ensure(sizeof(ScanResult) * rounds * group);
+        d_redo.ensure(sizeof(uint32_t) * frame_count);
+        dev::DeviceBuffer d_plane_scratch;
+        d_plane_scratch.ensure(scratch_samples * sizeof(uint16_t) * rounds * group);
+        std::vector<ScanDesc> plane_descs(static_cast<size_t>(rounds) * group);
+        const uint32_t sos_size = static_cast<uint32_t>(sos[0].size());
+        for (uint32_t first = 0; first < frame_count; first += group)
+        {
+            const uint32_t n = std::min(group, frame_count - first);
+            for (uint32_t i = 0; i < n; ++i)
+                for (uint32_t r = 0; r < rounds; ++r)
+                {
+                    ScanDesc d = base_desc(f, 1, 0, p.near_lossless, p.color_transformation, pc, 0);
+                    d.pixels = const_cast<uint8_t*>(frames) + (first + i) * frame_pitch_bytes + r * stride * f.height;
+                    d.pixel_stride = stride;
+                    d.stream = priv + (static_cast<size_t>(i) * rounds + r) * capacity;
+                    d.stream_capacity = std::min(stream_pitch_bytes, worst);
+                    d.line_scratch = d_plane_scratch.as<uint16_t>() + (static_cast<size_t>(i) * rounds + r) * scratch_samples;
+                    plane_descs[static_cast<size_t>(i) * rounds + r] = d;
+                }
+            hip_check(hipMemcpyAsync(d_plane_descs.as<ScanDesc>(), plane_descs.data(), sizeof(ScanDesc) * rounds * n, hipMemcpyHostToDevice, stream));
+            hip_check(hipStreamSynchronize(stream)); // plane_descs is reused by the next group
+            scans.start();
+            {
+                ScanDesc proto = plane_descs[0];
+                dev::launch_encode(proto, d_plane_descs.as<ScanDesc>(), d_plane_results.as<ScanResult>(), rounds * n, stream);
+            }
+            scans.stop();
+            scan_ms += scans.ms();
+            dev::launch_place_plane_scans(slots + first * stream_pitch_bytes, stream_pitch_bytes, d_blob.as<uint8_t>() + prologue_size, sos_size,
+                                          rounds, priv, capacity, d_plane_results.as<ScanResult>(),
+                                          d_cursors.as<dev::FrameCursorPod>() + first, d_redo.as<uint32_t>() + first, n, stream);
+        }
+        std::vector<uint32_t> redo(frame_count);
+        hip_check(hipMemcpyAsync(redo.data(), d_redo.as<uint32_t>(), sizeof(uint32_t) * frame_count, hipMemcpyDeviceToHost, stream));
+        hip_check(hipStreamSynchronize(stream));
+        redo_frames.assign(frame_count, 0);
+        for (uint32_t i = 0; i < frame_count; ++i)
+            redo_frames[i] = redo[i] != 0;
+    }
+    const bool in_rounds = redo_frames.empty();
+    for (uint32_t r = 0; r < rounds && in_rounds; ++r)
     {
         for (uint32_t i = 0; i < frame_count; ++i)
         {
@@ -273,6 +337,20 @@ try
     t.values[1] = scan_ms;
     if (t.count < 2)
         t.count = 2; // the pipeline adds its stage breakdown in values[2..6]
+    // frames whose scans could not simply be put in place: scan by scan, with the capacities the reference passes
+    for (uint32_t i = 0; i < redo_frames.size(); ++i)
+        if (redo_frames[i])
+        {
+            struct ForceRounds
+            {
+                ForceRounds() { t_force_rounds = true; }
+                ~ForceRounds() { t_force_rounds = false; }
+            } force;
+            const charls_jpegls_errc rc = charls_amd_encode_batch_device(params, 1, frames + i * frame_pitch_bytes, frame_pitch_bytes, stride_arg,
+                                                                         slots + i * stream_pitch_bytes, stream_pitch_bytes, sizes + i, errcs + i, hip_stream);
+            if (rc != CHARLS_JPEGLS_ERRC_SUCCESS)
+                return rc;
+        }
     return CHARLS_JPEGLS_ERRC_SUCCESS;
 }
 catch (...)

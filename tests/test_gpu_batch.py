@@ -223,3 +223,56 @@ def test_config5_full_size_equals_reference_hash(torch, name):
     else:
         assert (out.int() - rgb.int()).abs().max().item() <= c["near_lossless"]
     assert common.sha(out.cpu().numpy().tobytes()) == c["decoded_sha256"]
+
+
+def test_planar_batch_codes_all_component_scans_in_one_launch(torch):
+    """the component scans of planar frames are coded by ONE launch (frames x components scans) and
+    put in place afterwards.  A 3-plane 2048 x 2048 batch, bytes against the oracle; the time of the batch against the time
+    of the same planes as single-component frames."""
+    import time
+    n, w, h = 4, 2048, 2048
+    imgs = [synth.frame_numpy(w, h, seed=300 + f, components=3, kind="mixed", interleaved=False) for f in range(n)]
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    batch.encode_batch(frames, component_count=3)  # warm-up (work areas)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    enc = batch.encode_batch(frames, component_count=3)
+    t_planar = time.perf_counter() - t0
+    host = enc.streams.cpu().numpy()
+    for f in range(n):
+        want = ob.encode(imgs[f], width=w, height=h, component_count=3)
+        assert enc.errcs[f] == 0 and host[f, :int(enc.sizes[f])].tobytes() == want, f
+    planes = frames.reshape(n * 3, h, w)
+    batch.encode_batch(planes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    batch.encode_batch(planes)
+    t_planes = time.perf_counter() - t0
+    assert t_planar < 1.5 * t_planes + 0.002, (t_planar, t_planes)  # (in rounds it took three times the launches of a third of the scans)
+    out = torch.empty_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+    assert (errcs == 0).all() and torch.equal(out, frames)
+
+
+@pytest.mark.parametrize("bits,near,comps", [(8, 0, 3), (8, 2, 3), (16, 0, 2), (12, 0, 4)])
+def test_planar_batch_every_capacity_around_the_fit(torch, bits, near, comps):
+    """Slots that are too small for some component, exactly large enough, or within the 4 bytes in which the reference's
+    verdict depends on the capacity it passes to the scan: every frame gets the oracle's errc / bytes (frames whose scans
+    cannot simply be put in place are coded again scan by scan)."""
+    n, w, h = 3, 80, 40
+    imgs = [synth.frame_numpy(w, h, seed=400 + f, bits=bits, components=comps, kind="mixed", interleaved=False) for f in range(n)]
+    frames = torch.from_numpy(np.stack(imgs).astype(np.int16 if bits > 8 else np.uint8)).cuda()
+    kw = dict(width=w, height=h, bits_per_sample=bits, component_count=comps, near_lossless=near)
+    full = [ob.encode(img, **kw) for img in imgs]
+    for pitch in sorted({len(full[0]) + d for d in (-40, -5, -3, -2, -1, 0, 1, 2, 3, 4, 5, 64)} | {len(full[1]), len(full[2]) + 1}):
+        streams = torch.zeros((n, pitch), dtype=torch.uint8, device="cuda")
+        enc = batch.encode_batch(frames, bits_per_sample=bits, component_count=comps, near_lossless=near, streams=streams)
+        host = enc.streams.cpu().numpy()
+        for f in range(n):
+            try:
+                want, ew = ob.encode(imgs[f], destination_size=pitch, **kw), 0
+            except ob.OracleError as e:
+                want, ew = None, e.errc
+            assert enc.errcs[f] == ew, (pitch, f, enc.errcs[f], ew)
+            if want is not None:
+                assert host[f, :int(enc.sizes[f])].tobytes() == want, (pitch, f)
