@@ -131,89 +131,117 @@ JLS_DEV CodeWord golomb_word(const Traits& t, int k, int m, int limit)
 // and including this tile), bits 0..61 the value; zero before the launch.
 constexpr uint64_t kBlockOwn = 1ull << 62, kBlockUpTo = 2ull << 62, kBlockValue = (1ull << 62) - 1ull;
 
-// E: one wavefront per scan: raw bits -> stuffed bytes.  After a 0xFF byte the next byte carries 7 bits (MSB 0); a final
-// 0xFF is followed by 0x00; the last partial byte is zero padded (src/scan_encoder.hpp:103-180).
+// E: raw bits -> stuffed bytes.  After a 0xFF byte the next byte carries 7 bits (MSB 0); a final 0xFF is followed by 0x00;
+// the last partial byte is zero padded (src/scan_encoder.hpp:103-180).
 //
-// Stuffing is sequential only through the (rare) 0xFF bytes, so the wavefront speculates: lane l cuts output byte l of
-// the next 64 out of the raw bit stream assuming no 0xFF occurs before it; a ballot finds the first 0xFF, everything up
-// to and including it is final and is stored with one coalesced write, and the next round starts behind it with a
-// 7-bit first byte.  Result flags: bit 1 = the capacity is within 3 bytes of the output size, where the reference's
-// accept/reject decision depends on its 32-bit flush history; the host then re-runs the exact serial kernel.
+// Stuffing is sequential only through the (rare) 0xFF bytes -- one byte in 256 of random bits, one in ~760 of real coded
+// data --, so a wavefront speculates: lane l cuts output bytes 8 l .. 8 l + 7 of the next 512 out of the raw bit stream
+// assuming no 0xFF occurs before them (64 bits straight from memory, the lanes' windows contiguous: 512 bytes per request),
+// finds the first 0xFF among its own eight bytes with three folds, a ballot finds the first lane that has one, everything up
+// to and including that byte is final and leaves as 8-byte stores, and the next round starts behind it with a 7-bit byte --
+// which is the ordinary case again once the window is read one bit earlier and its first bit cleared.  (Until round 4 a lane
+// cut ONE byte per round out of an LDS ring: 4.2 ns per byte, 99 ms for the 23.5 MB of a 4096 x 4096 RGB frame.)
+struct StuffCursor
+{
+    uint64_t bp;       // raw bit at which the next output byte starts
+    uint64_t written;  // output bytes so far
+    bool short_first;  // that byte follows a 0xFF: 7 payload bits
+};
+
+struct __attribute__((packed)) UnalignedQuad
+{
+    uint64_t v;
+};
+JLS_DEV uint64_t raw_window(const uint8_t* raw, uint64_t bit) // the 64 raw bits from `bit` on, first bit most significant
+{
+    const uint8_t* p = raw + (bit >> 3);
+    const uint64_t v = __builtin_bswap64(reinterpret_cast<const UnalignedQuad*>(p)->v);
+    const uint32_t s = (uint32_t)(bit & 7u);
+    return s == 0 ? v : (v << s) | ((uint64_t)p[8] >> (8 - s));
+}
+
+// The output bytes that START in [cur.bp, end), by ONE wavefront (all 64 lanes call it).  kEmit: they are stored at
+// out + cur.written (bytes at or behind `capacity` are dropped).  raw must be readable 16 bytes beyond bit `end`.
+template <bool kEmit>
+JLS_DEV void stuff_walk(const uint8_t* raw, StuffCursor& cur, uint64_t end, uint8_t* out, uint64_t capacity)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    while (cur.bp < end)
+    {
+        const uint64_t base = cur.bp - (cur.short_first ? 1u : 0u); // (a 0xFF byte lies before a short byte: no underflow)
+        const uint64_t pos = base + 64ull * lane;
+        uint64_t w = pos < end ? raw_window(raw, pos) : 0ull;
+        if (cur.short_first && lane == 0)
+            w &= ~(1ull << 63); // the 7-bit byte: its first bit is the stuffed zero
+        const uint32_t valid = pos >= end ? 0u : (end - pos >= 64 ? 8u : (uint32_t)((end - pos + 7) / 8)); // bytes of this lane that start before `end`
+        uint64_t ones = w & (w >> 1);
+        ones &= ones >> 2;
+        ones &= ones >> 4;
+        ones &= 0x0101010101010101ull;
+        const uint32_t first_ff = ones ? (uint32_t)(__builtin_clzll(ones) / 8) : 8u; // in stream order
+        const unsigned long long ffm = __ballot(first_ff < valid);
+        const uint64_t left = end - base;
+        const uint32_t round_bytes = left >= 512 * 8 ? 512u : (uint32_t)((left + 7) / 8);
+        uint32_t total = round_bytes;
+        if (ffm != 0)
+        {
+            const int f = (int)__ffsll(ffm) - 1;
+            total = 8u * (uint32_t)f + (uint32_t)__shfl((int)first_ff, f) + 1u;
+        }
+        if (kEmit)
+        {
+            const uint32_t mine = total > 8u * lane ? (total - 8u * lane >= 8u ? 8u : total - 8u * lane) : 0u;
+            const uint64_t at = cur.written + 8ull * lane;
+            if (mine == 8 && at + 8 <= capacity)
+                reinterpret_cast<UnalignedQuad*>(out + at)->v = __builtin_bswap64(w);
+            else
+                for (uint32_t k = 0; k < mine; ++k)
+                    if (at + k < capacity)
+                        out[at + k] = (uint8_t)(w >> (56 - 8 * k));
+        }
+        cur.written += total;
+        cur.bp = base + 8ull * total;
+        cur.short_first = ffm != 0;
+    }
+}
+
+// One wavefront per scan: the whole stream in sequence (the passes whose stuffing runs under the next pass's first stages;
+// batches take speculative_stuffing.hip, single frames block_stuffing.hip).  Result flags: bit 1 = the capacity is within 3
+// bytes of the output size, where the reference's accept/reject decision depends on its 32-bit flush history; the host then
+// re-runs the exact serial kernel.
+JLS_DEV ScanResult stuff_stream_sequential(const ScanDesc& d, const Work& w, uint64_t total_bits)
+{
+    ScanResult r{kOk, 0, 0};
+    StuffCursor cur{0, 0, false};
+    stuff_walk<true>(reinterpret_cast<const uint8_t*>(w.raw), cur, total_bits, d.stream, d.stream_capacity);
+    if (cur.short_first)
+    { // src/scan_encoder.hpp:107-112: a trailing 0xFF is followed by a byte of seven zero bits
+        if ((threadIdx.x & 63u) == 0 && cur.written < d.stream_capacity)
+            d.stream[cur.written] = 0;
+        ++cur.written;
+    }
+    r.bytes = cur.written;
+    if (cur.written > d.stream_capacity)
+        r.errc = kDestinationTooSmall;
+    else if (d.stream_capacity - cur.written < 4)
+        r.flags = 2; // undecidable here, see above
+    return r;
+}
+
 __global__ void __launch_bounds__(64) stuff_scan(const ScanDesc* __restrict__ descs, const Work* __restrict__ works,
                                                  ScanResult* __restrict__ results)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[4096];
     const ScanDesc d = descs[blockIdx.x];
     const Work w = works[blockIdx.x];
-    const int lane = threadIdx.x;
     const uint64_t total_bits = *w.total_bits;
-    const uint64_t raw_bytes_cap = w.raw_words * 4;
-    const uint8_t* raw = reinterpret_cast<const uint8_t*>(w.raw);
     ScanResult r{kOk, 0, 0};
-
     if ((*w.status & kStatusInvalid) != 0)
         r.errc = kInvalidData;
-    else if ((total_bits + 7) / 8 > raw_bytes_cap)
+    else if ((total_bits + 7) / 8 > w.raw_words * 4)
         r.errc = kDestinationTooSmall; // the unstuffed stream alone exceeds the destination
-    if (r.errc != kOk)
-    {
-        if (lane == 0)
-            results[blockIdx.x] = r;
-        return;
-    }
-
-    uint64_t loaded = 0;  // raw bytes [loaded - 4096, loaded) are resident in s_in (ring)
-    uint64_t bp = 0;      // next raw bit
-    uint64_t written = 0; // output bytes so far
-    bool first_short = false; // the next output byte follows a 0xFF: 7 payload bits
-    bool last_ff = false;
-
-    while (bp < total_bits)
-    {
-        JLS_LOCKSTEP();
-        // raw bytes needed by this round: 64 output bytes + slack
-        while (loaded < (bp >> 3) + 80 && loaded < raw_bytes_cap)
-        {
-            const uint64_t o = loaded + (uint64_t)lane * 16;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (o + 16 <= raw_bytes_cap)
-                v = *reinterpret_cast<const uint4*>(raw + o);
-            *reinterpret_cast<uint4*>(s_in + (o & 4095)) = v;
-            loaded += 1024;
-            __syncthreads();
-        }
-        // lane l: bits [start, start + n) with n = 7 for a byte that follows a 0xFF
-        const int n = (lane == 0 && first_short) ? 7 : 8;
-        const uint64_t start = bp + (uint64_t)lane * 8 - ((lane != 0 && first_short) ? 1 : 0);
-        const bool active = start < total_bits;
-        const uint32_t b0 = s_in[(start >> 3) & 4095];
-        const uint32_t b1 = s_in[((start >> 3) + 1) & 4095];
-        const uint32_t two = (b0 << 8) | b1; // 16 raw bits, MSB first (zeros beyond the end of the stream)
-        const uint32_t byte = (two >> (16 - (int)(start & 7) - n)) & ((1u << n) - 1u);
-        const unsigned long long act = __ballot(active);
-        const unsigned long long ffm = __ballot(active && byte == 0xFFu);
-        const int count = __popcll(act);                              // active lanes are a prefix
-        const int upto = ffm ? (int)__ffsll(ffm) : count;             // bytes that are final in this round
-        if (lane < upto && written + (uint64_t)lane < d.stream_capacity)
-            d.stream[written + lane] = (uint8_t)byte;
-        written += (uint64_t)upto;
-        bp = bp + (uint64_t)upto * 8 - (first_short ? 1 : 0);
-        first_short = ffm != 0 && upto <= count;
-        last_ff = ffm != 0;
-    }
-    if (last_ff)
-    { // src/scan_encoder.hpp:107-112: a trailing 0xFF is followed by a byte of seven zero bits
-        if (lane == 0 && written < d.stream_capacity)
-            d.stream[written] = 0;
-        ++written;
-    }
-
-    r.bytes = written;
-    if (written > d.stream_capacity)
-        r.errc = kDestinationTooSmall;
-    else if (d.stream_capacity - written < 4)
-        r.flags = 2; // undecidable here, see above
-    if (lane == 0)
+    else
+        r = stuff_stream_sequential(d, w, total_bits);
+    if (threadIdx.x == 0)
         results[blockIdx.x] = r;
 }
 

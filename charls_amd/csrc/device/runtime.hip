@@ -969,9 +969,9 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             hipLaunchKernelGGL(pipe::stuff_emit, dim3(chunk_waves, n), dim3(64), 0, stuff_stream, descs, d_stuff, d_results + first);
         }
         else if (spec_stuffing_enabled() && (pass + 1 == passes || lay.raw_bytes >= kSpecStuffingAlwaysBytes))
-        { // a lane per 16 KB of raw stream, from guessed entry states
+        { // a wavefront per 64 KB of raw stream, from guessed entry states
             const pipe::SpecGeometry spec = pipe::stuff_spec_geometry();
-            const uint32_t waves = static_cast<uint32_t>((lay.raw_bytes / spec.chunk_bytes + 1 + 63) / 64);
+            const uint32_t waves = static_cast<uint32_t>(lay.raw_bytes / spec.chunk_bytes + 1);
             hipLaunchKernelGGL(pipe::stuff_spec_survey, dim3(waves, n), dim3(64), 0, stuff_stream, d_stuff, spec.chunk_bytes, spec.warm_bytes);
             hipLaunchKernelGGL(pipe::stuff_spec_resolve, dim3(n), dim3(64), 0, stuff_stream, d_stuff, spec.chunk_bytes);
             hipLaunchKernelGGL(pipe::stuff_spec_emit, dim3(waves, n), dim3(64), 0, stuff_stream, descs, d_stuff, d_results + first, spec.chunk_bytes);

@@ -8,20 +8,22 @@
 // meets moves its boundaries by one bit against the other's, so their distance is a random walk on eight positions that is
 // absorbed at zero -- within a few KB of ordinary coded data (one byte in 256 is 0xFF).  So:
 //
-//   survey   one LANE per chunk (16 KB of raw stream) walks from `warm` bytes before its chunk, from state 0, to its
-//            chunk's first bit -- a guess of the entry state -- and on through the chunk: bytes owned, exit state;
+//   survey   one WAVEFRONT per chunk (64 KB of raw stream) walks from `warm` bytes before its chunk, from state 0, to its
+//            chunk's first bit -- a guess of the entry state -- and on through the chunk: bytes owned, exit state
+//            (stuff_walk: 512 bytes per round);
 //   resolve  one wavefront per scan checks every chunk boundary (the guess must equal the predecessor's exit state; chunk 0
 //            is entered in state 0 by definition), walks a chunk whose guess was wrong again from the true state, and leaves
 //            every chunk its entry state and the index of its first output byte (a prefix sum).  A scan with more wrong
 //            guesses than a handful (coded data without 0xFF bytes: nothing makes walks meet) is handed to the sequential
 //            form instead;
-//   emit     one lane per chunk walks once more, from its real entry state, and stores its bytes; the last chunk closes the
-//            scan.  For a scan that resolve gave up on, the first wavefront runs stuff_scan's loop over the whole stream.
+//   emit     one wavefront per chunk walks once more, from its real entry state, and stores its bytes; the last chunk closes
+//            the scan.  For a scan that resolve gave up on, the first wavefront walks the whole stream.
 //
-// Against stuff_scan (one wavefront per scan: 99 ms for the 23.5 MB of a 4096 x 4096 RGB frame, whatever the number of
-// scans in the pass) this reads the raw stream 2 + warm / chunk times but with a lane per 16 KB; against the block form
-// (block_stuffing.hip: exact tables for all 16 entry states of every 1 KB chunk, 17 reads of the stream) it is what a pass of
-// hundreds of scans can afford.  Output and result words are those of stuff_scan, byte for byte
+// Measured on real coded data (tools: a 1024 x 1024 test frame has one 0xFF in 760 bytes): with a warm-up of 16 KB three
+// guesses in a hundred are wrong, with 64 KB none in 170.  Against stuff_scan (one wavefront per scan, whatever the number
+// of scans in the pass) this reads the raw stream 2 + warm / chunk times, with a wavefront per 64 KB; against the block form
+// (block_stuffing.hip: exact tables for all 16 entry states of every 1 KB chunk, 17 reads of the stream, a LANE per walk) it
+// is what a pass of hundreds of scans can afford.  Output and result words are those of stuff_scan, byte for byte
 // (tests/test_emu_block_stuffing.py, GPU suite).  CHARLS_AMD_SPEC_STUFFING=0 switches it off; CHARLS_AMD_SPEC_CHUNK /
 // CHARLS_AMD_SPEC_WARM (bytes) size it (the tests use tiny values so that guesses fail).
 #pragma once
@@ -42,42 +44,46 @@ constexpr uint32_t kSpecWords = 8;
 constexpr uint32_t kSpecMaxFixes = 16;    // wrong guesses resolve repairs itself before it gives the scan up
 constexpr uint32_t kSpecGiveUp = 0xFFFFFFFFu;
 
-JLS_DEV uint32_t entry_state_of(uint64_t r, uint32_t wd, uint64_t boundary) // r: first byte start at or behind `boundary`
+JLS_DEV uint32_t entry_state_of(const StuffCursor& cur, uint64_t boundary) // cur.bp: first byte start at or behind `boundary`
 {
-    return (uint32_t)((r - boundary) & 7u) | (wd == 7 ? 8u : 0u);
+    return (uint32_t)((cur.bp - boundary) & 7u) | (cur.short_first ? 8u : 0u);
+}
+JLS_DEV StuffCursor cursor_from(uint32_t state, uint64_t boundary)
+{
+    return StuffCursor{boundary + (state & 7u), 0, (state & 8u) != 0};
 }
 
-// grid (ceil(max_chunks / 64), scans) x 64 lanes.
+// grid (max_chunks, scans) x 64 lanes: one wavefront per chunk.
 __global__ void __launch_bounds__(64) stuff_spec_survey(const Work* __restrict__ works, uint32_t chunk_bytes, uint32_t warm_bytes)
 {
     const Work w = works[blockIdx.y];
     const uint64_t total_bits = *w.total_bits;
     const uint64_t chunk_bits = (uint64_t)chunk_bytes * 8;
     const uint32_t chunks = (uint32_t)((total_bits + chunk_bits - 1) / chunk_bits);
-    const uint32_t chunk = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t chunk = blockIdx.x;
     if (chunk >= chunks || (*w.status & kStatusInvalid) != 0 || (uint64_t)(total_bits + 7) / 8 > (uint64_t)w.raw_words * 4)
         return;
     const uint8_t* raw = reinterpret_cast<const uint8_t*>(w.raw);
     const uint64_t begin = (uint64_t)chunk * chunk_bits;
     const uint64_t end = begin + chunk_bits < total_bits ? begin + chunk_bits : total_bits;
-    bool last_ff;
     uint32_t guess = 0;
     if (chunk != 0)
     { // (a warm-up that reaches back to bit 0 starts in the true state: its guess is exact)
         const uint64_t warm_bits = (uint64_t)warm_bytes * 8;
-        uint64_t r = begin > warm_bits ? begin - warm_bits : 0;
-        uint32_t wd = 8;
-        (void)walk_chunk<false>(raw, r, wd, begin, last_ff, [](uint32_t, uint32_t) {});
-        guess = entry_state_of(r, wd, begin);
+        StuffCursor warm{begin > warm_bits ? begin - warm_bits : 0, 0, false};
+        stuff_walk<false>(raw, warm, begin, nullptr, 0);
+        guess = entry_state_of(warm, begin);
     }
-    uint64_t r = begin + (guess & 7u);
-    uint32_t wd = (guess & 8u) ? 7u : 8u;
-    const uint32_t count = walk_chunk<false>(raw, r, wd, end, last_ff, [](uint32_t, uint32_t) {});
-    uint32_t* mine = w.stuff_tables + (size_t)chunk * kSpecWords;
-    mine[0] = guess;
-    mine[1] = count;
-    mine[2] = entry_state_of(r, wd, begin + chunk_bits);
-    mine[3] = 0;
+    StuffCursor cur = cursor_from(guess, begin);
+    stuff_walk<false>(raw, cur, end, nullptr, 0);
+    if (threadIdx.x == 0)
+    {
+        uint32_t* mine = w.stuff_tables + (size_t)chunk * kSpecWords;
+        mine[0] = guess;
+        mine[1] = (uint32_t)cur.written;
+        mine[2] = entry_state_of(cur, begin + chunk_bits);
+        mine[3] = 0;
+    }
 }
 
 // grid (scans) x 64 lanes.
@@ -100,8 +106,8 @@ __global__ void __launch_bounds__(64) stuff_spec_resolve(const Work* __restrict_
         const bool live = c < chunks;
         uint32_t* mine = w.stuff_tables + (size_t)(live ? c : 0) * kSpecWords;
         uint32_t guess = live ? mine[0] : 0u, count = live ? mine[1] : 0u, exit_state = live ? mine[2] : 0u;
-        // a chunk whose guess differs from what its predecessor hands over is walked again; lanes in order, because the
-        // repaired chunk's own exit state is what its successor has to be checked against
+        // a chunk whose guess differs from what its predecessor hands over is walked again (by the whole wavefront); chunks in
+        // order, because the repaired chunk's own exit state is what its successor has to be checked against
         for (;;)
         {
             uint32_t before = __shfl_up(exit_state, 1);
@@ -114,16 +120,16 @@ __global__ void __launch_bounds__(64) stuff_spec_resolve(const Work* __restrict_
             ++fixes;
             if (fixes > kSpecMaxFixes)
                 break;
+            const uint32_t true_state = (uint32_t)__shfl((int)before, f);
+            const uint64_t begin = (uint64_t)(c0 + (uint32_t)f) * chunk_bits;
+            const uint64_t end = begin + chunk_bits < total_bits ? begin + chunk_bits : total_bits;
+            StuffCursor cur = cursor_from(true_state, begin);
+            stuff_walk<false>(raw, cur, end, nullptr, 0);
             if (lane == f)
             {
-                const uint64_t begin = (uint64_t)c * chunk_bits;
-                const uint64_t end = begin + chunk_bits < total_bits ? begin + chunk_bits : total_bits;
-                uint64_t r = begin + (before & 7u);
-                uint32_t wd = (before & 8u) ? 7u : 8u;
-                bool last_ff;
-                count = walk_chunk<false>(raw, r, wd, end, last_ff, [](uint32_t, uint32_t) {});
-                exit_state = entry_state_of(r, wd, begin + chunk_bits);
-                guess = before;
+                count = (uint32_t)cur.written;
+                exit_state = entry_state_of(cur, begin + chunk_bits);
+                guess = true_state;
             }
         }
         if (fixes > kSpecMaxFixes)
@@ -151,76 +157,21 @@ __global__ void __launch_bounds__(64) stuff_spec_resolve(const Work* __restrict_
         w.stuff_tables[3] = fixes > kSpecMaxFixes ? kSpecGiveUp : 0u;
 }
 
-// stuff_scan's loop as a device function: the whole stream by ONE wavefront (all 64 lanes call it); s_in: 4096 bytes of LDS.
-JLS_DEV ScanResult stuff_stream_sequential(const ScanDesc& d, const Work& w, uint64_t total_bits, uint8_t* s_in)
-{
-    const int lane = threadIdx.x & 63;
-    const uint64_t raw_bytes_cap = w.raw_words * 4;
-    const uint8_t* raw = reinterpret_cast<const uint8_t*>(w.raw);
-    ScanResult r{kOk, 0, 0};
-    uint64_t loaded = 0, bp = 0, written = 0;
-    bool first_short = false, last_ff = false;
-    while (bp < total_bits)
-    {
-        JLS_LOCKSTEP();
-        while (loaded < (bp >> 3) + 80 && loaded < raw_bytes_cap)
-        {
-            const uint64_t o = loaded + (uint64_t)lane * 16;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (o + 16 <= raw_bytes_cap)
-                v = *reinterpret_cast<const uint4*>(raw + o);
-            *reinterpret_cast<uint4*>(s_in + (o & 4095)) = v;
-            loaded += 1024;
-            JLS_LOCKSTEP();
-        }
-        const int n = (lane == 0 && first_short) ? 7 : 8;
-        const uint64_t start = bp + (uint64_t)lane * 8 - ((lane != 0 && first_short) ? 1 : 0);
-        const bool active = start < total_bits;
-        const uint32_t b0 = s_in[(start >> 3) & 4095];
-        const uint32_t b1 = s_in[((start >> 3) + 1) & 4095];
-        const uint32_t two = (b0 << 8) | b1;
-        const uint32_t byte = (two >> (16 - (int)(start & 7) - n)) & ((1u << n) - 1u);
-        const unsigned long long act = __ballot(active);
-        const unsigned long long ffm = __ballot(active && byte == 0xFFu);
-        const int count = __popcll(act);
-        const int upto = ffm ? (int)__ffsll(ffm) : count;
-        if (lane < upto && written + (uint64_t)lane < d.stream_capacity)
-            d.stream[written + lane] = (uint8_t)byte;
-        written += (uint64_t)upto;
-        bp = bp + (uint64_t)upto * 8 - (first_short ? 1 : 0);
-        first_short = ffm != 0 && upto <= count;
-        last_ff = ffm != 0;
-    }
-    if (last_ff)
-    {
-        if (lane == 0 && written < d.stream_capacity)
-            d.stream[written] = 0;
-        ++written;
-    }
-    r.bytes = written;
-    if (written > d.stream_capacity)
-        r.errc = kDestinationTooSmall;
-    else if (d.stream_capacity - written < 4)
-        r.flags = 2;
-    return r;
-}
-
-// grid (max(1, ceil(max_chunks / 64)), scans) x 64 lanes; writes the scan's result (stuff_scan's words).
+// grid (max(1, max_chunks), scans) x 64 lanes: one wavefront per chunk; writes the scan's result (stuff_scan's words).
 __global__ void __launch_bounds__(64) stuff_spec_emit(const ScanDesc* __restrict__ descs, const Work* __restrict__ works,
                                                       ScanResult* __restrict__ results, uint32_t chunk_bytes)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[4096];
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const uint64_t total_bits = *w.total_bits;
     const uint64_t chunk_bits = (uint64_t)chunk_bytes * 8;
     const uint32_t chunks = (uint32_t)((total_bits + chunk_bits - 1) / chunk_bits);
-    const uint32_t chunk = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t chunk = blockIdx.x;
     const bool invalid = (*w.status & kStatusInvalid) != 0;
     const bool overflow = (uint64_t)(total_bits + 7) / 8 > (uint64_t)w.raw_words * 4;
     if (invalid || overflow || chunks == 0)
     {
-        if (chunk == 0)
+        if (chunk == 0 && threadIdx.x == 0)
         {
             ScanResult res{invalid ? kInvalidData : (overflow ? kDestinationTooSmall : kOk), 0, 0};
             if (res.errc == kOk && d.stream_capacity < 4)
@@ -230,10 +181,10 @@ __global__ void __launch_bounds__(64) stuff_spec_emit(const ScanDesc* __restrict
         return;
     }
     if (w.stuff_tables[3] == kSpecGiveUp)
-    { // too many wrong guesses: the sequential form, by the scan's first wavefront
-        if (blockIdx.x == 0)
+    { // too many wrong guesses: the whole stream in sequence, by the scan's first wavefront
+        if (chunk == 0)
         {
-            const ScanResult res = stuff_stream_sequential(d, w, total_bits, s_in);
+            const ScanResult res = stuff_stream_sequential(d, w, total_bits);
             if (threadIdx.x == 0)
                 results[blockIdx.y] = res;
         }
@@ -243,26 +194,20 @@ __global__ void __launch_bounds__(64) stuff_spec_emit(const ScanDesc* __restrict
         return;
     const uint8_t* raw = reinterpret_cast<const uint8_t*>(w.raw);
     const uint32_t* mine = w.stuff_tables + (size_t)chunk * kSpecWords + 4;
-    const uint32_t state = mine[0];
     const uint64_t first = (uint64_t)mine[1] | ((uint64_t)mine[2] << 32);
     const uint64_t begin = (uint64_t)chunk * chunk_bits;
     const uint64_t end = begin + chunk_bits < total_bits ? begin + chunk_bits : total_bits;
-    uint64_t r = begin + (state & 7u);
-    uint32_t wd = (state & 8u) ? 7u : 8u;
-    bool last_ff;
-    uint8_t* out = d.stream;
+    StuffCursor cur = cursor_from(mine[0], begin);
+    cur.written = first;
     const uint64_t capacity = d.stream_capacity;
-    const uint32_t count = walk_chunk<true>(raw, r, wd, end, last_ff, [&](uint32_t byte, uint32_t k) {
-        if (first + k < capacity)
-            out[first + k] = (uint8_t)byte;
-    });
+    stuff_walk<true>(raw, cur, end, d.stream, capacity);
     if (chunk + 1 == chunks)
     { // the last chunk closes the scan: src/scan_encoder.hpp:107-112, a trailing 0xFF is followed by seven zero bits
-        uint64_t written = first + count;
-        if (last_ff)
+        uint64_t written = cur.written;
+        if (cur.short_first)
         {
-            if (written < capacity)
-                out[written] = 0;
+            if (threadIdx.x == 0 && written < capacity)
+                d.stream[written] = 0;
             ++written;
         }
         ScanResult res{kOk, 0, written};
@@ -270,11 +215,12 @@ __global__ void __launch_bounds__(64) stuff_spec_emit(const ScanDesc* __restrict
             res.errc = kDestinationTooSmall;
         else if (capacity - written < 4)
             res.flags = 2;
-        results[blockIdx.y] = res;
+        if (threadIdx.x == 0)
+            results[blockIdx.y] = res;
     }
 }
 
-// Chunk and warm-up of the speculative form (bytes of raw stream): 16 KB each; CHARLS_AMD_SPEC_CHUNK / CHARLS_AMD_SPEC_WARM
+// Chunk and warm-up of the speculative form (bytes of raw stream): 64 KB each; CHARLS_AMD_SPEC_CHUNK / CHARLS_AMD_SPEC_WARM
 // override them (multiples of 8 bytes; the tests use tiny values so that guesses fail).
 struct SpecGeometry
 {
@@ -282,7 +228,7 @@ struct SpecGeometry
 };
 inline SpecGeometry stuff_spec_geometry()
 {
-    SpecGeometry g{16384, 16384};
+    SpecGeometry g{65536, 65536};
     if (const char* env = std::getenv("CHARLS_AMD_SPEC_CHUNK"))
         g.chunk_bytes = (uint32_t)std::max(64, std::atoi(env)) / 8 * 8;
     if (const char* env = std::getenv("CHARLS_AMD_SPEC_WARM"))

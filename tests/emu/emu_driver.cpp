@@ -96,7 +96,7 @@ void emu_stuff_raw(const uint8_t* raw, uint64_t total_bits, uint64_t raw_bytes, 
     d.stream_capacity = capacity;
     if (blocks == 2)
     { // the speculative form (speculative_stuffing.hip), grids as in runtime.hip
-        const unsigned waves = (unsigned)((raw_bytes / spec.chunk_bytes + 1 + 63) / 64);
+        const unsigned waves = (unsigned)(raw_bytes / spec.chunk_bytes + 1);
         emu::launch(pipe::stuff_spec_survey, dim3(waves, 1), dim3(64), 0, (const pipe::Work*)&w, spec.chunk_bytes, spec.warm_bytes);
         emu::launch(pipe::stuff_spec_resolve, dim3(1), dim3(64), 0, (const pipe::Work*)&w, spec.chunk_bytes);
         emu::launch(pipe::stuff_spec_emit, dim3(waves, 1), dim3(64), 0, (const ScanDesc*)&d, (const pipe::Work*)&w, result, spec.chunk_bytes);

@@ -137,7 +137,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         size_t most = 0;
         for (int i = 0; i < count; ++i)
             most = std::max(most, (size_t)works[i].raw_words * 4);
-        const unsigned waves = (unsigned)((most / spec.chunk_bytes + 1 + 63) / 64);
+        const unsigned waves = (unsigned)(most / spec.chunk_bytes + 1);
         emu::launch(pipe::stuff_spec_survey, dim3(waves, count), dim3(64), 0, sk, spec.chunk_bytes, spec.warm_bytes);
         emu::launch(pipe::stuff_spec_resolve, dim3(count), dim3(64), 0, sk, spec.chunk_bytes);
         emu::launch(pipe::stuff_spec_emit, dim3(waves, count), dim3(64), 0, descs, sk, results, spec.chunk_bytes);

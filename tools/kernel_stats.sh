@@ -5,7 +5,7 @@ set -u
 name=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$name
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/raw -o k -- "$@" > $out/run.log 2>&1
 f=$(find $out/raw -name "k_kernel_stats.csv" | head -1)
 if [ -n "$f" ]; then
