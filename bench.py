@@ -67,8 +67,11 @@ def _cpu_codec():
     if os.path.exists(ref_path):
         from charls_amd.capi import CharLSLibrary
         codec = CharLSLibrary(ref_path)
-        return ("reference", img, lambda: codec.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS),
-                lambda data: codec.decode(data),
+        # destination buffers allocated once, outside the clock (cli/benchmark.cpp:40-55,60-90), handles inside
+        dst = np.empty(WIDTH * HEIGHT + WIDTH * HEIGHT // 16 + 2048, dtype=np.uint8)
+        px = np.empty(WIDTH * HEIGHT, dtype=np.uint8)
+        return ("reference", img, lambda: codec.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS, destination=dst),
+                lambda data: codec.decode(data, out=px),
                 "g++ -O3 -flto -DNDEBUG -std=c++17 (oracle/Makefile: the flags of the reference's Release shared build)")
     import oracle_bind as ob
     return ("port", img, lambda: ob.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS),
@@ -461,16 +464,23 @@ def extras(lib, batch, torch, frames, streams, out, enc, dev, mpix, pitch):
     # batch-sized work areas go first: giving ~90 GB back to the driver takes seconds and is not part of coding a frame
     batch.release_work_areas(lib)
     img = frames[0].cpu().numpy()
-    lib.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS)  # warm-up (allocations, module load)
-    a = time.perf_counter()
-    jls = lib.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS)
+    dst = np.empty(pitch, dtype=np.uint8)          # destinations allocated outside the clock, handles inside it: the
+    px = np.empty(WIDTH * HEIGHT, dtype=np.uint8)  # methodology of the reference's cli/benchmark.cpp:40-55,60-90
+    lib.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS, destination=dst)  # warm-up (allocations, module load)
+    best = 1e9
+    for _ in range(5):
+        a = time.perf_counter()
+        jls = lib.encode(img, width=WIDTH, height=HEIGHT, bits_per_sample=BITS, destination=dst)
+        best = min(best, time.perf_counter() - a)
+    jls = jls.tobytes()
     b = time.perf_counter()
-    _, px = lib.decode(jls)
+    lib.decode(jls, out=px)
     c = time.perf_counter()
     assert px.tobytes() == img.tobytes()
-    result["single_frame_ms"] = {"encode": round((b - a) * 1e3, 1), "decode": round((c - b) * 1e3, 1),
+    result["single_frame_ms"] = {"encode": round(best * 1e3, 2), "decode": round((c - b) * 1e3, 1),
                                  "path": "charls_jpegls_encoder_encode_from_buffer / charls_jpegls_decoder_decode_to_buffer, "
-                                         "host buffers in and out (PCIe inclusive), one 4096x4096 8-bit frame"}
+                                         "host buffers in and out (PCIe inclusive), one 4096x4096 8-bit frame; handle created "
+                                         "inside the clock, destination allocated outside (cli/benchmark.cpp); encode: best of 5"}
     # ---- a batch with the PCIe copies inside the clock: pinned host frames -> HBM -> encode -> .jls back to pinned host
     # memory, and the way back for decode
     n = min(256, frames.shape[0])

@@ -176,9 +176,11 @@ class CharLSLibrary:
     # -- jpegls_encoder::encode convenience (include/charls/jpegls_encoder.hpp:58-110) --------------------------
     def encode(self, image, *, width=None, height=None, bits_per_sample=8, component_count=1, near_lossless=0,
                interleave_mode=0, color_transformation=0, preset=None, encoding_options=0, stride=0,
-               destination_size=None, restart_interval=0) -> bytes:
+               destination_size=None, restart_interval=0, destination=None):
         """Encode `image` (ndarray or bytes, user layout of SURVEY 8a row a20) to a .jls byte string.
-        restart_interval != 0 uses charls_amd_jpegls_encoder_set_restart_interval (product library only)."""
+        restart_interval != 0 uses charls_amd_jpegls_encoder_set_restart_interval (product library only).
+        destination: a preallocated uint8 ndarray to encode into -- the methodology of the reference's cli/benchmark.cpp:60-90
+        (destination allocated outside the measurement loop, handle inside); the result is then a VIEW of it, not a copy."""
         L = self.lib
         if isinstance(image, np.ndarray) and (width is None or height is None):
             if interleave_mode == 0 and component_count > 1:
@@ -211,14 +213,14 @@ class CharLSLibrary:
                 n = C.c_size_t()
                 self._check(L.charls_jpegls_encoder_get_estimated_destination_size(enc, C.byref(n)), "estimate")
                 destination_size = n.value
-            dst = np.empty(destination_size, dtype=np.uint8)
+            dst = destination if destination is not None else np.empty(destination_size, dtype=np.uint8)
             self._check(L.charls_jpegls_encoder_set_destination_buffer(enc, dst.ctypes.data, dst.nbytes), "set_dest")
             ptr, nbytes, keep = self._buf(image)
             self._check(L.charls_jpegls_encoder_encode_from_buffer(enc, ptr, nbytes, stride), "encode_from_buffer")
             n = C.c_size_t()
             self._check(L.charls_jpegls_encoder_get_bytes_written(enc, C.byref(n)), "get_bytes_written")
             del keep
-            return dst[:n.value].tobytes()
+            return dst[:n.value] if destination is not None else dst[:n.value].tobytes()
         finally:
             L.charls_jpegls_encoder_destroy(enc)
 
@@ -247,8 +249,9 @@ class CharLSLibrary:
         return Header(fi.width, fi.height, fi.bits_per_sample, fi.component_count, near.value, ilv.value, ct.value,
                       (pc.maximum_sample_value, pc.threshold1, pc.threshold2, pc.threshold3, pc.reset_value))
 
-    def decode(self, data, stride=0, destination_size=None):
-        """Decode a .jls byte string. Returns (Header, uint8 ndarray of the raw destination bytes)."""
+    def decode(self, data, stride=0, destination_size=None, out=None):
+        """Decode a .jls byte string. Returns (Header, uint8 ndarray of the raw destination bytes).
+        out: a preallocated uint8 ndarray to decode into (cli/benchmark.cpp:40-55: allocated outside the loop)."""
         L = self.lib
         dec = L.charls_jpegls_decoder_create()
         if not dec:
@@ -262,7 +265,8 @@ class CharLSLibrary:
                 sz = C.c_size_t()
                 self._check(L.charls_jpegls_decoder_get_destination_size(dec, stride, C.byref(sz)), "get_dest_size")
                 destination_size = sz.value
-            out = np.zeros(destination_size, dtype=np.uint8)
+            if out is None:
+                out = np.zeros(destination_size, dtype=np.uint8)
             self._check(L.charls_jpegls_decoder_decode_to_buffer(dec, out.ctypes.data, out.nbytes, stride),
                         "decode_to_buffer")
             del keep

@@ -691,7 +691,7 @@ struct TileLayout
 {
     tile::TilePlan plan;
     size_t samples, lines, raw_bytes, max_jobs, max_run_jobs;
-    uint32_t lines_per_tile, tiles, job_events, warm_events, run_job_events, run_warm_events, run_long_warm_events;
+    uint32_t lines_per_tile, tiles, job_events, warm_events, run_job_events, run_warm_events;
     size_t off_keyinv, off_seg, off_total, off_base, off_jobfirst, off_rec, off_code, off_jobs, off_runjobs, off_bbase, off_raw,
         off_bits, off_status, off_stuff, bytes;
     TileLayout(const ScanDesc& d, size_t capacity_hint, uint32_t count)
@@ -711,15 +711,15 @@ struct TileLayout
         job_events = env_job ? static_cast<uint32_t>(std::max(16, std::atoi(env_job)) / 16 * 16) : static_cast<uint32_t>(job);
         warm_events = env_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_warm))) : 1024u;
         max_jobs = samples / job_events + pipe::kChains;
-        // the run chain: jobs of 2048 run events with a warm-up of as many, and of 32768 more for the rarer of the two
-        // run-interruption contexts (a test frame has 55 000 run events, 2 300 of them of the rarer type)
+        // the run chain: jobs of 2048 run events with a warm-up of as many (a test frame has 55 000 run events); small batches
+        // take smaller jobs -- ONE frame has the whole chip, and the walk of a job and its warm-up is what the frame waits for
         const char* env_run_job = std::getenv("CHARLS_AMD_RUN_JOB_EVENTS");
         const char* env_run_warm = std::getenv("CHARLS_AMD_RUN_WARM_EVENTS");
-        run_job_events = env_run_job ? static_cast<uint32_t>(std::max(32, std::atoi(env_run_job)) / 32 * 32) : 2048u;
+        const uint64_t batch_samples = static_cast<uint64_t>(samples) * count;
+        const uint32_t run_job_default = batch_samples <= (uint64_t{1} << 26) ? 256u : (batch_samples <= (uint64_t{1} << 29) ? 512u : 2048u);
+        run_job_events = env_run_job ? static_cast<uint32_t>(std::max(32, std::atoi(env_run_job)) / 32 * 32) : run_job_default;
         run_warm_events = env_run_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_warm))) : 2048u;
-        const char* env_run_long = std::getenv("CHARLS_AMD_RUN_LONG_WARM_EVENTS");
-        run_long_warm_events = env_run_long ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_long))) : 32768u;
-        max_run_jobs = samples / run_job_events + 1;
+        max_run_jobs = samples / run_job_events + 2; // (+ the entry of the totals)
         const size_t worst = worst_case_scan_bytes(plan.line_samples, static_cast<uint32_t>(lines), 1, d.bits_per_sample);
         raw_bytes = align_up((capacity_hint < worst ? capacity_hint : worst) + 64, 16);
         size_t o = 0;
@@ -857,7 +857,6 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             w.run_jobs = reinterpret_cast<tile::RunJob*>(base + lay.off_runjobs);
             w.run_job_events = lay.run_job_events;
             w.run_warm_events = lay.run_warm_events;
-            w.run_long_warm_events = lay.run_long_warm_events;
             w.blockbase = reinterpret_cast<uint64_t*>(base + lay.off_bbase);
             w.tile_tail = reinterpret_cast<uint64_t*>(base + lay.off_bbase) + lay.tiles;
             w.raw = reinterpret_cast<uint32_t*>(base + lay.off_raw);
@@ -916,12 +915,20 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         {
             const uint32_t run_jobs = static_cast<uint32_t>(lay.max_run_jobs);
             const dim3 lanes((static_cast<uint64_t>(run_jobs) * n + 63) / 64);
-            const dim3 count_grid(std::min<uint32_t>(run_jobs, 32), n), settle_grid((n + 63) / 64);
+            const dim3 count_grid(std::min<uint32_t>(run_jobs, std::max<uint32_t>(32, 4096 / n)), n), settle_grid((n + 63) / 64);
             if (pixel_mode)
                 hipLaunchKernelGGL((tile::count_runs<S, 1>), count_grid, dim3(64), 0, runs_stream, d_works, plan.nc);
             else
                 hipLaunchKernelGGL((tile::count_runs<S, 0>), count_grid, dim3(64), 0, runs_stream, d_works, 1u);
             hipLaunchKernelGGL(tile::scan_runs, dim3(n), dim3(64), 0, runs_stream, d_works);
+            if (proto.interleave_mode != 2)
+            { // the context of the rarer interruption type, exactly (a sample-interleaved scan has one type only)
+                if (pixel_mode)
+                    hipLaunchKernelGGL((tile::compact_rare_runs<S, 1>), count_grid, dim3(64), 0, runs_stream, d_works);
+                else
+                    hipLaunchKernelGGL((tile::compact_rare_runs<S, 0>), count_grid, dim3(64), 0, runs_stream, d_works);
+                hipLaunchKernelGGL(tile::walk_rare_context, settle_grid, dim3(64), 0, runs_stream, descs, d_works, n);
+            }
 #define JLS_RUN_CHAIN(ILV, FMT)                                                                                          \
     do                                                                                                                   \
     {                                                                                                                    \
@@ -949,7 +956,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
         hipLaunchKernelGGL(tile::clear_pack_state, dim3(1, n), dim3(256), 0, s, d_works,
                            static_cast<uint32_t>(static_cast<size_t>(lay.tiles) * 16));
-        hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::kPackThreads), tile::pack_lds_bytes(lay.plan.tile_capacity, proto.bits_per_sample), s,
+        hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::pack_threads_for(lay.plan.tile_capacity)), tile::pack_lds_bytes(lay.plan.tile_capacity, proto.bits_per_sample), s,
                            descs, d_works);
         t.mark();
         if (overlap_stuffing)

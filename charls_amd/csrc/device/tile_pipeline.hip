@@ -100,7 +100,7 @@ struct Work
     uint32_t* rec;         // [samples + kSlack] records in chain order
     uint32_t* code;        // [samples + kSlack] code words in chain order (run starts: interruption record until C3)
     JobState* jobs;        // [samples / job_events + kChains]
-    struct RunJob* run_jobs; // [samples / run_job_events + 1] jobs of the run chain
+    struct RunJob* run_jobs; // [samples / run_job_events + 2] jobs of the run chain, and an entry behind the last one (totals)
     uint64_t* blockbase;   // [tiles] look-back states of pack_tiles; followed by tile_tail (cleared together)
     uint64_t* tile_tail;   // [tiles] pack_tiles: the bits of the tile's last, partial word | valid << 63
     uint32_t* raw;
@@ -111,7 +111,7 @@ struct Work
     // the launch's geometry (all scans of a launch share width, sample type and interleave mode; a scan may have FEWER
     // lines than the launch was sized for -- the last restart interval of a frame -- and then has fewer tiles)
     uint32_t lines_per_tile, tiles, job_events, warm_events;
-    uint32_t run_job_events, run_warm_events, run_long_warm_events; // (run_job_events: a multiple of 8)
+    uint32_t run_job_events, run_warm_events; // (run_job_events: a multiple of 8)
     // lines that do not fit a tile are cut into segs_per_line tiles of seg_pixels pixels (a multiple of 64; the last one
     // shorter), lines_per_tile is then 1; otherwise segs_per_line = 1.  tile_capacity: samples of a tile at most.
     uint32_t segs_per_line, seg_pixels, tile_capacity;
@@ -1120,7 +1120,7 @@ struct RunJob
 {
     uint32_t type0, type1, own_slot, pad; // count_runs: events of the job; scan_runs: events before the job
     RunState in, out;
-    uint32_t pad2[2];
+    int32_t rare_a, rare_nn; // walk_rare_context: A and Nn of the context of the RARER interruption type when the job starts (exact)
 };
 
 JLS_DEV bool same_state(const RunState& x, const RunState& y)
@@ -1137,12 +1137,10 @@ JLS_DEV uint32_t run_word(int ones, int tail_len, uint32_t tail)
 // One lane's walk over run events [from, to) of a scan.  counts = {type-0, type-1, own-slot} interruptions before `from`.
 // kStore: write the code words (the run-length code to the slot of the sample where the run starts, the code of the
 // interruption sample to the next slot of chain kInterruptChain: its events are these samples, in this order).
-// kOnly = 0 / 1: only the interruptions of that type are looked at, and only their context moves (the long warm-up of the
-// rarer context, see walk_run_jobs); -1: everything.
 // FMT = 1: the records of pixel mode (RunRecord2): error value and type of an interruption sample with a slot of its own are
 // the record of that slot (int_rec, in the order of the slots); a sample-interleaved scan (ILV = 2) codes the `nc`
 // components of an interruption pixel one after the other on run context 0 (src/scan_encoder_impl.hpp:277-302).
-template <typename S, int ILV, bool kStore, int kOnly = -1, int FMT = 0>
+template <typename S, int ILV, bool kStore, int FMT = 0>
 JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code, uint32_t* int_code, uint32_t from, uint32_t to,
                        RunState& s, uint32_t type0, uint32_t type1, uint32_t own_slot, const uint32_t* int_rec = nullptr, uint32_t nc = 1)
 {
@@ -1153,23 +1151,6 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
         if (FMT == 1)
         {
             const bool eol = RunRecord2::is_end_of_line(v), zero = RunRecord2::is_zero_run(v);
-            if (kOnly >= 0)
-            { // (single-component lines only: the context of one interruption type alone)
-                if (!eol)
-                {
-                    const uint32_t mine = own_slot;
-                    own_slot += zero ? 0u : 1u;
-                    if (RunRecord2::which(v) == kOnly)
-                    {
-                        RunCtx& ctx = kOnly ? rc1 : rc0;
-                        const int err = RunRecord2::err(zero ? v : int_rec[mine]);
-                        const int k = run_k(ctx);
-                        const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - run_map(ctx, err, k);
-                        run_update(ctx, err, em, t.reset);
-                    }
-                }
-                return 0u;
-            }
             uint32_t run = RunRecord2::run(v);
             const uint32_t shift = ILV == 1 ? RunRecord2::component(v) * 8u : 0u;
             int run_index = (int)((run_index_packed >> shift) & 0xFFu);
@@ -1222,18 +1203,6 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
             }
             run_index_packed = (run_index_packed & ~(0xFFu << shift)) | ((uint32_t)run_index << shift);
             return word;
-        }
-        if (kOnly >= 0)
-        { // the context of one type alone: it depends on the error values of its own interruptions and on nothing else
-            if (!RunRecord<S>::is_end_of_line(v) && RunRecord<S>::which(v) == kOnly)
-            {
-                RunCtx& ctx = kOnly ? rc1 : rc0;
-                const int err = RunRecord<S>::err(v);
-                const int k = run_k(ctx);
-                const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - run_map(ctx, err, k);
-                run_update(ctx, err, em, t.reset);
-            }
-            return 0u;
         }
         uint32_t run = RunRecord<S>::run(v);
         const bool eol = RunRecord<S>::is_end_of_line(v);
@@ -1289,7 +1258,7 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
     // thirty-two where only one bit of most records is looked at (little work per event: the requests have to be further
     // ahead).  Chains start on 64-byte boundaries and are followed by kSlack records, so whole groups can be read; `from` is
     // the start of a job, a multiple of the group size.
-    constexpr uint32_t kQuads = kOnly >= 0 ? 8 : 2; // 16-byte quads per group
+    constexpr uint32_t kQuads = 2; // 16-byte quads per group
     const JLS_GLOBAL_AS u32x4* runs4 = (const JLS_GLOBAL_AS u32x4*)runs;
     JLS_GLOBAL_AS u32x4* code4 = (JLS_GLOBAL_AS u32x4*)run_code;
     for (; from % (kQuads * 4) != 0 && from < to; ++from) // (jobs smaller than a group: the CPU tests)
@@ -1415,6 +1384,109 @@ __global__ void __launch_bounds__(64) scan_runs(const Work* __restrict__ works)
         for (int q = 0; q < 3; ++q)
             carry[q] += __shfl(incl[q], 63);
     }
+    if (lane == 0)
+    { // the totals, in the entry behind the last job
+        w.run_jobs[jobs].type0 = carry[0];
+        w.run_jobs[jobs].type1 = carry[1];
+        w.run_jobs[jobs].own_slot = carry[2];
+    }
+}
+
+// The context of the RARER of the two interruption types (Ra == Rb or not: 4 % of the interruptions of a test frame are of the
+// rarer type) needs thousands of run events before two walks of it meet -- a warm-up of 32 768 events per job until round 4,
+// 3.5 ms of the 4.9 ms ONE frame took to encode.  Its events are few, so it is computed exactly instead: compact_rare_runs
+// gathers the error values of the rarer type in event order (a wavefront per job; the temporary list lives in the code words
+// of the run chain, which nobody writes before walk_run_jobs), walk_rare_context walks them with ONE lane per scan and leaves
+// every job the state in which the context is when the job starts.  (A sample-interleaved scan has one type only.)
+JLS_DEV bool rarer_is_type1(const Work& w, uint32_t jobs)
+{
+    return w.run_jobs[jobs].type1 < w.run_jobs[jobs].type0;
+}
+
+// grid (up to 32, scans) x 64: a wavefront compacts a job (and every gridDim.x-th job after it).
+template <typename S, int FMT>
+__global__ void __launch_bounds__(64) compact_rare_runs(const Work* __restrict__ works)
+{
+    const Work w = works[blockIdx.y];
+    const uint32_t n = w.chain_total[0];
+    const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
+    if (jobs == 0)
+        return;
+    const uint32_t* runs = w.rec + w.chain_base[0];
+    const uint32_t* int_rec = w.rec + w.chain_base[kInterruptChain]; // (pixel mode)
+    int32_t* rare = reinterpret_cast<int32_t*>(w.code + w.chain_base[0]);
+    const int rare_type = rarer_is_type1(w, jobs) ? 1 : 0;
+    const int lane = threadIdx.x;
+    for (uint32_t job = blockIdx.x; job < jobs; job += gridDim.x)
+    {
+        const uint32_t from = job * w.run_job_events;
+        const uint32_t to = from + w.run_job_events < n ? from + w.run_job_events : n;
+        const RunJob mine = w.run_jobs[job];
+        uint32_t at = rare_type ? mine.type1 : mine.type0, own_at = mine.own_slot;
+        for (uint32_t e0 = from; e0 < to; e0 += 64)
+        {
+            const uint32_t e = e0 + (uint32_t)lane;
+            const uint32_t v = e < to ? runs[e] : 0u;
+            bool is_rare, own;
+            if (FMT == 1)
+            {
+                const bool interrupted = e < to && !RunRecord2::is_end_of_line(v);
+                is_rare = interrupted && RunRecord2::which(v) == rare_type;
+                own = interrupted && !RunRecord2::is_zero_run(v);
+            }
+            else
+            {
+                const bool interrupted = e < to && !RunRecord<S>::is_end_of_line(v);
+                is_rare = interrupted && RunRecord<S>::which(v) == rare_type;
+                own = interrupted && RunRecord<S>::run(v) != 0;
+            }
+            const unsigned long long rare_m = __ballot(is_rare), own_m = __ballot(own);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (is_rare)
+            {
+                int err;
+                if (FMT == 1)
+                    err = RunRecord2::err(own ? int_rec[own_at + (uint32_t)__popcll(own_m & below)] : v);
+                else
+                    err = RunRecord<S>::err(v);
+                rare[at + (uint32_t)__popcll(rare_m & below)] = err;
+            }
+            at += (uint32_t)__popcll(rare_m);
+            own_at += (uint32_t)__popcll(own_m);
+        }
+    }
+}
+
+// grid (ceil(scans / 64)) x 64: one lane per scan.
+__global__ void __launch_bounds__(64) walk_rare_context(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
+{
+    const uint32_t frame = blockIdx.x * 64u + threadIdx.x;
+    if (frame >= scans)
+        return;
+    const ScanDesc d = descs[frame];
+    const Work w = works[frame];
+    const Traits t = make_traits(d);
+    const uint32_t n = w.chain_total[0];
+    const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
+    if (jobs == 0)
+        return;
+    const bool rare1 = rarer_is_type1(w, jobs);
+    const int32_t* rare = reinterpret_cast<const int32_t*>(w.code + w.chain_base[0]);
+    RunCtx ctx{rare1 ? 1 : 0, initial_a(t), 1, 0};
+    uint32_t i = 0;
+    for (uint32_t j = 0; j < jobs; ++j)
+    {
+        w.run_jobs[j].rare_a = ctx.a;
+        w.run_jobs[j].rare_nn = ctx.nn;
+        const uint32_t upto = rare1 ? w.run_jobs[j + 1].type1 : w.run_jobs[j + 1].type0; // (entry `jobs` holds the totals)
+        for (; i < upto; ++i)
+        {
+            const int err = rare[i];
+            const int k = run_k(ctx);
+            const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - run_map(ctx, err, k);
+            run_update(ctx, err, em, t.reset);
+        }
+    }
 }
 
 // grid (ceil(max_run_jobs * scans / 64)) x 64: one lane per (job, scan), lanes of a wavefront = the same job of different scans.
@@ -1436,32 +1508,32 @@ __global__ void __launch_bounds__(64) walk_run_jobs(const ScanDesc* __restrict__
     uint32_t* int_code = w.code + w.chain_base[kInterruptChain];
     const uint32_t* int_rec = w.rec + w.chain_base[kInterruptChain]; // (pixel mode)
     const uint32_t nc = samples_per_pixel(d);
-    // The warm-ups start at job boundaries (that is where the counts are known).  RUNindex and the context of the more
-    // frequent interruption type forget within run_warm_events run events; the context of the rarer type (4 % of the
-    // interruptions of a test frame) needs as many of ITS OWN events, so it alone is warmed up over run_long_warm_events
-    // before that -- a walk that looks at one bit of every other record.  (A sample-interleaved scan has one type only.)
+    // The warm-up starts at a job boundary (that is where the counts are known): RUNindex and the context of the more frequent
+    // interruption type forget within run_warm_events run events; the context of the rarer type starts the warm-up in its
+    // exact state (walk_rare_context) and stays exact through it.
     const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
-    const RunJob last = w.run_jobs[jobs - 1]; // (counts before the last job: good enough to tell which type is the rarer one)
-    const bool rare1 = last.type1 < last.type0;
     const uint32_t warm_jobs = (w.run_warm_events + w.run_job_events - 1) / w.run_job_events;
-    const uint32_t long_jobs = warm_jobs + (ILV == 2 ? 0u : (w.run_long_warm_events + w.run_job_events - 1) / w.run_job_events);
     const uint32_t warm_job = job > warm_jobs ? job - warm_jobs : 0u;
-    const uint32_t long_job = job > long_jobs ? job - long_jobs : 0u;
     RunState s{0, initial_a(t), 0, initial_a(t), 0};
     RunJob mine = w.run_jobs[job];
     const RunJob before = w.run_jobs[warm_job];
-    if (long_job < warm_job)
+    if (ILV != 2)
     {
-        const RunJob far = w.run_jobs[long_job];
-        if (rare1)
-            walk_runs<S, ILV, false, 1, FMT>(t, runs, run_code, int_code, long_job * w.run_job_events, warm_job * w.run_job_events, s, before.type0, far.type1, far.own_slot, int_rec, nc);
+        if (rarer_is_type1(w, jobs))
+        {
+            s.a1 = before.rare_a;
+            s.nn1 = before.rare_nn;
+        }
         else
-            walk_runs<S, ILV, false, 0, FMT>(t, runs, run_code, int_code, long_job * w.run_job_events, warm_job * w.run_job_events, s, far.type0, before.type1, far.own_slot, int_rec, nc);
+        {
+            s.a0 = before.rare_a;
+            s.nn0 = before.rare_nn;
+        }
     }
     if (warm_job < job)
-        walk_runs<S, ILV, false, -1, FMT>(t, runs, run_code, int_code, warm_job * w.run_job_events, from, s, before.type0, before.type1, before.own_slot, int_rec, nc);
+        walk_runs<S, ILV, false, FMT>(t, runs, run_code, int_code, warm_job * w.run_job_events, from, s, before.type0, before.type1, before.own_slot, int_rec, nc);
     mine.in = s;
-    walk_runs<S, ILV, true, -1, FMT>(t, runs, run_code, int_code, from, to, s, mine.type0, mine.type1, mine.own_slot, int_rec, nc);
+    walk_runs<S, ILV, true, FMT>(t, runs, run_code, int_code, from, to, s, mine.type0, mine.type1, mine.own_slot, int_rec, nc);
     mine.out = s;
     w.run_jobs[job] = mine;
 }
@@ -1500,7 +1572,7 @@ __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ d
             out = prev;
             const uint32_t from = j * w.run_job_events;
             const uint32_t to = from + w.run_job_events < n ? from + w.run_job_events : n;
-            walk_runs<S, ILV, true, -1, FMT>(t, runs, run_code, int_code, from, to, out, cur.type0, cur.type1, cur.own_slot, int_rec, nc);
+            walk_runs<S, ILV, true, FMT>(t, runs, run_code, int_code, from, to, out, cur.type0, cur.type1, cur.own_slot, int_rec, nc);
         }
         prev = out;
     }
@@ -1554,9 +1626,10 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     if (tile >= tiles)
         return;
     const uint32_t tile_capacity = w.tile_capacity;
-    const uint32_t per_thread = ((tile_capacity + kPackThreads - 1) / kPackThreads + 7u) & ~7u; // consecutive samples of a thread
+    const uint32_t threads = blockDim.x; // pack_threads_for(tile_capacity): 512, fewer when a tile holds fewer than 16 samples per thread of 512
+    const uint32_t per_thread = ((tile_capacity + threads - 1) / threads + 7u) & ~7u; // consecutive samples of a thread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr uint32_t kPackWaves = kPackThreads / 64;
+    const uint32_t kPackWaves = threads / 64;
     uint32_t* s_code = reinterpret_cast<uint32_t*>(smem);
     uint32_t* s_tileoff = s_code + tile_capacity;
     uint32_t* s_count = s_tileoff + kChains + 1;
@@ -1572,13 +1645,13 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
 
     // the slot map of the tile: coalesced into LDS (a thread's 32 consecutive slots straight from memory were 32 requests
     // of one cache line each per wavefront instruction)
-    for (uint32_t i = threadIdx.x; i < kPackThreads * per_thread; i += kPackThreads)
+    for (uint32_t i = threadIdx.x; i < threads * per_thread; i += threads)
         s_inv[i] = i < tile_samples ? inv[i] : kNoLocalSlot;
     { // the tile's pieces, chain by chain, in the order sort_tiles laid them out
         uint32_t n[2] = {0, 0}, g[2] = {0, 0};
         for (int half = 0; half < 2; ++half)
         {
-            const uint32_t c = threadIdx.x + (uint32_t)half * kPackThreads;
+            const uint32_t c = threadIdx.x + (uint32_t)half * threads;
             if (c < (uint32_t)kChains)
             {
                 g[half] = w.seg[(size_t)tile * kChains + c];
@@ -1589,7 +1662,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         block_exclusive_scan(off[0], off[1], s_tmp);
         for (int half = 0; half < 2; ++half)
         {
-            const uint32_t c = threadIdx.x + (uint32_t)half * kPackThreads;
+            const uint32_t c = threadIdx.x + (uint32_t)half * threads;
             if (c < (uint32_t)kChains)
             {
                 s_tileoff[c] = off[half];
@@ -1605,14 +1678,14 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         uint32_t rows[2] = {0, 0};
         for (int half = 0; half < 2; ++half)
         {
-            const uint32_t c = threadIdx.x + (uint32_t)half * kPackThreads;
+            const uint32_t c = threadIdx.x + (uint32_t)half * threads;
             rows[half] = c < (uint32_t)kChains ? (s_count[c] + 63) / 64 : 0u;
         }
         uint32_t row_base[2] = {rows[0], rows[1]};
         block_exclusive_scan(row_base[0], row_base[1], s_tmp);
         for (int half = 0; half < 2; ++half)
         {
-            const uint32_t c = threadIdx.x + (uint32_t)half * kPackThreads;
+            const uint32_t c = threadIdx.x + (uint32_t)half * threads;
             if (c < (uint32_t)kChains)
             {
                 s_rowbase[c] = row_base[half];
@@ -1669,7 +1742,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         }
     s_scan[threadIdx.x] = sum;
     __syncthreads();
-    for (uint32_t stride = 1; stride < kPackThreads; stride <<= 1) // Hillis-Steele inclusive scan
+    for (uint32_t stride = 1; stride < threads; stride <<= 1) // Hillis-Steele inclusive scan
     {
         const uint32_t add = threadIdx.x >= stride ? s_scan[threadIdx.x - stride] : 0;
         __syncthreads();
@@ -1679,7 +1752,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     // ---- where this tile starts: the first wavefront looks back, 64 predecessors at a time (see write_raw_bits)
     if (threadIdx.x < 64)
     {
-        const uint64_t own = s_scan[kPackThreads - 1];
+        const uint64_t own = s_scan[threads - 1];
         const uint32_t b = tile;
         if (lane == 0)
             store_relaxed(&w.blockbase[b], (b == 0 ? pipe::kBlockUpTo : pipe::kBlockOwn) | own);
@@ -1724,11 +1797,11 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     // whole buffer, 17.8 MB per frame for 7.3 MB of stream, and every thread wrote its two or three words with atomics:
     // 48 MB of write traffic.)
     const uint64_t tile_start = (uint64_t)s_tmp[12] | ((uint64_t)s_tmp[13] << 32);
-    const uint32_t tile_bits = s_scan[kPackThreads - 1];
+    const uint32_t tile_bits = s_scan[threads - 1];
     const uint32_t head = (uint32_t)(tile_start & 31);
     const uint32_t tile_words = (head + tile_bits + 31) / 32; // (<= pack_bits_words: a code has at most LIMIT bits per sample it stands for)
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_inv);
-    for (uint32_t i = threadIdx.x; i < tile_words + 1; i += kPackThreads)
+    for (uint32_t i = threadIdx.x; i < tile_words + 1; i += threads)
         s_bits[i] = 0;
     __syncthreads();
     if (sum != 0)
@@ -1801,7 +1874,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     __syncthreads();
     const uint64_t first_global = tile_start >> 5;
     const uint32_t stored_words = partial_last ? tile_words - 1 : tile_words;
-    for (uint32_t i = threadIdx.x; i < stored_words; i += kPackThreads)
+    for (uint32_t i = threadIdx.x; i < stored_words; i += threads)
     {
         const uint64_t at = first_global + i;
         if (at < w.raw_words)
@@ -1841,10 +1914,22 @@ inline size_t sort_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t s
     return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode, false) + (size_t)sort_segments(lines_per_tile) * kChains * 4 +
            4 * ((size_t)kChains + 1) * 4 + 16 * 4 + (size_t)kWaves * (kChains + 1) * 4 + 252 * 4 + (size_t)lines_per_tile * width * 4;
 }
-inline size_t pack_lds_bytes(uint32_t tile_capacity, int32_t bits_per_sample)
+// Threads of a pack_tiles workgroup: 512 with 8 or 16 consecutive samples each; a tile that would leave more than a fifth of
+// those samples empty (6144 samples of a 4096-pixel RGB line cut in two) gets fewer threads instead (never fewer than 192: the
+// 367 chains are dealt to the threads two at a time).
+inline uint32_t pack_threads_for(uint32_t tile_capacity)
 {
     const uint32_t per_thread = ((tile_capacity + kPackThreads - 1) / kPackThreads + 7u) & ~7u;
-    const size_t slot_map = (size_t)kPackThreads * per_thread * 2, bit_buffer = (size_t)pack_bits_words(tile_capacity, bits_per_sample) * 4;
+    if ((uint64_t)per_thread * kPackThreads * 4 <= (uint64_t)tile_capacity * 5)
+        return kPackThreads;
+    const uint32_t fewer = ((tile_capacity + per_thread - 1) / per_thread + 63u) / 64u * 64u;
+    return fewer < 192u ? 192u : (fewer > kPackThreads ? kPackThreads : fewer);
+}
+inline size_t pack_lds_bytes(uint32_t tile_capacity, int32_t bits_per_sample)
+{
+    const uint32_t threads = pack_threads_for(tile_capacity);
+    const uint32_t per_thread = ((tile_capacity + threads - 1) / threads + 7u) & ~7u;
+    const size_t slot_map = (size_t)threads * per_thread * 2, bit_buffer = (size_t)pack_bits_words(tile_capacity, bits_per_sample) * 4;
     return (size_t)pack_inv_offset(tile_capacity) + (slot_map > bit_buffer ? slot_map : bit_buffer); // (the bits take the map's place)
 }
 // How a scan is cut into tiles.  A tile holds up to `cap` samples (8192 of one byte, 4096 of two: the sort stage keeps the

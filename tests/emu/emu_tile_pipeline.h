@@ -28,7 +28,8 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     const uint32_t lines_per_tile = plan.lines_per_tile;
     const uint32_t tiles = plan.tiles;
     const size_t max_jobs = samples / job_events + pipe::kChains;
-    const size_t max_run_jobs = samples / run_job_events + 1;
+    const size_t max_run_jobs = samples / run_job_events + 2;
+    (void)run_long_warm_events; // (the long warm-up of the rarer run context is gone: walk_rare_context computes it exactly)
     std::vector<tile::Work> works(count);
     std::vector<pipe::Work> stuff(count);
     std::vector<void*> allocs;
@@ -59,7 +60,6 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         w.run_jobs = (tile::RunJob*)galloc(max_run_jobs * sizeof(tile::RunJob));
         w.run_job_events = run_job_events;
         w.run_warm_events = run_warm_events;
-        w.run_long_warm_events = run_long_warm_events;
         uint8_t* pack_state = (uint8_t*)zalloc((size_t)tiles * 16 + 16);
         w.blockbase = (uint64_t*)pack_state;
         w.tile_tail = w.blockbase + tiles;
@@ -112,6 +112,14 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     else
         emu::launch(tile::count_runs<S, 0>, count_grid, dim3(64), 0, wk, 1u);
     emu::launch(tile::scan_runs, dim3(count), dim3(64), 0, wk);
+    if (p.interleave_mode != 2)
+    {
+        if (pixel_mode)
+            emu::launch(tile::compact_rare_runs<S, 1>, count_grid, dim3(64), 0, wk);
+        else
+            emu::launch(tile::compact_rare_runs<S, 0>, count_grid, dim3(64), 0, wk);
+        emu::launch(tile::walk_rare_context, settle_grid, dim3(64), 0, descs, wk, (uint32_t)count);
+    }
 #define EMU_RUN_CHAIN(ILV, FMT)                                                                                  \
     do                                                                                                           \
     {                                                                                                            \
@@ -129,7 +137,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     else
         EMU_RUN_CHAIN(0, 1);
 #undef EMU_RUN_CHAIN
-    emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::kPackThreads), tile::pack_lds_bytes(plan.tile_capacity, p.bits_per_sample), descs, wk);
+    emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::pack_threads_for(plan.tile_capacity)), tile::pack_lds_bytes(plan.tile_capacity, p.bits_per_sample), descs, wk);
     const pipe::Work* sk = stuff.data();
     if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env != nullptr && std::atoi(env) == 2)
     { // the speculative form (CHARLS_AMD_BLOCK_STUFFING=2 is a switch of this harness only: the product picks by batch size)
