@@ -685,8 +685,9 @@ PipelineLanes& pipeline_lanes()
 // ---------------------------------------------------------------------------------------------------------------
 // Tile pipeline (tile_pipeline.hip, tile_pixel_mode.hip): every lossless scan the pipeline is eligible for.
 
-// Work area of one scan: 10 B per sample (key / slot 2, record 4, code 4), the (tiles + 1) x 367 piece table, the job
-// states and the unstuffed stream.
+// Work area of one scan: 8 B per sample of up to 8 bits (key / slot map 2, records 3, code words 3: 2-byte slots, of which the
+// run starts -- at most every second sample -- take two), 10 B per wider sample (2 + 4 + 4), the (tiles + 1) x 367 piece table,
+// the job states and the unstuffed stream.
 struct TileLayout
 {
     tile::TilePlan plan;
@@ -708,7 +709,7 @@ struct TileLayout
         uint64_t job = 1024;
         while (job < 8192 && samples * count / (job * 2) >= (uint64_t{1} << 18))
             job *= 2;
-        job_events = env_job ? static_cast<uint32_t>(std::max(16, std::atoi(env_job)) / 16 * 16) : static_cast<uint32_t>(job);
+        job_events = env_job ? static_cast<uint32_t>(std::max(32, std::atoi(env_job)) / 32 * 32) : static_cast<uint32_t>(job); // (whole rounds of the walkers: 32 two-byte slots)
         warm_events = env_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_warm))) : 1024u;
         max_jobs = samples / job_events + pipe::kChains;
         // the run chain: jobs of 2048 run events with a warm-up of as many (a test frame has 55 000 run events); small batches
@@ -733,8 +734,12 @@ struct TileLayout
         off_total = take(pipe::kChains * 4);
         off_base = take(pipe::kChains * 4);
         off_jobfirst = take((pipe::kChains + 1) * 4);
-        off_rec = take((samples + tile::kSlack) * 4);
-        off_code = take((samples + tile::kSlack) * 4);
+        // records and code words: 2-byte slots for samples of up to 8 bits (a run start takes two), 4-byte slots otherwise
+        const uint32_t run_slots = d.bits_per_sample > 8 ? 1u : 2u;
+        const size_t slot_bytes = d.bits_per_sample > 8 ? 4 : 2;
+        const size_t slots = static_cast<size_t>(tile::slots_capacity(samples, run_slots, lines)) + tile::kSlack;
+        off_rec = take(slots * slot_bytes);
+        off_code = take(slots * slot_bytes);
         off_jobs = take(max_jobs * sizeof(tile::JobState));
         off_runjobs = take(max_run_jobs * sizeof(tile::RunJob));
         off_bbase = take(static_cast<size_t>(tiles) * 16); // look-back states and tile tails, 8 B each
@@ -762,7 +767,8 @@ void ensure_tile_attributes()
     auto set = [&](const void* kernel) { hip_check(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); };
     set(reinterpret_cast<const void*>(tile::analyze_tiles<uint8_t, 0>));
     set(reinterpret_cast<const void*>(tile::analyze_tiles<uint16_t, 0>));
-    set(reinterpret_cast<const void*>(tile::pack_tiles));
+    set(reinterpret_cast<const void*>(tile::pack_tiles<uint8_t>));
+    set(reinterpret_cast<const void*>(tile::pack_tiles<uint16_t>));
     set(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 0>));
     set(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 1>));
     set(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 0>));
@@ -871,6 +877,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             w.segs_per_line = lay.plan.segs_per_line;
             w.seg_pixels = lay.plan.seg_pixels;
             w.tile_capacity = lay.plan.tile_capacity;
+            w.run_slots = tile::run_slots_of<S>();
             pipe::Work& sw = stuff_works[pass][i];
             std::memset(&sw, 0, sizeof sw);
             sw.raw = w.raw;
@@ -956,7 +963,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             hip_check(hipStreamWaitEvent(s, stuffed[pass - 1], 0)); // the raw bits of the pass before have been read
         hipLaunchKernelGGL(tile::clear_pack_state, dim3(1, n), dim3(256), 0, s, d_works,
                            static_cast<uint32_t>(static_cast<size_t>(lay.tiles) * 16));
-        hipLaunchKernelGGL(tile::pack_tiles, dim3(lay.tiles, n), dim3(tile::pack_threads_for(lay.plan.tile_capacity)), tile::pack_lds_bytes(lay.plan.tile_capacity, proto.bits_per_sample), s,
+        hipLaunchKernelGGL((tile::pack_tiles<S>), dim3(lay.tiles, n), dim3(tile::pack_threads_for(lay.plan.tile_capacity)), tile::pack_lds_bytes(lay.plan.tile_capacity, proto.bits_per_sample), s,
                            descs, d_works);
         t.mark();
         if (overlap_stuffing)

@@ -65,8 +65,44 @@ constexpr uint32_t kThreads = 512;         // workgroup of analyze_tiles / sort_
 constexpr uint32_t kWaves = kThreads / 64;
 constexpr uint32_t kPackThreads = 512;     // workgroup of pack_tiles (16 consecutive samples per thread at most)
 constexpr uint16_t kNoLocalSlot = 0xFFFF;
-constexpr uint32_t kChainPad = 16;         // chains start on multiples of 16 records (one 64-byte line)
-constexpr uint32_t kSlack = kChains * kChainPad + 64; // spare records behind rec / code: padding + read-ahead of the walkers
+// Records and code words live in SLOTS: 4 bytes for samples wider than 8 bits, 2 bytes otherwise (an 8-bit record is {x, Px}
+// with the sign of the context folded in by reflection, an 8-bit code word {length : 6 | bits : 10}: round 3 moved 4 + 4 bytes
+// per sample for 17 + 16 bits of information, and the walkers' time is their bytes).  An entry of the RUN chain (chain 0:
+// run records and run-length code words need 32 bits) takes run_slots slots: two of the 2-byte ones.
+template <typename S>
+struct SlotOf
+{
+    typedef uint32_t type;
+};
+template <>
+struct SlotOf<uint8_t>
+{
+    typedef uint16_t type;
+};
+template <typename S>
+using Slot = typename SlotOf<S>::type;
+template <typename S>
+constexpr uint32_t run_slots_of()
+{
+    return sizeof(Slot<S>) == 2 ? 2u : 1u;
+}
+constexpr uint32_t kRowChainWords = 288;    // LDS words of the sort stage's row table: a tile has at most (12288 + 16) / 64 + 367 rows of 64 slots (2 bytes each)
+constexpr uint32_t kChainPad = 32;         // chains start on multiples of 32 slots (64 or 128 bytes: whole lines)
+constexpr uint32_t kSlack = kChains * kChainPad + 128; // spare slots behind rec / code: padding + read-ahead of the walkers
+// Slots the chains of `samples` samples in `lines` lines can take at most: every sample has at most one event, a run start
+// takes run_slots of them, and two run starts of a line are never neighbours (a run of length 0 is interrupted by a sample
+// that differs from the line above it, so the next sample's gradients are not all zero): at most samples / 2 + lines run starts.
+__host__ __device__ inline uint64_t slots_capacity(uint64_t samples, uint32_t run_slots, uint64_t lines)
+{
+    const uint64_t runs = samples / 2 + lines < samples ? samples / 2 + lines : samples;
+    return samples + (run_slots > 1 ? runs : 0);
+}
+// Bytes of the slots a tile of `tile_capacity` samples can fill at most (sorted records in the sort stage, code words in the
+// pack stage): 4-byte slots, or 2-byte ones of which a run start takes two.
+__host__ __device__ inline size_t stage_bytes(uint32_t tile_capacity, uint32_t sample_bytes)
+{
+    return sample_bytes == 1 ? (size_t)slots_capacity(tile_capacity, 2, kTileLines) * 2 : (size_t)tile_capacity * 4;
+}
 constexpr uint32_t kPlanGroups = 16;       // plan_chains sums the tiles of a scan in this many groups
 #define JLS_HOST_DEV_EARLY __host__ __device__ inline
 constexpr uint32_t kRunTag = 1u << 31;     // code word of a run-length code: ones : 6 | tail length : 5 | tail : 20
@@ -97,8 +133,8 @@ struct Work
     uint32_t* chain_total; // [kChains]
     uint32_t* chain_base;  // [kChains]
     uint32_t* job_first;   // [kChains + 1] first job of the chain (chains coded by walk_jobs), number of jobs at the end
-    uint32_t* rec;         // [samples + kSlack] records in chain order
-    uint32_t* code;        // [samples + kSlack] code words in chain order (run starts: interruption record until C3)
+    uint32_t* rec;         // [slots_capacity + kSlack] slots: records in chain order (Slot<S>; the run chain's entries are 32-bit)
+    uint32_t* code;        // [slots_capacity + kSlack] slots: code words in chain order
     JobState* jobs;        // [samples / job_events + kChains]
     struct RunJob* run_jobs; // [samples / run_job_events + 2] jobs of the run chain, and an entry behind the last one (totals)
     uint64_t* blockbase;   // [tiles] look-back states of pack_tiles; followed by tile_tail (cleared together)
@@ -115,7 +151,18 @@ struct Work
     // lines that do not fit a tile are cut into segs_per_line tiles of seg_pixels pixels (a multiple of 64; the last one
     // shorter), lines_per_tile is then 1; otherwise segs_per_line = 1.  tile_capacity: samples of a tile at most.
     uint32_t segs_per_line, seg_pixels, tile_capacity;
+    uint32_t run_slots;    // slots an entry of the run chain takes (run_slots_of<S>())
 };
+template <typename S>
+JLS_DEV Slot<S>* rec_slots(const Work& w)
+{
+    return reinterpret_cast<Slot<S>*>(w.rec);
+}
+template <typename S>
+JLS_DEV Slot<S>* code_slots(const Work& w)
+{
+    return reinterpret_cast<Slot<S>*>(w.code);
+}
 
 JLS_DEV uint32_t tile_of_block(uint32_t block, uint32_t tiles) // XCD-aware: workgroup b runs on XCD b % 8; each XCD gets a band of tiles
 {
@@ -463,6 +510,8 @@ __global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__
     const uint32_t tiles = scan_tiles(d, w);
     const uint32_t per_group = (tiles + kPlanGroups - 1) / kPlanGroups;
     const uint32_t pairs = kPlanGroups * (uint32_t)kChains;
+    // (everything below is in SLOTS: an event of the run chain -- chain 0 -- takes w.run_slots of them, every other event one;
+    // chain_total alone counts EVENTS)
     for (uint32_t p = threadIdx.x; p < pairs; p += 1024)
     {
         const uint32_t g = p / kChains, c = p % kChains;
@@ -470,7 +519,7 @@ __global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__
         uint32_t sum = 0;
         for (uint32_t t = t0; t < t1; ++t)
             sum += w.seg[(size_t)t * kChains + c];
-        s_part[g][c] = sum;
+        s_part[g][c] = sum * (c == 0 ? w.run_slots : 1u);
     }
     __syncthreads();
     if (threadIdx.x < (uint32_t)kChains)
@@ -483,7 +532,7 @@ __global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__
             s_part[g][c] = running;
             running += n;
         }
-        w.chain_total[c] = running;
+        w.chain_total[c] = running / (c == 0 ? w.run_slots : 1u);
         s_base[c] = running;
     }
     if (threadIdx.x == 1023)
@@ -497,7 +546,7 @@ __global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__
         uint32_t acc = 0, jobs = 0;
         for (int c = 0; c < kChains; ++c)
         {
-            const uint32_t n = s_base[c];
+            const uint32_t n = s_base[c]; // slots
             s_base[c] = acc;
             w.chain_base[c] = acc;
             acc += (n + kChainPad - 1) / kChainPad * kChainPad;
@@ -515,7 +564,7 @@ __global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__
         uint32_t running = s_base[c] + s_part[g][c];
         for (uint32_t t = t0; t < t1; ++t)
         {
-            const uint32_t n = w.seg[(size_t)t * kChains + c];
+            const uint32_t n = w.seg[(size_t)t * kChains + c] * (c == 0 ? w.run_slots : 1u);
             w.seg[(size_t)t * kChains + c] = running;
             running += n;
         }
@@ -525,7 +574,7 @@ __global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Records.  Samples of up to 8 bits: x | Px << 16 | sign << 31.  Wider samples: what the walker needs of x and Px is
+// Records.  Samples of up to 8 bits: see make_record.  Wider samples: what the walker needs of x and Px is
 // d = sign * (x - Px) mod 2^16 and how far Px is from the end of the sample range it is nearer to (the bias C only ever
 // moves the prediction by up to 128, so only one end can clip it): d | room << 16 | side << 24 | sign << 31 with
 // room = min(distance, 255), side = 1 for the upper end.  src/scan_encoder_core.hpp:57-67.
@@ -533,13 +582,29 @@ template <typename S>
 JLS_DEV uint32_t make_record(int x, int px, int sign_bit, int maxval)
 {
     if (sizeof(S) == 1)
-        return (uint32_t)x | ((uint32_t)px << 16) | ((uint32_t)sign_bit << 31);
+    { // {x, Px} reflected about the sample range when the sign of the context is negative: sign (x - clamp(Px + sign C)) =
+      // (maxval - x) - clamp((maxval - Px) + C), so the walker computes every event as one of positive sign and the sign
+      // needs no bit -- 16 bits per record
+        const int xr = sign_bit ? maxval - x : x, pr = sign_bit ? maxval - px : px;
+        return (uint32_t)xr | ((uint32_t)pr << 8);
+    }
     const int d = sign_bit ? px - x : x - px;
     const int lo = px, hi = maxval - px;
     const int side = hi < lo ? 1 : 0;
     int room = side ? hi : lo;
     room = room > 255 ? 255 : room;
     return ((uint32_t)d & 0xFFFFu) | ((uint32_t)room << 16) | ((uint32_t)side << 24) | ((uint32_t)sign_bit << 31);
+}
+
+// Code word of a sample in a slot: 8-bit samples {length : 6 | bits : 10} (a Golomb code of an 8-bit sample has at most LIMIT =
+// 32 bits, of which at most 9 -- the one and the k <= 8 low bits, or the escape's one and qbpp = 8 bits -- are not leading
+// zeros: A / N stays below 132), wider samples {length : 8 | bits : 24}.
+template <typename S>
+JLS_DEV Slot<S> pack_code(int len, uint32_t bits)
+{
+    if (sizeof(S) == 1)
+        return (Slot<S>)(((uint32_t)len << 10) | (bits & 0x3FFu));
+    return (Slot<S>)(((uint32_t)len << 24) | bits);
 }
 
 // Record of a run start: everything the run chain needs of the image.  The length of the run; whether it ends with the line;
@@ -592,8 +657,8 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     uint32_t* s_tmp = s_global + kChains + 1;             // kWaves words (+ padding to 16 words)
     uint32_t* s_same = s_tmp + 16;                        // [kWaves][kChains + 1] lanes of a chunk per chain, see P2; zero between uses
     uint32_t* s_rowbase = s_same + kWaves * (kChains + 1); // [kChains + 1] first row of the chain's piece (P3)
-    uint16_t* s_rowchain = reinterpret_cast<uint16_t*>(s_rowbase + kChains + 1); // [kMaxTileSamples / 64 + kChains + 1] (1008 B)
-    uint32_t* s_stage = s_rowbase + kChains + 1 + 252;
+    uint16_t* s_rowchain = reinterpret_cast<uint16_t*>(s_rowbase + kChains + 1); // [slots of a tile / 64 + kChains + 1] (kRowChainWords words)
+    Slot<S>* s_stage = reinterpret_cast<Slot<S>*>(s_rowbase + kChains + 1 + kRowChainWords);
     const int mask = (1 << d.bits_per_sample) - 1;
     const Samples<S, ILV> sample{d, s_rows, g.first_line, mask};
     const uint16_t* key_tile = w.keyinv + (size_t)g.first_line * width;
@@ -628,7 +693,7 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
                     const uint32_t x = k * 64 + lane;
                     const uint16_t key = held[j];
                     if (x < width && key != kNoEvent)
-                        atomicAdd(&s_segoff[sgm * kChains + (key & 0x1FF)], 1u);
+                        atomicAdd(&s_segoff[sgm * kChains + (key & 0x1FF)], (key & 0x1FF) == 0 ? run_slots_of<S>() : 1u); // (slots)
                     const unsigned long long m = __ballot(x < width && key == kNoEvent);
                     if (lane == 0)
                         s_noev[r * chunks + k] = m;
@@ -753,10 +818,11 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
             if (has && upper)
                 same_of[chain] = 0;
             const uint32_t rank = upper ? (uint32_t)__popc(lo) + (uint32_t)__popc(hi & below) : (uint32_t)__popc(lo & below);
+            const uint32_t per_event = chain == 0 ? run_slots_of<S>() : 1u; // slots an event of this chain takes
             if (has && rank == 0)
-                segoff[chain] = base + (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
+                segoff[chain] = base + ((uint32_t)__popc(lo) + (uint32_t)__popc(hi)) * per_event;
             JLS_LOCKSTEP();
-            const uint32_t slot = base + rank;
+            const uint32_t slot = base + rank * per_event;
             // the record of a regular sample, worked out for every lane (no divergence; lanes without an event discard it)
             uint32_t record = 0;
             if (ILV == 0)
@@ -815,7 +881,15 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
                 }
             }
             if (has)
-                s_stage[slot] = record;
+            {
+                if (run_slots_of<S>() == 2 && chain == 0)
+                { // a run record: 32 bits in two slots
+                    s_stage[slot] = (Slot<S>)(record & 0xFFFFu);
+                    s_stage[slot + 1] = (Slot<S>)(record >> 16);
+                }
+                else
+                    s_stage[slot] = (Slot<S>)record;
+            }
             if (inside)
                 inv_row[x] = has ? (uint16_t)slot : kNoLocalSlot;
         }
@@ -825,7 +899,8 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     const uint32_t total_rows = s_rowbase[kChains];
     for (uint32_t q0 = (uint32_t)wave * 4; q0 < total_rows; q0 += kWaves * 4)
     { // four rows at a time: their LDS reads overlap
-        uint32_t to[4], held[4];
+        uint32_t to[4];
+        Slot<S> held[4];
         bool live[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -835,12 +910,12 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
             const uint32_t i = (q - s_rowbase[c]) * 64 + (uint32_t)lane;
             live[j] = q < total_rows && i < s_count[c];
             to[j] = s_global[c] + i;
-            held[j] = live[j] ? s_stage[s_tileoff[c] + i] : 0u;
+            held[j] = live[j] ? s_stage[s_tileoff[c] + i] : (Slot<S>)0;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (live[j])
-                w.rec[to[j]] = held[j];
+                rec_slots<S>(w)[to[j]] = held[j];
     }
 }
 
@@ -868,17 +943,17 @@ JLS_DEV int chain_n_before(uint32_t i, uint32_t reset)
 }
 
 template <typename S>
-JLS_DEV uint32_t code_event(Chain& s, uint32_t rec, const Traits& t)
+JLS_DEV Slot<S> code_event(Chain& s, uint32_t rec, const Traits& t)
 {
-    const int sgn = ((int)rec >> 31) | 1;
     int err;
     if (sizeof(S) == 1)
-    {
-        const int px = med3(mad24(s.c, sgn, (int)((rec >> 16) & 0x7FFFu)), 0, t.maxval);
-        err = sign_extend(__mul24((int)(rec & 0xFFFFu) - px, sgn), t.bpp);
+    { // (the record is reflected where the context's sign is negative: every event is one of positive sign, see make_record)
+        const int px = med3(s.c + (int)(rec >> 8), 0, t.maxval);
+        err = sign_extend((int)(rec & 0xFFu) - px, t.bpp);
     }
     else
     {
+        const int sgn = ((int)rec >> 31) | 1;
         const int room = (int)((rec >> 16) & 0xFFu);
         const int sc = __mul24(s.c, sgn);
         const int delta = (rec >> 24) & 1u ? (sc < room ? sc : room) : (sc > -room ? sc : -room);
@@ -903,7 +978,7 @@ JLS_DEV uint32_t code_event(Chain& s, uint32_t rec, const Traits& t)
     const int minus_delta = 1 - med3(tb, 0, 1) - med3(tb + s.n, 0, 1);
     s.b = med3(mad24(minus_delta, s.n, tb), 1 - s.n, 0);
     s.c = med3(s.c - minus_delta, -128, 127);
-    return ((uint32_t)cw.len << 24) | (uint32_t)cw.bits;
+    return pack_code<S>(cw.len, (uint32_t)cw.bits);
 }
 
 typedef uint32_t u32x4 __attribute__((vector_size(16)));
@@ -935,6 +1010,8 @@ template <typename S>
 __global__ void __launch_bounds__(64) walk_jobs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
     constexpr uint32_t kRow = 20; // words from one lane's 16 words to the next lane's (80 bytes: 16-byte aligned, banks spread)
+    constexpr uint32_t kPer = 64 / (uint32_t)sizeof(Slot<S>); // events of a round: 64 bytes of records in, 64 bytes of code words out
+    constexpr bool kNarrow = sizeof(Slot<S>) == 2;
     __shared__ uint32_t s_first[kChains + 1];
     __shared__ uint64_t s_in[64], s_out[64];       // where the lane's first round of records / code words is
     __shared__ uint32_t s_rounds[64], s_quiet[64]; // rounds of the lane; rounds of warm-up before its first stored one
@@ -953,14 +1030,14 @@ __global__ void __launch_bounds__(64) walk_jobs(const ScanDesc* __restrict__ des
     const bool live = job < jobs;
     const uint32_t chain = live ? chain_of_job(s_first, job) : 1u;
     const uint32_t n = live ? w.chain_total[chain] : 0u;
-    const uint32_t start = live ? (job - s_first[chain]) * w.job_events : 0u; // multiple of 16
+    const uint32_t start = live ? (job - s_first[chain]) * w.job_events : 0u; // multiple of kPer
     const uint32_t end = start + w.job_events < n ? start + w.job_events : n;
-    const uint32_t warm = start > w.warm_events ? (start - w.warm_events) & ~15u : 0u;
-    const uint32_t* in = w.rec + w.chain_base[chain];
-    uint32_t* out = w.code + w.chain_base[chain];
-    const uint32_t rounds = end / 16 - warm / 16, quiet = start / 16 - warm / 16;
-    s_in[lane] = (uint64_t)reinterpret_cast<uintptr_t>(in + (warm & ~15u));
-    s_out[lane] = (uint64_t)reinterpret_cast<uintptr_t>(out + (warm & ~15u));
+    const uint32_t warm = start > w.warm_events ? (start - w.warm_events) & ~(kPer - 1u) : 0u;
+    const Slot<S>* in = rec_slots<S>(w) + w.chain_base[chain];
+    Slot<S>* out = code_slots<S>(w) + w.chain_base[chain];
+    const uint32_t rounds = end / kPer - warm / kPer, quiet = start / kPer - warm / kPer;
+    s_in[lane] = (uint64_t)reinterpret_cast<uintptr_t>(in + warm);
+    s_out[lane] = (uint64_t)reinterpret_cast<uintptr_t>(out + warm);
     s_rounds[lane] = rounds;
     s_quiet[lane] = quiet;
     __syncthreads();
@@ -1021,7 +1098,16 @@ __global__ void __launch_bounds__(64) walk_jobs(const ScanDesc* __restrict__ des
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    o[j][e] = code_event<S>(s, cur[j][e], t);
+                {
+                    if (kNarrow)
+                    { // two records in a word, two code words out
+                        const uint32_t lo = (uint32_t)code_event<S>(s, cur[j][e] & 0xFFFFu, t);
+                        const uint32_t hi = (uint32_t)code_event<S>(s, cur[j][e] >> 16, t);
+                        o[j][e] = lo | (hi << 16);
+                    }
+                    else
+                        o[j][e] = (uint32_t)code_event<S>(s, cur[j][e], t);
+                }
         }
         if (__any(r >= quiet && r < rounds))
         { // (uniform) some lane has code words to store
@@ -1041,8 +1127,8 @@ __global__ void __launch_bounds__(64) walk_jobs(const ScanDesc* __restrict__ des
     if (!started)
         note_start();
     // ---- the last, partial group of a chain (its tail is the chain's padding)
-    for (uint32_t i = end & ~15u; i < end; ++i)
-        out[i] = code_event<S>(s, in[i], t);
+    for (uint32_t i = end & ~(kPer - 1u); i < end; ++i)
+        out[i] = code_event<S>(s, (uint32_t)in[i], t);
     st.out_a = s.a;
     st.out_b = s.b;
     st.out_c = s.c;
@@ -1069,8 +1155,8 @@ __global__ void __launch_bounds__(64) settle_chains(const ScanDesc* __restrict__
     if (j0 == j1)
         return;
     const uint32_t n = w.chain_total[chain];
-    const uint32_t* in = w.rec + w.chain_base[chain];
-    uint32_t* out = w.code + w.chain_base[chain];
+    const Slot<S>* in = rec_slots<S>(w) + w.chain_base[chain];
+    Slot<S>* out = code_slots<S>(w) + w.chain_base[chain];
     uint32_t bad = 0, rewalked = 0;
     JobState prev = w.jobs[j0];
     bad |= prev.bad;
@@ -1084,7 +1170,7 @@ __global__ void __launch_bounds__(64) settle_chains(const ScanDesc* __restrict__
             const uint32_t end = start + w.job_events < n ? start + w.job_events : n;
             Chain s{prev.out_a, prev.out_b, prev.out_c, chain_n_before(start, (uint32_t)t.reset), 0};
             for (uint32_t i = start; i < end; ++i)
-                out[i] = code_event<S>(s, in[i], t);
+                out[i] = code_event<S>(s, (uint32_t)in[i], t);
             cur.out_a = s.a;
             cur.out_b = s.b;
             cur.out_c = s.c;
@@ -1141,8 +1227,8 @@ JLS_DEV uint32_t run_word(int ones, int tail_len, uint32_t tail)
 // the record of that slot (int_rec, in the order of the slots); a sample-interleaved scan (ILV = 2) codes the `nc`
 // components of an interruption pixel one after the other on run context 0 (src/scan_encoder_impl.hpp:277-302).
 template <typename S, int ILV, bool kStore, int FMT = 0>
-JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code, uint32_t* int_code, uint32_t from, uint32_t to,
-                       RunState& s, uint32_t type0, uint32_t type1, uint32_t own_slot, const uint32_t* int_rec = nullptr, uint32_t nc = 1)
+JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code, Slot<S>* int_code, uint32_t from, uint32_t to,
+                       RunState& s, uint32_t type0, uint32_t type1, uint32_t own_slot, const Slot<S>* int_rec = nullptr, uint32_t nc = 1)
 {
     RunCtx rc0{0, s.a0, chain_n_before(type0, (uint32_t)t.reset), s.nn0};
     RunCtx rc1{1, s.a1, chain_n_before(type1, (uint32_t)t.reset), s.nn1};
@@ -1176,9 +1262,8 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
                 for (uint32_t c = 0; c < (ILV == 2 ? nc : 1u); ++c)
                 {
                     const bool shares = zero && c == 0; // the run's own sample: both codes in one word
-                    const uint32_t ir = shares ? v : int_rec[own_slot];
                     const int which = ILV == 2 ? 0 : RunRecord2::which(v);
-                    const int err = RunRecord2::err(ir);
+                    const int err = shares ? RunRecord2::err(v) : interruption_err<S>(int_rec[own_slot]);
                     RunCtx ctx = which ? rc1 : rc0;
                     const int k = run_k(ctx);
                     const int map = run_map(ctx, err, k);
@@ -1194,7 +1279,7 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
                     else
                     {
                         if (kStore)
-                            int_code[own_slot] = ((uint32_t)cw.len << 24) | (uint32_t)cw.bits;
+                            int_code[own_slot] = pack_code<S>(cw.len, (uint32_t)cw.bits);
                         ++own_slot;
                     }
                 }
@@ -1247,7 +1332,7 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
             {
                 word = run_word(ones, jb + 1, run);
                 if (kStore)
-                    int_code[own_slot] = ((uint32_t)c.len << 24) | (uint32_t)c.bits;
+                    int_code[own_slot] = pack_code<S>(c.len, (uint32_t)c.bits);
                 ++own_slot;
             }
         }
@@ -1310,7 +1395,7 @@ __global__ void __launch_bounds__(64) count_runs(const Work* __restrict__ works,
 {
     const Work w = works[blockIdx.y];
     const uint32_t n = w.chain_total[0];
-    const uint32_t* runs = w.rec + w.chain_base[0];
+    const uint32_t* runs = reinterpret_cast<const uint32_t*>(rec_slots<S>(w) + w.chain_base[0]);
     for (uint32_t job = blockIdx.x; job * w.run_job_events < n; job += gridDim.x)
     {
         const uint32_t from = job * w.run_job_events;
@@ -1412,9 +1497,9 @@ __global__ void __launch_bounds__(64) compact_rare_runs(const Work* __restrict__
     const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
     if (jobs == 0)
         return;
-    const uint32_t* runs = w.rec + w.chain_base[0];
-    const uint32_t* int_rec = w.rec + w.chain_base[kInterruptChain]; // (pixel mode)
-    int32_t* rare = reinterpret_cast<int32_t*>(w.code + w.chain_base[0]);
+    const uint32_t* runs = reinterpret_cast<const uint32_t*>(rec_slots<S>(w) + w.chain_base[0]);
+    const Slot<S>* int_rec = rec_slots<S>(w) + w.chain_base[kInterruptChain]; // (pixel mode)
+    int32_t* rare = reinterpret_cast<int32_t*>(w.code); // (the run chain's code words: chain 0 starts the array, one 32-bit entry per run event)
     const int rare_type = rarer_is_type1(w, jobs) ? 1 : 0;
     const int lane = threadIdx.x;
     for (uint32_t job = blockIdx.x; job < jobs; job += gridDim.x)
@@ -1446,7 +1531,7 @@ __global__ void __launch_bounds__(64) compact_rare_runs(const Work* __restrict__
             {
                 int err;
                 if (FMT == 1)
-                    err = RunRecord2::err(own ? int_rec[own_at + (uint32_t)__popcll(own_m & below)] : v);
+                    err = own ? interruption_err<S>(int_rec[own_at + (uint32_t)__popcll(own_m & below)]) : RunRecord2::err(v);
                 else
                     err = RunRecord<S>::err(v);
                 rare[at + (uint32_t)__popcll(rare_m & below)] = err;
@@ -1471,7 +1556,7 @@ __global__ void __launch_bounds__(64) walk_rare_context(const ScanDesc* __restri
     if (jobs == 0)
         return;
     const bool rare1 = rarer_is_type1(w, jobs);
-    const int32_t* rare = reinterpret_cast<const int32_t*>(w.code + w.chain_base[0]);
+    const int32_t* rare = reinterpret_cast<const int32_t*>(w.code);
     RunCtx ctx{rare1 ? 1 : 0, initial_a(t), 1, 0};
     uint32_t i = 0;
     for (uint32_t j = 0; j < jobs; ++j)
@@ -1503,10 +1588,10 @@ __global__ void __launch_bounds__(64) walk_run_jobs(const ScanDesc* __restrict__
         return;
     const Traits t = make_traits(d);
     const uint32_t to = from + w.run_job_events < n ? from + w.run_job_events : n;
-    const uint32_t* runs = w.rec + w.chain_base[0];
-    uint32_t* run_code = w.code + w.chain_base[0];
-    uint32_t* int_code = w.code + w.chain_base[kInterruptChain];
-    const uint32_t* int_rec = w.rec + w.chain_base[kInterruptChain]; // (pixel mode)
+    const uint32_t* runs = reinterpret_cast<const uint32_t*>(rec_slots<S>(w) + w.chain_base[0]); // (chain 0 starts the arrays: aligned)
+    uint32_t* run_code = reinterpret_cast<uint32_t*>(code_slots<S>(w) + w.chain_base[0]);
+    Slot<S>* int_code = code_slots<S>(w) + w.chain_base[kInterruptChain];
+    const Slot<S>* int_rec = rec_slots<S>(w) + w.chain_base[kInterruptChain]; // (pixel mode)
     const uint32_t nc = samples_per_pixel(d);
     // The warm-up starts at a job boundary (that is where the counts are known): RUNindex and the context of the more frequent
     // interruption type forget within run_warm_events run events; the context of the rarer type starts the warm-up in its
@@ -1555,10 +1640,10 @@ __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ d
         atomicAdd(&w.counters[kCountRunJobs], jobs);
         return;
     }
-    const uint32_t* runs = w.rec + w.chain_base[0];
-    uint32_t* run_code = w.code + w.chain_base[0];
-    uint32_t* int_code = w.code + w.chain_base[kInterruptChain];
-    const uint32_t* int_rec = w.rec + w.chain_base[kInterruptChain];
+    const uint32_t* runs = reinterpret_cast<const uint32_t*>(rec_slots<S>(w) + w.chain_base[0]);
+    uint32_t* run_code = reinterpret_cast<uint32_t*>(code_slots<S>(w) + w.chain_base[0]);
+    Slot<S>* int_code = code_slots<S>(w) + w.chain_base[kInterruptChain];
+    const Slot<S>* int_rec = rec_slots<S>(w) + w.chain_base[kInterruptChain];
     const uint32_t nc = samples_per_pixel(d);
     RunState prev = w.run_jobs[0].out;
     uint32_t rewalked = 0;
@@ -1586,10 +1671,10 @@ __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ d
 // LDS: codes[tile] u32 | tileoff / count / global [kChains + 1] each | scan[256] | tmp
 #define JLS_HOST_DEV __host__ __device__ inline
 // LDS of pack_tiles: where the staged slot map starts (behind the code words, the piece tables and the row table)
-JLS_HOST_DEV uint32_t pack_inv_offset(uint32_t tile_capacity) // 16-byte aligned
+JLS_HOST_DEV uint32_t pack_inv_offset(uint32_t tile_capacity, uint32_t sample_bytes) // 16-byte aligned
 {
-    const uint32_t head = tile_capacity * 4 + 4 * ((uint32_t)kChains + 1) * 4 + kPackThreads * 4 + 16 * 4 +
-                          (tile_capacity / 64 + (uint32_t)kChains + 8) * 2;
+    const uint32_t codes = (uint32_t)stage_bytes(tile_capacity, sample_bytes);
+    const uint32_t head = ((codes + 3u) & ~3u) + 4 * ((uint32_t)kChains + 1) * 4 + kPackThreads * 4 + 16 * 4 + kRowChainWords * 4;
     return (head + 15u) & ~15u;
 }
 
@@ -1616,9 +1701,11 @@ JLS_DEV void expand_code(uint32_t word, uint64_t& bits, int& len)
     }
 }
 
+template <typename S>
 __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
     JLS_DYNAMIC_LDS(smem);
+    constexpr bool kNarrow = sizeof(Slot<S>) == 2;
     const ScanDesc d = descs[blockIdx.y];
     const Work w = works[blockIdx.y];
     const uint32_t tile = blockIdx.x;
@@ -1630,15 +1717,16 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     const uint32_t per_thread = ((tile_capacity + threads - 1) / threads + 7u) & ~7u; // consecutive samples of a thread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t kPackWaves = threads / 64;
-    uint32_t* s_code = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* s_tileoff = s_code + tile_capacity;
+    Slot<S>* s_code = reinterpret_cast<Slot<S>*>(smem); // the tile's code words, in slots
+    const uint32_t code_bytes = (uint32_t)stage_bytes(tile_capacity, (uint32_t)sizeof(S));
+    uint32_t* s_tileoff = reinterpret_cast<uint32_t*>(smem + ((code_bytes + 3u) & ~3u));
     uint32_t* s_count = s_tileoff + kChains + 1;
     uint32_t* s_global = s_count + kChains + 1;
     uint32_t* s_scan = s_global + kChains + 1; // 256
     uint32_t* s_tmp = s_scan + kPackThreads;   // one word per wavefront (16 reserved)
     uint32_t* s_rowbase = s_tmp + 16;          // [kChains + 1] first row of the chain's piece
-    uint16_t* s_rowchain = reinterpret_cast<uint16_t*>(s_rowbase + kChains + 1); // [tile / 64 + kChains + 8]
-    uint16_t* s_inv = reinterpret_cast<uint16_t*>(smem + pack_inv_offset(tile_capacity)); // [kPackThreads * per_thread] slot map of the tile
+    uint16_t* s_rowchain = reinterpret_cast<uint16_t*>(s_rowbase + kChains + 1); // [slots of the tile / 64 + kChains + 1]: kRowChainWords words
+    uint16_t* s_inv = reinterpret_cast<uint16_t*>(smem + pack_inv_offset(tile_capacity, (uint32_t)sizeof(S))); // [threads * per_thread] slot map of the tile
     const TileSpan span = tile_span(d, w, tile);
     const uint32_t tile_samples = span.count;
     const uint16_t* inv = w.keyinv + span.first;
@@ -1699,7 +1787,8 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         const uint32_t total_rows = s_rowbase[kChains];
         for (uint32_t q0 = (uint32_t)wave * 8; q0 < total_rows; q0 += kPackWaves * 8)
         {
-            uint32_t to[8], held[8];
+            uint32_t to[8];
+            Slot<S> held[8];
             bool live[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -1709,7 +1798,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
                 const uint32_t i = (q - s_rowbase[c]) * 64 + (uint32_t)lane;
                 live[j] = q < total_rows && i < s_count[c];
                 to[j] = s_tileoff[c] + i;
-                held[j] = live[j] ? w.code[s_global[c] + i] : 0u;
+                held[j] = live[j] ? code_slots<S>(w)[s_global[c] + i] : (Slot<S>)0;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -1730,14 +1819,26 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         const uint32_t word = (j >> 1) == 0 ? mine[q].x : (j >> 1) == 1 ? mine[q].y : (j >> 1) == 2 ? mine[q].z : mine[q].w;
         return (j & 1) ? word >> 16 : word & 0xFFFFu;
     };
+    // The code word of the sample in `slot`, in the 32-bit form (length : 8 | bits : 24, or a run-length code): the entries of
+    // the run chain come first in a tile's local order and take two of the 2-byte slots.
+    const uint32_t run_slots_end = kNarrow ? s_count[0] : 0u;
+    auto word_of = [&](uint32_t slot) -> uint32_t {
+        if (slot == kNoLocalSlot)
+            return 0u; // (no bits)
+        if (!kNarrow)
+            return (uint32_t)s_code[slot];
+        if (slot < run_slots_end)
+            return (uint32_t)s_code[slot] | ((uint32_t)s_code[slot + 1] << 16);
+        const uint32_t c = (uint32_t)s_code[slot];
+        return ((c >> 10) << 24) | (c & 0x3FFu);
+    };
     uint32_t sum = 0;
 #pragma unroll
     for (int q = 0; q < kGroups; ++q)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
         {
-            const uint32_t slot = slot_of(q, j);
-            const uint32_t word = slot != kNoLocalSlot ? s_code[slot] : 0u; // (0: no bits)
+            const uint32_t word = word_of(slot_of(q, j));
             sum += word & kRunTag ? ((word >> 25) & 63u) + ((word >> 20) & 31u) : word >> 24;
         }
     s_scan[threadIdx.x] = sum;
@@ -1837,7 +1938,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
                     continue;
                 uint64_t v;
                 int len;
-                expand_code(s_code[slot], v, len);
+                expand_code(word_of(slot), v, len);
                 if (len > 32)
                 { // (codes of wide samples, long runs: rare)
                     put((uint32_t)(v >> 32), (uint32_t)len - 32u);
@@ -1912,7 +2013,8 @@ inline size_t analyze_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_
 inline size_t sort_lds_bytes(uint32_t width, uint32_t lines_per_tile, uint32_t sample_bytes, int interleave_mode)
 {
     return tile_common_lds_bytes(width, lines_per_tile, sample_bytes, interleave_mode, false) + (size_t)sort_segments(lines_per_tile) * kChains * 4 +
-           4 * ((size_t)kChains + 1) * 4 + 16 * 4 + (size_t)kWaves * (kChains + 1) * 4 + 252 * 4 + (size_t)lines_per_tile * width * 4;
+           4 * ((size_t)kChains + 1) * 4 + 16 * 4 + (size_t)kWaves * (kChains + 1) * 4 + kRowChainWords * 4 +
+           stage_bytes((uint32_t)lines_per_tile * width, sample_bytes);
 }
 // Threads of a pack_tiles workgroup: 512 with 8 or 16 consecutive samples each; a tile that would leave more than a fifth of
 // those samples empty (6144 samples of a 4096-pixel RGB line cut in two) gets fewer threads instead (never fewer than 192: the
@@ -1930,7 +2032,7 @@ inline size_t pack_lds_bytes(uint32_t tile_capacity, int32_t bits_per_sample)
     const uint32_t threads = pack_threads_for(tile_capacity);
     const uint32_t per_thread = ((tile_capacity + threads - 1) / threads + 7u) & ~7u;
     const size_t slot_map = (size_t)threads * per_thread * 2, bit_buffer = (size_t)pack_bits_words(tile_capacity, bits_per_sample) * 4;
-    return (size_t)pack_inv_offset(tile_capacity) + (slot_map > bit_buffer ? slot_map : bit_buffer); // (the bits take the map's place)
+    return (size_t)pack_inv_offset(tile_capacity, bits_per_sample > 8 ? 2u : 1u) + (slot_map > bit_buffer ? slot_map : bit_buffer); // (the bits take the map's place)
 }
 // How a scan is cut into tiles.  A tile holds up to `cap` samples (8192 of one byte, 4096 of two: the sort stage keeps the
 // lines, the sorted records and its tables of a tile in LDS; CHARLS_AMD_TILE_SAMPLES lowers it -- more workgroups per CU for

@@ -47,6 +47,12 @@ struct RunRecord2
     static JLS_DEV int err(uint32_t v) { return (int)(v << 15) >> 15; }
     static JLS_DEV int which(uint32_t v) { return (int)((v >> 27) & 1u); }
 };
+// The error value in the record of an interruption sample with a slot of its own (a slot holds its low bits).
+template <typename S>
+JLS_DEV int interruption_err(Slot<S> v)
+{
+    return sizeof(Slot<S>) == 2 ? (int)(int16_t)v : RunRecord2::err((uint32_t)v);
+}
 
 // A tile of pixel mode.
 struct PixelTile
@@ -507,7 +513,7 @@ __global__ void __launch_bounds__(kThreads) sort_pixel_tiles(const ScanDesc* __r
     uint32_t* s_same = s_tmp + 16;
     uint32_t* s_rowbase = s_same + kWaves * (kChains + 1);
     uint16_t* s_rowchain = reinterpret_cast<uint16_t*>(s_rowbase + kChains + 1);
-    uint32_t* s_stage = s_rowbase + kChains + 1 + 252;
+    Slot<S>* s_stage = reinterpret_cast<Slot<S>*>(s_rowbase + kChains + 1 + kRowChainWords);
     const int mask = (1 << d.bits_per_sample) - 1;
     auto key_row = [&](uint32_t r) -> uint16_t* { return w.keyinv + (size_t)(g.first_line + r) * g.line_samples + (size_t)g.px0 * nc; };
 
@@ -542,7 +548,7 @@ __global__ void __launch_bounds__(kThreads) sort_pixel_tiles(const ScanDesc* __r
                     const uint32_t q = k * 64 + lane;
                     const uint16_t key = held[j];
                     if (q < Ps && key != kNoEvent)
-                        atomicAdd(&s_segoff[sgm * kChains + (key & 0x1FF)], 1u);
+                        atomicAdd(&s_segoff[sgm * kChains + (key & 0x1FF)], (key & 0x1FF) == 0 ? run_slots_of<S>() : 1u); // (slots)
                     const unsigned long long m = __ballot(q < Ps && key == kNoEvent);
                     if (lane == 0)
                         s_noev[r * max_chunks + k] = m;
@@ -657,10 +663,11 @@ __global__ void __launch_bounds__(kThreads) sort_pixel_tiles(const ScanDesc* __r
             if (has && upper)
                 same_of[chain] = 0;
             const uint32_t rank = upper ? (uint32_t)__popc(lo) + (uint32_t)__popc(hi & below) : (uint32_t)__popc(lo & below);
+            const uint32_t per_event = chain == 0 ? run_slots_of<S>() : 1u; // slots an event of this chain takes
             if (has && rank == 0)
-                segoff[chain] = base + (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
+                segoff[chain] = base + ((uint32_t)__popc(lo) + (uint32_t)__popc(hi)) * per_event;
             JLS_LOCKSTEP();
-            const uint32_t slot = base + rank;
+            const uint32_t slot = base + rank * per_event;
             // the neighbourhood of the sample, for every lane (no divergence; lanes without an event discard it)
             uint32_t record = 0;
             int v = 0, ra = 0, rb = 0;
@@ -717,7 +724,15 @@ __global__ void __launch_bounds__(kThreads) sort_pixel_tiles(const ScanDesc* __r
                 }
             }
             if (has)
-                s_stage[slot] = record;
+            {
+                if (run_slots_of<S>() == 2 && chain == 0)
+                { // a run record: 32 bits in two slots
+                    s_stage[slot] = (Slot<S>)(record & 0xFFFFu);
+                    s_stage[slot + 1] = (Slot<S>)(record >> 16);
+                }
+                else
+                    s_stage[slot] = (Slot<S>)record;
+            }
             if (inside)
                 inv_row[q] = has ? (uint16_t)slot : kNoLocalSlot;
         }
@@ -727,7 +742,8 @@ __global__ void __launch_bounds__(kThreads) sort_pixel_tiles(const ScanDesc* __r
     const uint32_t total_rows = s_rowbase[kChains];
     for (uint32_t q0 = (uint32_t)wave * 4; q0 < total_rows; q0 += kWaves * 4)
     {
-        uint32_t to[4], held[4];
+        uint32_t to[4];
+        Slot<S> held[4];
         bool live[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -737,12 +753,12 @@ __global__ void __launch_bounds__(kThreads) sort_pixel_tiles(const ScanDesc* __r
             const uint32_t i = (q - s_rowbase[c]) * 64 + (uint32_t)lane;
             live[j] = q < total_rows && i < s_count[c];
             to[j] = s_global[c] + i;
-            held[j] = live[j] ? s_stage[s_tileoff[c] + i] : 0u;
+            held[j] = live[j] ? s_stage[s_tileoff[c] + i] : (Slot<S>)0;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (live[j])
-                w.rec[to[j]] = held[j];
+                rec_slots<S>(w)[to[j]] = held[j];
     }
 }
 
@@ -755,7 +771,7 @@ inline size_t sort_pixel_lds_bytes(uint32_t lines_per_tile, uint32_t max_pixels,
 {
     const PixelLds l = pixel_lds(lines_per_tile, max_pixels, nc, sample_bytes, tile_capacity, false, (max_pixels * nc + 63) / 64);
     return (size_t)l.table + (size_t)sort_segments(lines_per_tile) * kChains * 4 + 4 * ((size_t)kChains + 1) * 4 + 16 * 4 +
-           (size_t)kWaves * (kChains + 1) * 4 + 252 * 4 + (size_t)tile_capacity * 4;
+           (size_t)kWaves * (kChains + 1) * 4 + kRowChainWords * 4 + stage_bytes(tile_capacity, sample_bytes);
 }
 
 } // namespace tile

@@ -22,6 +22,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
                               uint32_t run_job_events, uint32_t run_warm_events, uint32_t run_long_warm_events)
 {
     using namespace jls;
+    job_events = std::max<uint32_t>(32, job_events / 32 * 32); // (whole rounds of the walkers, as runtime.hip rounds it)
     const ScanDesc& p = descs[0];
     const tile::TilePlan plan = tile::plan_tiles(p);
     const size_t samples = (size_t)plan.samples;
@@ -54,8 +55,10 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         w.chain_total = (uint32_t*)galloc(pipe::kChains * 4);
         w.chain_base = (uint32_t*)galloc(pipe::kChains * 4);
         w.job_first = (uint32_t*)galloc((pipe::kChains + 1) * 4);
-        w.rec = (uint32_t*)galloc((samples + tile::kSlack) * 4);
-        w.code = (uint32_t*)galloc((samples + tile::kSlack) * 4);
+        const size_t slots = (size_t)tile::slots_capacity(samples, tile::run_slots_of<S>(), plan.lines) + tile::kSlack;
+        w.rec = (uint32_t*)galloc(slots * sizeof(tile::Slot<S>));
+        w.code = (uint32_t*)galloc(slots * sizeof(tile::Slot<S>));
+        w.run_slots = tile::run_slots_of<S>();
         w.jobs = (tile::JobState*)galloc(max_jobs * sizeof(tile::JobState));
         w.run_jobs = (tile::RunJob*)galloc(max_run_jobs * sizeof(tile::RunJob));
         w.run_job_events = run_job_events;
@@ -137,7 +140,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     else
         EMU_RUN_CHAIN(0, 1);
 #undef EMU_RUN_CHAIN
-    emu::launch(tile::pack_tiles, dim3(tiles, count), dim3(tile::pack_threads_for(plan.tile_capacity)), tile::pack_lds_bytes(plan.tile_capacity, p.bits_per_sample), descs, wk);
+    emu::launch(tile::pack_tiles<S>, dim3(tiles, count), dim3(tile::pack_threads_for(plan.tile_capacity)), tile::pack_lds_bytes(plan.tile_capacity, p.bits_per_sample), descs, wk);
     const pipe::Work* sk = stuff.data();
     if (const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING"); env != nullptr && std::atoi(env) == 2)
     { // the speculative form (CHARLS_AMD_BLOCK_STUFFING=2 is a switch of this harness only: the product picks by batch size)
