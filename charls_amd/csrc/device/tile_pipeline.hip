@@ -1841,13 +1841,22 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
             const uint32_t word = word_of(slot_of(q, j));
             sum += word & kRunTag ? ((word >> 25) & 63u) + ((word >> 20) & 31u) : word >> 24;
         }
-    s_scan[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t stride = 1; stride < threads; stride <<= 1) // Hillis-Steele inclusive scan
-    {
-        const uint32_t add = threadIdx.x >= stride ? s_scan[threadIdx.x - stride] : 0;
+    { // inclusive scan of the threads' bit counts: inside a wavefront with shuffles, the wavefronts' totals through LDS (two
+      // barriers; the Hillis-Steele scan through LDS that stood here until round 4 took eighteen)
+        uint32_t incl = sum;
+        for (int delta = 1; delta < 64; delta <<= 1)
+        {
+            const uint32_t up = __shfl_up(incl, delta);
+            if (lane >= delta)
+                incl += up;
+        }
+        if (lane == 63)
+            s_tmp[wave] = incl;
         __syncthreads();
-        s_scan[threadIdx.x] += add;
+        uint32_t before = 0;
+        for (uint32_t w2 = 0; w2 < kPackWaves; ++w2)
+            before += (int)w2 < wave ? s_tmp[w2] : 0u;
+        s_scan[threadIdx.x] = before + incl;
         __syncthreads();
     }
     // ---- where this tile starts: the first wavefront looks back, 64 predecessors at a time (see write_raw_bits)

@@ -60,7 +60,8 @@ struct charls_jpegls_decoder
     // scans with the same coding parameters.  Returns false, with nothing changed, whenever anything is out of the ordinary
     // (a segment that does not parse, different parameters, a scan that does not end where the next marker is, any decoding
     // error): the scan-by-scan path then runs from the start and raises what the reference would.
-    bool decode_planes_together(uint8_t* dst, size_t dst_left, size_t stride_arg, const uint8_t* base)
+    // `uploaded` is set once the source bytes are on the device (the scan-by-scan path does not send them again).
+    bool decode_planes_together(uint8_t* dst, size_t dst_left, size_t stride_arg, const uint8_t* base, bool& uploaded)
     {
         const size_t count = reader.component_count();
         if (count < 2 || reader.scan_interleave_mode() != 0 || reader.scan_component_count() != 1)
@@ -68,9 +69,21 @@ struct charls_jpegls_decoder
         const charls_frame_info f = reader.frame_info();
         const size_t min_stride = static_cast<size_t>(f.width) * bytes_per_sample(f.bits_per_sample);
         const size_t stride = stride_arg == 0 ? min_stride : stride_arg;
-        if (stride < min_stride || dst_left < stride * f.height * count - (stride - min_stride))
+        if (stride < min_stride)
             return false;
-        std::vector<size_t> offsets;
+        size_t needed = 0;
+        try
+        {
+            needed = checked_mul(checked_mul(stride, f.height), count) - (stride - min_stride);
+        }
+        catch (const error&)
+        {
+            return false;
+        }
+        if (dst_left < needed)
+            return false;
+        std::vector<size_t> offsets, marker_at; // where scan c starts; where the marker that ends it was found
+        StreamReader after; // the probe behind the last scan's header
         std::vector<ScanSpec> specs;
         try
         {
@@ -97,9 +110,11 @@ struct charls_jpegls_decoder
                     if (p[1] >= 0x80 && !(p[1] >= 0xD0 && p[1] <= 0xD7))
                         break;
                 }
+                marker_at.push_back(static_cast<size_t>(p - base));
                 probe.advance(static_cast<size_t>(p - probe.position()));
                 probe.read_next_start_of_scan();
             }
+            after = probe;
         }
         catch (const error&)
         {
@@ -113,6 +128,7 @@ struct charls_jpegls_decoder
                 return false;
         }
         engine.upload_stream(base, reader.remaining());
+        uploaded = true;
         std::vector<ScanResult> results(count);
         try
         {
@@ -126,15 +142,21 @@ struct charls_jpegls_decoder
         {
             if (results[c].errc != kOk)
                 return false;
-            if (c + 1 < count)
-            { // scan c must end exactly where the probe found the marker that leads to scan c + 1 (the SOS segment of a
-              // single-component scan is 10 bytes, other segments may sit before it: checked by replaying the reader below)
-                const size_t end_of_scan = offsets[c] + static_cast<size_t>(results[c].bytes);
-                if (end_of_scan > offsets[c + 1])
-                    return false;
-            }
+            // scan c must end exactly at the marker the probe found behind it
+            if (c + 1 < count && offsets[c] + static_cast<size_t>(results[c].bytes) != marker_at[c])
+                return false;
         }
-        // replay the real reader over the same path (handlers fire exactly as in the scan-by-scan path), planes out
+        try
+        { // what follows the last scan must read as the end of the image, before anything is handed to the caller
+            after.advance(static_cast<size_t>(results[count - 1].bytes));
+            after.read_end_of_image();
+        }
+        catch (const error&)
+        {
+            return false;
+        }
+        // replay the real reader over the same path (handlers fire exactly as in the scan-by-scan path), planes out; the
+        // probe took every one of these steps without raising
         for (size_t c = 0; c < count; ++c)
         {
             if (static_cast<size_t>(reader.position() - base) != offsets[c])
@@ -156,9 +178,9 @@ struct charls_jpegls_decoder
         auto* dst = static_cast<uint8_t*>(destination);
         size_t dst_left = destination_size_bytes;
         const uint8_t* base = reader.position();
-        if (decode_planes_together(dst, dst_left, stride_arg, base))
-            return;
         bool uploaded = false;
+        if (decode_planes_together(dst, dst_left, stride_arg, base, uploaded))
+            return;
 
         for (size_t component = 0;;)
         {

@@ -3,7 +3,7 @@
 The tile pipeline (DESIGN 4.1) codes every context chain and the run chain in JOBS that start from a guessed state;
 settle_chains / settle_runs check every job boundary and code a job again where the guess was wrong.  With the default
 job sizes and warm-ups nearly every guess is right on natural data, so the ordinary parity tests never execute the
-re-walks on the GPU.  Here the knobs (read per call, runtime.hip: TileLayout) make every boundary disagree -- jobs of 16
+re-walks on the GPU.  Here the knobs (read per call, runtime.hip: TileLayout) make every boundary disagree -- jobs of 32
 events with no warm-up -- and full-range noise, which never converges, goes through with the DEFAULT knobs.  The bytes must
 be the oracle's in every case, and charls_amd_speculation_counters must show that the re-walks really ran.
 
@@ -18,7 +18,7 @@ from charls_amd import batch, capi, synth
 
 pytestmark = pytest.mark.gpu
 
-FORCED = {"CHARLS_AMD_JOB_EVENTS": "16", "CHARLS_AMD_WARM_EVENTS": "0", "CHARLS_AMD_RUN_JOB_EVENTS": "32",
+FORCED = {"CHARLS_AMD_JOB_EVENTS": "32", "CHARLS_AMD_WARM_EVENTS": "0", "CHARLS_AMD_RUN_JOB_EVENTS": "32",
           "CHARLS_AMD_RUN_WARM_EVENTS": "0", "CHARLS_AMD_RUN_LONG_WARM_EVENTS": "0"}
 
 
@@ -52,7 +52,7 @@ def test_every_job_boundary_disagrees_gray(lib, monkeypatch, kind, bits, w, h, s
     got = lib.encode(img, width=w, height=h, bits_per_sample=bits)
     did = counters(lib) - before
     assert got == ob.encode(img, width=w, height=h, bits_per_sample=bits)
-    assert did[0] >= w * h // 16 // 2 and did[1] > did[0] // 4, did  # most jobs of the regular chains walked again
+    assert did[0] >= w * h // 32 // 2 and did[1] > did[0] // 4, did  # (jobs of 32 events: whole rounds of the walkers) most of them walked again
     if kind == "mixed":
         assert did[2] > 1 and did[3] > 0, did  # flat patches: the run chain has jobs, and they were settled too
     assert lib.decode(got)[1].tobytes() == img.tobytes()
