@@ -366,7 +366,8 @@ def main():
         # profiles/README.md); they are used only when they were taken for THIS kernel instantiation and batch size
         traffic, traffic_source, issue = None, None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_dominant_kernel_pmc.json")) as f:
+            pmc_file = next(p for p in (os.path.join(ROOT, "profiles", f"r0{r}_dominant_kernel_pmc.json") for r in (4, 3)) if os.path.exists(p))
+            with open(pmc_file) as f:
                 tj = json.load(f)
             if tj.get("kernel") == dom_name and int(tj.get("frames", -1)) == frames_n:
                 traffic = int(tj["hbm_bytes_per_frame"] * frames_n)
@@ -381,7 +382,7 @@ def main():
                          "unit": "G wave-instructions/s", "frac": round(valu / (dom_ms * 1e-3) / peak, 4),
                          "valu_wave_instructions_per_sample": tj["valu_wave_instructions_per_sample"],
                          "source": tj.get("instruction_source")}
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, StopIteration):
             pass
         line = {
             "metric": "MPixels/s encode+decode, 4096x4096 8-bit gray, bit-exact vs CharLS" if args.restart_interval == 0 else

@@ -26,9 +26,11 @@ CHARLS_AMD_DECODE_GROUP=8 timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "decode_scans" --output-format csv -d $out/pmc4096_$c -o p -- python bench.py --distinct 64 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/pmc4096_$c.log 2>&1
 done
-# one frame: where single-frame latency goes
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/one -o one -- python bench.py --frames 1 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/one.json 2> $out/one.log
-# the other BASELINE configurations (parity cases, not bench lines)
-timeout 200 python tools/measure_configs.py --only 2,3,5a,5c > $out/other_configs.txt 2>&1
+# one frame through the host-pointer C ABI: latency, and where it goes
+python tools/one_frame_latency.py --decode > $out/one_frame_latency.txt 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/one -o one -- python tools/one_frame_latency.py --calls 6 > $out/one.log 2>&1
+python tools/copy_probe.py > $out/copy_probe.txt 2>&1
+# the other BASELINE configurations (parity cases, not bench lines): EVERY row of DESIGN 6.3
+timeout 900 python tools/measure_configs.py --only 2,3,5a,5b,5c,5d,5e,6,6w > $out/other_configs.txt 2>&1
 find $out -name "*kernel_trace.csv" -size +8M -delete
 du -sh $out; find $out -type f | head -40

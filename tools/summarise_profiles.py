@@ -125,6 +125,20 @@ def main():
             if c.get("SQ_INSTS_VALU") and li.get(k):
                 f.write(f"    per sample: VALU {c['SQ_INSTS_VALU']/samples:.2f}  SALU {c['SQ_INSTS_SALU']/samples:.2f}  "
                         f"LDS {c['SQ_INSTS_LDS']/samples:.3f}  wave-cycles(x4) {4*c['SQ_WAVE_CYCLES']/samples:.1f}\n")
+    # ---- the rest of the collection run, as it is
+    import shutil
+    for src, dst in (("other_configs.txt", "other_configs.txt"), ("one_frame_latency.txt", "one_frame_latency.txt"),
+                     ("copy_probe.txt", "copy_probe.txt"), ("pytest_gpu.log", "pytest_gpu.log")):
+        if os.path.exists(os.path.join(SRC, src)):
+            shutil.copyfile(os.path.join(SRC, src), os.path.join(DST, f"{TAG}_{dst}"))
+    one = os.path.join(SRC, "one", "one_kernel_stats.csv")
+    if os.path.exists(one):
+        with open(one, newline="") as f, open(os.path.join(DST, f"{TAG}_rocprof_kernel_stats_one_frame.csv"), "w") as g:
+            g.write("# rocprofv3 --kernel-trace --stats -- python tools/one_frame_latency.py --calls 6 (ONE 4096 x 4096 frame through the host-pointer C ABI, 7 calls)\n")
+            g.write("kernel,calls,total_ms,avg_us\n")
+            for r in csv.DictReader(f):
+                if "jls" in r["Name"]:
+                    g.write(f"\"{short(r['Name'])}\",{r['Calls']},{float(r['TotalDurationNs'])/1e6:.3f},{float(r['AverageNs'])/1e3:.1f}\n")
     print("profiles written for", TAG, "value", bench["value"])
 
 
