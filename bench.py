@@ -523,19 +523,19 @@ def extras(lib, batch, torch, frames, streams, out, enc, dev, mpix, pitch):
         e = batch.encode_batch(out[rng(k)], bits_per_sample=BITS, streams=streams[rng(k)], lib=lib)
         sizes[rng(k)] = e.sizes
 
-    longest = [0]
-
-    def download_streams(k):
-        longest[0] = max(longest[0], int(sizes[rng(k)].max()))
-        w = int(sizes[rng(k)].max())
-        host_streams[rng(k), :w].copy_(streams[rng(k), :w], non_blocking=True)
+    def download_streams(k):  # one copy of exactly its bytes per stream (a strided 2-D copy of the chunk's slots takes ten times as long)
+        for f in range(k * chunk, (k + 1) * chunk):
+            host_streams[f, :int(sizes[f])].copy_(streams[f, :int(sizes[f])], non_blocking=True)
 
     a = time.perf_counter()
     pipelined(lambda k: out[rng(k)].copy_(host_frames[rng(k)], non_blocking=True), encode_chunk, download_streams, n // chunk)
     b = time.perf_counter()
     # (decoding is one serial chain per frame: its rate is the number of frames in flight, so the whole batch is ONE chunk)
-    w = longest[0]
-    pipelined(lambda k: streams[:n, :w].copy_(host_streams[:, :w], non_blocking=True),
+    def upload_streams(k):
+        for f in range(n):
+            streams[f, :int(sizes[f])].copy_(host_streams[f, :int(sizes[f])], non_blocking=True)
+
+    pipelined(upload_streams,
               lambda k: batch.decode_batch(streams[:n], sizes, out[:n], lib=lib),
               lambda k: host_out.copy_(out[:n], non_blocking=True), 1)
     c = time.perf_counter()
