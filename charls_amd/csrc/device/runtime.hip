@@ -893,9 +893,9 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         const uint32_t tiles_grid = 8 * ((lay.tiles + 7) / 8);
         const tile::TilePlan& plan = lay.plan;
         const bool pixel_mode = plan.mode == 2;
-        const size_t lds_a = pixel_mode ? tile::analyze_pixel_lds_bytes(plan.lines_per_tile, plan.max_pixels, plan.nc, sizeof(S), plan.tile_capacity)
+        const size_t lds_a = pixel_mode ? tile::analyze_pixel_lds_bytes(plan.lines_per_tile, plan.step, plan.max_pixels, plan.nc, sizeof(S), plan.tile_capacity)
                                         : tile::analyze_lds_bytes(proto.width, lay.lines_per_tile, sizeof(S), proto.interleave_mode);
-        const size_t lds_b = pixel_mode ? tile::sort_pixel_lds_bytes(plan.lines_per_tile, plan.max_pixels, plan.nc, sizeof(S), plan.tile_capacity)
+        const size_t lds_b = pixel_mode ? tile::sort_pixel_lds_bytes(plan.lines_per_tile, plan.step, plan.max_pixels, plan.nc, sizeof(S), plan.tile_capacity)
                                         : tile::sort_lds_bytes(proto.width, lay.lines_per_tile, sizeof(S), proto.interleave_mode);
         timers.emplace_back(s);
         StageTimer& t = timers.back();

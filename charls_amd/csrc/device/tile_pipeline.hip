@@ -2052,7 +2052,7 @@ inline size_t pack_lds_bytes(uint32_t tile_capacity, int32_t bits_per_sample)
 // every scan there -- for tests).
 struct TilePlan
 {
-    uint32_t mode, nc, lines, line_samples, lines_per_tile, segs_per_line, seg_pixels, tiles, tile_capacity, max_pixels;
+    uint32_t mode, nc, step, lines, line_samples, lines_per_tile, segs_per_line, seg_pixels, tiles, tile_capacity, max_pixels;
     uint64_t samples;
 };
 inline TilePlan plan_tiles(const ScanDesc& d)
@@ -2065,17 +2065,18 @@ inline TilePlan plan_tiles(const ScanDesc& d)
     const char* force = std::getenv("CHARLS_AMD_PIXEL_MODE");
     const bool force_pixel_mode = force != nullptr && std::atoi(force) != 0;
     p.nc = d.interleave_mode == 2 ? (uint32_t)d.components : 1u;
+    p.step = d.interleave_mode == 1 ? (uint32_t)d.components : 1u; // distance of a coded line to the line above it
     p.lines = d.height * (d.interleave_mode == 1 ? (uint32_t)d.components : 1u);
     p.line_samples = d.width * p.nc;
     p.samples = (uint64_t)p.line_samples * p.lines;
-    if (p.line_samples <= cap && !(force_pixel_mode && d.interleave_mode == 1))
-    { // (a line-interleaved scan in pixel mode keeps ONE line above the tile: segments of single lines only)
+    if (p.line_samples <= cap)
+    {
         const uint32_t n = cap / p.line_samples;
         p.lines_per_tile = n < 1 ? 1 : (n > kTileLines ? kTileLines : n);
         p.segs_per_line = 1;
         p.seg_pixels = d.width;
         p.tile_capacity = p.lines_per_tile * p.line_samples;
-        p.mode = d.interleave_mode == 2 || force_pixel_mode ? 2u : (uint32_t)d.interleave_mode;
+        p.mode = d.interleave_mode != 0 || force_pixel_mode ? 2u : 0u;
     }
     else
     {

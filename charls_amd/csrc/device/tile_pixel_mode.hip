@@ -111,19 +111,20 @@ JLS_DEV void load_coded_pixel(const ScanDesc& d, uint32_t line, uint32_t x, int 
     out[0] = (int)row[x] & mask;
 }
 
-// Rows of the staging area: row 0 = the line above the tile's first line, rows 1.. = the tile's lines; slot j of a row =
-// pixel px0 - 1 + j.  Margins: left of pixel 0 sits pixel 0 of the line above (cur[0] = prev[1], src/scan_codec.hpp:189-195),
+// Rows of the staging area: row r = coded line first_line - step + r -- `step` lines above the tile (one; the components of a
+// line-interleaved scan, whose line above is the line of the same component of the pixel row above), then the tile's lines;
+// slot j of a row = pixel px0 - 1 + j.  Margins: left of pixel 0 sits pixel 0 of the line above (cur[0] = prev[1], src/scan_codec.hpp:189-195),
 // right of the last pixel of a line that pixel again (prev[w + 1] = prev[w]); lines above the scan are zeros.
 //
 // Pixel by pixel (line-interleaved scans: the staged line holds ONE component of the pixels in memory).
 template <typename S>
 JLS_DEV void stage_pixel_rows_generic(const ScanDesc& d, const PixelTile& g, S* rows, int mask)
 {
-    const uint32_t total = (g.tile_lines + 1) * g.slots;
+    const uint32_t total = (g.tile_lines + g.step) * g.slots;
     for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
     {
         const uint32_t row = i / g.slots, slot = i - row * g.slots;
-        int64_t line = row == 0 ? (int64_t)g.first_line - (int64_t)g.step : (int64_t)g.first_line + row - 1;
+        int64_t line = (int64_t)g.first_line - (int64_t)g.step + row;
         int64_t p = (int64_t)g.px0 + slot - 1;
         if (p < 0)
         { // left margin of the line's first pixel
@@ -311,16 +312,16 @@ struct PixelLds
 {
     uint32_t rows, keys, masks, table;
 };
-JLS_HOST_DEV_EARLY uint32_t pixel_rows_bytes(uint32_t lines_per_tile, uint32_t max_pixels, uint32_t nc, uint32_t sample_bytes)
+JLS_HOST_DEV_EARLY uint32_t pixel_rows_bytes(uint32_t lines_per_tile, uint32_t step, uint32_t max_pixels, uint32_t nc, uint32_t sample_bytes)
 {
-    return ((lines_per_tile + 1) * (max_pixels + 2) * nc * sample_bytes + 15u) & ~15u;
+    return ((lines_per_tile + step) * (max_pixels + 2) * nc * sample_bytes + 15u) & ~15u;
 }
-JLS_HOST_DEV_EARLY PixelLds pixel_lds(uint32_t lines_per_tile, uint32_t max_pixels, uint32_t nc, uint32_t sample_bytes, uint32_t tile_capacity,
-                                      bool with_keys, uint32_t chunks)
+JLS_HOST_DEV_EARLY PixelLds pixel_lds(uint32_t lines_per_tile, uint32_t step, uint32_t max_pixels, uint32_t nc, uint32_t sample_bytes,
+                                      uint32_t tile_capacity, bool with_keys, uint32_t chunks)
 {
     PixelLds l;
     l.rows = 0;
-    l.keys = pixel_rows_bytes(lines_per_tile, max_pixels, nc, sample_bytes);
+    l.keys = pixel_rows_bytes(lines_per_tile, step, max_pixels, nc, sample_bytes);
     l.masks = l.keys + (with_keys ? ((tile_capacity * 2u + 15u) & ~15u) : 0u);
     l.table = l.masks + ((lines_per_tile * chunks * 16u + 15u) & ~15u);
     return l;
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(kThreads) analyze_pixel_tiles(const ScanDesc* 
     const uint32_t max_chunks = (max_pixels + 63) / 64, chunks = (P + 63) / 64;
     const uint32_t chunks_per_piece = (chunks + g.pieces - 1) / g.pieces;
     const uint32_t segments = g.tile_lines * g.pieces;
-    const PixelLds lds = pixel_lds(w.lines_per_tile, max_pixels, nc, (uint32_t)sizeof(S), w.tile_capacity, true, max_chunks);
+    const PixelLds lds = pixel_lds(w.lines_per_tile, g.step, max_pixels, nc, (uint32_t)sizeof(S), w.tile_capacity, true, max_chunks);
     S* s_rows = reinterpret_cast<S*>(smem + lds.rows);
     uint16_t* s_key = reinterpret_cast<uint16_t*>(smem + lds.keys); // [row][pixel][component]
     uint64_t* s_eq = reinterpret_cast<uint64_t*>(smem + lds.masks); // [row][chunk]
@@ -387,8 +388,8 @@ __global__ void __launch_bounds__(kThreads) analyze_pixel_tiles(const ScanDesc* 
             bool eq = false, q0 = false;
             if (xl < P)
             {
-                const S* cur = s_rows + ((size_t)(r + 1) * g.slots + xl + 1) * nc;
-                const S* above = cur - (size_t)g.slots * nc;
+                const S* cur = s_rows + ((size_t)(r + g.step) * g.slots + xl + 1) * nc;
+                const S* above = cur - (size_t)g.step * g.slots * nc;
                 uint16_t* keys = s_key + ((size_t)r * P + xl) * nc;
                 eq = true;
                 q0 = true;
@@ -501,7 +502,7 @@ __global__ void __launch_bounds__(kThreads) sort_pixel_tiles(const ScanDesc* __r
     const uint32_t max_chunks = (max_pixels * nc + 63) / 64, chunks = (Ps + 63) / 64;
     const uint32_t chunks_per_piece = (chunks + g.pieces - 1) / g.pieces;
     const uint32_t segments = g.tile_lines * g.pieces;
-    const PixelLds lds = pixel_lds(w.lines_per_tile, max_pixels, nc, (uint32_t)sizeof(S), w.tile_capacity, false, max_chunks);
+    const PixelLds lds = pixel_lds(w.lines_per_tile, g.step, max_pixels, nc, (uint32_t)sizeof(S), w.tile_capacity, false, max_chunks);
     S* s_rows = reinterpret_cast<S*>(smem + lds.rows);
     uint64_t* s_noev = reinterpret_cast<uint64_t*>(smem + lds.masks);                               // [row][chunk]
     uint32_t* s_lead = reinterpret_cast<uint32_t*>(s_noev + (size_t)w.lines_per_tile * max_chunks); // [row][chunk + 1]
@@ -633,8 +634,8 @@ __global__ void __launch_bounds__(kThreads) sort_pixel_tiles(const ScanDesc* __r
             return k < k1 && q < Ps ? inv_row[q] : kNoEvent;
         };
         uint16_t key_1 = key_at(k0), key_2 = key_at(k0 + 1);
-        const S* cur_row = s_rows + ((size_t)(r + 1) * g.slots + 1) * nc; // sample 0 of the tile row; its left neighbour nc before
-        const S* above_row = cur_row - (size_t)g.slots * nc;
+        const S* cur_row = s_rows + ((size_t)(r + g.step) * g.slots + 1) * nc; // sample 0 of the tile row; its left neighbour nc before
+        const S* above_row = cur_row - (size_t)g.step * g.slots * nc;
         const uint32_t lane_bit = 1u << (lane & 31), below = lane_bit - 1u;
         const bool upper = lane >= 32;
         for (uint32_t k = k0; k < k1; ++k)
@@ -762,14 +763,14 @@ __global__ void __launch_bounds__(kThreads) sort_pixel_tiles(const ScanDesc* __r
     }
 }
 
-inline size_t analyze_pixel_lds_bytes(uint32_t lines_per_tile, uint32_t max_pixels, uint32_t nc, uint32_t sample_bytes, uint32_t tile_capacity)
+inline size_t analyze_pixel_lds_bytes(uint32_t lines_per_tile, uint32_t step, uint32_t max_pixels, uint32_t nc, uint32_t sample_bytes, uint32_t tile_capacity)
 {
-    const PixelLds l = pixel_lds(lines_per_tile, max_pixels, nc, sample_bytes, tile_capacity, true, (max_pixels + 63) / 64);
+    const PixelLds l = pixel_lds(lines_per_tile, step, max_pixels, nc, sample_bytes, tile_capacity, true, (max_pixels + 63) / 64);
     return (size_t)l.table + ((size_t)kChains + 1) * 4 + pipe::kGradientTable + 16;
 }
-inline size_t sort_pixel_lds_bytes(uint32_t lines_per_tile, uint32_t max_pixels, uint32_t nc, uint32_t sample_bytes, uint32_t tile_capacity)
+inline size_t sort_pixel_lds_bytes(uint32_t lines_per_tile, uint32_t step, uint32_t max_pixels, uint32_t nc, uint32_t sample_bytes, uint32_t tile_capacity)
 {
-    const PixelLds l = pixel_lds(lines_per_tile, max_pixels, nc, sample_bytes, tile_capacity, false, (max_pixels * nc + 63) / 64);
+    const PixelLds l = pixel_lds(lines_per_tile, step, max_pixels, nc, sample_bytes, tile_capacity, false, (max_pixels * nc + 63) / 64);
     return (size_t)l.table + (size_t)sort_segments(lines_per_tile) * kChains * 4 + 4 * ((size_t)kChains + 1) * 4 + 16 * 4 +
            (size_t)kWaves * (kChains + 1) * 4 + kRowChainWords * 4 + stage_bytes(tile_capacity, sample_bytes);
 }

@@ -90,9 +90,9 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     const tile::Work* wk = works.data();
     const unsigned tiles_grid = 8 * ((tiles + 7) / 8);
     const bool pixel_mode = plan.mode == 2;
-    const size_t lds_a = pixel_mode ? tile::analyze_pixel_lds_bytes(plan.lines_per_tile, plan.max_pixels, plan.nc, (uint32_t)sizeof(S), plan.tile_capacity)
+    const size_t lds_a = pixel_mode ? tile::analyze_pixel_lds_bytes(plan.lines_per_tile, plan.step, plan.max_pixels, plan.nc, (uint32_t)sizeof(S), plan.tile_capacity)
                                     : tile::analyze_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode);
-    const size_t lds_b = pixel_mode ? tile::sort_pixel_lds_bytes(plan.lines_per_tile, plan.max_pixels, plan.nc, (uint32_t)sizeof(S), plan.tile_capacity)
+    const size_t lds_b = pixel_mode ? tile::sort_pixel_lds_bytes(plan.lines_per_tile, plan.step, plan.max_pixels, plan.nc, (uint32_t)sizeof(S), plan.tile_capacity)
                                     : tile::sort_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode);
     if (pixel_mode)
         emu::launch(tile::analyze_pixel_tiles<S>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_a, descs, wk);

@@ -435,3 +435,14 @@ def test_pixel_mode_masks_bits_above_the_sample_precision(monkeypatch, comps, il
     assert want == ob.encode(clean, **kw)
     errc, flags, data = _encode_scan(dirty, w, h, comps, ilv, bits)
     assert errc == 0 and data == _scan_bytes(want)
+
+
+@pytest.mark.parametrize("bits,ct,w,h,comps", [(8, 0, 700, 14, 3), (8, 1, 130, 40, 3), (16, 3, 129, 9, 3), (12, 0, 65, 12, 4), (8, 0, 64, 33, 2),
+                                               (8, 2, 3000, 5, 3)])
+def test_line_interleaved_scans_whole_line_tiles(bits, ct, w, h, comps):
+    """ILV_LINE scans take pixel mode with tiles of several coded lines (the line above a coded line is `components` lines up)."""
+    img = _rgb(w, h, seed=w + bits, bits=bits, comps=comps, flat=1.0)
+    kw = dict(width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=1, color_transformation=ct)
+    for job, warm in ((32, 0), (256, 128)):
+        errc, flags, data = _encode_scan(img, w, h, comps, 1, bits, ct, job=job, warm=warm)
+        assert errc == 0 and data == _scan_bytes(ob.encode(img, **kw)), (job, warm)

@@ -12,6 +12,9 @@ from charls_amd import batch, capi, synth  # noqa: E402
 
 lib = capi.load_product()
 dev = torch.device("cuda:0")
+# the encoder's work areas: as much as the batches below need to be coded in ONE pass where they fit (the caller's decision,
+# charls_amd_set_workspace_limit; the library's default is a quarter of the device)
+batch.set_workspace_limit(int(os.environ.get("CHARLS_AMD_MEASURE_WORKSPACE_GIB", "160")) << 30, lib)
 
 
 def run(name, frames, *, bits, comps=1, ilv=0, near=0, xform=0, restart=0):
