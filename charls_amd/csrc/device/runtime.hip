@@ -770,9 +770,7 @@ void ensure_tile_attributes()
     set(reinterpret_cast<const void*>(tile::pack_tiles<uint8_t>));
     set(reinterpret_cast<const void*>(tile::pack_tiles<uint16_t>));
     set(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 0>));
-    set(reinterpret_cast<const void*>(tile::sort_tiles<uint8_t, 1>));
     set(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 0>));
-    set(reinterpret_cast<const void*>(tile::sort_tiles<uint16_t, 1>));
     set(reinterpret_cast<const void*>(tile::analyze_pixel_tiles<uint8_t>));
     set(reinterpret_cast<const void*>(tile::analyze_pixel_tiles<uint16_t>));
     set(reinterpret_cast<const void*>(tile::sort_pixel_tiles<uint8_t>));
@@ -902,16 +900,12 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         t.mark();
         if (pixel_mode)
             hipLaunchKernelGGL((tile::analyze_pixel_tiles<S>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_a, s, descs, d_works);
-        else if (proto.interleave_mode == 1)
-            hipLaunchKernelGGL((tile::analyze_tiles<S, 1>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_a, s, descs, d_works);
         else
             hipLaunchKernelGGL((tile::analyze_tiles<S, 0>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_a, s, descs, d_works);
         t.mark();
         hipLaunchKernelGGL(tile::plan_chains, dim3(n), dim3(1024), 0, s, descs, d_works);
         if (pixel_mode)
             hipLaunchKernelGGL((tile::sort_pixel_tiles<S>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_b, s, descs, d_works);
-        else if (proto.interleave_mode == 1)
-            hipLaunchKernelGGL((tile::sort_tiles<S, 1>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_b, s, descs, d_works);
         else
             hipLaunchKernelGGL((tile::sort_tiles<S, 0>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_b, s, descs, d_works);
         t.mark();
@@ -942,9 +936,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         hipLaunchKernelGGL((tile::walk_run_jobs<S, ILV, FMT>), lanes, dim3(64), 0, runs_stream, descs, d_works, n);      \
         hipLaunchKernelGGL((tile::settle_runs<S, ILV, FMT>), settle_grid, dim3(64), 0, runs_stream, descs, d_works, n);  \
     } while (0)
-            if (!pixel_mode && proto.interleave_mode == 1)
-                JLS_RUN_CHAIN(1, 0);
-            else if (!pixel_mode)
+            if (!pixel_mode)
                 JLS_RUN_CHAIN(0, 0);
             else if (proto.interleave_mode == 2)
                 JLS_RUN_CHAIN(2, 1);

@@ -268,8 +268,8 @@ JLS_DEV void block_exclusive_scan(uint32_t& lo, uint32_t& hi, uint32_t* s_tmp)
 // ---------------------------------------------------------------------------------------------------------------
 // The lines of a tile and the line above it, staged in LDS (planar scans): analysis reads every sample five times (x, Ra,
 // Rb, Rc, Rd); out of LDS those reads cost an LDS latency instead of a trip to the L2, and the staging itself is wide
-// coalesced loads issued back to back.  Line-interleaved scans (a colour transform may sit between the source and the
-// samples) read through pipe::load_sample.
+// coalesced loads issued back to back.  (analyze_tiles / sort_tiles are the specialisation for PLANAR scans whose lines fit
+// a tile -- the headline path; every other scan takes tile_pixel_mode.hip.  The template parameter ILV is 0.)
 template <typename S, int ILV>
 struct Samples
 {
@@ -279,8 +279,7 @@ struct Samples
     int mask;
     JLS_DEV int operator()(uint32_t line, uint32_t x) const
     {
-        if (ILV == 1)
-            return pipe::load_sample<S, 1>(d, line, x, mask);
+        static_assert(ILV == 0, "planar scans only");
         return (int)rows[(size_t)(line + 1 - first_line) * d.width + x] & mask;
     }
 };
@@ -288,8 +287,6 @@ struct Samples
 template <typename S, int ILV>
 JLS_DEV void stage_lines(const ScanDesc& d, const TileGeometry& g, S* rows)
 {
-    if (ILV == 1)
-        return;
     const uint32_t width = g.width;
     const uint32_t bytes = width * (uint32_t)sizeof(S);
     const uint32_t first = g.first_line == 0 ? 1u : 0u; // line 0 of the staging area lies above the scan: zeros
@@ -361,7 +358,7 @@ JLS_DEV TileLds tile_lds(uint32_t width, uint32_t lines_per_tile, bool with_keys
     TileLds l;
     const uint32_t chunks = (width + 63) / 64;
     l.rows = 0;
-    l.keys = up(ILV == 1 ? 0u : (lines_per_tile + 1) * width * (uint32_t)sizeof(S));
+    l.keys = up((lines_per_tile + 1) * width * (uint32_t)sizeof(S));
     l.masks = l.keys + (with_keys ? up(lines_per_tile * width * 2u) : 0u);
     l.table = l.masks + up(lines_per_tile * chunks * 16u);
     l.end = l.table;
@@ -382,7 +379,7 @@ __global__ void __launch_bounds__(kThreads) analyze_tiles(const ScanDesc* __rest
     if (tile >= scan_tiles(d, w))
         return;
     const TileGeometry g = tile_geometry(d, w, tile);
-    const uint32_t step = ILV == 1 ? pipe::line_step(d) : 1u;
+    constexpr uint32_t step = 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t width = g.width, chunks = g.chunks;
     const TileLds lds = tile_lds<S, ILV>(width, w.lines_per_tile, true);
@@ -412,7 +409,7 @@ __global__ void __launch_bounds__(kThreads) analyze_tiles(const ScanDesc* __rest
         const uint32_t k1 = k0 + g.chunks_per_piece < chunks ? k0 + g.chunks_per_piece : chunks;
         // edge samples of the line (src/scan_codec.hpp:189-195 and the two-line ping-pong of src/scan_encoder_impl.hpp:55-106)
         const int edge_a = y >= step ? sample(y - step, 0) : 0; // cur[0]  = prev[1]
-        const int edge_c = y >= 2 * step ? (ILV == 1 || r >= 1 ? sample(y - 2 * step, 0) : pipe::load_sample<S, ILV>(d, y - 2, 0, mask)) : 0; // prev[0]
+        const int edge_c = y >= 2 * step ? (r >= 1 ? sample(y - 2 * step, 0) : pipe::load_sample<S, 0>(d, y - 2, 0, mask)) : 0; // prev[0]
         for (uint32_t k = k0; k < k1; ++k)
         {
             const uint32_t x = k * 64 + lane;
@@ -643,7 +640,7 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     if (tile >= scan_tiles(d, w))
         return;
     const TileGeometry g = tile_geometry(d, w, tile);
-    const uint32_t step = ILV == 1 ? pipe::line_step(d) : 1u;
+    constexpr uint32_t step = 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t width = g.width, chunks = g.chunks;
     const TileLds lds = tile_lds<S, ILV>(width, w.lines_per_tile, false);
@@ -789,7 +786,7 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
         uint16_t key_1 = key_at(k0), key_2 = key_at(k0 + 1);
         const S* cur = s_rows + (r + 1) * width; // (planar scans: the line in LDS, the line above it `width` samples before)
         const int edge_a = y >= step ? sample(y - step, 0) : 0;
-        const int edge_c = y >= 2 * step ? (ILV == 1 || r >= 1 ? sample(y - 2 * step, 0) : pipe::load_sample<S, ILV>(d, y - 2, 0, mask)) : 0;
+        const int edge_c = y >= 2 * step ? (r >= 1 ? sample(y - 2 * step, 0) : pipe::load_sample<S, 0>(d, y - 2, 0, mask)) : 0;
         const uint32_t lane_bit = 1u << (lane & 31), below = lane_bit - 1u;
         const bool upper = lane >= 32;
         for (uint32_t k = k0; k < k1; ++k)
@@ -825,29 +822,12 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
             const uint32_t slot = base + rank * per_event;
             // the record of a regular sample, worked out for every lane (no divergence; lanes without an event discard it)
             uint32_t record = 0;
-            if (ILV == 0)
+            if (inside)
             {
-                if (inside)
-                {
-                    const int v = (int)cur[x] & mask;
-                    const int ra = x > 0 ? (int)cur[x - 1] & mask : edge_a;
-                    const int rb = (int)(cur - width)[x] & mask;
-                    const int rc = x > 0 ? (int)(cur - width)[x - 1] & mask : edge_c;
-                    record = make_record<S>(v, med3(ra + rb - rc, ra, rb), (key >> 9) & 1, t.maxval);
-                }
-            }
-            else if (has && chain != 0 && chain != (uint32_t)kInterruptChain)
-            {
-                const int v = sample(y, x);
-                const int ra = x > 0 ? sample(y, x - 1) : edge_a;
-                int rb = 0, rc = 0;
-                if (y >= step)
-                {
-                    rb = sample(y - step, x);
-                    rc = x > 0 ? sample(y - step, x - 1) : edge_c;
-                }
-                else
-                    rc = x > 0 ? 0 : edge_c;
+                const int v = (int)cur[x] & mask;
+                const int ra = x > 0 ? (int)cur[x - 1] & mask : edge_a;
+                const int rb = (int)(cur - width)[x] & mask;
+                const int rc = x > 0 ? (int)(cur - width)[x - 1] & mask : edge_c;
                 record = make_record<S>(v, med3(ra + rb - rc, ra, rb), (key >> 9) & 1, t.maxval);
             }
             if (__any(has && chain == 0))
@@ -868,7 +848,7 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
                     }
                     const uint32_t xi = x + run;
                     if (xi >= width)
-                        record = RunRecord<S>::end_of_line(run, ILV == 1 ? y % step : 0u);
+                        record = RunRecord<S>::end_of_line(run, 0u);
                     else
                     {
                         const int xv = sample(y, xi);
@@ -876,7 +856,7 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
                         const int ib = y >= step ? sample(y - step, xi) : 0;
                         const int which = ia == ib ? 1 : 0;
                         const int err = which ? error_value(t, xv - ia) : error_value(t, (xv - ib) * ((ib - ia) < 0 ? -1 : 1));
-                        record = RunRecord<S>::interrupted(run, err, which, ILV == 1 ? y % step : 0u);
+                        record = RunRecord<S>::interrupted(run, err, which, 0u);
                     }
                 }
             }

@@ -96,15 +96,11 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
                                     : tile::sort_lds_bytes(p.width, lines_per_tile, (uint32_t)sizeof(S), p.interleave_mode);
     if (pixel_mode)
         emu::launch(tile::analyze_pixel_tiles<S>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_a, descs, wk);
-    else if (p.interleave_mode == 1)
-        emu::launch(tile::analyze_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_a, descs, wk);
     else
         emu::launch(tile::analyze_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_a, descs, wk);
     emu::launch(tile::plan_chains, dim3(count), dim3(1024), 0, descs, wk);
     if (pixel_mode)
         emu::launch(tile::sort_pixel_tiles<S>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_b, descs, wk);
-    else if (p.interleave_mode == 1)
-        emu::launch(tile::sort_tiles<S, 1>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_b, descs, wk);
     else
         emu::launch(tile::sort_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_b, descs, wk);
     emu::launch(tile::walk_jobs<S>, dim3((unsigned)((max_jobs + 63) / 64), count), dim3(64), 0, descs, wk);
@@ -129,9 +125,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         emu::launch(tile::walk_run_jobs<S, ILV, FMT>, lanes, dim3(64), 0, descs, wk, (uint32_t)count);          \
         emu::launch(tile::settle_runs<S, ILV, FMT>, settle_grid, dim3(64), 0, descs, wk, (uint32_t)count);       \
     } while (0)
-    if (!pixel_mode && p.interleave_mode == 1)
-        EMU_RUN_CHAIN(1, 0);
-    else if (!pixel_mode)
+    if (!pixel_mode)
         EMU_RUN_CHAIN(0, 0);
     else if (p.interleave_mode == 2)
         EMU_RUN_CHAIN(2, 1);
