@@ -112,3 +112,31 @@ def test_batch_of_sample_interleaved_frames(lib):
     out = torch.empty_like(frames)
     _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out, lib=lib)
     assert (errcs == 0).all() and torch.equal(out, frames)
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_random_lossless_scans_with_small_tiles(lib, monkeypatch, chunk):
+    """Random lossless scans of every interleave mode with tiles of 64 - 512 samples (CHARLS_AMD_TILE_SAMPLES, read per call):
+    lines cut into segments at every phase, look-backs, runs across segments, tiles of one to sixteen lines -- and, every
+    third case, every scan through pixel mode.  Bytes against the oracle."""
+    rng = np.random.default_rng(900 + chunk)
+    for it in range(40):
+        bits = int(rng.choice([8, 8, 8, 12, 16, 5, 2]))
+        comps = int(rng.choice([1, 1, 3, 3, 2, 4]))
+        ilv = 0 if comps == 1 else int(rng.integers(1, 3))
+        w = int(rng.choice([1, 2, 63, 64, 65, 130, 257, 700, 1500]))
+        h = int(rng.choice([1, 2, 3, 9, 20]))
+        ct = int(rng.integers(1, 4)) if (comps == 3 and bits in (8, 16) and rng.random() < 0.5) else 0
+        kind = str(rng.choice(["mixed", "gradient", "hard", "zero", "noise"]))
+        monkeypatch.setenv("CHARLS_AMD_TILE_SAMPLES", str(int(rng.choice([64, 128, 192, 256, 512]))))
+        if it % 3 == 0:
+            monkeypatch.setenv("CHARLS_AMD_PIXEL_MODE", "1")
+        else:
+            monkeypatch.delenv("CHARLS_AMD_PIXEL_MODE", raising=False)
+        img = synth.frame_numpy(w, h, seed=1000 * chunk + it, bits=bits, components=comps, kind=kind, interleaved=True)
+        if kind == "mixed" and h > 1:  # flat stretches common to all components, across segment boundaries
+            x0 = int(rng.integers(0, w))
+            img[h // 2, x0:] = img[h // 2, x0]
+        kw = dict(width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=ilv, color_transformation=ct)
+        want = ob.encode(img, destination_size=4 * img.nbytes + 4096, **kw)
+        assert lib.encode(img, destination_size=4 * img.nbytes + 4096, **kw) == want, (kw, kind, it)
