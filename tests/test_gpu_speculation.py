@@ -134,3 +134,24 @@ def test_batch_with_forced_knobs_and_two_passes(lib, monkeypatch):
     for i, img in enumerate(host):
         assert enc.errcs[i] == 0 and got[i, :int(enc.sizes[i])].tobytes() == ob.encode(img, width=w, height=h), i
     assert did[1] > did[0] // 4 and did[3] > 0, did
+
+
+@pytest.mark.parametrize("chunk,warm", [("64", "0"), ("256", "512"), ("4096", "1024")])
+def test_speculative_stuffing_with_failing_guesses(lib, monkeypatch, chunk, warm):
+    """Stage E in its speculative form (passes of more than 8 scans; speculative_stuffing.hip) with chunks and warm-ups so small
+    that entry-state guesses fail: chunks walked again by the resolving wavefront, and -- 64-byte chunks without warm-up --
+    scans given up and stuffed in sequence by their first wavefront.  Bytes against the oracle."""
+    import torch
+    monkeypatch.setenv("CHARLS_AMD_SPEC_CHUNK", chunk)
+    monkeypatch.setenv("CHARLS_AMD_SPEC_WARM", warm)
+    w = h = 256
+    kinds = ["mixed", "noise", "gradient", "hard", "zero", "noise", "mixed", "hard", "gradient", "noise", "mixed", "zero"]
+    host = [synth.frame_numpy(w, h, seed=90 + i, kind=k) for i, k in enumerate(kinds)]
+    host[1][:] = 255  # all ones in the raw stream: 0xFF bytes everywhere
+    frames = torch.from_numpy(np.stack(host)).cuda()
+    streams = torch.empty((len(kinds), 2 * w * h + 4096), dtype=torch.uint8, device="cuda")
+    enc = batch.encode_batch(frames, streams=streams)
+    got = enc.streams.cpu().numpy()
+    for i, img in enumerate(host):
+        want = ob.encode(img, width=w, height=h, destination_size=2 * w * h + 4096)
+        assert enc.errcs[i] == 0 and got[i, :int(enc.sizes[i])].tobytes() == want, (i, kinds[i])
