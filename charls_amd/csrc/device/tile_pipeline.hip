@@ -1,4 +1,4 @@
-// tile_pipeline.hip -- round-3 parallel JPEG-LS encoder for lossless single-component and line-interleaved scans.
+// tile_pipeline.hip -- the parallel JPEG-LS encoder for lossless scans (every interleave mode, every line width).
 //
 // In lossless mode everything except the adaptive statistics is a pure function of the image (reference
 // src/scan_encoder_impl.hpp:109-144).  The pipeline is built around two observations (round 2 had the same idea as a
@@ -7,9 +7,10 @@
 //  1. HBM traffic.  The round-2 pipeline moved 1.48 GB per 4096 x 4096 frame (61 x the algorithmic bytes): 6 B/sample of
 //     analysis results written and read back, 4-byte records scattered line by line to ~30 chains per 64 samples (every
 //     32-byte sector written several times), 8-byte codes + 1-byte lengths + a 4-byte slot map gathered back.  Here the
-//     image is cut into TILES of up to kMaxTileSamples samples (whole lines); a tile's events are sorted by chain INSIDE LDS
-//     and leave as contiguous pieces (one per chain, hundreds of bytes), the slot map is a 2-byte tile-local index that
-//     overwrites the 2-byte key in place, and a code is one 4-byte word.  10 B/sample of work area instead of 21.
+//     image is cut into TILES of up to kMaxTileSamples samples (whole lines, or segments of lines that do not fit:
+//     plan_tiles); a tile's events are sorted by chain INSIDE LDS and leave as contiguous pieces (one per chain, hundreds of
+//     bytes), the slot map is a 2-byte tile-local index that overwrites the 2-byte key in place, and records and code words
+//     live in SLOTS of 2 bytes for samples of up to 8 bits (4 otherwise; see Slot).  8 B/sample of work area instead of 21.
 //
 //  2. The chain floor.  {A,B,C,N} of a context is a serial recurrence over the context's samples; round 2
 //     walked every chain with ONE lane (58 ms for the 1.09 M events of the longest chain of a test frame, whatever the
@@ -21,23 +22,25 @@
 //     every job started in exactly the state its predecessor ended in.  Where that holds -- everywhere, on anything but
 //     noise-like data (tools/spec_convergence.c: 0 of 16 253 jobs of the test frame disagree with a warm-up of 1024
 //     events) -- the job's codes are the sequential ones by construction; a job that disagrees is walked again from the
-//     true state by the settling lane, so the result is exact in every case and only the time depends on the data.
-//     One walker computes k, the error correction and the Golomb word as well: bias_chains + code_events became one pass.
+//     true state by the settling lane, so the result is exact in every case and only the time depends on the data (and is
+//     counted: Counter).  One walker computes k, the error correction and the Golomb word as well.
 //
-// Stages (planar scan; ILV_LINE: "coded lines", see pipeline_common.hip):
-//   A  analyze_tiles   one workgroup per tile, one wavefront per line at a time: chain id + sign of every sample (key,
-//                      2 B), run-mode segmentation as a carry chain over ballot masks, events per (tile, chain)
-//   B1 plan_chains     per scan: exclusive prefix over tiles per chain -> where each tile's piece of each chain goes;
-//                      chain bases; jobs per chain
-//   B2 sort_tiles      one workgroup per tile: stable ranks (ballot per key bit, no order-dependent atomics), records
-//                      {x, Px, sign} into LDS in (chain, line, column) order, out as pieces; key -> tile-local slot
+// Stages:
+//   A  analyze_tiles   (planar scans whose lines fit a tile; every other scan: analyze_pixel_tiles, tile_pixel_mode.hip)
+//                      one workgroup per tile: chain id + sign of every sample (key, 2 B), run-mode segmentation as a
+//                      carry chain over ballot masks, events per (tile, chain)
+//   B1 plan_chains     per scan: exclusive prefix over tiles per chain -> where each tile's piece of each chain goes (in
+//                      slots); chain bases; jobs per chain
+//   B2 sort_tiles      (sort_pixel_tiles) one workgroup per tile: stable ranks through LDS mask tables, records into LDS in
+//                      (chain, line, column) order, out as pieces; key -> tile-local slot
 //   C1 walk_jobs       one LANE per job: warm-up, then record -> code word, in chain order
 //   C2 settle_chains   one lane per chain: job boundaries checked, disagreeing jobs re-walked
-//   C3 count_runs / scan_runs / walk_run_jobs / settle_runs   the run chain (RUNindex, the two run-interruption contexts),
-//                      cut into jobs like the regular chains
+//   C3 count_runs / scan_runs / compact_rare_runs / walk_rare_context / walk_run_jobs / settle_runs   the run chain (RUNindex,
+//                      the two run-interruption contexts) cut into jobs like the regular chains; the context of the rarer
+//                      interruption type is computed exactly
 //   D  pack_tiles      one workgroup per tile: the tile's codes back into LDS piece by piece, gathered in raster order
 //                      through the 2-byte slots, concatenated MSB-first; bit offset of a tile by chained look-back
-//   E  stuff_scan / block_stuffing.hip  (unchanged)
+//   E  stuff_scan (pipeline_common.hip) / speculative_stuffing.hip / block_stuffing.hip
 //
 // Output is byte-identical to scan_encoder::encode_scan.  No MFMA: nothing here is a contraction.
 #pragma once
