@@ -1653,8 +1653,8 @@ __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ d
 // D: grid (tiles, scans) x 256; tiles in index order (a tile only waits for tiles that were started before it).
 // LDS: codes[tile] u32 | tileoff / count / global [kChains + 1] each | scan[256] | tmp
 #define JLS_HOST_DEV __host__ __device__ inline
-// LDS of pack_tiles: where the staged slot map starts (behind the code words, the piece tables and the row table)
-JLS_HOST_DEV uint32_t pack_inv_offset(uint32_t tile_capacity, uint32_t sample_bytes) // 16-byte aligned
+// LDS of pack_tiles: where the bit buffer starts (behind the code words, the piece tables and the row table)
+JLS_HOST_DEV uint32_t pack_bits_offset(uint32_t tile_capacity, uint32_t sample_bytes) // 16-byte aligned
 {
     const uint32_t codes = (uint32_t)stage_bytes(tile_capacity, sample_bytes);
     const uint32_t head = ((codes + 3u) & ~3u) + 4 * ((uint32_t)kChains + 1) * 4 + kPackThreads * 4 + 16 * 4 + kRowChainWords * 4;
@@ -1684,6 +1684,10 @@ JLS_DEV void expand_code(uint32_t word, uint64_t& bits, int& len)
     }
 }
 
+struct __attribute__((packed)) UnalignedQuadPair
+{
+    uint64_t lo, hi;
+};
 template <typename S>
 __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
 {
@@ -1709,15 +1713,35 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     uint32_t* s_tmp = s_scan + kPackThreads;   // one word per wavefront (16 reserved)
     uint32_t* s_rowbase = s_tmp + 16;          // [kChains + 1] first row of the chain's piece
     uint16_t* s_rowchain = reinterpret_cast<uint16_t*>(s_rowbase + kChains + 1); // [slots of the tile / 64 + kChains + 1]: kRowChainWords words
-    uint16_t* s_inv = reinterpret_cast<uint16_t*>(smem + pack_inv_offset(tile_capacity, (uint32_t)sizeof(S))); // [threads * per_thread] slot map of the tile
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(smem + pack_bits_offset(tile_capacity, (uint32_t)sizeof(S))); // [pack_bits_words] the tile's bits
     const TileSpan span = tile_span(d, w, tile);
     const uint32_t tile_samples = span.count;
     const uint16_t* inv = w.keyinv + span.first;
 
-    // the slot map of the tile: coalesced into LDS (a thread's 32 consecutive slots straight from memory were 32 requests
-    // of one cache line each per wavefront instruction)
-    for (uint32_t i = threadIdx.x; i < threads * per_thread; i += threads)
-        s_inv[i] = i < tile_samples ? inv[i] : kNoLocalSlot;
+    // the slot map of this thread's samples: 16 bytes (eight slots) per load, straight into registers and requested before
+    // anything else (lane by lane and two bytes at a time these were 32 requests of one cache line each per wavefront
+    // instruction; round 3 staged the map through LDS instead: sixteen 2-byte loads and stores per thread)
+    constexpr int kGroups = (int)(kMaxTileSamples / kPackThreads / 8); // 16 samples at most
+    uint4 mine[kGroups];
+#pragma unroll
+    for (int q = 0; q < kGroups; ++q)
+    {
+        const uint32_t at = threadIdx.x * per_thread + (uint32_t)q * 8;
+        mine[q] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if ((uint32_t)q * 8 < per_thread && at + 8 <= tile_samples)
+        {
+            const UnalignedQuadPair v = *reinterpret_cast<const UnalignedQuadPair*>(inv + at);
+            mine[q] = make_uint4((uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32));
+        }
+        else if ((uint32_t)q * 8 < per_thread && at < tile_samples)
+        { // (the tile's last, partial group)
+            uint32_t e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                e[j] = at + (uint32_t)j < tile_samples ? inv[at + j] : kNoLocalSlot;
+            mine[q] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        }
+    }
     { // the tile's pieces, chain by chain, in the order sort_tiles laid them out
         uint32_t n[2] = {0, 0}, g[2] = {0, 0};
         for (int half = 0; half < 2; ++half)
@@ -1791,13 +1815,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     }
     __syncthreads();
 
-    // ---- bits of this thread's samples.  The slots of a thread are 16-byte groups of the staged slot map (eight samples
-    // each), read once and kept in registers for both passes.
-    constexpr int kGroups = (int)(kMaxTileSamples / kPackThreads / 8); // 16 samples at most
-    uint4 mine[kGroups];
-#pragma unroll
-    for (int q = 0; q < kGroups; ++q)
-        mine[q] = (uint32_t)q * 8 < per_thread ? reinterpret_cast<const uint4*>(s_inv + threadIdx.x * per_thread)[q] : make_uint4(~0u, ~0u, ~0u, ~0u);
+    // ---- bits of this thread's samples (their slots are in `mine`)
     auto slot_of = [&](int q, int j) -> uint32_t { // sample 8 q + j of this thread
         const uint32_t word = (j >> 1) == 0 ? mine[q].x : (j >> 1) == 1 ? mine[q].y : (j >> 1) == 2 ? mine[q].z : mine[q].w;
         return (j & 1) ? word >> 16 : word & 0xFFFFu;
@@ -1815,6 +1833,8 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         const uint32_t c = (uint32_t)s_code[slot];
         return ((c >> 10) << 24) | (c & 0x3FFu);
     };
+    // (the code words of a thread's samples stay in registers for the second pass: one LDS read per sample, not two)
+    uint32_t words[kGroups * 8];
     uint32_t sum = 0;
 #pragma unroll
     for (int q = 0; q < kGroups; ++q)
@@ -1822,6 +1842,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         for (int j = 0; j < 8; ++j)
         {
             const uint32_t word = word_of(slot_of(q, j));
+            words[q * 8 + j] = word;
             sum += word & kRunTag ? ((word >> 25) & 63u) + ((word >> 20) & 31u) : word >> 24;
         }
     { // inclusive scan of the threads' bit counts: inside a wavefront with shuffles, the wavefronts' totals through LDS (two
@@ -1881,7 +1902,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         }
     }
     __syncthreads();
-    // ---- the tile's bits are put together in LDS (over the slot map, which lives in registers by now) and leave as whole
+    // ---- the tile's bits are put together in LDS and leave as whole
     // words, coalesced.  Nothing of the raw stream is cleared beforehand and no word is written twice: the last, partial
     // word of a tile is not stored by that tile but PUBLISHED (tile_tail: the bits and a valid flag in one 64-bit word, like
     // the look-back states -- the word carries everything, no fence), and the next tile, whose first bits complete it, ORs
@@ -1893,7 +1914,6 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     const uint32_t tile_bits = s_scan[threads - 1];
     const uint32_t head = (uint32_t)(tile_start & 31);
     const uint32_t tile_words = (head + tile_bits + 31) / 32; // (<= pack_bits_words: a code has at most LIMIT bits per sample it stands for)
-    uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_inv);
     for (uint32_t i = threadIdx.x; i < tile_words + 1; i += threads)
         s_bits[i] = 0;
     __syncthreads();
@@ -1925,12 +1945,12 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
 #pragma unroll
             for (int j = 0; j < 8; ++j)
             {
-                const uint32_t slot = slot_of(q, j);
-                if (slot == kNoLocalSlot)
-                    continue;
+                const uint32_t word = words[q * 8 + j];
+                if (word == 0)
+                    continue; // (a sample without a code of its own)
                 uint64_t v;
                 int len;
-                expand_code(word_of(slot), v, len);
+                expand_code(word, v, len);
                 if (len > 32)
                 { // (codes of wide samples, long runs: rare)
                     put((uint32_t)(v >> 32), (uint32_t)len - 32u);
@@ -2021,10 +2041,7 @@ inline uint32_t pack_threads_for(uint32_t tile_capacity)
 }
 inline size_t pack_lds_bytes(uint32_t tile_capacity, int32_t bits_per_sample)
 {
-    const uint32_t threads = pack_threads_for(tile_capacity);
-    const uint32_t per_thread = ((tile_capacity + threads - 1) / threads + 7u) & ~7u;
-    const size_t slot_map = (size_t)threads * per_thread * 2, bit_buffer = (size_t)pack_bits_words(tile_capacity, bits_per_sample) * 4;
-    return (size_t)pack_inv_offset(tile_capacity, bits_per_sample > 8 ? 2u : 1u) + (slot_map > bit_buffer ? slot_map : bit_buffer); // (the bits take the map's place)
+    return (size_t)pack_bits_offset(tile_capacity, bits_per_sample > 8 ? 2u : 1u) + (size_t)pack_bits_words(tile_capacity, bits_per_sample) * 4;
 }
 // How a scan is cut into tiles.  A tile holds up to `cap` samples (8192 of one byte, 4096 of two: the sort stage keeps the
 // lines, the sorted records and its tables of a tile in LDS; CHARLS_AMD_TILE_SAMPLES lowers it -- more workgroups per CU for
