@@ -104,7 +104,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     obj_dir = os.path.join(OUT_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     common = ["--offload-arch=" + OFFLOAD_ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra",
-              "-Wno-unused-parameter", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+              "-Wno-unused-parameter", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+              *os.environ.get("CHARLS_AMD_CXXFLAGS", "").split()]  # (e.g. -DJLS_PHASE_CLOCKS, tools/phase_clocks.py)
     objs = []
     procs = []
     for src in SOURCES:

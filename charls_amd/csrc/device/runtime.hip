@@ -996,6 +996,16 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     hip_check(hipStreamSynchronize(stream)); // the host copies of the work descriptors and the timers go out of scope
     for (uint32_t i = 0; i < tile::kCounters; ++i)
         g_speculation[i].fetch_add(counters[i]);
+#ifdef JLS_PHASE_CLOCKS
+    { // debug build (tools/phase_clocks.sh): the clocks the wavefronts of the tile kernels spent in each of their phases
+        unsigned long long all[(kCounterBytes - 32) / 8] = {};
+        hip_check(hipMemcpy(all, reinterpret_cast<const uint8_t*>(d_counters) + 32, sizeof all, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "phase_clocks");
+        for (unsigned long long v : all)
+            std::fprintf(stderr, " %llu", v);
+        std::fprintf(stderr, "\n");
+    }
+#endif
     Timings& tm = last_timings();
     double stage_ms[5] = {0, 0, 0, 0, 0};
     for (StageTimer& t : timers)

@@ -120,6 +120,29 @@ enum Counter : uint32_t
     kCountRunJobsRewalked = 3,
     kCounters = 4
 };
+// Debug build (-DJLS_PHASE_CLOCKS, tools/phase_clocks.sh): the shader clocks every wavefront of the tile kernels
+// of every 64th workgroup spends between the marks (all of them queue up behind their own atomics), summed per mark in 64-bit words behind the counters of the call -- which phase of a kernel the
+// time goes to, where rocprofv3 only has the kernel's total.  The marks compile to nothing otherwise.
+#ifdef JLS_PHASE_CLOCKS
+#define JLS_PHASE_BEGIN() uint64_t phase_t = __builtin_amdgcn_s_memtime()
+#define JLS_PHASE(slot)                                                                                                  \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        const uint64_t phase_now = __builtin_amdgcn_s_memtime();                                                         \
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0 && phase_now - phase_t < (1ull << 32)) /* (a sample) */   \
+            atomicAdd(reinterpret_cast<unsigned long long*>(w.counters + 8) + (slot), (unsigned long long)(phase_now - phase_t)); \
+        phase_t = phase_now;                                                                                             \
+    } while (0)
+#else
+#define JLS_PHASE_BEGIN() \
+    do                    \
+    {                     \
+    } while (0)
+#define JLS_PHASE(slot) \
+    do                  \
+    {                   \
+    } while (0)
+#endif
 
 // State of a job at its first event (after the warm-up) and behind its last one (N is a function of the event index);
 // bad: an event of the job would make the reference raise invalid_data.
@@ -663,12 +686,15 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
     const Samples<S, ILV> sample{d, s_rows, g.first_line, mask};
     const uint16_t* key_tile = w.keyinv + (size_t)g.first_line * width;
 
+    JLS_PHASE_BEGIN();
     stage_lines<S, ILV>(d, g, s_rows);
+    JLS_PHASE(0);
     for (uint32_t i = threadIdx.x; i < g.segments * (uint32_t)kChains; i += kThreads)
         s_segoff[i] = 0;
     for (uint32_t i = threadIdx.x; i < kWaves * ((uint32_t)kChains + 1); i += kThreads)
         s_same[i] = 0;
     __syncthreads();
+    JLS_PHASE(1);
     // ---- P1: keys into LDS, events per (segment, chain), samples inside runs per chunk
     for (uint32_t sgm = wave; sgm < g.segments; sgm += kWaves)
     {
@@ -701,7 +727,9 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
             }
         }
     }
+    JLS_PHASE(2);
     __syncthreads();
+    JLS_PHASE(3);
     // ---- offsets: chains in order, inside a chain the segments in (raster) order; per line, the number of samples
     // inside runs from the first sample of every chunk on
     {
@@ -766,7 +794,9 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
             }
         }
     }
+    JLS_PHASE(4);
     __syncthreads();
+    JLS_PHASE(5);
     // ---- P2: ranks, records.  The lanes of a chunk that share a chain find each other through a table in LDS: every lane
     // ORs its own bit into the word of its chain (the result does not depend on the order in which the LDS serves the
     // lanes), reads the word back and clears it -- 32 lanes at a time, six LDS instructions per chunk where a ballot per
@@ -877,7 +907,9 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
                 inv_row[x] = has ? (uint16_t)slot : kNoLocalSlot;
         }
     }
+    JLS_PHASE(6);
     __syncthreads();
+    JLS_PHASE(7);
     // ---- P3: pieces out (the interruption chain has no records)
     const uint32_t total_rows = s_rowbase[kChains];
     for (uint32_t q0 = (uint32_t)wave * 4; q0 < total_rows; q0 += kWaves * 4)
@@ -900,6 +932,7 @@ __global__ void __launch_bounds__(kThreads) sort_tiles(const ScanDesc* __restric
             if (live[j])
                 rec_slots<S>(w)[to[j]] = held[j];
     }
+    JLS_PHASE(8);
 }
 
 } // namespace tile
@@ -1723,6 +1756,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
     // instruction; round 3 staged the map through LDS instead: sixteen 2-byte loads and stores per thread)
     constexpr int kGroups = (int)(kMaxTileSamples / kPackThreads / 8); // 16 samples at most
     uint4 mine[kGroups];
+    JLS_PHASE_BEGIN();
 #pragma unroll
     for (int q = 0; q < kGroups; ++q)
     {
@@ -1766,7 +1800,9 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
             }
         }
     }
+    JLS_PHASE(9);
     __syncthreads();
+    JLS_PHASE(10);
     { // ---- the tile's code words into LDS.  The pieces are cut into rows of 64 words; row q belongs to chain s_rowchain[q].
       // A wavefront takes eight rows at a time and requests them together: fetched piece by piece (a piece is ~80 events on
       // average, a few are hundreds), it spent its time waiting for one trip to memory per row.
@@ -1791,6 +1827,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
             }
         }
         __syncthreads();
+        JLS_PHASE(11);
         const uint32_t total_rows = s_rowbase[kChains];
         for (uint32_t q0 = (uint32_t)wave * 8; q0 < total_rows; q0 += kPackWaves * 8)
         {
@@ -1813,7 +1850,9 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
                     s_code[to[j]] = held[j];
         }
     }
+    JLS_PHASE(12);
     __syncthreads();
+    JLS_PHASE(13);
 
     // ---- bits of this thread's samples (their slots are in `mine`)
     auto slot_of = [&](int q, int j) -> uint32_t { // sample 8 q + j of this thread
@@ -1845,6 +1884,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
             words[q * 8 + j] = word;
             sum += word & kRunTag ? ((word >> 25) & 63u) + ((word >> 20) & 31u) : word >> 24;
         }
+    JLS_PHASE(14);
     { // inclusive scan of the threads' bit counts: inside a wavefront with shuffles, the wavefronts' totals through LDS (two
       // barriers; the Hillis-Steele scan through LDS that stood here until round 4 took eighteen)
         uint32_t incl = sum;
@@ -1863,6 +1903,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         s_scan[threadIdx.x] = before + incl;
         __syncthreads();
     }
+    JLS_PHASE(15);
     // ---- where this tile starts: the first wavefront looks back, 64 predecessors at a time (see write_raw_bits)
     if (threadIdx.x < 64)
     {
@@ -1901,7 +1942,9 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
                 *w.total_bits = start + own;
         }
     }
+    JLS_PHASE(16);
     __syncthreads();
+    JLS_PHASE(17);
     // ---- the tile's bits are put together in LDS and leave as whole
     // words, coalesced.  Nothing of the raw stream is cleared beforehand and no word is written twice: the last, partial
     // word of a tile is not stored by that tile but PUBLISHED (tile_tail: the bits and a valid flag in one 64-bit word, like
@@ -1961,7 +2004,9 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         if (pending > 0)
             atomicOr(&s_bits[word_at], (uint32_t)(acc >> 32)); // tail shared with the next thread
     }
+    JLS_PHASE(18);
     __syncthreads();
+    JLS_PHASE(19);
     const bool last_tile = tile + 1 == tiles;
     const bool shared_first = head != 0;                                     // my first word starts in the tile before
     const bool partial_last = ((head + tile_bits) & 31u) != 0 && !last_tile; // my last word is completed by the next tile
@@ -1985,6 +2030,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
             store_relaxed(&w.tile_tail[tile], kTailValid | (partial_last ? s_bits[0] : 0u));
     }
     __syncthreads();
+    JLS_PHASE(20);
     const uint64_t first_global = tile_start >> 5;
     const uint32_t stored_words = partial_last ? tile_words - 1 : tile_words;
     for (uint32_t i = threadIdx.x; i < stored_words; i += threads)
@@ -1999,6 +2045,7 @@ __global__ void __launch_bounds__(kPackThreads) pack_tiles(const ScanDesc* __res
         if (at < w.raw_words)
             w.raw[at] = 0;
     }
+    JLS_PHASE(21);
 }
 
 // Zeroes the look-back states and the tile tails of every scan of a pass (contiguous in a work area).
