@@ -130,6 +130,7 @@ void launch_place_epilogue(uint8_t* slots, uint64_t slot_pitch, FrameCursorPod* 
 // The limit is process-wide (0 = a quarter of the device's memory); the areas themselves belong to the calling thread,
 // grow on demand up to the limit and stay allocated between calls until released.
 void set_workspace_limit(uint64_t bytes) noexcept;
+DeviceBuffer& plane_arena(); // the calling thread's private stream buffers of the planar batch encoder (a work area)
 void release_work_areas() noexcept;
 size_t work_area_bytes() noexcept;
 

@@ -1161,16 +1161,26 @@ void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_resul
             launch_encode_serial(d_descs + i, d_results + i, 1, stream);
 }
 
+// Private stream buffers of the batch encoder's planar path (the component scans of a group of frames are coded into them
+// and then put in place): gigabytes, so they are kept between calls like the pipeline's work areas -- allocating and
+// freeing 8 GiB per call cost three times the coding of 256 4096 x 4096 RGB frames.
+DeviceBuffer& plane_arena()
+{
+    static thread_local DeviceBuffer arena;
+    return arena;
+}
+
 void release_work_areas() noexcept
 {
     pipeline_arena().release();
+    plane_arena().release();
     for (int i = 0; i < kIntervalArenas; ++i)
         interval_arena(i).release();
 }
 
 size_t work_area_bytes() noexcept
 {
-    size_t total = pipeline_arena().capacity();
+    size_t total = pipeline_arena().capacity() + plane_arena().capacity();
     for (int i = 0; i < kIntervalArenas; ++i)
         total += interval_arena(i).capacity();
     return total;
@@ -1206,8 +1216,10 @@ void launch_place_plane_scans(uint8_t* slots, uint64_t slot_pitch, const uint8_t
                               const uint8_t* private_streams, uint64_t capacity, const ScanResult* results, FrameCursorPod* cursors,
                               uint32_t* redo, uint32_t frames, hipStream_t stream)
 {
-    hipLaunchKernelGGL(place_plane_scans, dim3(frames), dim3(256), 0, stream, slots, slot_pitch, headers, header_size, rounds,
-                       private_streams, capacity, results, reinterpret_cast<FrameCursor*>(cursors), redo);
+    hipLaunchKernelGGL(place_plane_scans, dim3(frames * rounds, kPlaceShares), dim3(256), 0, stream, slots, slot_pitch, headers, header_size,
+                       rounds, private_streams, capacity, results, reinterpret_cast<const FrameCursor*>(cursors));
+    hipLaunchKernelGGL(advance_plane_cursors, dim3((frames + 63) / 64), dim3(64), 0, stream, slot_pitch, header_size, rounds, results,
+                       reinterpret_cast<FrameCursor*>(cursors), redo, frames);
     hip_check(hipGetLastError());
 }
 

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -38,6 +39,80 @@ __global__ void gather_windows(const uint8_t* __restrict__ slots, const WindowSp
         dst[b] = src[b];
 }
 
+// Where the entropy-coded segment that starts at `from` ends: the first 0xFF that is followed by a byte with its high
+// bit set and is not a restart marker (inside a segment the byte after a 0xFF starts with a stuffed zero bit, T.87 A.1 /
+// src/jpeg_stream_reader.cpp: read_next_marker_code).  One workgroup per stream, 16 KB per trip, first position by atomicMin.
+struct MarkerSearch
+{
+    uint64_t from, end; // offsets from the first slot
+};
+constexpr unsigned long long kNoMarker = ~0ull;
+struct __attribute__((packed)) UnalignedU64
+{
+    uint64_t v;
+};
+__device__ inline bool ends_segment(uint32_t byte, uint32_t next)
+{
+    return byte == 0xFFu && next >= 0x80u && !(next >= 0xD0u && next <= 0xD7u);
+}
+__global__ void __launch_bounds__(256) find_scan_end(const uint8_t* __restrict__ slots, const MarkerSearch* __restrict__ specs,
+                                                     unsigned long long* __restrict__ found)
+{
+    __shared__ unsigned long long first;
+    const MarkerSearch s = specs[blockIdx.x];
+    if (threadIdx.x == 0)
+        first = kNoMarker;
+    __syncthreads();
+    constexpr uint64_t kPer = 64; // bytes of a thread per trip: a 0xFF at [at, at + kPer) is this thread's, its follower is read with it
+    for (uint64_t base = s.from; base < s.end; base += 256 * kPer)
+    {
+        const uint64_t at = base + threadIdx.x * kPer;
+        if (at + kPer + 8 <= s.end)
+        { // eight bytes at a time (gfx950 takes the loads at any address); words without a 0xFF byte are passed over
+            uint64_t v[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j)
+                v[j] = reinterpret_cast<const UnalignedU64*>(slots + at + 8 * j)->v;
+            bool mine = false;
+#pragma unroll
+            for (int j = 0; j < 8 && !mine; ++j)
+            {
+                const uint64_t inv = ~v[j];
+                if (((inv - 0x0101010101010101ull) & ~inv & 0x8080808080808080ull) == 0)
+                    continue; // (no byte of v[j] is 0xFF)
+                const uint64_t after = (v[j] >> 8) | (v[j + 1] << 56);
+                for (int q = 0; q < 8; ++q)
+                    if (ends_segment((uint32_t)(v[j] >> (8 * q)) & 0xFFu, (uint32_t)(after >> (8 * q)) & 0xFFu))
+                    {
+                        atomicMin(&first, static_cast<unsigned long long>(at + 8 * j + q));
+                        mine = true;
+                        break;
+                    }
+            }
+        }
+        else if (at + 1 < s.end)
+        { // the last bytes of the stream, one by one
+            const uint64_t last = at + kPer < s.end - 1 ? at + kPer : s.end - 1;
+            uint32_t byte = slots[at];
+            for (uint64_t q = at; q < last; ++q)
+            {
+                const uint32_t next = slots[q + 1];
+                if (ends_segment(byte, next))
+                {
+                    atomicMin(&first, static_cast<unsigned long long>(q));
+                    break;
+                }
+                byte = next;
+            }
+        }
+        __syncthreads();
+        if (first != kNoMarker)
+            break; // (every thread reads the same value: nothing writes between the two barriers of a trip)
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        found[blockIdx.x] = first;
+}
 
 struct EventTimer
 {
@@ -245,14 +320,18 @@ try
                 return false;
         return true;
     }();
-    if (rounds > 1 && p.restart_interval == 0 && equal_headers && !t_force_rounds && std::getenv("CHARLS_AMD_BATCH_ROUNDS") == nullptr)
+    // (Worth it while a round alone does not fill the chip: 256 4096 x 4096 RGB frames code at 17.9 GPix/s together and at
+    // 18.8 in rounds of 256 scans -- the scans' second trip through memory --, four 2048 x 2048 frames three times faster.)
+    constexpr uint32_t kTogetherFrames = 128;
+    if (rounds > 1 && p.restart_interval == 0 && equal_headers && !t_force_rounds && frame_count <= kTogetherFrames &&
+        std::getenv("CHARLS_AMD_BATCH_ROUNDS") == nullptr)
     {
         const size_t worst = dev::worst_case_scan_bytes(f.width, f.height, 1, f.bits_per_sample);
         const size_t capacity = (std::min(stream_pitch_bytes, worst) + 255) & ~size_t{255};
         constexpr size_t kPrivateBudget = size_t{8} << 30;
         const uint32_t group = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(frame_count, kPrivateBudget / (capacity * rounds))));
-        dev::DeviceBuffer d_private, d_plane_descs, d_plane_results, d_redo;
-        auto* priv = static_cast<uint8_t*>(d_private.ensure(capacity * rounds * group));
+        dev::DeviceBuffer d_plane_descs, d_plane_results, d_redo;
+        auto* priv = static_cast<uint8_t*>(dev::plane_arena().ensure(capacity * rounds * group)); // (kept between calls: a work area)
         d_plane_descs.ensure(sizeof(ScanDesc) * rounds * group);
         d_plane_results.ensure(sizeof(ScanResult) * rounds * group);
         d_redo.ensure(sizeof(uint32_t) * frame_count);
@@ -392,8 +471,7 @@ try
     };
     std::vector<Frame> fr(frame_count);
 
-    auto fetch = [&](uint32_t i, size_t base, size_t bytes) {
-        Frame& x = fr[i];
+    auto fetch = [&](Frame& x, uint32_t i, size_t base, size_t bytes) {
         const size_t avail = base < sizes[i] ? static_cast<size_t>(sizes[i]) - base : 0;
         const size_t n = std::min(bytes, avail);
         x.window.resize(n);
@@ -404,7 +482,7 @@ try
     // the same for many frames at once (bases[k] is the offset of frame which[k]'s window): one gather on the device, one copy
     dev::DeviceBuffer d_specs, d_windows;
     dev::PinnedBuffer h_specs, h_windows;
-    auto fetch_many = [&](const std::vector<uint32_t>& which, const std::vector<size_t>& bases) {
+    auto fetch_many = [&](std::vector<Frame>& set, const std::vector<uint32_t>& which, const std::vector<size_t>& bases) {
         const size_t n = which.size();
         if (n == 0)
             return;
@@ -427,14 +505,14 @@ try
         hip_check(hipStreamSynchronize(stream));
         for (size_t k = 0; k < n; ++k)
         {
-            Frame& x = fr[which[k]];
+            Frame& x = set[which[k]];
             x.window.assign(staged + k * kWindow, staged + k * kWindow + specs[k].bytes);
             x.window_base = bases[k];
         }
     };
     // A parse that runs off the end of the window while the stream has more bytes is retried with a larger window.
-    auto parse = [&](uint32_t i, auto&& body) {
-        Frame& x = fr[i];
+    auto parse = [&](std::vector<Frame>& set, uint32_t i, auto&& body) {
+        Frame& x = set[i];
         size_t want = kWindow;
         const StreamReader snapshot = x.reader; // a failed attempt may have advanced the reader's state machine
         for (;;)
@@ -458,7 +536,7 @@ try
                 }
             }
             want *= 8;
-            fetch(i, x.window_base, want);
+            fetch(x, i, x.window_base, want);
             hip_check(hipStreamSynchronize(stream));
             x.reader = snapshot;
         }
@@ -474,10 +552,10 @@ try
                 raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
             all[i] = i;
         }
-        fetch_many(all, std::vector<size_t>(frame_count, 0));
+        fetch_many(fr, all, std::vector<size_t>(frame_count, 0));
     }
     for (uint32_t i = 0; i < frame_count; ++i)
-        parse(i, [&](Frame& x) {
+        parse(fr, i, [&](Frame& x) {
             x.reader.set_source(x.window.data(), x.window.size());
             x.reader.read_header();
             if (x.reader.end_of_image())
@@ -486,72 +564,56 @@ try
         });
 
     dev::DeviceBuffer d_descs, d_results, d_scratch;
-    d_descs.ensure(sizeof(ScanDesc) * frame_count);
-    d_results.ensure(sizeof(ScanResult) * frame_count);
-    std::vector<ScanDesc> descs(frame_count);
-    std::vector<ScanResult> results(frame_count);
+    std::vector<ScanDesc> descs;
+    std::vector<ScanResult> results;
     std::vector<uint32_t> active;
     EventTimer total(stream);
     double scan_ms = 0;
     bool first_params = true;
 
-    for (;;)
-    {
-        active.clear();
-        size_t scratch_total = 0;
-        for (uint32_t i = 0; i < frame_count; ++i)
+    // What a frame's scan needs besides its stream position: geometry and coding parameters from the reader (which stands
+    // behind the scan's header), the destination of its first plane, the line scratch (an offset until run_scans places it).
+    auto scan_desc = [&](uint32_t i, Frame& x, size_t& scratch_total) -> ScanDesc {
+        const charls_frame_info& f = x.reader.frame_info();
+        const int32_t ilv = x.reader.scan_interleave_mode();
+        const uint32_t nc = x.reader.scan_component_count();
+        const size_t row = (ilv == 0 ? 1u : nc) * static_cast<size_t>(f.width) * bytes_per_sample(f.bits_per_sample);
+        size_t stride = stride_arg;
+        if (stride == 0)
+            stride = row;
+        else if (stride < row)
+            raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_STRIDE);
+        const size_t need = (ilv == 0 ? stride * nc * f.height : stride * f.height) - (stride - row);
+        if (frame_pitch_bytes < x.plane_offset + need)
+            raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
+        ScanDesc d = base_desc(f, static_cast<int32_t>(nc), ilv, x.reader.parameters().near_lossless,
+                               x.reader.parameters().transformation, x.reader.validated_pc(),
+                               x.reader.parameters().restart_interval);
+        d.pixels = frames + i * frame_pitch_bytes + x.plane_offset;
+        d.pixel_stride = stride;
+        d.stream = const_cast<uint8_t*>(slots) + i * stream_pitch_bytes + x.cursor;
+        d.stream_capacity = sizes[i] - x.cursor;
+        d.line_scratch = reinterpret_cast<uint16_t*>(scratch_total); // placed by run_scans
+        scratch_total += dev::line_scratch_samples(f.width, ilv, static_cast<int32_t>(nc)) * sizeof(uint16_t);
+        scratch_total = (scratch_total + 255) & ~size_t{255};
+        return d;
+    };
+    auto report_params = [&](Frame& x) {
+        if (params_out && first_params)
         {
-            Frame& x = fr[i];
-            if (x.done)
-                continue;
-            try
-            {
-                const charls_frame_info& f = x.reader.frame_info();
-                const int32_t ilv = x.reader.scan_interleave_mode();
-                const uint32_t nc = x.reader.scan_component_count();
-                const size_t row = (ilv == 0 ? 1u : nc) * static_cast<size_t>(f.width) * bytes_per_sample(f.bits_per_sample);
-                size_t stride = stride_arg;
-                if (stride == 0)
-                    stride = row;
-                else if (stride < row)
-                    raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_STRIDE);
-                const size_t need = (ilv == 0 ? stride * nc * f.height : stride * f.height) - (stride - row);
-                if (frame_pitch_bytes < x.plane_offset + need)
-                    raise(CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_SIZE);
-                if (params_out && first_params)
-                {
-                    *params_out = charls_amd_codec_params{f, x.reader.parameters().near_lossless, ilv,
-                                                          x.reader.parameters().transformation,
-                                                          x.reader.preset_coding_parameters(), 0,
-                                                          x.reader.parameters().restart_interval};
-                    first_params = false;
-                }
-                ScanDesc d = base_desc(f, static_cast<int32_t>(nc), ilv, x.reader.parameters().near_lossless,
-                                       x.reader.parameters().transformation, x.reader.validated_pc(),
-                                       x.reader.parameters().restart_interval);
-                d.pixels = frames + i * frame_pitch_bytes + x.plane_offset;
-                d.pixel_stride = stride;
-                d.stream = const_cast<uint8_t*>(slots) + i * stream_pitch_bytes + x.cursor;
-                d.stream_capacity = sizes[i] - x.cursor;
-                d.line_scratch = reinterpret_cast<uint16_t*>(scratch_total); // patched below
-                scratch_total += dev::line_scratch_samples(f.width, ilv, static_cast<int32_t>(nc)) * sizeof(uint16_t);
-                scratch_total = (scratch_total + 255) & ~size_t{255};
-                descs[active.size()] = d;
-                active.push_back(i);
-            }
-            catch (const error& e)
-            {
-                x.errc = e.code;
-                x.done = true;
-            }
+            *params_out = charls_amd_codec_params{x.reader.frame_info(), x.reader.parameters().near_lossless,
+                                                  x.reader.scan_interleave_mode(), x.reader.parameters().transformation,
+                                                  x.reader.preset_coding_parameters(), 0, x.reader.parameters().restart_interval};
+            first_params = false;
         }
-        if (active.empty())
-            break;
+    };
+    // Decodes descs[0, n) (tags[k] says whose scan descs[k] is; both are permuted: scans that can share a kernel
+    // specialisation are made contiguous, one launch per group) and leaves results[k] beside descs[k].
+    auto run_scans = [&](std::vector<uint32_t>& tags, size_t scratch_total) {
+        const uint32_t n = static_cast<uint32_t>(descs.size());
         auto* scratch = static_cast<uint8_t*>(d_scratch.ensure(scratch_total));
-        for (size_t k = 0; k < active.size(); ++k)
-            descs[k].line_scratch = reinterpret_cast<uint16_t*>(scratch + reinterpret_cast<size_t>(descs[k].line_scratch));
-        const uint32_t n = static_cast<uint32_t>(active.size());
-        // scans that can share a kernel specialisation are made contiguous (stable), one launch per group
+        for (ScanDesc& d : descs)
+            d.line_scratch = reinterpret_cast<uint16_t*>(scratch + reinterpret_cast<size_t>(d.line_scratch));
         {
             std::vector<uint32_t> order(n);
             for (uint32_t k = 0; k < n; ++k)
@@ -560,15 +622,18 @@ try
                 return dev::decode_launch_key(descs[a]) < dev::decode_launch_key(descs[b]);
             });
             std::vector<ScanDesc> d2(n);
-            std::vector<uint32_t> a2(n);
+            std::vector<uint32_t> t2(n);
             for (uint32_t k = 0; k < n; ++k)
             {
                 d2[k] = descs[order[k]];
-                a2[k] = active[order[k]];
+                t2[k] = tags[order[k]];
             }
-            std::copy(d2.begin(), d2.end(), descs.begin());
-            active = a2;
+            descs = std::move(d2);
+            tags = std::move(t2);
         }
+        d_descs.ensure(sizeof(ScanDesc) * n);
+        d_results.ensure(sizeof(ScanResult) * n);
+        results.resize(n);
         hip_check(hipMemcpyAsync(d_descs.as<ScanDesc>(), descs.data(), sizeof(ScanDesc) * n, hipMemcpyHostToDevice, stream));
         total.start();
         for (uint32_t first = 0; first < n;)
@@ -582,8 +647,215 @@ try
         }
         total.stop();
         hip_check(hipMemcpyAsync(results.data(), d_results.as<ScanResult>(), sizeof(ScanResult) * n, hipMemcpyDeviceToHost, stream));
-        hip_check(hipStreamSynchronize(stream));
+        hip_check(hipStreamSynchronize(stream)); // (descs and results are reused by the next call)
         scan_ms += total.ms();
+    };
+
+    // ---- Planar frames: the component scans of all of them in ONE launch (the decoder's rate is the number of scans in
+    // flight: scan by scan, a batch of RGB planes ran three rounds of a third of its scans).  Where scan c + 1 starts is only
+    // known once scan c has been decoded -- or once the marker that ends scan c has been found: inside an entropy-coded
+    // segment no 0xFF is followed by a byte with its high bit set, so a search finds it (find_scan_end), and the part-1 reader
+    // parses on from there, on a COPY of the frame's state.  The copy replaces the frame only if every scan then ends exactly
+    // at the marker found behind it and the end of the image parses; any frame that does not is decoded again by the rounds
+    // below, which report whatever part 1 reports for it.  src/charls_jpegls_decoder.cpp:211-236 is the scan-by-scan loop.
+    if (std::getenv("CHARLS_AMD_BATCH_ROUNDS") == nullptr)
+    {
+        struct Plan
+        {
+            uint32_t frame;
+            std::vector<ScanDesc> scans;   // (line scratch: an offset until run_scans places it)
+            std::vector<size_t> starts;    // first byte of scan c
+            std::vector<size_t> marker_at; // the marker found behind scan c
+            bool ok{true};
+        };
+        std::vector<Frame> probe;
+        std::vector<Plan> plans;
+        size_t scratch_total = 0;
+        for (uint32_t i = 0; i < frame_count; ++i)
+        {
+            const Frame& x = fr[i];
+            if (x.done || x.reader.component_count() < 2 || x.reader.scan_interleave_mode() != 0 || x.reader.scan_component_count() != 1)
+                continue;
+            if (probe.empty())
+                probe = fr; // (readers, windows and cursors of every frame; only the planned ones are touched)
+            Plan p;
+            p.frame = i;
+            try
+            { // every plane must fit behind the first (the rounds raise the error where it belongs otherwise)
+                const charls_frame_info& f = x.reader.frame_info();
+                const size_t row = static_cast<size_t>(f.width) * bytes_per_sample(f.bits_per_sample);
+                const size_t stride = stride_arg == 0 ? row : stride_arg;
+                if (stride < row || frame_pitch_bytes < checked_mul(checked_mul(stride, f.height), x.reader.component_count()) - (stride - row))
+                    continue;
+                p.scans.push_back(scan_desc(i, probe[i], scratch_total));
+            }
+            catch (const error&)
+            {
+                continue;
+            }
+            p.starts.push_back(x.cursor);
+            plans.push_back(std::move(p));
+        }
+        dev::DeviceBuffer d_search, d_found;
+        dev::PinnedBuffer h_search, h_found;
+        for (uint32_t c = 1; !plans.empty(); ++c)
+        {
+            std::vector<uint32_t> need; // plans whose frame has a scan c
+            for (uint32_t k = 0; k < plans.size(); ++k)
+                if (plans[k].ok && probe[plans[k].frame].reader.component_count() > c)
+                    need.push_back(k);
+            if (need.empty())
+                break;
+            const size_t n = need.size();
+            auto* search = static_cast<MarkerSearch*>(h_search.ensure(sizeof(MarkerSearch) * n));
+            auto* found = static_cast<unsigned long long*>(h_found.ensure(sizeof(unsigned long long) * n));
+            for (size_t q = 0; q < n; ++q)
+            {
+                const uint32_t i = plans[need[q]].frame;
+                search[q] = MarkerSearch{static_cast<uint64_t>(i) * stream_pitch_bytes + plans[need[q]].starts.back(),
+                                         static_cast<uint64_t>(i) * stream_pitch_bytes + sizes[i]};
+            }
+            d_search.ensure(sizeof(MarkerSearch) * n);
+            d_found.ensure(sizeof(unsigned long long) * n);
+            hip_check(hipMemcpyAsync(d_search.as<MarkerSearch>(), search, sizeof(MarkerSearch) * n, hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(find_scan_end, dim3(static_cast<uint32_t>(n)), dim3(256), 0, stream, slots, d_search.as<const MarkerSearch>(),
+                               d_found.as<unsigned long long>());
+            hip_check(hipGetLastError());
+            hip_check(hipMemcpyAsync(found, d_found.as<unsigned long long>(), sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, stream));
+            hip_check(hipStreamSynchronize(stream));
+            std::vector<uint32_t> which;
+            std::vector<size_t> bases;
+            for (size_t q = 0; q < n; ++q)
+            {
+                Plan& p = plans[need[q]];
+                if (found[q] == kNoMarker)
+                {
+                    p.ok = false;
+                    continue;
+                }
+                p.marker_at.push_back(static_cast<size_t>(found[q] - static_cast<uint64_t>(p.frame) * stream_pitch_bytes));
+                which.push_back(p.frame);
+                bases.push_back(p.marker_at.back());
+            }
+            fetch_many(probe, which, bases);
+            for (size_t q = 0; q < n; ++q)
+            {
+                Plan& p = plans[need[q]];
+                if (!p.ok)
+                    continue;
+                Frame& y = probe[p.frame];
+                const charls_frame_info f = y.reader.frame_info();
+                const size_t row = static_cast<size_t>(f.width) * bytes_per_sample(f.bits_per_sample);
+                y.plane_offset += (stride_arg ? stride_arg : row) * f.height;
+                parse(probe, p.frame, [&](Frame& z) {
+                    z.reader.continue_on_window(z.window.data(), z.window.size());
+                    z.reader.read_next_start_of_scan();
+                    z.cursor = z.window_base + static_cast<size_t>(z.reader.position() - z.window.data());
+                });
+                if (y.done || y.reader.scan_interleave_mode() != 0 || y.reader.scan_component_count() != 1)
+                {
+                    p.ok = false;
+                    continue;
+                }
+                try
+                {
+                    p.scans.push_back(scan_desc(p.frame, y, scratch_total));
+                    p.starts.push_back(y.cursor);
+                }
+                catch (const error&)
+                {
+                    p.ok = false;
+                }
+            }
+        }
+        descs.clear();
+        std::vector<uint32_t> tags; // plan << 8 | component
+        for (uint32_t k = 0; k < plans.size(); ++k)
+        {
+            Plan& p = plans[k];
+            p.ok = p.ok && p.scans.size() == probe[p.frame].reader.component_count() && p.scans.size() < 256;
+            for (uint32_t c = 0; p.ok && c < p.scans.size(); ++c)
+            {
+                descs.push_back(p.scans[c]);
+                tags.push_back((k << 8) | c);
+            }
+        }
+        if (!descs.empty())
+        {
+            run_scans(tags, scratch_total);
+            std::vector<std::vector<size_t>> used(plans.size());
+            for (Plan& p : plans)
+                used[&p - plans.data()].assign(p.scans.size(), 0);
+            for (uint32_t k = 0; k < tags.size(); ++k)
+            {
+                Plan& p = plans[tags[k] >> 8];
+                const uint32_t c = tags[k] & 0xFFu;
+                if (results[k].errc != kOk)
+                    p.ok = false;
+                used[tags[k] >> 8][c] = static_cast<size_t>(results[k].bytes);
+            }
+            std::vector<uint32_t> which;
+            std::vector<size_t> bases;
+            for (uint32_t k = 0; k < plans.size(); ++k)
+            {
+                Plan& p = plans[k];
+                for (uint32_t c = 0; p.ok && c + 1 < p.scans.size(); ++c)
+                    p.ok = p.starts[c] + used[k][c] == p.marker_at[c]; // the scan ends exactly at the marker found behind it
+                if (!p.ok)
+                    continue;
+                probe[p.frame].cursor = p.starts.back() + used[k].back();
+                which.push_back(p.frame);
+                bases.push_back(probe[p.frame].cursor);
+            }
+            fetch_many(probe, which, bases);
+            for (Plan& p : plans)
+            {
+                if (!p.ok)
+                    continue;
+                parse(probe, p.frame, [&](Frame& z) {
+                    z.reader.continue_on_window(z.window.data(), z.window.size());
+                    z.reader.read_end_of_image();
+                    z.cursor = z.window_base + static_cast<size_t>(z.reader.position() - z.window.data());
+                });
+                Frame& y = probe[p.frame];
+                if (y.errc != CHARLS_JPEGLS_ERRC_SUCCESS)
+                    continue; // (the rounds decode it again and report this)
+                report_params(fr[p.frame]);
+                y.decoded_components = static_cast<uint32_t>(p.scans.size());
+                y.done = true;
+                fr[p.frame] = std::move(y);
+            }
+        }
+    }
+
+
+    for (;;)
+    {
+        active.clear();
+        descs.clear();
+        size_t scratch_total = 0;
+        for (uint32_t i = 0; i < frame_count; ++i)
+        {
+            Frame& x = fr[i];
+            if (x.done)
+                continue;
+            try
+            {
+                const ScanDesc d = scan_desc(i, x, scratch_total);
+                report_params(x);
+                descs.push_back(d);
+                active.push_back(i);
+            }
+            catch (const error& e)
+            {
+                x.errc = e.code;
+                x.done = true;
+            }
+        }
+        if (active.empty())
+            break;
+        const uint32_t n = static_cast<uint32_t>(active.size());
+        run_scans(active, scratch_total);
 
         // advance every frame past its scan; fetch the bytes that follow (next SOS or EOI)
         {
@@ -604,7 +876,7 @@ try
                 which.push_back(active[k]);
                 bases.push_back(x.cursor);
             }
-            fetch_many(which, bases);
+            fetch_many(fr, which, bases);
         }
         for (uint32_t k = 0; k < n; ++k)
         {
@@ -623,7 +895,7 @@ try
                 const size_t stride = stride_arg ? stride_arg : row;
                 x.plane_offset += stride * f.height;
             }
-            parse(i, [&](Frame& y) {
+            parse(fr, i, [&](Frame& y) {
                 // continue the same reader on the freshly fetched window
                 y.reader.continue_on_window(y.window.data(), y.window.size());
                 if (last)

@@ -49,7 +49,7 @@ def _run(L, raw: bytes, total_bits: int, capacity: int, blocks):
 def _streams():
     rng = np.random.default_rng(5)
     cases = [(b"", 0), (b"\xff", 8), (b"\xff", 3), (b"\xff\xff\xff", 24), (b"\x00" * 40, 313), (b"\xff" * 3000, 24000 - 5)]
-    for n, p_one in [(17, 0.5), (1023, 0.5), (1024, 0.97), (1025, 0.9), (5000, 0.99), (70000, 0.93), (150000, 0.6)]:
+    for n, p_one in [(17, 0.5), (1023, 0.5), (1024, 0.97), (1025, 0.9), (5000, 0.99), (40000, 0.93), (90000, 0.6)]:
         bits = (rng.random(n * 8) < p_one).astype(np.uint8)
         cases.append((np.packbits(bits).tobytes(), n * 8 - int(rng.integers(0, 8))))
     # long stretches of ones with single zeros at every alignment: every entry state of a chunk occurs
@@ -58,7 +58,7 @@ def _streams():
     cases.append((np.packbits(bits).tobytes(), 40000 - 3))
     # more chunks than the resolve step has lanes: every lane composes the tables of several chunks into one map, and with
     # a 0xFF in every second or third byte the maps do not collapse to one exit state
-    for n, p_one in [(300000, 0.9), (270001, 0.97)]:
+    for n, p_one in [(160000, 0.9), (150001, 0.97)]:
         bits = (rng.random(n * 8) < p_one).astype(np.uint8)
         cases.append((np.packbits(bits).tobytes(), n * 8 - int(rng.integers(0, 8))))
     return cases

@@ -276,3 +276,94 @@ def test_planar_batch_every_capacity_around_the_fit(torch, bits, near, comps):
             assert enc.errcs[f] == ew, (pitch, f, enc.errcs[f], ew)
             if want is not None:
                 assert host[f, :int(enc.sizes[f])].tobytes() == want, (pitch, f)
+
+
+def _decode_both_ways(torch, streams, sizes, like, monkeypatch):
+    """The batch decoder with the component scans of planar frames in one launch, and scan by scan (CHARLS_AMD_BATCH_ROUNDS)."""
+    out_a, out_b = torch.zeros_like(like), torch.zeros_like(like)
+    monkeypatch.delenv("CHARLS_AMD_BATCH_ROUNDS", raising=False)
+    _, errcs_a, _ = batch.decode_batch(streams, sizes, out_a)
+    monkeypatch.setenv("CHARLS_AMD_BATCH_ROUNDS", "1")
+    _, errcs_b, _ = batch.decode_batch(streams, sizes, out_b)
+    monkeypatch.delenv("CHARLS_AMD_BATCH_ROUNDS", raising=False)
+    return out_a, errcs_a, out_b, errcs_b
+
+
+def test_planar_batch_decodes_all_component_scans_in_one_launch(torch, monkeypatch):
+    """VERDICT round 3, item 8, the decoder's half: the scans of planar frames are found (the marker that ends a scan is
+    searched for on the device, the part-1 reader parses on from there) and decoded by ONE launch.  Pixels against the
+    frames, the same pixels and error codes as scan by scan, and the time against the same planes as separate frames."""
+    import time
+    n, w, h = 6, 1024, 1024
+    imgs = [synth.frame_numpy(w, h, seed=500 + f, components=3, kind="mixed", interleaved=False) for f in range(n)]
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    enc = batch.encode_batch(frames, component_count=3)
+    assert (enc.errcs == 0).all()
+    out_a, errcs_a, out_b, errcs_b = _decode_both_ways(torch, enc.streams, enc.sizes, frames, monkeypatch)
+    assert (errcs_a == 0).all() and (errcs_b == 0).all()
+    assert torch.equal(out_a, frames) and torch.equal(out_b, frames)
+    planes = batch.encode_batch(frames.reshape(n * 3, h, w))
+    out_p = torch.zeros((n * 3, h, w), dtype=frames.dtype, device="cuda")
+    batch.decode_batch(planes.streams, planes.sizes, out_p)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    batch.decode_batch(planes.streams, planes.sizes, out_p)
+    t_planes = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    batch.decode_batch(enc.streams, enc.sizes, out_a)
+    t_planar = time.perf_counter() - t0
+    assert t_planar < 1.5 * t_planes + 0.005, (t_planar, t_planes)  # (scan by scan: three rounds of a third of the scans)
+
+
+@pytest.mark.parametrize("bits,comps,near,restart", [(8, 3, 0, 0), (8, 3, 2, 0), (16, 2, 0, 0), (12, 4, 0, 0), (8, 3, 0, 7)])
+def test_planar_batch_decode_modes_and_damage(torch, monkeypatch, bits, comps, near, restart):
+    """Planar frames of several widths of sample, near-lossless, with restart intervals; then the same batch with one stream
+    cut short, one damaged inside its second scan, one whose end-of-image marker is gone and one with a comment segment THAT
+    CONTAINS A START-OF-SCAN MARKER between two scans: pixels and error codes equal what the scan-by-scan decoder gives."""
+    n, w, h = 5, 96, 56
+    imgs = [synth.frame_numpy(w, h, seed=520 + f, bits=bits, components=comps, kind="mixed", interleaved=False) for f in range(n)]
+    frames = torch.from_numpy(np.stack(imgs).astype(np.int16 if bits > 8 else np.uint8)).cuda()
+    enc = batch.encode_batch(frames, bits_per_sample=bits, component_count=comps, near_lossless=near, restart_interval=restart)
+    assert (enc.errcs == 0).all()
+    out_a, errcs_a, out_b, errcs_b = _decode_both_ways(torch, enc.streams, enc.sizes, frames, monkeypatch)
+    assert (errcs_a == 0).all() and (errcs_b == 0).all() and torch.equal(out_a, out_b)
+    if near == 0:
+        assert torch.equal(out_a, frames)
+    else:
+        assert int((out_a.to(torch.int32) - frames.to(torch.int32)).abs().max()) <= near
+    host = enc.streams.cpu().numpy().copy()
+    sizes = np.array(enc.sizes, dtype=np.uint64)
+    pitch = host.shape[1] + 64
+    bad = np.zeros((n, pitch), dtype=np.uint8)
+    bad[:, :host.shape[1]] = host
+
+    def scan_starts(f):  # offsets of the SOS markers of frame f
+        b = bytes(host[f, :int(sizes[f])])
+        at, found = 0, []
+        while True:
+            at = b.find(b"\xff\xda", at)
+            if at < 0:
+                return found
+            found.append(at)
+            at += 2
+
+    sizes[0] = sizes[0] * 2 // 3                      # cut short
+    second = scan_starts(1)[1]
+    bad[1, second + 30:second + 40] = 0xFF            # damage inside the second scan
+    sizes[2] -= 2                                     # no end-of-image marker
+    s3 = scan_starts(3)[1]
+    comment = bytes([0xFF, 0xFE, 0x00, 0x08, 0xFF, 0xDA, 0x00, 0x08, 0x01, 0x01])  # COM, length 8: FF DA 00 08 01 01
+    tail = bytes(bad[3, s3:int(sizes[3])])
+    bad[3, s3:s3 + len(comment)] = np.frombuffer(comment, dtype=np.uint8)
+    bad[3, s3 + len(comment):s3 + len(comment) + len(tail)] = np.frombuffer(tail, dtype=np.uint8)
+    sizes[3] += len(comment)
+    streams = torch.from_numpy(bad).cuda()
+    out_a, errcs_a, out_b, errcs_b = _decode_both_ways(torch, streams, sizes, frames, monkeypatch)
+    assert list(errcs_a) == list(errcs_b), (errcs_a, errcs_b)
+    assert errcs_a[0] != 0 and errcs_a[1] != 0 and errcs_a[2] != 0 and errcs_a[3] == 0 and errcs_a[4] == 0
+    assert torch.equal(out_a[3], out_b[3]) and torch.equal(out_a[4], out_b[4])
+    if near == 0:
+        assert torch.equal(out_a[3], frames[3]) and torch.equal(out_a[4], frames[4])
+    # the reference decodes the frame with the comment to the same pixels
+    _, want = ob.decode(bytes(bad[3, :int(sizes[3])]))
+    assert out_a[3].cpu().numpy().tobytes() == want.tobytes()

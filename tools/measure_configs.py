@@ -94,6 +94,17 @@ if "5c" in only:
     del rgb
     torch.cuda.empty_cache()
     batch.release_work_areas(lib)
+if "5p" in only:  # planar RGB: the component scans of every frame in one launch, both directions
+    planes = torch.empty((args.rgb_frames, 3, 4096, 4096), dtype=torch.uint8, device=dev)
+    for k in range(3):
+        planes[:, k] = synth.frames_torch(args.rgb_frames, 4096, 4096, seed0=5 + 7919 * k, bits=8, device=dev)
+    run("4096x4096 RGB planar (ILV_NONE) lossless (5p)", planes, bits=8, comps=3)
+    os.environ["CHARLS_AMD_BATCH_ROUNDS"] = "1"
+    run("the same, scan by scan (CHARLS_AMD_BATCH_ROUNDS=1: rounds of one component scan per frame, as until round 4)", planes, bits=8, comps=3)
+    del os.environ["CHARLS_AMD_BATCH_ROUNDS"]
+    del planes
+    torch.cuda.empty_cache()
+    batch.release_work_areas(lib)
 if "5d" in only:
     rgb = rgb_frames(args.rgb_frames, 4096, 5)
     run("config 4 line-interleaved near-lossless (5d): 4096x4096 RGB ILV_LINE NEAR=2", rgb, bits=8, comps=3, ilv=1, near=2)
