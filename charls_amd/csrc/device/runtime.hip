@@ -693,7 +693,7 @@ struct TileLayout
     tile::TilePlan plan;
     size_t samples, lines, raw_bytes, max_jobs, max_run_jobs;
     uint32_t lines_per_tile, tiles, job_events, warm_events, run_job_events, run_warm_events;
-    size_t off_keyinv, off_seg, off_total, off_base, off_jobfirst, off_rec, off_code, off_jobs, off_runjobs, off_bbase, off_raw,
+    size_t off_keyinv, off_seg, off_total, off_base, off_jobfirst, off_planpart, off_rec, off_code, off_jobs, off_runjobs, off_bbase, off_raw,
         off_bits, off_status, off_stuff, bytes;
     TileLayout(const ScanDesc& d, size_t capacity_hint, uint32_t count)
     {
@@ -714,12 +714,14 @@ struct TileLayout
         max_jobs = samples / job_events + pipe::kChains;
         // the run chain: jobs of 2048 run events with a warm-up of as many (a test frame has 55 000 run events); small batches
         // take smaller jobs -- ONE frame has the whole chip, and the walk of a job and its warm-up is what the frame waits for
+        // (up to four 4096 x 4096 frames: 128 events behind a warm-up of 1024 -- 2.35 ms per frame where 256 / 2048 took 2.65;
+        // 512 events of warm-up are enough for the test frame and 256 are not: every job walked again, 10.8 ms)
         const char* env_run_job = std::getenv("CHARLS_AMD_RUN_JOB_EVENTS");
         const char* env_run_warm = std::getenv("CHARLS_AMD_RUN_WARM_EVENTS");
         const uint64_t batch_samples = static_cast<uint64_t>(samples) * count;
-        const uint32_t run_job_default = batch_samples <= (uint64_t{1} << 26) ? 256u : (batch_samples <= (uint64_t{1} << 29) ? 512u : 2048u);
+        const uint32_t run_job_default = batch_samples <= (uint64_t{1} << 26) ? 128u : (batch_samples <= (uint64_t{1} << 29) ? 512u : 2048u);
         run_job_events = env_run_job ? static_cast<uint32_t>(std::max(32, std::atoi(env_run_job)) / 32 * 32) : run_job_default;
-        run_warm_events = env_run_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_warm))) : 2048u;
+        run_warm_events = env_run_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_warm))) : (run_job_default == 128u ? 1024u : 2048u);
         max_run_jobs = samples / run_job_events + 2; // (+ the entry of the totals)
         const size_t worst = worst_case_scan_bytes(plan.line_samples, static_cast<uint32_t>(lines), 1, d.bits_per_sample);
         raw_bytes = align_up((capacity_hint < worst ? capacity_hint : worst) + 64, 16);
@@ -734,6 +736,7 @@ struct TileLayout
         off_total = take(pipe::kChains * 4);
         off_base = take(pipe::kChains * 4);
         off_jobfirst = take((pipe::kChains + 1) * 4);
+        off_planpart = take(static_cast<size_t>(tile::kPlanGroups) * pipe::kChains * 4);
         // records and code words: 2-byte slots for samples of up to 8 bits (a run start takes two), 4-byte slots otherwise
         const uint32_t run_slots = d.bits_per_sample > 8 ? 1u : 2u;
         const size_t slot_bytes = d.bits_per_sample > 8 ? 4 : 2;
@@ -852,6 +855,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             tile::Work& w = works[pass][i];
             w.keyinv = reinterpret_cast<uint16_t*>(base + lay.off_keyinv);
             w.seg = reinterpret_cast<uint32_t*>(base + lay.off_seg);
+            w.plan_part = reinterpret_cast<uint32_t*>(base + lay.off_planpart);
             w.chain_total = reinterpret_cast<uint32_t*>(base + lay.off_total);
             w.chain_base = reinterpret_cast<uint32_t*>(base + lay.off_base);
             w.job_first = reinterpret_cast<uint32_t*>(base + lay.off_jobfirst);
@@ -903,7 +907,9 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         else
             hipLaunchKernelGGL((tile::analyze_tiles<S, 0>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_a, s, descs, d_works);
         t.mark();
-        hipLaunchKernelGGL(tile::plan_chains, dim3(n), dim3(1024), 0, s, descs, d_works);
+        hipLaunchKernelGGL(tile::sum_chains, dim3(tile::kPlanGroups, n), dim3(tile::kPlanThreads), 0, s, descs, d_works);
+        hipLaunchKernelGGL(tile::plan_chains, dim3(n), dim3(tile::kPlanThreads), 0, s, descs, d_works);
+        hipLaunchKernelGGL(tile::apply_chains, dim3(tile::kPlanGroups, n), dim3(tile::kPlanThreads), 0, s, descs, d_works);
         if (pixel_mode)
             hipLaunchKernelGGL((tile::sort_pixel_tiles<S>), dim3(tiles_grid, n), dim3(tile::kThreads), lds_b, s, descs, d_works);
         else
@@ -928,11 +934,12 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
                     hipLaunchKernelGGL((tile::compact_rare_runs<S, 1>), count_grid, dim3(64), 0, runs_stream, d_works);
                 else
                     hipLaunchKernelGGL((tile::compact_rare_runs<S, 0>), count_grid, dim3(64), 0, runs_stream, d_works);
-                hipLaunchKernelGGL(tile::walk_rare_context, settle_grid, dim3(64), 0, runs_stream, descs, d_works, n);
             }
+            const uint32_t rare_blocks = proto.interleave_mode != 2 ? settle_grid.x : 0u; // (the walk of the rarer context rides with the warm-ups)
 #define JLS_RUN_CHAIN(ILV, FMT)                                                                                          \
     do                                                                                                                   \
     {                                                                                                                    \
+        hipLaunchKernelGGL((tile::warm_run_jobs<S, ILV, FMT>), dim3(rare_blocks + lanes.x), dim3(64), 0, runs_stream, descs, d_works, n, rare_blocks); \
         hipLaunchKernelGGL((tile::walk_run_jobs<S, ILV, FMT>), lanes, dim3(64), 0, runs_stream, descs, d_works, n);      \
         hipLaunchKernelGGL((tile::settle_runs<S, ILV, FMT>), settle_grid, dim3(64), 0, runs_stream, descs, d_works, n);  \
     } while (0)

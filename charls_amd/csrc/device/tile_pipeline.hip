@@ -106,7 +106,7 @@ __host__ __device__ inline size_t stage_bytes(uint32_t tile_capacity, uint32_t s
 {
     return sample_bytes == 1 ? (size_t)slots_capacity(tile_capacity, 2, kTileLines) * 2 : (size_t)tile_capacity * 4;
 }
-constexpr uint32_t kPlanGroups = 16;       // plan_chains sums the tiles of a scan in this many groups
+constexpr uint32_t kPlanGroups = 64;       // sum_chains / apply_chains take the tiles of a scan in this many groups
 #define JLS_HOST_DEV_EARLY __host__ __device__ inline
 constexpr uint32_t kRunTag = 1u << 31;     // code word of a run-length code: ones : 6 | tail length : 5 | tail : 20
 
@@ -162,6 +162,7 @@ struct Work
     uint32_t* rec;         // [slots_capacity + kSlack] slots: records in chain order (Slot<S>; the run chain's entries are 32-bit)
     uint32_t* code;        // [slots_capacity + kSlack] slots: code words in chain order
     JobState* jobs;        // [samples / job_events + kChains]
+    uint32_t* plan_part;   // [kPlanGroups][kChains] sum_chains: slots of a group of tiles; plan_chains: where its first tile's pieces start
     struct RunJob* run_jobs; // [samples / run_job_events + 2] jobs of the run chain, and an entry behind the last one (totals)
     uint64_t* blockbase;   // [tiles] look-back states of pack_tiles; followed by tile_tail (cleared together)
     uint64_t* tile_tail;   // [tiles] pack_tiles: the bits of the tile's last, partial word | valid << 63
@@ -521,44 +522,50 @@ __global__ void __launch_bounds__(kThreads) analyze_tiles(const ScanDesc* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// B1: grid (scans) x 1024.  Column-wise exclusive prefix of the (tiles x kChains) count matrix: where the piece of every
-// (tile, chain) starts in rec / code.  The tiles are summed in kPlanGroups groups so that the loads of a thread do not form
-// one long dependent chain.
-__global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+// B1: column-wise exclusive prefix of the (tiles x kChains) count matrix: where the piece of every (tile, chain) starts in
+// rec / code.  Three launches: sum_chains adds up the tiles of a scan in kPlanGroups groups (a workgroup per group and scan),
+// plan_chains (a workgroup per scan) turns the 64 x 367 sums into the chains' totals, their places and job numbers and every
+// group's starting offsets, apply_chains walks the groups' tiles again and leaves the offsets.  (One workgroup per scan did all
+// of it until the end of round 4: 6 MB through ONE CU, 264 us of the 2.1 ms ONE frame took.)
+// sum_chains / apply_chains: grid (kPlanGroups, scans) x 384.  plan_chains: grid (scans) x 384.
+constexpr uint32_t kPlanThreads = 384; // >= kChains
+JLS_DEV void plan_group(const ScanDesc& d, const Work& w, uint32_t g, uint32_t& t0, uint32_t& t1)
 {
-    __shared__ uint32_t s_part[kPlanGroups][kChains + 1];
-    __shared__ uint32_t s_base[kChains + 1];
-    const ScanDesc d = descs[blockIdx.x];
-    const Work w = works[blockIdx.x];
     const uint32_t tiles = scan_tiles(d, w);
     const uint32_t per_group = (tiles + kPlanGroups - 1) / kPlanGroups;
-    const uint32_t pairs = kPlanGroups * (uint32_t)kChains;
+    t0 = g * per_group < tiles ? g * per_group : tiles;
+    t1 = t0 + per_group < tiles ? t0 + per_group : tiles;
+}
+__global__ void __launch_bounds__(kPlanThreads) sum_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const uint32_t g = blockIdx.x, c = threadIdx.x;
+    if (c >= (uint32_t)kChains)
+        return;
+    uint32_t t0, t1;
+    plan_group(d, w, g, t0, t1);
     // (everything below is in SLOTS: an event of the run chain -- chain 0 -- takes w.run_slots of them, every other event one;
     // chain_total alone counts EVENTS)
-    for (uint32_t p = threadIdx.x; p < pairs; p += 1024)
-    {
-        const uint32_t g = p / kChains, c = p % kChains;
-        const uint32_t t0 = g * per_group < tiles ? g * per_group : tiles, t1 = t0 + per_group < tiles ? t0 + per_group : tiles;
-        uint32_t sum = 0;
-        for (uint32_t t = t0; t < t1; ++t)
-            sum += w.seg[(size_t)t * kChains + c];
-        s_part[g][c] = sum * (c == 0 ? w.run_slots : 1u);
-    }
-    __syncthreads();
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; ++t)
+        sum += w.seg[(size_t)t * kChains + c];
+    w.plan_part[g * kChains + c] = sum * (c == 0 ? w.run_slots : 1u);
+}
+__global__ void __launch_bounds__(kPlanThreads) plan_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    __shared__ uint32_t s_base[kChains + 1];
+    const Work w = works[blockIdx.x];
+    uint32_t total = 0;
     if (threadIdx.x < (uint32_t)kChains)
     {
         const uint32_t c = threadIdx.x;
-        uint32_t running = 0;
         for (uint32_t g = 0; g < kPlanGroups; ++g)
-        {
-            const uint32_t n = s_part[g][c];
-            s_part[g][c] = running;
-            running += n;
-        }
-        w.chain_total[c] = running / (c == 0 ? w.run_slots : 1u);
-        s_base[c] = running;
+            total += w.plan_part[g * kChains + c];
+        w.chain_total[c] = total / (c == 0 ? w.run_slots : 1u);
+        s_base[c] = total;
     }
-    if (threadIdx.x == 1023)
+    if (threadIdx.x == kPlanThreads - 1)
     { // the two result words of the later stages start at zero
         *w.total_bits = 0;
         *w.status = 0;
@@ -580,20 +587,37 @@ __global__ void __launch_bounds__(1024) plan_chains(const ScanDesc* __restrict__
         w.job_first[kChains] = jobs;
     }
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < pairs; p += 1024)
-    {
-        const uint32_t g = p / kChains, c = p % kChains;
-        const uint32_t t0 = g * per_group < tiles ? g * per_group : tiles, t1 = t0 + per_group < tiles ? t0 + per_group : tiles;
-        uint32_t running = s_base[c] + s_part[g][c];
-        for (uint32_t t = t0; t < t1; ++t)
+    if (threadIdx.x < (uint32_t)kChains)
+    { // where the pieces of every group's first tile start
+        const uint32_t c = threadIdx.x;
+        uint32_t running = s_base[c];
+        for (uint32_t g = 0; g < kPlanGroups; ++g)
         {
-            const uint32_t n = w.seg[(size_t)t * kChains + c] * (c == 0 ? w.run_slots : 1u);
-            w.seg[(size_t)t * kChains + c] = running;
+            const uint32_t n = w.plan_part[g * kChains + c];
+            w.plan_part[g * kChains + c] = running;
             running += n;
         }
-        if (t1 == tiles && t0 < t1)
-            w.seg[(size_t)tiles * kChains + c] = running;
     }
+}
+__global__ void __launch_bounds__(kPlanThreads) apply_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works)
+{
+    const ScanDesc d = descs[blockIdx.y];
+    const Work w = works[blockIdx.y];
+    const uint32_t g = blockIdx.x, c = threadIdx.x;
+    if (c >= (uint32_t)kChains)
+        return;
+    const uint32_t tiles = scan_tiles(d, w);
+    uint32_t t0, t1;
+    plan_group(d, w, g, t0, t1);
+    uint32_t running = w.plan_part[g * kChains + c];
+    for (uint32_t t = t0; t < t1; ++t)
+    {
+        const uint32_t n = w.seg[(size_t)t * kChains + c] * (c == 0 ? w.run_slots : 1u);
+        w.seg[(size_t)t * kChains + c] = running;
+        running += n;
+    }
+    if (t1 == tiles && t0 < t1)
+        w.seg[(size_t)tiles * kChains + c] = running;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1559,14 +1583,11 @@ __global__ void __launch_bounds__(64) compact_rare_runs(const Work* __restrict__
     }
 }
 
-// grid (ceil(scans / 64)) x 64: one lane per scan.
-__global__ void __launch_bounds__(64) walk_rare_context(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
+// One lane per scan: the context of the rarer interruption type, event by event (what a lane does per event -- k, the map
+// bit, the update -- is some 350 clocks of dependent arithmetic; fetching the values 64 at a time with a broadcast per
+// event was measured and is slower, 507 us against 397 for the test frame's 2200 events).
+JLS_DEV void walk_rare_context(const ScanDesc& d, const Work& w)
 {
-    const uint32_t frame = blockIdx.x * 64u + threadIdx.x;
-    if (frame >= scans)
-        return;
-    const ScanDesc d = descs[frame];
-    const Work w = works[frame];
     const Traits t = make_traits(d);
     const uint32_t n = w.chain_total[0];
     const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
@@ -1591,6 +1612,49 @@ __global__ void __launch_bounds__(64) walk_rare_context(const ScanDesc* __restri
     }
 }
 
+// The run chain's two speculative ingredients in ONE launch, side by side: the first `rare_blocks` wavefronts walk the
+// context of the rarer interruption type (a lane per scan, exact), the others warm up a job each (a lane per (job, scan):
+// RUNindex and the context of the more frequent type from run_warm_events events before the job -- what the rarer
+// context is meanwhile does not matter to either, and the job takes it from the exact walk afterwards).  The two were one
+// after the other until the end of round 4: 0.4 ms each of the 2.7 ms ONE frame took.
+// grid (rare_blocks + ceil(max_run_jobs * scans / 64)) x 64.
+template <typename S, int ILV, int FMT = 0>
+__global__ void __launch_bounds__(64) warm_run_jobs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans,
+                                                    uint32_t rare_blocks)
+{
+    if (blockIdx.x < rare_blocks)
+    {
+        const uint32_t frame = blockIdx.x * 64u + threadIdx.x;
+        if (frame < scans)
+            walk_rare_context(descs[frame], works[frame]);
+        return;
+    }
+    const uint32_t tid = (blockIdx.x - rare_blocks) * 64u + threadIdx.x;
+    const uint32_t job = tid / scans, frame = tid % scans;
+    const ScanDesc d = descs[frame];
+    const Work w = works[frame];
+    const uint32_t n = w.chain_total[0];
+    const uint32_t from = job * w.run_job_events;
+    if (from >= n)
+        return;
+    const Traits t = make_traits(d);
+    const uint32_t* runs = reinterpret_cast<const uint32_t*>(rec_slots<S>(w) + w.chain_base[0]); // (chain 0 starts the arrays: aligned)
+    uint32_t* run_code = reinterpret_cast<uint32_t*>(code_slots<S>(w) + w.chain_base[0]);
+    Slot<S>* int_code = code_slots<S>(w) + w.chain_base[kInterruptChain];
+    const Slot<S>* int_rec = rec_slots<S>(w) + w.chain_base[kInterruptChain]; // (pixel mode)
+    // The warm-up starts at a job boundary (that is where the counts are known).
+    const uint32_t warm_jobs = (w.run_warm_events + w.run_job_events - 1) / w.run_job_events;
+    const uint32_t warm_job = job > warm_jobs ? job - warm_jobs : 0u;
+    RunState s{0, initial_a(t), 0, initial_a(t), 0};
+    if (warm_job < job)
+    {
+        const RunJob before = w.run_jobs[warm_job];
+        walk_runs<S, ILV, false, FMT>(t, runs, run_code, int_code, warm_job * w.run_job_events, from, s, before.type0, before.type1, before.own_slot, int_rec,
+                                      samples_per_pixel(d));
+    }
+    w.run_jobs[job].in = s; // (only this field: the rarer context's walk writes others of the same entry meanwhile)
+}
+
 // grid (ceil(max_run_jobs * scans / 64)) x 64: one lane per (job, scan), lanes of a wavefront = the same job of different scans.
 template <typename S, int ILV, int FMT = 0>
 __global__ void __launch_bounds__(64) walk_run_jobs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
@@ -1610,30 +1674,23 @@ __global__ void __launch_bounds__(64) walk_run_jobs(const ScanDesc* __restrict__
     Slot<S>* int_code = code_slots<S>(w) + w.chain_base[kInterruptChain];
     const Slot<S>* int_rec = rec_slots<S>(w) + w.chain_base[kInterruptChain]; // (pixel mode)
     const uint32_t nc = samples_per_pixel(d);
-    // The warm-up starts at a job boundary (that is where the counts are known): RUNindex and the context of the more frequent
-    // interruption type forget within run_warm_events run events; the context of the rarer type starts the warm-up in its
-    // exact state (walk_rare_context) and stays exact through it.
     const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
-    const uint32_t warm_jobs = (w.run_warm_events + w.run_job_events - 1) / w.run_job_events;
-    const uint32_t warm_job = job > warm_jobs ? job - warm_jobs : 0u;
-    RunState s{0, initial_a(t), 0, initial_a(t), 0};
+    // the state warm_run_jobs guessed for the start of this job; the context of the rarer type is the exact one
     RunJob mine = w.run_jobs[job];
-    const RunJob before = w.run_jobs[warm_job];
+    RunState s = mine.in;
     if (ILV != 2)
     {
         if (rarer_is_type1(w, jobs))
         {
-            s.a1 = before.rare_a;
-            s.nn1 = before.rare_nn;
+            s.a1 = mine.rare_a;
+            s.nn1 = mine.rare_nn;
         }
         else
         {
-            s.a0 = before.rare_a;
-            s.nn0 = before.rare_nn;
+            s.a0 = mine.rare_a;
+            s.nn0 = mine.rare_nn;
         }
     }
-    if (warm_job < job)
-        walk_runs<S, ILV, false, FMT>(t, runs, run_code, int_code, warm_job * w.run_job_events, from, s, before.type0, before.type1, before.own_slot, int_rec, nc);
     mine.in = s;
     walk_runs<S, ILV, true, FMT>(t, runs, run_code, int_code, from, to, s, mine.type0, mine.type1, mine.own_slot, int_rec, nc);
     mine.out = s;

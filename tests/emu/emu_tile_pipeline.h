@@ -55,6 +55,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         w.chain_total = (uint32_t*)galloc(pipe::kChains * 4);
         w.chain_base = (uint32_t*)galloc(pipe::kChains * 4);
         w.job_first = (uint32_t*)galloc((pipe::kChains + 1) * 4);
+        w.plan_part = (uint32_t*)galloc((size_t)tile::kPlanGroups * pipe::kChains * 4);
         const size_t slots = (size_t)tile::slots_capacity(samples, tile::run_slots_of<S>(), plan.lines) + tile::kSlack;
         w.rec = (uint32_t*)galloc(slots * sizeof(tile::Slot<S>));
         w.code = (uint32_t*)galloc(slots * sizeof(tile::Slot<S>));
@@ -98,7 +99,9 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         emu::launch(tile::analyze_pixel_tiles<S>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_a, descs, wk);
     else
         emu::launch(tile::analyze_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_a, descs, wk);
-    emu::launch(tile::plan_chains, dim3(count), dim3(1024), 0, descs, wk);
+    emu::launch(tile::sum_chains, dim3(tile::kPlanGroups, count), dim3(tile::kPlanThreads), 0, descs, wk);
+    emu::launch(tile::plan_chains, dim3(count), dim3(tile::kPlanThreads), 0, descs, wk);
+    emu::launch(tile::apply_chains, dim3(tile::kPlanGroups, count), dim3(tile::kPlanThreads), 0, descs, wk);
     if (pixel_mode)
         emu::launch(tile::sort_pixel_tiles<S>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_b, descs, wk);
     else
@@ -117,11 +120,12 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
             emu::launch(tile::compact_rare_runs<S, 1>, count_grid, dim3(64), 0, wk);
         else
             emu::launch(tile::compact_rare_runs<S, 0>, count_grid, dim3(64), 0, wk);
-        emu::launch(tile::walk_rare_context, settle_grid, dim3(64), 0, descs, wk, (uint32_t)count);
     }
+    const unsigned rare_blocks = p.interleave_mode != 2 ? settle_grid.x : 0u;
 #define EMU_RUN_CHAIN(ILV, FMT)                                                                                  \
     do                                                                                                           \
     {                                                                                                            \
+        emu::launch(tile::warm_run_jobs<S, ILV, FMT>, dim3(rare_blocks + lanes.x), dim3(64), 0, descs, wk, (uint32_t)count, (uint32_t)rare_blocks); \
         emu::launch(tile::walk_run_jobs<S, ILV, FMT>, lanes, dim3(64), 0, descs, wk, (uint32_t)count);          \
         emu::launch(tile::settle_runs<S, ILV, FMT>, settle_grid, dim3(64), 0, descs, wk, (uint32_t)count);       \
     } while (0)
