@@ -941,7 +941,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     {                                                                                                                    \
         hipLaunchKernelGGL((tile::warm_run_jobs<S, ILV, FMT>), dim3(rare_blocks + lanes.x), dim3(64), 0, runs_stream, descs, d_works, n, rare_blocks); \
         hipLaunchKernelGGL((tile::walk_run_jobs<S, ILV, FMT>), lanes, dim3(64), 0, runs_stream, descs, d_works, n);      \
-        hipLaunchKernelGGL((tile::settle_runs<S, ILV, FMT>), settle_grid, dim3(64), 0, runs_stream, descs, d_works, n);  \
+        hipLaunchKernelGGL((tile::settle_runs<S, ILV, FMT>), dim3(n), dim3(64), 0, runs_stream, descs, d_works, n);  \
     } while (0)
             if (!pixel_mode)
                 JLS_RUN_CHAIN(0, 0);
@@ -955,7 +955,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         }
         hip_check(hipEventRecord(runs_coded[pass], runs_stream));
         hipLaunchKernelGGL((tile::walk_jobs<S>), dim3(static_cast<uint32_t>((lay.max_jobs + 63) / 64), n), dim3(64), 0, s, descs, d_works);
-        hipLaunchKernelGGL((tile::settle_chains<S>), dim3((n * pipe::kChains + 63) / 64), dim3(64), 0, s, descs, d_works, n);
+        hipLaunchKernelGGL((tile::settle_chains<S>), dim3(pipe::kChains, n), dim3(64), 0, s, descs, d_works, n);
         hip_check(hipStreamWaitEvent(s, runs_coded[pass], 0));
         t.mark();
         if (overlap_stuffing && pass > 0)

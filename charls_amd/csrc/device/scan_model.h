@@ -519,6 +519,18 @@ JLS_DEV int run_k(const RunCtx& x) // src/run_mode_context.hpp:34-62 (k > 32 -> 
     return k;
 }
 
+// The same k for the states an ENCODER can be in (A, N >= 1 and the sum below 2^31: A grows by at most the largest mapped
+// error per event and is halved every RESET events), without the loop: N 2^k >= temp first holds for k = floor(log2 temp) -
+// floor(log2 N) or the k after it.  The walkers of the tile pipeline's run chain are one dependent chain per lane.
+JLS_DEV int run_k_of_encoder(const RunCtx& x)
+{
+    const uint32_t temp = (uint32_t)x.a + (uint32_t)(x.n >> 1) * (uint32_t)x.ritype, n = (uint32_t)x.n;
+    if (temp <= n)
+        return 0;
+    const int k = __builtin_clz(n) - __builtin_clz(temp);
+    return (n << k) < temp ? k + 1 : k;
+}
+
 JLS_DEV int run_map(const RunCtx& x, int e, int k) // src/run_mode_context.hpp:103-115
 {
     return (k == 0 && e > 0 && 2 * x.nn < x.n) || (e < 0 && 2 * x.nn >= x.n) || (e < 0 && k != 0);

@@ -1178,16 +1178,16 @@ __global__ void __launch_bounds__(64) walk_jobs(const ScanDesc* __restrict__ des
     w.jobs[job] = st;
 }
 
-// C2: grid (ceil(kChains * scans / 64)) x 64, one lane per (chain, scan), lanes of a wavefront = the same chain of
-// different scans.  A job whose predecessor did not end in the state the job assumed is walked again from the true state.
+// C2: grid (kChains, scans) x 64, a wavefront per (chain, scan).  The lanes compare every job's entry state with the state
+// its predecessor ended in, 64 boundaries at a time; only where one differs does lane 0 go through the chain job by job and
+// walk a job whose predecessor did not end in the state the job assumed again from the true state.  (A lane per chain
+// looked at its boundaries one after the other until the end of round 4: a trip to memory per job, 0.3 ms for the longest
+// chain of ONE frame.)
 template <typename S>
 __global__ void __launch_bounds__(64) settle_chains(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
 {
-    const uint32_t tid = blockIdx.x * 64u + threadIdx.x;
-    if (tid >= scans * (uint32_t)kChains)
-        return;
-    const uint32_t chain = tid / scans, frame = tid % scans;
-    if (chain == 0 || chain == (uint32_t)kInterruptChain)
+    const uint32_t chain = blockIdx.x, frame = blockIdx.y;
+    if (frame >= scans || chain == 0 || chain == (uint32_t)kInterruptChain)
         return;
     const ScanDesc d = descs[frame];
     const Work w = works[frame];
@@ -1198,6 +1198,33 @@ __global__ void __launch_bounds__(64) settle_chains(const ScanDesc* __restrict__
     const uint32_t n = w.chain_total[chain];
     const Slot<S>* in = rec_slots<S>(w) + w.chain_base[chain];
     Slot<S>* out = code_slots<S>(w) + w.chain_base[chain];
+    {
+        bool differs = false;
+        uint32_t any_bad = 0;
+        for (uint32_t j = j0 + threadIdx.x; j < j1; j += 64)
+        {
+            const JobState cur = w.jobs[j];
+            any_bad |= cur.bad;
+            if (j > j0)
+            {
+                const JobState before = w.jobs[j - 1];
+                differs = differs || cur.in_a != before.out_a || cur.in_b != before.out_b || cur.in_c != before.out_c;
+            }
+        }
+        const bool some_bad = __any(any_bad != 0);
+        if (!__any(differs))
+        { // (the ordinary case)
+            if (threadIdx.x == 0)
+            {
+                if (some_bad)
+                    atomicOr(w.status, kStatusInvalid);
+                atomicAdd(&w.counters[kCountJobs], j1 - j0);
+            }
+            return;
+        }
+        if (threadIdx.x != 0)
+            return;
+    }
     uint32_t bad = 0, rewalked = 0;
     JobState prev = w.jobs[j0];
     bad |= prev.bad;
@@ -1306,7 +1333,7 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
                     const int which = ILV == 2 ? 0 : RunRecord2::which(v);
                     const int err = shares ? RunRecord2::err(v) : interruption_err<S>(int_rec[own_slot]);
                     RunCtx ctx = which ? rc1 : rc0;
-                    const int k = run_k(ctx);
+                    const int k = run_k_of_encoder(ctx);
                     const int map = run_map(ctx, err, k);
                     const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - map;
                     const pipe::CodeWord cw = pipe::golomb_word(t, k, em, t.limit - jb - 1);
@@ -1356,7 +1383,7 @@ JLS_DEV void walk_runs(const Traits& t, const uint32_t* runs, uint32_t* run_code
             const int which = RunRecord<S>::which(v);
             const int err = RunRecord<S>::err(v);
             RunCtx ctx = which ? rc1 : rc0; // (selected by value: an indexed pair of records lives in scratch)
-            const int k = run_k(ctx);
+            const int k = run_k_of_encoder(ctx);
             const int map = run_map(ctx, err, k);
             const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - map;
             const pipe::CodeWord c = pipe::golomb_word(t, k, em, t.limit - jb - 1);
@@ -1583,9 +1610,7 @@ __global__ void __launch_bounds__(64) compact_rare_runs(const Work* __restrict__
     }
 }
 
-// One lane per scan: the context of the rarer interruption type, event by event (what a lane does per event -- k, the map
-// bit, the update -- is some 350 clocks of dependent arithmetic; fetching the values 64 at a time with a broadcast per
-// event was measured and is slower, 507 us against 397 for the test frame's 2200 events).
+// One lane per scan: the context of the rarer interruption type, event by event.
 JLS_DEV void walk_rare_context(const ScanDesc& d, const Work& w)
 {
     const Traits t = make_traits(d);
@@ -1605,7 +1630,7 @@ JLS_DEV void walk_rare_context(const ScanDesc& d, const Work& w)
         for (; i < upto; ++i)
         {
             const int err = rare[i];
-            const int k = run_k(ctx);
+            const int k = run_k_of_encoder(ctx);
             const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - run_map(ctx, err, k);
             run_update(ctx, err, em, t.reset);
         }
@@ -1697,11 +1722,12 @@ __global__ void __launch_bounds__(64) walk_run_jobs(const ScanDesc* __restrict__
     w.run_jobs[job] = mine;
 }
 
-// grid (ceil(scans / 64)) x 64: one lane per scan checks its jobs' boundaries.
+// grid (scans) x 64: a wavefront per scan checks its jobs' boundaries, 64 at a time; lane 0 goes through them one by one
+// only if one of them does not fit.
 template <typename S, int ILV, int FMT = 0>
 __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ descs, const Work* __restrict__ works, uint32_t scans)
 {
-    const uint32_t frame = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t frame = blockIdx.x;
     if (frame >= scans)
         return;
     const ScanDesc d = descs[frame];
@@ -1709,10 +1735,18 @@ __global__ void __launch_bounds__(64) settle_runs(const ScanDesc* __restrict__ d
     const Traits t = make_traits(d);
     const uint32_t n = w.chain_total[0];
     const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
-    if (jobs < 2)
     {
-        atomicAdd(&w.counters[kCountRunJobs], jobs);
-        return;
+        bool differs = false;
+        for (uint32_t j = 1 + threadIdx.x; j < jobs; j += 64)
+            differs = differs || !same_state(w.run_jobs[j].in, w.run_jobs[j - 1].out);
+        if (!__any(differs))
+        { // (the ordinary case)
+            if (threadIdx.x == 0)
+                atomicAdd(&w.counters[kCountRunJobs], jobs);
+            return;
+        }
+        if (threadIdx.x != 0)
+            return;
     }
     const uint32_t* runs = reinterpret_cast<const uint32_t*>(rec_slots<S>(w) + w.chain_base[0]);
     uint32_t* run_code = reinterpret_cast<uint32_t*>(code_slots<S>(w) + w.chain_base[0]);

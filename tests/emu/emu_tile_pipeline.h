@@ -107,7 +107,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     else
         emu::launch(tile::sort_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_b, descs, wk);
     emu::launch(tile::walk_jobs<S>, dim3((unsigned)((max_jobs + 63) / 64), count), dim3(64), 0, descs, wk);
-    emu::launch(tile::settle_chains<S>, dim3((count * pipe::kChains + 63) / 64), dim3(64), 0, descs, wk, (uint32_t)count);
+    emu::launch(tile::settle_chains<S>, dim3(pipe::kChains, count), dim3(64), 0, descs, wk, (uint32_t)count);
     const dim3 count_grid((unsigned)std::min<size_t>(max_run_jobs, 32), count), lanes((unsigned)((max_run_jobs * count + 63) / 64)), settle_grid((count + 63) / 64);
     if (pixel_mode)
         emu::launch(tile::count_runs<S, 1>, count_grid, dim3(64), 0, wk, plan.nc);
@@ -127,7 +127,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     {                                                                                                            \
         emu::launch(tile::warm_run_jobs<S, ILV, FMT>, dim3(rare_blocks + lanes.x), dim3(64), 0, descs, wk, (uint32_t)count, (uint32_t)rare_blocks); \
         emu::launch(tile::walk_run_jobs<S, ILV, FMT>, lanes, dim3(64), 0, descs, wk, (uint32_t)count);          \
-        emu::launch(tile::settle_runs<S, ILV, FMT>, settle_grid, dim3(64), 0, descs, wk, (uint32_t)count);       \
+        emu::launch(tile::settle_runs<S, ILV, FMT>, dim3((unsigned)count), dim3(64), 0, descs, wk, (uint32_t)count);       \
     } while (0)
     if (!pixel_mode)
         EMU_RUN_CHAIN(0, 0);
