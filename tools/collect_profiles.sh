@@ -31,6 +31,6 @@ python tools/one_frame_latency.py --decode > $out/one_frame_latency.txt 2>&1
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/one -o one -- python tools/one_frame_latency.py --calls 6 > $out/one.log 2>&1
 python tools/copy_probe.py > $out/copy_probe.txt 2>&1
 # the other BASELINE configurations (parity cases, not bench lines): EVERY row of DESIGN 6.3
-timeout 900 python tools/measure_configs.py --only 2,3,5a,5b,5c,5d,5e,6,6w > $out/other_configs.txt 2>&1
+timeout 900 python tools/measure_configs.py --only 2,3,5a,5b,5c,5d,5e,5p,6,6w > $out/other_configs.txt 2>&1
 find $out -name "*kernel_trace.csv" -size +8M -delete
 du -sh $out; find $out -type f | head -40
