@@ -29,15 +29,15 @@
 //   A  analyze_tiles   (planar scans whose lines fit a tile; every other scan: analyze_pixel_tiles, tile_pixel_mode.hip)
 //                      one workgroup per tile: chain id + sign of every sample (key, 2 B), run-mode segmentation as a
 //                      carry chain over ballot masks, events per (tile, chain)
-//   B1 plan_chains     per scan: exclusive prefix over tiles per chain -> where each tile's piece of each chain goes (in
-//                      slots); chain bases; jobs per chain
+//   B1 sum_chains / plan_chains / apply_chains   per scan: exclusive prefix over tiles per chain -> where each tile's piece
+//                      of each chain goes (in slots); chain bases; jobs per chain (the tiles in 64 groups, a workgroup each)
 //   B2 sort_tiles      (sort_pixel_tiles) one workgroup per tile: stable ranks through LDS mask tables, records into LDS in
 //                      (chain, line, column) order, out as pieces; key -> tile-local slot
 //   C1 walk_jobs       one LANE per job: warm-up, then record -> code word, in chain order
-//   C2 settle_chains   one lane per chain: job boundaries checked, disagreeing jobs re-walked
-//   C3 count_runs / scan_runs / compact_rare_runs / walk_rare_context / walk_run_jobs / settle_runs   the run chain (RUNindex,
+//   C2 settle_chains   one wavefront per chain: job boundaries checked 64 at a time, disagreeing jobs re-walked
+//   C3 count_runs / scan_runs / compact_rare_runs / warm_run_jobs / walk_run_jobs / settle_runs   the run chain (RUNindex,
 //                      the two run-interruption contexts) cut into jobs like the regular chains; the context of the rarer
-//                      interruption type is computed exactly
+//                      interruption type is computed exactly, beside the jobs' warm-ups
 //   D  pack_tiles      one workgroup per tile: the tile's codes back into LDS piece by piece, gathered in raster order
 //                      through the 2-byte slots, concatenated MSB-first; bit offset of a tile by chained look-back
 //   E  stuff_scan (pipeline_common.hip) / speculative_stuffing.hip / block_stuffing.hip
@@ -1610,7 +1610,10 @@ __global__ void __launch_bounds__(64) compact_rare_runs(const Work* __restrict__
     }
 }
 
-// One lane per scan: the context of the rarer interruption type, event by event.
+// One lane per scan: the context of the rarer interruption type, event by event.  Three ways of fetching the values ahead of
+// their use were measured and are all SLOWER than this loop (0.48 ms for the test frame): 64 at a time with a broadcast per
+// event (0.51), eight at a time in registers with the jobs' counts one job ahead (0.58), 1024 at a time through LDS (0.64) --
+// the loop is not waiting for memory.
 JLS_DEV void walk_rare_context(const ScanDesc& d, const Work& w)
 {
     const Traits t = make_traits(d);
