@@ -120,6 +120,9 @@ void launch_place_scan_header(uint8_t* slots, uint64_t slot_pitch, const uint8_t
                               FrameCursorPod* cursors, ScanDesc* descs, uint32_t frames, hipStream_t stream);
 void launch_advance_cursor(FrameCursorPod* cursors, const ScanResult* results, uint32_t header_size, uint32_t frames,
                            hipStream_t stream);
+// Where the entropy-coded segments that start at searches[k].from end (the first marker that is not a restart marker;
+// kNoMarker: none before searches[k].end): the batch decoder's way from one component scan of a planar frame to the next.
+void launch_find_scan_end(const uint8_t* slots, const MarkerSearch* searches, unsigned long long* found, uint32_t count, hipStream_t stream);
 void launch_place_plane_scans(uint8_t* slots, uint64_t slot_pitch, const uint8_t* headers, uint32_t header_size, uint32_t rounds,
                               const uint8_t* private_streams, uint64_t capacity, const ScanResult* results, FrameCursorPod* cursors,
                               uint32_t* redo, uint32_t frames, hipStream_t stream);

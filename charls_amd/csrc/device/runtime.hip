@@ -1230,6 +1230,12 @@ void launch_place_plane_scans(uint8_t* slots, uint64_t slot_pitch, const uint8_t
     hip_check(hipGetLastError());
 }
 
+void launch_find_scan_end(const uint8_t* slots, const MarkerSearch* searches, unsigned long long* found, uint32_t count, hipStream_t stream)
+{
+    hipLaunchKernelGGL(find_scan_end, dim3(count), dim3(256), 0, stream, slots, searches, found);
+    hip_check(hipGetLastError());
+}
+
 void launch_place_epilogue(uint8_t* slots, uint64_t slot_pitch, FrameCursorPod* cursors, bool even_size, uint64_t* sizes,
                            uint32_t* errcs, uint32_t frames, hipStream_t stream)
 {

@@ -54,4 +54,11 @@ struct Traits
     int32_t maxval, near, range, qbpp, limit, t1, t2, t3, reset, bpp;
 };
 
+// find_scan_end (container_kernels.hip): the stretch of a batch's stream slots to search, as offsets from the first slot.
+struct MarkerSearch
+{
+    uint64_t from, end; // offsets from the first slot
+};
+constexpr unsigned long long kNoMarker = ~0ull;
+
 } // namespace jls

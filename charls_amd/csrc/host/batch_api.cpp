@@ -39,81 +39,6 @@ __global__ void gather_windows(const uint8_t* __restrict__ slots, const WindowSp
         dst[b] = src[b];
 }
 
-// Where the entropy-coded segment that starts at `from` ends: the first 0xFF that is followed by a byte with its high
-// bit set and is not a restart marker (inside a segment the byte after a 0xFF starts with a stuffed zero bit, T.87 A.1 /
-// src/jpeg_stream_reader.cpp: read_next_marker_code).  One workgroup per stream, 16 KB per trip, first position by atomicMin.
-struct MarkerSearch
-{
-    uint64_t from, end; // offsets from the first slot
-};
-constexpr unsigned long long kNoMarker = ~0ull;
-struct __attribute__((packed)) UnalignedU64
-{
-    uint64_t v;
-};
-__device__ inline bool ends_segment(uint32_t byte, uint32_t next)
-{
-    return byte == 0xFFu && next >= 0x80u && !(next >= 0xD0u && next <= 0xD7u);
-}
-__global__ void __launch_bounds__(256) find_scan_end(const uint8_t* __restrict__ slots, const MarkerSearch* __restrict__ specs,
-                                                     unsigned long long* __restrict__ found)
-{
-    __shared__ unsigned long long first;
-    const MarkerSearch s = specs[blockIdx.x];
-    if (threadIdx.x == 0)
-        first = kNoMarker;
-    __syncthreads();
-    constexpr uint64_t kPer = 64; // bytes of a thread per trip: a 0xFF at [at, at + kPer) is this thread's, its follower is read with it
-    for (uint64_t base = s.from; base < s.end; base += 256 * kPer)
-    {
-        const uint64_t at = base + threadIdx.x * kPer;
-        if (at + kPer + 8 <= s.end)
-        { // eight bytes at a time (gfx950 takes the loads at any address); words without a 0xFF byte are passed over
-            uint64_t v[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j)
-                v[j] = reinterpret_cast<const UnalignedU64*>(slots + at + 8 * j)->v;
-            bool mine = false;
-#pragma unroll
-            for (int j = 0; j < 8 && !mine; ++j)
-            {
-                const uint64_t inv = ~v[j];
-                if (((inv - 0x0101010101010101ull) & ~inv & 0x8080808080808080ull) == 0)
-                    continue; // (no byte of v[j] is 0xFF)
-                const uint64_t after = (v[j] >> 8) | (v[j + 1] << 56);
-                for (int q = 0; q < 8; ++q)
-                    if (ends_segment((uint32_t)(v[j] >> (8 * q)) & 0xFFu, (uint32_t)(after >> (8 * q)) & 0xFFu))
-                    {
-                        atomicMin(&first, static_cast<unsigned long long>(at + 8 * j + q));
-                        mine = true;
-                        break;
-                    }
-            }
-        }
-        else if (at + 1 < s.end)
-        { // the last bytes of the stream, one by one
-            const uint64_t last = at + kPer < s.end - 1 ? at + kPer : s.end - 1;
-            uint32_t byte = slots[at];
-            for (uint64_t q = at; q < last; ++q)
-            {
-                const uint32_t next = slots[q + 1];
-                if (ends_segment(byte, next))
-                {
-                    atomicMin(&first, static_cast<unsigned long long>(q));
-                    break;
-                }
-                byte = next;
-            }
-        }
-        __syncthreads();
-        if (first != kNoMarker)
-            break; // (every thread reads the same value: nothing writes between the two barriers of a trip)
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        found[blockIdx.x] = first;
-}
-
 struct EventTimer
 {
     hipEvent_t a{}, b{};
@@ -718,9 +643,7 @@ try
             d_search.ensure(sizeof(MarkerSearch) * n);
             d_found.ensure(sizeof(unsigned long long) * n);
             hip_check(hipMemcpyAsync(d_search.as<MarkerSearch>(), search, sizeof(MarkerSearch) * n, hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL(find_scan_end, dim3(static_cast<uint32_t>(n)), dim3(256), 0, stream, slots, d_search.as<const MarkerSearch>(),
-                               d_found.as<unsigned long long>());
-            hip_check(hipGetLastError());
+            dev::launch_find_scan_end(slots, d_search.as<const MarkerSearch>(), d_found.as<unsigned long long>(), static_cast<uint32_t>(n), stream);
             hip_check(hipMemcpyAsync(found, d_found.as<unsigned long long>(), sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, stream));
             hip_check(hipStreamSynchronize(stream));
             std::vector<uint32_t> which;

@@ -15,6 +15,7 @@ thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 #include "../../charls_amd/csrc/device/scan_group_pixels.hip"
 #include "../../charls_amd/csrc/device/scan_group_encode.hip"
 #include "../../charls_amd/csrc/device/restart_intervals.hip"
+#include "../../charls_amd/csrc/device/container_kernels.hip"
 #include "emu_tile_pipeline.h"
 
 #include <algorithm>
@@ -321,5 +322,25 @@ void emu_encode_with_restart_intervals(const jls::ScanDesc* parents, jls::ScanRe
     emu_join_intervals(parents, subs.data(), intervals, sub_results.data(), offsets.data(), results, count);
 }
 
+// container_kernels.hip: the marker that ends an entropy-coded segment (the batch decoder's way from one component scan of
+// a planar frame to the next), for `count` stretches of one buffer.
+void emu_find_scan_end(const uint8_t* slots, const uint64_t* from_end_pairs, unsigned long long* found, int count)
+{
+    emu::launch(jls::find_scan_end, dim3(count), dim3(256), 0, slots, reinterpret_cast<const jls::MarkerSearch*>(from_end_pairs), found);
+}
+
+// container_kernels.hip: the component scans of planar frames, coded into private buffers, put in place behind their SOS
+// headers (place_plane_scans + advance_plane_cursors).  cursors: {offset, errc} pairs of 64 bits + 2 x 32 bits per frame.
+void emu_place_plane_scans(uint8_t* slots, uint64_t slot_pitch, const uint8_t* headers, uint32_t header_size, uint32_t rounds,
+                           const uint8_t* private_streams, uint64_t capacity, const jls::ScanResult* results, void* cursors,
+                           uint32_t* redo, uint32_t frames)
+{
+    auto* c = static_cast<jls::FrameCursor*>(cursors);
+    emu::launch(jls::place_plane_scans, dim3(frames * rounds, jls::kPlaceShares), dim3(256), 0, slots, slot_pitch, headers, header_size, rounds,
+                private_streams, capacity, results, (const jls::FrameCursor*)c);
+    emu::launch(jls::advance_plane_cursors, dim3((frames + 63) / 64), dim3(64), 0, slot_pitch, header_size, rounds, results, c, redo, frames);
+}
+
+size_t emu_sizeof_scan_result() { return sizeof(jls::ScanResult); }
 size_t emu_sizeof_scan_desc() { return sizeof(jls::ScanDesc); }
 }

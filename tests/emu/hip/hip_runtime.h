@@ -216,6 +216,15 @@ inline T atomicMax(T* p, T v)
     return old;
 }
 template <typename T>
+inline T atomicMin(T* p, T v)
+{
+    T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST))
+    {
+    }
+    return old;
+}
+template <typename T>
 inline T atomicExch(T* p, T v)
 {
     return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST);
