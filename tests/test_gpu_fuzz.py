@@ -90,3 +90,44 @@ def test_mutated_streams_decode_like_the_oracle(lib, name):
             mismatches.append((k, want[0], want[1] if want[0] == "err" else len(want[1]), got[0],
                                got[1] if got[0] == "err" else len(got[1])))
     assert not mismatches, mismatches
+
+
+@pytest.mark.parametrize("restart", [0, 6])
+def test_mutated_planar_streams_through_the_batch_decoder(lib, monkeypatch, restart):
+    """The batch decoder finds the component scans of planar frames by searching for the marker that ends each of them and
+    decodes them by one launch; a frame for which anything is out of the ordinary is decoded again scan by scan.  Eighty
+    mutated planar RGB streams in ONE batch: every frame's error code equals what part 1 (one stream through the C ABI)
+    and the scan-by-scan batch decoder report for it, and its pixels are the oracle's wherever the oracle decodes it."""
+    import torch
+    from charls_amd import batch
+    w, h, n = 48, 20, 80
+    rgb = np.stack([synth.frame_numpy(w, h, seed=23 + c, kind="mixed") for c in range(3)])  # planar
+    base = lib.encode(rgb, component_count=3, restart_interval=restart) if restart else ob.encode(rgb, width=w, height=h, component_count=3)
+    base = bytes(base)
+    start = jls_container.parse(base).scans[0].data_start
+    rng = np.random.default_rng(77 + restart)
+    streams = [base] + [_mutate(rng, base, start) for _ in range(n - 1)]
+    pitch = max(len(s) for s in streams) + 16
+    host = np.zeros((n, pitch), dtype=np.uint8)
+    for f, s in enumerate(streams):
+        host[f, :len(s)] = np.frombuffer(s, dtype=np.uint8)
+    sizes = np.array([len(s) for s in streams], dtype=np.uint64)
+    dev = torch.from_numpy(host).cuda()
+    out_a = torch.zeros((n, 3, h, w), dtype=torch.uint8, device="cuda")
+    out_b = torch.zeros_like(out_a)
+    monkeypatch.delenv("CHARLS_AMD_BATCH_ROUNDS", raising=False)
+    _, errcs_a, _ = batch.decode_batch(dev, sizes, out_a)
+    monkeypatch.setenv("CHARLS_AMD_BATCH_ROUNDS", "1")
+    _, errcs_b, _ = batch.decode_batch(dev, sizes, out_b)
+    monkeypatch.delenv("CHARLS_AMD_BATCH_ROUNDS", raising=False)
+    assert list(errcs_a) == list(errcs_b)
+    assert errcs_a[0] == 0 and (errcs_a != 0).sum() > 10 and (errcs_a == 0).sum() > 3  # (the mutations do both)
+    mismatches = []
+    for f, s in enumerate(streams):
+        part1 = _outcome(lib.decode, s)
+        want = _outcome(ob.decode, s)
+        if (part1[1] if part1[0] == "err" else 0) != int(errcs_a[f]):
+            mismatches.append((f, "errc", part1, int(errcs_a[f])))
+        elif want[0] == "ok" and (errcs_a[f] != 0 or out_a[f].cpu().numpy().tobytes() != want[1] or not torch.equal(out_a[f], out_b[f])):
+            mismatches.append((f, "pixels", int(errcs_a[f])))
+    assert not mismatches, mismatches
