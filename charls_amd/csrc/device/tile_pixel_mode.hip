@@ -147,6 +147,52 @@ struct __attribute__((packed)) UnalignedU32
     uint32_t v;
 };
 
+// Line-interleaved scans: the staged rows are COMPONENTS of pixel rows (coded line L = component L % components of pixel row
+// L / components), so every source pixel under the tile is loaded and colour-transformed ONCE and its components go to the
+// staged rows they belong to (pixel by pixel -- stage_pixel_rows_generic -- every staged sample loaded a whole pixel and
+// transformed it: 2.5 pixels per coded sample for a tile of two lines and the three lines above them).
+template <typename S>
+JLS_DEV void stage_line_interleaved_rows(const ScanDesc& d, const PixelTile& g, S* rows, int mask)
+{
+    const uint32_t comps = g.step;                            // (the distance to the line above IS the number of components)
+    const int64_t first = (int64_t)g.first_line - (int64_t)g.step; // coded line of staged row 0; lines above the scan are zeros
+    const uint32_t R = g.tile_lines + g.step;
+    const uint32_t a = g.px0 > 0 ? g.px0 - 1 : 0;             // first and last pixel of a row that are real neighbours in memory
+    const uint32_t b = g.px0 + g.pixels < d.width ? g.px0 + g.pixels : d.width - 1;
+    const uint32_t per = b - a + 1;
+    const uint32_t zero_rows = first < 0 ? (uint32_t)(-first) : 0u; // (a multiple of the components or the whole margin above line 0)
+    for (uint32_t i = threadIdx.x; i < zero_rows * g.slots; i += blockDim.x)
+        rows[i] = 0;
+    const uint32_t y0 = first > 0 ? (uint32_t)first / comps : 0u;
+    const uint32_t y1 = (uint32_t)(first + (int64_t)R - 1) / comps;
+    for (uint32_t i = threadIdx.x; i < (y1 - y0 + 1) * per; i += blockDim.x)
+    {
+        const uint32_t y = y0 + i / per, x = a + i % per;
+        int px[4];
+        pipe::load_pixel<S>(d, y, x, mask, px);
+        for (uint32_t c = 0; c < comps; ++c)
+        {
+            const int64_t r = (int64_t)y * comps + c - first;
+            if (r >= 0 && r < (int64_t)R)
+                rows[(size_t)r * g.slots + (x + 1 - g.px0)] = (S)(c == 0 ? px[0] : c == 1 ? px[1] : c == 2 ? px[2] : px[3]);
+        }
+    }
+    if (threadIdx.x < 2 * R)
+    { // the margins at the edges of the scan: left of pixel 0 sits pixel 0 of the line above, right of the last pixel that pixel again
+        const uint32_t row = threadIdx.x / 2;
+        const bool right = (threadIdx.x & 1u) != 0;
+        const int64_t line = first + row;
+        if (right ? g.px0 + g.pixels == d.width : g.px0 == 0)
+        {
+            const int64_t from_line = right ? line : line - (int64_t)g.step;
+            int px[4] = {0, 0, 0, 0};
+            if (from_line >= 0)
+                load_coded_pixel<S>(d, (uint32_t)from_line, right ? d.width - 1 : 0u, mask, px);
+            rows[(size_t)row * g.slots + (right ? g.slots - 1 : 0u)] = (S)px[0];
+        }
+    }
+}
+
 // Planar and sample-interleaved scans: the pixels of a staged row are the bytes of the source row, so they come as whole
 // words (gfx950 takes a 4-byte global load at any address; the LDS side is kept aligned: up to three bytes at either end
 // of a row go one by one), masked to the sample precision on the way; a colour transform then runs over the staged pixels
@@ -157,7 +203,7 @@ JLS_DEV void stage_pixel_rows(const ScanDesc& d, const PixelTile& g, S* rows, in
 {
     if (d.interleave_mode == 1)
     {
-        stage_pixel_rows_generic<S>(d, g, rows, mask);
+        stage_line_interleaved_rows<S>(d, g, rows, mask);
         return;
     }
     const uint32_t pb = g.nc * (uint32_t)sizeof(S), row_bytes = g.slots * pb;
