@@ -147,6 +147,7 @@ Timings& last_timings() noexcept;
 
 // Process-wide totals of what the speculative stages of the lossless encoder did (tile_pipeline.hip, tile::Counter):
 // regular-chain jobs, how many of them were walked again by the settling lane, the same two for the run chain.
-void speculation_counters(uint64_t out[4]) noexcept;
+constexpr int tile_counter_count = 6; // tile::kCounters
+void speculation_counters(uint64_t out[tile_counter_count]) noexcept;
 
 } // namespace jls::dev

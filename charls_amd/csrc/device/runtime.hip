@@ -126,11 +126,11 @@ Timings& last_timings() noexcept
 }
 
 namespace {
-std::atomic<uint64_t> g_speculation[4]{};
+std::atomic<uint64_t> g_speculation[tile_counter_count]{};
 }
-void speculation_counters(uint64_t out[4]) noexcept
+void speculation_counters(uint64_t out[tile_counter_count]) noexcept
 {
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < tile_counter_count; ++i)
         out[i] = g_speculation[i].load();
 }
 
@@ -692,7 +692,7 @@ struct TileLayout
 {
     tile::TilePlan plan;
     size_t samples, lines, raw_bytes, max_jobs, max_run_jobs;
-    uint32_t lines_per_tile, tiles, job_events, warm_events, run_job_events, run_warm_events;
+    uint32_t lines_per_tile, tiles, job_events, warm_events, run_job_events, run_warm_events, rare_warm_events;
     size_t off_keyinv, off_seg, off_total, off_base, off_jobfirst, off_planpart, off_rec, off_code, off_jobs, off_runjobs, off_bbase, off_raw,
         off_bits, off_status, off_stuff, bytes;
     TileLayout(const ScanDesc& d, size_t capacity_hint, uint32_t count)
@@ -723,6 +723,9 @@ struct TileLayout
         run_job_events = env_run_job ? static_cast<uint32_t>(std::max(32, std::atoi(env_run_job)) / 32 * 32) : run_job_default;
         run_warm_events = env_run_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_warm))) : (run_job_default == 128u ? 1024u : 2048u);
         max_run_jobs = samples / run_job_events + 2; // (+ the entry of the totals)
+        // the exact walk of the rarer run context: events of that type a lane walks before its segment of the list
+        const char* env_rare_warm = std::getenv("CHARLS_AMD_RARE_WARM_EVENTS");
+        rare_warm_events = env_rare_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_rare_warm))) : 512u;
         const size_t worst = worst_case_scan_bytes(plan.line_samples, static_cast<uint32_t>(lines), 1, d.bits_per_sample);
         raw_bytes = align_up((capacity_hint < worst ? capacity_hint : worst) + 64, 16);
         size_t o = 0;
@@ -865,6 +868,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
             w.run_jobs = reinterpret_cast<tile::RunJob*>(base + lay.off_runjobs);
             w.run_job_events = lay.run_job_events;
             w.run_warm_events = lay.run_warm_events;
+            w.rare_warm_events = lay.rare_warm_events;
             w.blockbase = reinterpret_cast<uint64_t*>(base + lay.off_bbase);
             w.tile_tail = reinterpret_cast<uint64_t*>(base + lay.off_bbase) + lay.tiles;
             w.raw = reinterpret_cast<uint32_t*>(base + lay.off_raw);
@@ -922,7 +926,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         {
             const uint32_t run_jobs = static_cast<uint32_t>(lay.max_run_jobs);
             const dim3 lanes((static_cast<uint64_t>(run_jobs) * n + 63) / 64);
-            const dim3 count_grid(std::min<uint32_t>(run_jobs, std::max<uint32_t>(32, 4096 / n)), n), settle_grid((n + 63) / 64);
+            const dim3 count_grid(std::min<uint32_t>(run_jobs, std::max<uint32_t>(32, 4096 / n)), n);
             if (pixel_mode)
                 hipLaunchKernelGGL((tile::count_runs<S, 1>), count_grid, dim3(64), 0, runs_stream, d_works, plan.nc);
             else
@@ -935,7 +939,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
                 else
                     hipLaunchKernelGGL((tile::compact_rare_runs<S, 0>), count_grid, dim3(64), 0, runs_stream, d_works);
             }
-            const uint32_t rare_blocks = proto.interleave_mode != 2 ? settle_grid.x : 0u; // (the walk of the rarer context rides with the warm-ups)
+            const uint32_t rare_blocks = proto.interleave_mode != 2 ? n : 0u; // (the walk of the rarer context rides with the warm-ups: a wavefront per scan)
 #define JLS_RUN_CHAIN(ILV, FMT)                                                                                          \
     do                                                                                                                   \
     {                                                                                                                    \
@@ -998,6 +1002,7 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     }
     if (overlap_stuffing)
         hip_check(hipStreamWaitEvent(stream, stuffed[passes - 1], 0));
+    static_assert(tile::kCounters == tile_counter_count, "runtime.h: tile_counter_count");
     uint32_t counters[tile::kCounters] = {};
     hip_check(hipMemcpyAsync(counters, d_counters, sizeof counters, hipMemcpyDeviceToHost, stream));
     hip_check(hipStreamSynchronize(stream)); // the host copies of the work descriptors and the timers go out of scope

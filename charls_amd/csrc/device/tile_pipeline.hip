@@ -118,7 +118,9 @@ enum Counter : uint32_t
     kCountJobsRewalked = 1,
     kCountRunJobs = 2,
     kCountRunJobsRewalked = 3,
-    kCounters = 4
+    kCountRareSegments = 4, // segments of the rarer run context's event lists that started from a guessed state
+    kCountRareSerial = 5,   // scans whose list had to be walked again, serially, because a guess was wrong
+    kCounters = 6
 };
 // Debug build (-DJLS_PHASE_CLOCKS, tools/phase_clocks.sh): the shader clocks every wavefront of the tile kernels
 // of every 64th workgroup spends between the marks (all of them queue up behind their own atomics), summed per mark in 64-bit words behind the counters of the call -- which phase of a kernel the
@@ -175,6 +177,7 @@ struct Work
     // lines than the launch was sized for -- the last restart interval of a frame -- and then has fewer tiles)
     uint32_t lines_per_tile, tiles, job_events, warm_events;
     uint32_t run_job_events, run_warm_events; // (run_job_events: a multiple of 8)
+    uint32_t rare_warm_events;                // walk_rare_context: events OF THE RARER TYPE a lane walks before its segment
     // lines that do not fit a tile are cut into segs_per_line tiles of seg_pixels pixels (a multiple of 64; the last one
     // shorter), lines_per_tile is then 1; otherwise segs_per_line = 1.  tile_capacity: samples of a tile at most.
     uint32_t segs_per_line, seg_pixels, tile_capacity;
@@ -1610,18 +1613,12 @@ __global__ void __launch_bounds__(64) compact_rare_runs(const Work* __restrict__
     }
 }
 
-// One lane per scan: the context of the rarer interruption type, event by event.  Three ways of fetching the values ahead of
-// their use were measured and are all SLOWER than this loop (0.48 ms for the test frame): 64 at a time with a broadcast per
-// event (0.51), eight at a time in registers with the jobs' counts one job ahead (0.58), 1024 at a time through LDS (0.64) --
-// the loop is not waiting for memory.
-JLS_DEV void walk_rare_context(const ScanDesc& d, const Work& w)
+// The context of the rarer interruption type, exactly, event by event: ONE lane walking a scan's events from the first to
+// the last.  (Three ways of fetching the values ahead of their use were measured and are all SLOWER than this loop -- 0.48 ms
+// for the test frame: 64 at a time with a broadcast per event 0.51, eight at a time in registers with the jobs' counts one job
+// ahead 0.58, 1024 at a time through LDS 0.64 -- the loop is not waiting for memory.)
+JLS_DEV void walk_rare_context_serially(const Traits& t, const Work& w, uint32_t jobs, bool rare1)
 {
-    const Traits t = make_traits(d);
-    const uint32_t n = w.chain_total[0];
-    const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
-    if (jobs == 0)
-        return;
-    const bool rare1 = rarer_is_type1(w, jobs);
     const int32_t* rare = reinterpret_cast<const int32_t*>(w.code);
     RunCtx ctx{rare1 ? 1 : 0, initial_a(t), 1, 0};
     uint32_t i = 0;
@@ -1640,8 +1637,90 @@ JLS_DEV void walk_rare_context(const ScanDesc& d, const Work& w)
     }
 }
 
+// A wavefront per scan.  Counted in ITS OWN events this context forgets as fast as any other (A and Nn are halved every
+// RESET events of the type; N is a function of the event's index): it is the run events between them that made a warm-up
+// expensive.  So the gathered list is cut into segments of at least kRareSegment events, a lane each, every lane warms up over
+// w.rare_warm_events events of the list before its segment and notes the state its jobs start in; then every lane's entry
+// state is compared with the state its predecessor ended in, and if one differs, lane 0 walks the whole list again, serially
+// -- the result is exact either way.
+constexpr uint32_t kRareSegment = 128;
+JLS_DEV void walk_rare_context(const ScanDesc& d, const Work& w)
+{
+    const uint32_t lane = threadIdx.x;
+    const Traits t = make_traits(d);
+    const uint32_t n = w.chain_total[0];
+    const uint32_t jobs = (n + w.run_job_events - 1) / w.run_job_events;
+    if (jobs == 0)
+        return;
+    const bool rare1 = rarer_is_type1(w, jobs);
+    auto starts_at = [&](uint32_t j) -> uint32_t { return rare1 ? w.run_jobs[j].type1 : w.run_jobs[j].type0; }; // events of the type before job j (entry `jobs`: all)
+    const uint32_t total = starts_at(jobs);
+    const uint32_t per_lane = (total + 63) / 64;
+    const uint32_t segment = per_lane > kRareSegment ? per_lane : kRareSegment;
+    const uint32_t s = lane * segment < total ? lane * segment : total;
+    const uint32_t e = s + segment < total ? s + segment : total;
+    const bool active = lane == 0 || s < total; // (lane 0 has the jobs of a scan without events of the type)
+    const bool last = e == total;               // the jobs that start behind the last event are this lane's too
+    const int32_t* rare = reinterpret_cast<const int32_t*>(w.code);
+    const uint32_t warm_from = s > w.rare_warm_events ? s - w.rare_warm_events : 0u;
+    RunCtx ctx{rare1 ? 1 : 0, initial_a(t), chain_n_before(warm_from, (uint32_t)t.reset), 0};
+    auto one = [&](uint32_t i) {
+        const int err = rare[i];
+        const int k = run_k_of_encoder(ctx);
+        const int em = 2 * (err < 0 ? -err : err) - ctx.ritype - run_map(ctx, err, k);
+        run_update(ctx, err, em, t.reset);
+    };
+    int in_a = 0, in_nn = 0;
+    if (active)
+    {
+        for (uint32_t i = warm_from; i < s; ++i)
+            one(i);
+        in_a = ctx.a;
+        in_nn = ctx.nn;
+        // the first job that starts at or behind event s (the counts do not decrease from job to job)
+        uint32_t lo = 0, hi = jobs;
+        while (lo < hi)
+        {
+            const uint32_t mid = (lo + hi) / 2;
+            if (starts_at(mid) < s)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        uint32_t j = lo, next = j < jobs ? starts_at(j) : ~0u;
+        for (uint32_t i = s;; ++i)
+        {
+            while (j < jobs && next == i && (i < e || last))
+            { // job j starts before event i of the type: it finds the context as it is now
+                w.run_jobs[j].rare_a = ctx.a;
+                w.run_jobs[j].rare_nn = ctx.nn;
+                ++j;
+                next = j < jobs ? starts_at(j) : ~0u;
+            }
+            if (i >= e)
+                break;
+            one(i);
+        }
+    }
+    // does every segment start in the state the one before it ended in?  (N is right by construction.)
+    const int before_a = __shfl_up(ctx.a, 1), before_nn = __shfl_up(ctx.nn, 1);
+    const bool differs = active && lane != 0 && (in_a != before_a || in_nn != before_nn);
+    const unsigned long long guessed = __ballot(active && lane != 0);
+    const bool again = __any(differs);
+    if (lane == 0)
+    {
+        if (guessed)
+            atomicAdd(&w.counters[kCountRareSegments], (uint32_t)__popcll(guessed));
+        if (again)
+        {
+            atomicAdd(&w.counters[kCountRareSerial], 1u);
+            walk_rare_context_serially(t, w, jobs, rare1);
+        }
+    }
+}
+
 // The run chain's two speculative ingredients in ONE launch, side by side: the first `rare_blocks` wavefronts walk the
-// context of the rarer interruption type (a lane per scan, exact), the others warm up a job each (a lane per (job, scan):
+// context of the rarer interruption type (a wavefront per scan, exact), the others warm up a job each (a lane per (job, scan):
 // RUNindex and the context of the more frequent type from run_warm_events events before the job -- what the rarer
 // context is meanwhile does not matter to either, and the job takes it from the exact walk afterwards).  The two were one
 // after the other until the end of round 4: 0.4 ms each of the 2.7 ms ONE frame took.
@@ -1652,9 +1731,7 @@ __global__ void __launch_bounds__(64) warm_run_jobs(const ScanDesc* __restrict__
 {
     if (blockIdx.x < rare_blocks)
     {
-        const uint32_t frame = blockIdx.x * 64u + threadIdx.x;
-        if (frame < scans)
-            walk_rare_context(descs[frame], works[frame]);
+        walk_rare_context(descs[blockIdx.x], works[blockIdx.x]);
         return;
     }
     const uint32_t tid = (blockIdx.x - rare_blocks) * 64u + threadIdx.x;

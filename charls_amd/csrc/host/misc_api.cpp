@@ -172,10 +172,10 @@ uint64_t charls_amd_work_area_bytes(void)
 
 int32_t charls_amd_speculation_counters(uint64_t* out, int32_t capacity)
 {
-    uint64_t v[4];
+    uint64_t v[dev::tile_counter_count];
     dev::speculation_counters(v);
     int32_t n = 0;
-    for (; out != nullptr && n < capacity && n < 4; ++n)
+    for (; out != nullptr && n < capacity && n < dev::tile_counter_count; ++n)
         out[n] = v[n];
     return n;
 }

@@ -441,8 +441,10 @@ CHARLS_AMD_API int32_t charls_amd_last_timings(double* out, int32_t capacity);
  * their predecessors afterwards; a job whose guess was wrong is coded again from the true state, so the bytes
  * never depend on the guesses -- only the time does.  Process-wide totals since the library was loaded:
  * out[0] jobs of the regular chains, out[1] how many of them were coded again, out[2] / out[3] the same for the run
- * chain.  Frames whose jobs are mostly coded again (full-range noise) encode at the speed of one lane per chain: a caller
- * can tell from these counters.  Returns the number of values written (4 at most). */
+ * chain; out[4] segments of the event lists of the rarer run-interruption context that were walked from a guessed state,
+ * out[5] scans whose list was walked again serially because such a guess was wrong.  Frames whose jobs are mostly coded
+ * again (full-range noise) encode at the speed of one lane per chain: a caller can tell from these counters.  Returns the
+ * number of values written (6 at most). */
 CHARLS_AMD_API int32_t charls_amd_speculation_counters(uint64_t* out, int32_t capacity);
 
 /* 0 when a gfx950 device is usable, otherwise CHARLS_AMD_ERRC_DEVICE_UNAVAILABLE. */

@@ -30,7 +30,6 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
     const uint32_t tiles = plan.tiles;
     const size_t max_jobs = samples / job_events + pipe::kChains;
     const size_t max_run_jobs = samples / run_job_events + 2;
-    (void)run_long_warm_events; // (the long warm-up of the rarer run context is gone: walk_rare_context computes it exactly)
     std::vector<tile::Work> works(count);
     std::vector<pipe::Work> stuff(count);
     std::vector<void*> allocs;
@@ -64,6 +63,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         w.run_jobs = (tile::RunJob*)galloc(max_run_jobs * sizeof(tile::RunJob));
         w.run_job_events = run_job_events;
         w.run_warm_events = run_warm_events;
+        w.rare_warm_events = run_long_warm_events; // (the third knob of the run chain: the warm-up of the exact walk's segments)
         uint8_t* pack_state = (uint8_t*)zalloc((size_t)tiles * 16 + 16);
         w.blockbase = (uint64_t*)pack_state;
         w.tile_tail = w.blockbase + tiles;
@@ -108,7 +108,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         emu::launch(tile::sort_tiles<S, 0>, dim3(tiles_grid, count), dim3(tile::kThreads), lds_b, descs, wk);
     emu::launch(tile::walk_jobs<S>, dim3((unsigned)((max_jobs + 63) / 64), count), dim3(64), 0, descs, wk);
     emu::launch(tile::settle_chains<S>, dim3(pipe::kChains, count), dim3(64), 0, descs, wk, (uint32_t)count);
-    const dim3 count_grid((unsigned)std::min<size_t>(max_run_jobs, 32), count), lanes((unsigned)((max_run_jobs * count + 63) / 64)), settle_grid((count + 63) / 64);
+    const dim3 count_grid((unsigned)std::min<size_t>(max_run_jobs, 32), count), lanes((unsigned)((max_run_jobs * count + 63) / 64));
     if (pixel_mode)
         emu::launch(tile::count_runs<S, 1>, count_grid, dim3(64), 0, wk, plan.nc);
     else
@@ -121,7 +121,7 @@ static void emu_tile_pipeline(const jls::ScanDesc* descs, jls::ScanResult* resul
         else
             emu::launch(tile::compact_rare_runs<S, 0>, count_grid, dim3(64), 0, wk);
     }
-    const unsigned rare_blocks = p.interleave_mode != 2 ? settle_grid.x : 0u;
+    const unsigned rare_blocks = p.interleave_mode != 2 ? (unsigned)count : 0u;
 #define EMU_RUN_CHAIN(ILV, FMT)                                                                                  \
     do                                                                                                           \
     {                                                                                                            \

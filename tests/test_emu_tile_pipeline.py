@@ -299,7 +299,7 @@ def test_tile_pipeline_counts_the_jobs_it_had_to_walk_again():
     img = synth.frame_numpy(300, 40, seed=3, kind="gradient")
     pc = jls_container.validated_pc((0,) * 5, 8, 0)
     want = _scan_bytes(ob.encode(img, width=300, height=40))
-    out = (C.c_uint32 * 4)()
+    out = (C.c_uint32 * 8)()
     (errc, flags, data), = _encode_planes([img], 300, 40, 8, pc, 300 * 40 * 2 + 1024, job=16, warm=0, runs=(32, 0, 0))
     assert errc == 0 and data == want
     L.emu_tile_counters(out)
@@ -308,6 +308,25 @@ def test_tile_pipeline_counts_the_jobs_it_had_to_walk_again():
     assert errc == 0 and data == want
     L.emu_tile_counters(out)
     assert out[0] > 0 and out[1] == 0 and out[3] == 0
+
+
+@pytest.mark.parametrize("rare_warm,serial", [(512, 0), (16, 1), (0, 1)])
+def test_rarer_run_context_in_segments(rare_warm, serial):
+    """The exact walk of the rarer run-interruption context goes in segments of its event list, a lane each, from a warm-up
+    counted in ITS events; a segment that starts from a wrong guess makes lane 0 walk the list again.  A frame with some 600
+    events of the rarer type: five segments, the oracle's bytes with a warm-up that converges and with ones that cannot, and
+    the counters say which of the two happened."""
+    import ctypes as C
+    L = emu_bind.tile_lib()
+    w, h = 700, 300
+    img = synth.frame_numpy(w, h, seed=5, kind="mixed")
+    pc = jls_container.validated_pc((0,) * 5, 8, 0)
+    want = _scan_bytes(ob.encode(img, width=w, height=h))
+    (errc, flags, data), = _encode_planes([img], w, h, 8, pc, w * h * 2 + 1024, job=256, warm=256, runs=(64, 512, rare_warm))
+    assert errc == 0 and data == want
+    out = (C.c_uint32 * 8)()
+    L.emu_tile_counters(out)
+    assert out[4] >= 3 and out[5] == serial, list(out)
 
 
 # ---- pixel mode (tile_pixel_mode.hip): sample-interleaved scans, and lines cut into segment tiles ---------------------
