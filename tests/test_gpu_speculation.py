@@ -155,3 +155,25 @@ def test_speculative_stuffing_with_failing_guesses(lib, monkeypatch, chunk, warm
     for i, img in enumerate(host):
         want = ob.encode(img, width=w, height=h, destination_size=2 * w * h + 4096)
         assert enc.errcs[i] == 0 and got[i, :int(enc.sizes[i])].tobytes() == want, (i, kinds[i])
+
+
+def _six(lib):
+    out = (C.c_uint64 * 6)()
+    assert lib.lib.charls_amd_speculation_counters(out, 6) == 6
+    return np.array(list(out), dtype=np.int64)
+
+
+@pytest.mark.parametrize("rare_warm,serial", [(None, 0), ("0", 1), ("24", 1)])
+def test_rarer_run_context_segments_and_their_fallback(lib, monkeypatch, rare_warm, serial):
+    """The exact walk of the rarer run-interruption context goes in segments of its event list from a warm-up counted in
+    its own events; a wrong guess makes one lane walk the list again.  Both ways on the MI355X: the oracle's bytes, and the
+    counters say which of the two ran."""
+    w, h = 1536, 1024
+    img = synth.frame_numpy(w, h, seed=41, kind="mixed")
+    if rare_warm is not None:
+        monkeypatch.setenv("CHARLS_AMD_RARE_WARM_EVENTS", rare_warm)
+    before = _six(lib)
+    got = lib.encode(img, width=w, height=h)
+    did = _six(lib) - before
+    assert got == ob.encode(img, width=w, height=h)
+    assert did[4] >= 3 and did[5] == serial, did
