@@ -288,3 +288,28 @@ def load_product() -> CharLSLibrary:
                 "(hipcc --offload-arch=gfx950). charls_amd has no CPU fallback.")
         _product = CharLSLibrary(PRODUCT_LIB)
     return _product
+
+
+KNOB_UNSET = -(1 << 63)
+
+
+def set_knob(name: str, value, lib: CharLSLibrary | None = None) -> None:
+    """charls_amd_debug_set_knob: a test / measurement knob of the engine (charls_amd/csrc/device/knobs.h); value None clears
+    it.  The environment variables of the same names are read once, when the library first looks at a knob."""
+    L = (lib or load_product()).lib
+    L.charls_amd_debug_set_knob.argtypes = [C.c_char_p, C.c_int64]
+    L.charls_amd_debug_set_knob.restype = C.c_int32
+    rc = L.charls_amd_debug_set_knob(name.encode(), KNOB_UNSET if value is None else int(value))
+    if rc != 0:
+        raise JpegLSError(rc, f"charls_amd_debug_set_knob({name})")
+
+
+def engine_counters(lib: CharLSLibrary | None = None) -> dict:
+    """charls_amd_engine_counters: what the coalescer of the host-pointer ABI did, and pipeline scans without a work area."""
+    L = (lib or load_product()).lib
+    L.charls_amd_engine_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int32]
+    L.charls_amd_engine_counters.restype = C.c_int32
+    out = (C.c_uint64 * 5)()
+    n = L.charls_amd_engine_counters(out, 5)
+    assert n == 5
+    return dict(zip(("calls", "launches", "merged_calls", "largest_launch", "pipeline_fallback_scans"), (int(v) for v in out)))

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "knobs.h"
 #include "scan_model.h"
 
 

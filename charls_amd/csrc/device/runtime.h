@@ -134,8 +134,28 @@ void launch_place_epilogue(uint8_t* slots, uint64_t slot_pitch, FrameCursorPod* 
 // grow on demand up to the limit and stay allocated between calls until released.
 void set_workspace_limit(uint64_t bytes) noexcept;
 DeviceBuffer& plane_arena(); // the calling thread's private stream buffers of the planar batch encoder (a work area)
+void* try_ensure(DeviceBuffer& buffer, size_t bytes) noexcept; // ensure() that reports failure (nullptr; the buffer is released) instead of raising
 void release_work_areas() noexcept;
 size_t work_area_bytes() noexcept;
+size_t work_area_budget() noexcept; // what the calling thread's work areas may grow to right now (limit, free memory)
+// Scans the lossless pipeline was eligible for that were coded by the one-wavefront kernel because no work area could be had.
+uint64_t pipeline_fallback_scans() noexcept;
+
+// The host-pointer ABI's merged launches (host/scan_engine.cpp) run on ONE set of work areas per device, shared by all
+// calling threads: while a scope is alive the calling thread's launches use that set (and nobody else does).
+class SharedAreasScope
+{
+public:
+    SharedAreasScope();
+    ~SharedAreasScope();
+    SharedAreasScope(const SharedAreasScope&) = delete;
+    SharedAreasScope& operator=(const SharedAreasScope&) = delete;
+    size_t bytes() const noexcept;
+    void release() noexcept;
+
+private:
+    int device_{0};
+};
 
 // Per-thread record of the last batch call's GPU time (charls_amd_last_timings).
 struct Timings

@@ -7,6 +7,7 @@
 #include <mutex>
 #include <vector>
 
+#include "knobs.h"
 #include "runtime.h"
 #include "scan_serial.hip"
 #include "container_kernels.hip"
@@ -127,6 +128,15 @@ Timings& last_timings() noexcept
 
 namespace {
 std::atomic<uint64_t> g_speculation[tile_counter_count]{};
+std::atomic<uint64_t> g_serial_fallback_scans{0}; // scans the tile pipeline was eligible for that ran on the one-wavefront kernel: no work area
+void note_pipeline_fallback(uint32_t scans) noexcept
+{
+    g_serial_fallback_scans.fetch_add(scans);
+}
+}
+uint64_t pipeline_fallback_scans() noexcept
+{
+    return g_serial_fallback_scans.load();
 }
 void speculation_counters(uint64_t out[tile_counter_count]) noexcept
 {
@@ -174,7 +184,7 @@ bool wave_decode_eligible(const ScanDesc& d)
 bool interval_decode_candidate(const ScanDesc& d)
 {
     return d.restart_interval != 0 && d.restart_interval < d.height && d.height <= 65535 && d.restart_interval <= 65535 &&
-           wave_decode_eligible(d) && std::getenv("CHARLS_AMD_SEQUENTIAL_INTERVALS") == nullptr;
+           wave_decode_eligible(d) && knobs::get_or(knobs::kSequentialIntervals, 0) == 0;
 }
 
 size_t fast_decode_lds(const ScanDesc& d)
@@ -203,12 +213,12 @@ size_t group_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
 // every run: 4096 frames with 4 scans per wavefront took 3.94 s in one sweep and 5.01 s in the next), so the scans are packed
 // as densely as it takes to stay at two wavefronts per CU, and no denser.
 // CHARLS_AMD_DECODE_GROUP overrides (0, 4, 8, 16, 32).
+constexpr long long kDecodeWavesPerCu = 2; // (DECODE_WAVES_PER_CU overrides: measurements)
 int decode_group_lanes(const ScanDesc& d, uint32_t count)
 {
     if (d.bits_per_sample > 8 && d.t3 > grp::kMaxTableT3)
         return 0;
-    const char* env = std::getenv("CHARLS_AMD_DECODE_GROUP");
-    const int forced = env ? std::atoi(env) : -1;
+    const int forced = static_cast<int>(knobs::get_or(knobs::kDecodeGroup, -1));
     if (forced == 0)
         return 0;
     if ((forced == 4 || forced == 8 || forced == 16 || forced == 32) && group_lds_bytes(d, 64u / forced) <= kGroupDecodeLds)
@@ -220,6 +230,7 @@ int decode_group_lanes(const ScanDesc& d, uint32_t count)
             return 256u;
         return static_cast<uint32_t>(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     }();
+    const uint32_t waves_per_cu = static_cast<uint32_t>(std::clamp<long long>(knobs::get_or(knobs::kDecodeWavesPerCu, kDecodeWavesPerCu), 1, 16));
     int best = 0;
     for (int lanes = 32; lanes >= 8; lanes /= 2)
     {
@@ -227,7 +238,7 @@ int decode_group_lanes(const ScanDesc& d, uint32_t count)
         if (group_lds_bytes(d, per_wave) > kGroupDecodeLds)
             break;
         best = lanes;
-        if ((count + per_wave - 1) / per_wave <= 2 * cus)
+        if ((count + per_wave - 1) / per_wave <= waves_per_cu * cus)
             break;
     }
     return best;
@@ -244,10 +255,9 @@ int pixel_group_lanes(const ScanDesc& d, uint32_t count)
         return 0;
     if (by_sample && d.bits_per_sample > 8 && ((reinterpret_cast<uintptr_t>(d.pixels) | d.pixel_stride) & 1u) != 0)
         return 0; // odd row address for 16-bit samples
-    if ((d.bits_per_sample > 8 && d.t3 > grp::kMaxTableT3) || std::getenv("CHARLS_AMD_EXACT_DECODER") != nullptr)
+    if ((d.bits_per_sample > 8 && d.t3 > grp::kMaxTableT3) || knobs::get_or(knobs::kExactDecoder, 0) != 0)
         return 0;
-    const char* env = std::getenv("CHARLS_AMD_DECODE_GROUP");
-    const int forced = env ? std::atoi(env) : -1;
+    const int forced = static_cast<int>(knobs::get_or(knobs::kDecodeGroup, -1));
     if (forced == 0)
         return 0;
     if ((forced == 8 || forced == 16 || forced == 32) && pixel_group_lds_bytes(d, 64u / forced) <= kGroupDecodeLds)
@@ -273,7 +283,7 @@ bool fast_decode_eligible(const ScanDesc& d)
     const bool by_line = d.interleave_mode == 1 && d.components >= 2 && d.components <= 4; // group kernel only
     return wave_decode_eligible(d) && d.near_lossless == 0 && (planar || by_line) &&
            ((planar && fast_decode_lds(d) <= kMaxDynamicLds) || decode_group_lanes(d, 1) != 0) &&
-           std::getenv("CHARLS_AMD_EXACT_DECODER") == nullptr;
+           knobs::get_or(knobs::kExactDecoder, 0) == 0;
 }
 
 // Scans the speed path handed back (ScanResult.flags & kFastRetry) are gathered so that ONE launch of the exact decoder
@@ -337,11 +347,81 @@ uint64_t decode_launch_key(const ScanDesc& d) noexcept
 }
 
 namespace {
+// Side streams of the pipeline (per thread and device): the stuffing stage of a pass runs on one of them under the next pass's
+// first stages, the run chain on another under the walkers of the regular chains.
+constexpr int kMaxPipelineLanes = 2;
+struct PipelineLanes
+{
+    hipStream_t streams[kMaxPipelineLanes]{};
+    bool created = false;
+    int device = -1; // streams belong to a device: a thread that moved on to another one gets new streams there
+    ~PipelineLanes() { destroy(); }
+    void destroy() noexcept
+    {
+        if (!created)
+            return;
+        int current = 0;
+        const bool switched = hipGetDevice(&current) == hipSuccess && current != device && hipSetDevice(device) == hipSuccess;
+        for (hipStream_t s : streams)
+            (void)hipStreamDestroy(s);
+        if (switched)
+            (void)hipSetDevice(current);
+        created = false;
+    }
+    void ensure()
+    {
+        int current = 0;
+        hip_check(hipGetDevice(&current));
+        if (created && current == device)
+            return;
+        destroy();
+        for (hipStream_t& s : streams)
+            hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        created = true;
+        device = current;
+    }
+};
+
+// Work areas: the HBM (and the side streams) a thread's launches keep between calls -- the tile pipeline's arena, the private
+// stream buffers of the planar batch encoder, the small tables of the restart-interval and retry paths.  Every thread has
+// a set of its own (the batch API; the workers of multi_device.cpp); the host-pointer ABI runs its merged launches on ONE
+// set per device that is shared by all calling threads (SharedAreasScope), so that a pool of 256 threads does not end up with
+// 256 arenas.
 constexpr int kIntervalArenas = 8;
+struct WorkAreas
+{
+    DeviceBuffer pipeline, plane, interval[kIntervalArenas];
+    PipelineLanes lanes;
+    size_t bytes() const noexcept
+    {
+        size_t total = pipeline.capacity() + plane.capacity();
+        for (const DeviceBuffer& b : interval)
+            total += b.capacity();
+        return total;
+    }
+    void release() noexcept
+    {
+        pipeline.release();
+        plane.release();
+        for (DeviceBuffer& b : interval)
+            b.release();
+    }
+};
+thread_local WorkAreas* t_shared_areas = nullptr; // set by SharedAreasScope
+WorkAreas& areas()
+{
+    if (t_shared_areas != nullptr)
+        return *t_shared_areas;
+    static thread_local WorkAreas mine;
+    return mine;
+}
 DeviceBuffer& interval_arena(int which)
 {
-    static thread_local DeviceBuffer buffers[kIntervalArenas];
-    return buffers[which];
+    return areas().interval[which];
+}
+PipelineLanes& pipeline_lanes()
+{
+    return areas().lanes;
 }
 
 void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanResult* d_results, uint32_t count,
@@ -581,11 +661,7 @@ size_t align_up(size_t v, size_t a)
 // Stage E in its block-parallel form (block_stuffing.hip) unless CHARLS_AMD_BLOCK_STUFFING=0 asks for stuff_scan.
 bool block_stuffing_enabled()
 {
-    static const bool enabled = [] {
-        const char* env = std::getenv("CHARLS_AMD_BLOCK_STUFFING");
-        return env == nullptr || std::atoi(env) != 0;
-    }();
-    return enabled;
+    return knobs::get_or(knobs::kBlockStuffing, 1) != 0;
 }
 
 // Stage E in its speculative form (speculative_stuffing.hip) unless CHARLS_AMD_SPEC_STUFFING=0: for the passes whose stuffing
@@ -593,11 +669,7 @@ bool block_stuffing_enabled()
 // pass's first stages (stuff_scan: 4.2 ns per byte, 99 ms for the 23.5 MB of a 4096 x 4096 RGB frame).
 bool spec_stuffing_enabled()
 {
-    static const bool enabled = [] {
-        const char* env = std::getenv("CHARLS_AMD_SPEC_STUFFING");
-        return env == nullptr || std::atoi(env) != 0;
-    }();
-    return enabled;
+    return knobs::get_or(knobs::kSpecStuffing, 1) != 0;
 }
 constexpr size_t kSpecStuffingAlwaysBytes = size_t{32} << 20; // destination capacity from which every pass takes the speculative form
 
@@ -606,8 +678,7 @@ constexpr uint32_t kBlockStuffingScans = 8; // scans per pass up to which stage 
 
 DeviceBuffer& pipeline_arena()
 {
-    static thread_local DeviceBuffer arena;
-    return arena;
+    return areas().pipeline;
 }
 
 constexpr size_t kArenaReserve = size_t{8} << 30; // HBM left to the caller (collective buffers, ...) when the device is nearly full
@@ -628,6 +699,8 @@ size_t arena_budget(size_t held)
     return std::min(limit, usable);
 }
 
+} // namespace
+
 // ensure() that reports failure instead of raising (the arena is released, so the next attempt starts clean).
 void* try_ensure(DeviceBuffer& buffer, size_t bytes) noexcept
 {
@@ -642,45 +715,8 @@ void* try_ensure(DeviceBuffer& buffer, size_t bytes) noexcept
     }
 }
 
-// Side streams of the pipeline (per thread and device): the stuffing stage of a pass runs on one of them under the next pass's
-// first stages, the run chain on another under the walkers of the regular chains.
-constexpr int kMaxPipelineLanes = 2;
-struct PipelineLanes
-{
-    hipStream_t streams[kMaxPipelineLanes]{};
-    bool created = false;
-    int device = -1; // streams belong to a device: a thread that moved on to another one gets new streams there
-    ~PipelineLanes() { destroy(); }
-    void destroy() noexcept
-    {
-        if (!created)
-            return;
-        int current = 0;
-        const bool switched = hipGetDevice(&current) == hipSuccess && current != device && hipSetDevice(device) == hipSuccess;
-        for (hipStream_t s : streams)
-            (void)hipStreamDestroy(s);
-        if (switched)
-            (void)hipSetDevice(current);
-        created = false;
-    }
-    void ensure()
-    {
-        int current = 0;
-        hip_check(hipGetDevice(&current));
-        if (created && current == device)
-            return;
-        destroy();
-        for (hipStream_t& s : streams)
-            hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        created = true;
-        device = current;
-    }
-};
-PipelineLanes& pipeline_lanes()
-{
-    static thread_local PipelineLanes lanes;
-    return lanes;
-}
+namespace {
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // Tile pipeline (tile_pipeline.hip, tile_pixel_mode.hip): every lossless scan the pipeline is eligible for.
@@ -704,28 +740,25 @@ struct TileLayout
         tiles = plan.tiles;
         // Jobs: every job pays warm_events of warm-up, so long jobs are cheaper; but ONE frame needs thousands of lanes to
         // fill the chip.  Aim at a quarter of a million lanes per launch, between 1024 and 8192 events per job.
-        const char* env_job = std::getenv("CHARLS_AMD_JOB_EVENTS");
-        const char* env_warm = std::getenv("CHARLS_AMD_WARM_EVENTS");
+        const long long knob_job = knobs::get(knobs::kJobEvents), knob_warm = knobs::get(knobs::kWarmEvents);
         uint64_t job = 1024;
         while (job < 8192 && samples * count / (job * 2) >= (uint64_t{1} << 18))
             job *= 2;
-        job_events = env_job ? static_cast<uint32_t>(std::max(32, std::atoi(env_job)) / 32 * 32) : static_cast<uint32_t>(job); // (whole rounds of the walkers: 32 two-byte slots)
-        warm_events = env_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_warm))) : 1024u;
+        job_events = knob_job != knobs::kUnset ? static_cast<uint32_t>(std::max<long long>(32, knob_job) / 32 * 32) : static_cast<uint32_t>(job); // (whole rounds of the walkers: 32 two-byte slots)
+        warm_events = knob_warm != knobs::kUnset ? static_cast<uint32_t>(std::max<long long>(0, knob_warm)) : 1024u;
         max_jobs = samples / job_events + pipe::kChains;
         // the run chain: jobs of 2048 run events with a warm-up of as many (a test frame has 55 000 run events); small batches
         // take smaller jobs -- ONE frame has the whole chip, and the walk of a job and its warm-up is what the frame waits for
         // (up to four 4096 x 4096 frames: 128 events behind a warm-up of 1024 -- 2.35 ms per frame where 256 / 2048 took 2.65;
         // 512 events of warm-up are enough for the test frame and 256 are not: every job walked again, 10.8 ms)
-        const char* env_run_job = std::getenv("CHARLS_AMD_RUN_JOB_EVENTS");
-        const char* env_run_warm = std::getenv("CHARLS_AMD_RUN_WARM_EVENTS");
+        const long long knob_run_job = knobs::get(knobs::kRunJobEvents), knob_run_warm = knobs::get(knobs::kRunWarmEvents);
         const uint64_t batch_samples = static_cast<uint64_t>(samples) * count;
         const uint32_t run_job_default = batch_samples <= (uint64_t{1} << 26) ? 128u : (batch_samples <= (uint64_t{1} << 29) ? 512u : 2048u);
-        run_job_events = env_run_job ? static_cast<uint32_t>(std::max(32, std::atoi(env_run_job)) / 32 * 32) : run_job_default;
-        run_warm_events = env_run_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_run_warm))) : (run_job_default == 128u ? 1024u : 2048u);
+        run_job_events = knob_run_job != knobs::kUnset ? static_cast<uint32_t>(std::max<long long>(32, knob_run_job) / 32 * 32) : run_job_default;
+        run_warm_events = knob_run_warm != knobs::kUnset ? static_cast<uint32_t>(std::max<long long>(0, knob_run_warm)) : (run_job_default == 128u ? 1024u : 2048u);
         max_run_jobs = samples / run_job_events + 2; // (+ the entry of the totals)
         // the exact walk of the rarer run context: events of that type a lane walks before its segment of the list
-        const char* env_rare_warm = std::getenv("CHARLS_AMD_RARE_WARM_EVENTS");
-        rare_warm_events = env_rare_warm ? static_cast<uint32_t>(std::max(0, std::atoi(env_rare_warm))) : 512u;
+        rare_warm_events = static_cast<uint32_t>(std::max<long long>(0, knobs::get_or(knobs::kRareWarmEvents, 512)));
         const size_t worst = worst_case_scan_bytes(plan.line_samples, static_cast<uint32_t>(lines), 1, d.bits_per_sample);
         raw_bytes = align_up((capacity_hint < worst ? capacity_hint : worst) + 64, 16);
         size_t o = 0;
@@ -812,7 +845,8 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
         resident = (resident + 1) / 2;
     }
     if (arena == nullptr)
-    {
+    { // no work area to be had: the one-wavefront kernel needs none (counted: charls_amd_engine_counters)
+        note_pipeline_fallback(count);
         launch_encode_serial(d_descs, d_results, count, stream);
         last_timings().count = 2;
         return;
@@ -1178,25 +1212,97 @@ void launch_encode(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_resul
 // freeing 8 GiB per call cost three times the coding of 256 4096 x 4096 RGB frames.
 DeviceBuffer& plane_arena()
 {
-    static thread_local DeviceBuffer arena;
-    return arena;
+    return areas().plane;
+}
+
+size_t work_area_budget() noexcept
+{
+    return arena_budget(areas().bytes());
+}
+
+// ---- the work areas of the host-pointer ABI: one set per device, used by one merged launch at a time
+namespace {
+constexpr int kMaxDevices = 32;
+struct SharedAreas
+{
+    std::mutex turn;
+    WorkAreas areas;
+    std::atomic<size_t> held{0};
+};
+std::atomic<SharedAreas*> g_shared[kMaxDevices]{};
+SharedAreas& shared_areas(int device)
+{
+    std::atomic<SharedAreas*>& slot = g_shared[device >= 0 && device < kMaxDevices ? device : 0];
+    SharedAreas* s = slot.load(std::memory_order_acquire);
+    if (s == nullptr)
+    {
+        auto* fresh = new SharedAreas; // never destroyed: at process exit the HIP runtime may already be gone
+        if (slot.compare_exchange_strong(s, fresh, std::memory_order_acq_rel))
+            s = fresh;
+        else
+            delete fresh;
+    }
+    return *s;
+}
+} // namespace
+
+SharedAreasScope::SharedAreasScope()
+{
+    hip_check(hipGetDevice(&device_));
+    SharedAreas& s = shared_areas(device_);
+    s.turn.lock();
+    t_shared_areas = &s.areas;
+}
+
+SharedAreasScope::~SharedAreasScope()
+{
+    SharedAreas& s = shared_areas(device_);
+    s.held.store(s.areas.bytes(), std::memory_order_relaxed);
+    t_shared_areas = nullptr;
+    s.turn.unlock();
+}
+
+size_t SharedAreasScope::bytes() const noexcept
+{
+    return shared_areas(device_).areas.bytes();
+}
+
+void SharedAreasScope::release() noexcept
+{
+    shared_areas(device_).areas.release();
 }
 
 void release_work_areas() noexcept
 {
-    pipeline_arena().release();
-    plane_arena().release();
-    for (int i = 0; i < kIntervalArenas; ++i)
-        interval_arena(i).release();
+    areas().release();
+    if (t_shared_areas != nullptr)
+        return; // (called from inside a merged launch: its areas are the ones just released)
+    int current = 0;
+    const bool have_device = hipGetDevice(&current) == hipSuccess;
+    for (int device = 0; device < kMaxDevices; ++device)
+    {
+        SharedAreas* s = g_shared[device].load(std::memory_order_acquire);
+        if (s == nullptr)
+            continue;
+        std::lock_guard<std::mutex> turn(s->turn); // (a merged launch that is running finishes first)
+        s->areas.lanes.destroy();
+        s->areas.release();
+        s->held.store(0, std::memory_order_relaxed);
+    }
+    if (have_device)
+        (void)hipSetDevice(current);
 }
 
 size_t work_area_bytes() noexcept
 {
-    size_t total = pipeline_arena().capacity() + plane_arena().capacity();
-    for (int i = 0; i < kIntervalArenas; ++i)
-        total += interval_arena(i).capacity();
+    size_t total = areas().bytes();
+    if (t_shared_areas == nullptr)
+        for (int device = 0; device < kMaxDevices; ++device)
+            if (SharedAreas* s = g_shared[device].load(std::memory_order_acquire))
+                total += s->held.load(std::memory_order_relaxed);
     return total;
 }
+
 
 static_assert(sizeof(FrameCursorPod) == sizeof(FrameCursor), "cursor layout");
 

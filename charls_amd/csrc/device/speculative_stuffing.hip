@@ -229,10 +229,10 @@ struct SpecGeometry
 inline SpecGeometry stuff_spec_geometry()
 {
     SpecGeometry g{65536, 65536};
-    if (const char* env = std::getenv("CHARLS_AMD_SPEC_CHUNK"))
-        g.chunk_bytes = (uint32_t)std::max(64, std::atoi(env)) / 8 * 8;
-    if (const char* env = std::getenv("CHARLS_AMD_SPEC_WARM"))
-        g.warm_bytes = (uint32_t)std::max(0, std::atoi(env)) / 8 * 8;
+    if (const long long knob = knobs::get(knobs::kSpecChunk); knob != knobs::kUnset)
+        g.chunk_bytes = (uint32_t)std::max<long long>(64, std::min<long long>(knob, 1 << 30)) / 8 * 8;
+    if (const long long knob = knobs::get(knobs::kSpecWarm); knob != knobs::kUnset)
+        g.warm_bytes = (uint32_t)std::max<long long>(0, std::min<long long>(knob, 1 << 30)) / 8 * 8;
     return g;
 }
 

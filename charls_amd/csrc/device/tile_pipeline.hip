@@ -2280,10 +2280,9 @@ inline TilePlan plan_tiles(const ScanDesc& d)
     TilePlan p{};
     const uint32_t sample_bytes = d.bits_per_sample > 8 ? 2u : 1u;
     uint32_t cap = sample_bytes == 1 ? kMaxTileSamples : kMaxTileSamples / 2;
-    if (const char* env = std::getenv("CHARLS_AMD_TILE_SAMPLES"))
-        cap = std::min<uint32_t>(cap, (uint32_t)std::max(64, std::atoi(env)));
-    const char* force = std::getenv("CHARLS_AMD_PIXEL_MODE");
-    const bool force_pixel_mode = force != nullptr && std::atoi(force) != 0;
+    if (const long long knob = knobs::get(knobs::kTileSamples); knob != knobs::kUnset)
+        cap = std::min<uint32_t>(cap, (uint32_t)std::max<long long>(64, std::min<long long>(knob, cap)));
+    const bool force_pixel_mode = knobs::get_or(knobs::kPixelMode, 0) != 0;
     p.nc = d.interleave_mode == 2 ? (uint32_t)d.components : 1u;
     p.step = d.interleave_mode == 1 ? (uint32_t)d.components : 1u; // distance of a coded line to the line above it
     p.lines = d.height * (d.interleave_mode == 1 ? (uint32_t)d.components : 1u);

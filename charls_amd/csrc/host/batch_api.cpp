@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../device/knobs.h"
 #include "../device/runtime.h"
 #include "common.h"
 #include "preset.h"
@@ -249,19 +250,27 @@ try
     // 18.8 in rounds of 256 scans -- the scans' second trip through memory --, four 2048 x 2048 frames three times faster.)
     constexpr uint32_t kTogetherFrames = 128;
     if (rounds > 1 && p.restart_interval == 0 && equal_headers && !t_force_rounds && frame_count <= kTogetherFrames &&
-        std::getenv("CHARLS_AMD_BATCH_ROUNDS") == nullptr)
+        knobs::get_or(knobs::kBatchRounds, 0) == 0)
     {
         const size_t worst = dev::worst_case_scan_bytes(f.width, f.height, 1, f.bits_per_sample);
         const size_t capacity = (std::min(stream_pitch_bytes, worst) + 255) & ~size_t{255};
-        constexpr size_t kPrivateBudget = size_t{8} << 30;
-        const uint32_t group = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(frame_count, kPrivateBudget / (capacity * rounds))));
+        // The private buffers are a work area like the pipeline's: they come out of the configured workspace
+        // (charls_amd_set_workspace_limit) -- half of what this thread may hold, the pipeline's arena wants the rest --, never
+        // more than 8 GiB, and when they cannot be had the frames are coded in rounds, which need none.
+        const size_t scratch_bytes = (scratch_samples * sizeof(uint16_t) + 255) & ~size_t{255}; // (the exact re-coding of a scan that ends within 3 bytes of its buffer)
+        const size_t per_frame = (capacity + scratch_bytes) * rounds;
+        const size_t budget = std::min<size_t>(size_t{8} << 30, dev::work_area_budget() / 2);
+        uint32_t group = static_cast<uint32_t>(std::min<size_t>(frame_count, budget / per_frame));
+        uint8_t* priv = nullptr;
+        while (group >= 1 && (priv = static_cast<uint8_t*>(dev::try_ensure(dev::plane_arena(), per_frame * group))) == nullptr) // (kept between calls)
+            group /= 2;
+        if (priv != nullptr)
+        {
+        auto* plane_scratch = reinterpret_cast<uint16_t*>(priv + static_cast<size_t>(capacity) * rounds * group);
         dev::DeviceBuffer d_plane_descs, d_plane_results, d_redo;
-        auto* priv = static_cast<uint8_t*>(dev::plane_arena().ensure(capacity * rounds * group)); // (kept between calls: a work area)
         d_plane_descs.ensure(sizeof(ScanDesc) * rounds * group);
         d_plane_results.ensure(sizeof(ScanResult) * rounds * group);
         d_redo.ensure(sizeof(uint32_t) * frame_count);
-        dev::DeviceBuffer d_plane_scratch;
-        d_plane_scratch.ensure(scratch_samples * sizeof(uint16_t) * rounds * group);
         std::vector<ScanDesc> plane_descs(static_cast<size_t>(rounds) * group);
         const uint32_t sos_size = static_cast<uint32_t>(sos[0].size());
         for (uint32_t first = 0; first < frame_count; first += group)
@@ -275,7 +284,7 @@ try
                     d.pixel_stride = stride;
                     d.stream = priv + (static_cast<size_t>(i) * rounds + r) * capacity;
                     d.stream_capacity = std::min(stream_pitch_bytes, worst);
-                    d.line_scratch = d_plane_scratch.as<uint16_t>() + (static_cast<size_t>(i) * rounds + r) * scratch_samples;
+                    d.line_scratch = plane_scratch + (static_cast<size_t>(i) * rounds + r) * (scratch_bytes / sizeof(uint16_t));
                     plane_descs[static_cast<size_t>(i) * rounds + r] = d;
                 }
             hip_check(hipMemcpyAsync(d_plane_descs.as<ScanDesc>(), plane_descs.data(), sizeof(ScanDesc) * rounds * n, hipMemcpyHostToDevice, stream));
@@ -297,6 +306,7 @@ try
         redo_frames.assign(frame_count, 0);
         for (uint32_t i = 0; i < frame_count; ++i)
             redo_frames[i] = redo[i] != 0;
+        } // (priv)
     }
     const bool in_rounds = redo_frames.empty();
     for (uint32_t r = 0; r < rounds && in_rounds; ++r)
@@ -341,20 +351,33 @@ try
     t.values[1] = scan_ms;
     if (t.count < 2)
         t.count = 2; // the pipeline adds its stage breakdown in values[2..6]
-    // frames whose scans could not simply be put in place: scan by scan, with the capacities the reference passes
-    for (uint32_t i = 0; i < redo_frames.size(); ++i)
-        if (redo_frames[i])
+    // frames whose scans could not simply be put in place: scan by scan, with the capacities the reference passes -- every RUN
+    // of such frames by one call in rounds (a batch with slots too small for anything flags every frame: one call, not
+    // frame_count calls of one frame each); the timings reported are those of this call, not of the re-coding.
+    const dev::Timings kept = dev::last_timings();
+    for (uint32_t i = 0; i < redo_frames.size();)
+    {
+        if (!redo_frames[i])
         {
-            struct ForceRounds
-            {
-                ForceRounds() { t_force_rounds = true; }
-                ~ForceRounds() { t_force_rounds = false; }
-            } force;
-            const charls_jpegls_errc rc = charls_amd_encode_batch_device(params, 1, frames + i * frame_pitch_bytes, frame_pitch_bytes, stride_arg,
-                                                                         slots + i * stream_pitch_bytes, stream_pitch_bytes, sizes + i, errcs + i, hip_stream);
-            if (rc != CHARLS_JPEGLS_ERRC_SUCCESS)
-                return rc;
+            ++i;
+            continue;
         }
+        uint32_t last = i + 1;
+        while (last < redo_frames.size() && redo_frames[last])
+            ++last;
+        struct ForceRounds
+        {
+            ForceRounds() { t_force_rounds = true; }
+            ~ForceRounds() { t_force_rounds = false; }
+        } force;
+        const charls_jpegls_errc rc = charls_amd_encode_batch_device(params, last - i, frames + i * frame_pitch_bytes, frame_pitch_bytes, stride_arg,
+                                                                     slots + i * stream_pitch_bytes, stream_pitch_bytes, sizes + i, errcs + i, hip_stream);
+        if (rc != CHARLS_JPEGLS_ERRC_SUCCESS)
+            return rc;
+        i = last;
+    }
+    if (!redo_frames.empty())
+        dev::last_timings() = kept;
     return CHARLS_JPEGLS_ERRC_SUCCESS;
 }
 catch (...)
@@ -583,7 +606,7 @@ try
     // parses on from there, on a COPY of the frame's state.  The copy replaces the frame only if every scan then ends exactly
     // at the marker found behind it and the end of the image parses; any frame that does not is decoded again by the rounds
     // below, which report whatever part 1 reports for it.  src/charls_jpegls_decoder.cpp:211-236 is the scan-by-scan loop.
-    if (std::getenv("CHARLS_AMD_BATCH_ROUNDS") == nullptr)
+    if (knobs::get_or(knobs::kBatchRounds, 0) == 0)
     {
         struct Plan
         {

@@ -175,6 +175,7 @@ struct charls_jpegls_decoder
     {
         check_buffer(destination, destination_size_bytes);
         check_operation(state == State::header_read);
+        const CallScope call(engine);
         auto* dst = static_cast<uint8_t*>(destination);
         size_t dst_left = destination_size_bytes;
         const uint8_t* base = reader.position();

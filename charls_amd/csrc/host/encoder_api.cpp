@@ -152,6 +152,7 @@ struct charls_jpegls_encoder
                 writer.define_restart_interval(restart_interval); // extension: charls_amd_jpegls_encoder_set_restart_interval
         }
 
+        const CallScope call(engine);
         engine.upload_pixels(static_cast<const uint8_t*>(source), min_size);
         ScanSpec spec{frame.width, frame.height, 1, interleave, frame.bits_per_sample, near, transformation, pc, restart_interval};
         if (interleave == 0)

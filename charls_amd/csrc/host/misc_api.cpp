@@ -3,6 +3,7 @@
 #include <string>
 #include <system_error>
 
+#include "../device/knobs.h"
 #include "../device/runtime.h"
 #include "common.h"
 #include "scan_engine.h"
@@ -178,6 +179,23 @@ int32_t charls_amd_speculation_counters(uint64_t* out, int32_t capacity)
     for (; out != nullptr && n < capacity && n < dev::tile_counter_count; ++n)
         out[n] = v[n];
     return n;
+}
+
+int32_t charls_amd_engine_counters(uint64_t* out, int32_t capacity)
+{
+    uint64_t v[5];
+    coalescer_stats(v);
+    v[4] = dev::pipeline_fallback_scans();
+    int32_t n = 0;
+    for (; out != nullptr && n < capacity && n < 5; ++n)
+        out[n] = v[n];
+    return n;
+}
+
+charls_jpegls_errc charls_amd_debug_set_knob(const char* name, int64_t value)
+{
+    return knobs::set(name, value == INT64_MIN ? knobs::kUnset : static_cast<long long>(value)) ? CHARLS_JPEGLS_ERRC_SUCCESS
+                                                                                                 : CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT;
 }
 
 int32_t charls_amd_last_timings(double* out, int32_t capacity)

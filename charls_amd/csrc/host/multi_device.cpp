@@ -24,12 +24,15 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../device/runtime.h"
@@ -79,6 +82,62 @@ const Rccl& rccl()
 }
 
 constexpr int kNcclUint8 = 1;
+
+// One line on stderr, once per process and message: a transport that silently degrades is a performance bug nobody finds.
+void note_once(const char* message)
+{
+    static std::mutex guard;
+    static std::vector<std::string> said;
+    std::lock_guard<std::mutex> lock(guard);
+    for (const std::string& m : said)
+        if (m == message)
+            return;
+    said.emplace_back(message);
+    std::fprintf(stderr, "%s\n", message);
+}
+
+// hipMemcpyPeerAsync between two devices goes over xGMI only when each may address the other's memory; otherwise the runtime
+// stages the copy through host memory.  Enabled once per pair and direction; where the devices cannot reach each other the
+// copies still work (through the host), and that is said once.
+void enable_peer_access(int a, int b)
+{
+    static std::mutex guard;
+    static std::vector<std::pair<int, int>> done;
+    std::lock_guard<std::mutex> lock(guard);
+    int current = 0;
+    (void)hipGetDevice(&current);
+    for (const auto& [from, to] : {std::pair<int, int>{a, b}, std::pair<int, int>{b, a}})
+    {
+        bool seen = false;
+        for (const auto& d : done)
+            seen = seen || d == std::pair<int, int>{from, to};
+        if (seen)
+            continue;
+        done.emplace_back(from, to);
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || can == 0)
+        {
+            (void)hipGetLastError();
+            char text[160];
+            std::snprintf(text, sizeof text, "charls_amd: device %d cannot address device %d: peer copies between them go through host memory", from, to);
+            note_once(text);
+            continue;
+        }
+        if (hipSetDevice(from) == hipSuccess)
+        {
+            const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+            {
+                char text[160];
+                std::snprintf(text, sizeof text, "charls_amd: hipDeviceEnablePeerAccess(%d -> %d) failed (%d): peer copies go through host memory", from, to,
+                              static_cast<int>(e));
+                note_once(text);
+            }
+            (void)hipGetLastError();
+        }
+    }
+    (void)hipSetDevice(current);
+}
 
 void check_shards(uint32_t shard_count, const charls_amd_device_shard* shards)
 {
@@ -272,9 +331,10 @@ charls_amd_devices& context_or_default(charls_amd_devices* ctx)
     return *g_default;
 }
 
-// Runs `work(shard)` for every shard on the context's worker of the shard's device; the first error wins.
-template <typename Work>
-charls_jpegls_errc on_every_shard(charls_amd_devices& ctx, uint32_t shard_count, const charls_amd_device_shard* shards, Work work)
+// Runs `work(shard)` for every shard on the context's worker of the shard's device; the first error wins.  `after(s)` runs on
+// the calling thread as soon as shards 0..s have all succeeded -- while the later shards are still at work.
+template <typename Work, typename After>
+charls_jpegls_errc on_every_shard(charls_amd_devices& ctx, uint32_t shard_count, const charls_amd_device_shard* shards, Work work, After after)
 {
     std::vector<Worker*> used(shard_count, nullptr);
     std::map<int, uint32_t> seen; // shards per device so far
@@ -296,8 +356,25 @@ charls_jpegls_errc on_every_shard(charls_amd_devices& ctx, uint32_t shard_count,
         const charls_jpegls_errc e = used[s]->wait();
         if (first_error == CHARLS_JPEGLS_ERRC_SUCCESS)
             first_error = e;
+        if (first_error == CHARLS_JPEGLS_ERRC_SUCCESS && submitted == shard_count)
+        {
+            try
+            {
+                after(s);
+            }
+            catch (...)
+            { // (the remaining shards are still waited for)
+                first_error = current_exception_to_errc();
+            }
+        }
     }
     return first_error;
+}
+
+template <typename Work>
+charls_jpegls_errc on_every_shard(charls_amd_devices& ctx, uint32_t shard_count, const charls_amd_device_shard* shards, Work work)
+{
+    return on_every_shard(ctx, shard_count, shards, work, [](uint32_t) {});
 }
 
 struct StreamGuard
@@ -329,6 +406,10 @@ extern "C" void charls_amd_devices_destroy(charls_amd_devices* context)
 {
     if (context != nullptr)
     {
+        { // a call that is running on the context finishes first (destroying a context WHILE starting a call on it stays the
+          // caller's bug: nothing can make a pointer that is being deleted safe to pass in)
+            std::lock_guard<std::mutex> running(context->call);
+        }
         delete context;
         return;
     }
@@ -338,6 +419,10 @@ extern "C" void charls_amd_devices_destroy(charls_amd_devices* context)
         std::lock_guard<std::mutex> lock(g_default_guard);
         d = g_default;
         g_default = nullptr;
+    }
+    if (d != nullptr)
+    {
+        std::lock_guard<std::mutex> running(d->call);
     }
     delete d;
 }
@@ -400,30 +485,24 @@ try
     int caller_device = 0;
     (void)hipGetDevice(&caller_device);
 
-    const charls_jpegls_errc coded = on_every_shard(ctx, shard_count, shards, [&](uint32_t s) -> charls_jpegls_errc {
+    auto code_shard = [&](uint32_t s) -> charls_jpegls_errc {
         const charls_amd_device_shard& sh = shards[s];
         if (sh.frame_count == 0)
             return CHARLS_JPEGLS_ERRC_SUCCESS;
         hipStream_t stream = static_cast<hipStream_t>(sh.hip_stream);
         return charls_amd_encode_batch_device(params, sh.frame_count, sh.d_frames, frame_pitch_bytes, stride, sh.d_streams,
                                               stream_pitch_bytes, sizes + first[s], errcs + first[s], stream);
-    });
-    if (coded != CHARLS_JPEGLS_ERRC_SUCCESS || gather == nullptr)
-        return coded;
+    };
+    if (gather == nullptr)
+        return on_every_shard(ctx, shard_count, shards, code_shard);
 
-    // ---- hand-over of the bitstreams to the root shard's device
+    // ---- with a hand-over of the bitstreams to the root shard's device.  The "all-gather of sizes" of SURVEY 8e is a prefix
+    // sum here (every shard's sizes are host values of this process), and it is known for shard s as soon as shards 0..s have
+    // coded: the streams of shard s start moving then, while the later shards are still coding (round 4 moved everything
+    // strictly after all coding).
     check_argument(gather->root_shard < shard_count);
     check_pointer(gather->d_gathered);
     check_pointer(gather->offsets);
-    const uint64_t total_frames = first[shard_count];
-    uint64_t at = 0;
-    for (uint64_t f = 0; f < total_frames; ++f)
-    { // (the "all-gather of sizes": every shard's sizes are host values of this process; frames that failed take no room)
-        gather->offsets[f] = at;
-        at += errcs[f] == CHARLS_JPEGLS_ERRC_SUCCESS ? sizes[f] : 0;
-    }
-    if (at > gather->capacity_bytes)
-        raise(CHARLS_JPEGLS_ERRC_DESTINATION_TOO_SMALL);
     const uint32_t root = gather->root_shard;
     const int root_device = shards[root].device;
     auto* gathered = static_cast<uint8_t*>(gather->d_gathered);
@@ -436,89 +515,97 @@ try
                           (shard_count > 1 || gather->transport == CHARLS_AMD_TRANSPORT_RCCL);
     if (gather->transport == CHARLS_AMD_TRANSPORT_RCCL && !use_rccl)
         raise(CHARLS_AMD_ERRC_DEVICE_FAILURE); // RCCL was asked for and is not usable here
+    if (gather->transport == CHARLS_AMD_TRANSPORT_AUTO && !use_rccl && shard_count > 1 && distinct_devices)
+        note_once("charls_amd: RCCL (librccl.so) is not usable in this process: bitstreams are gathered with hipMemcpyPeerAsync");
 
     struct RestoreDevice
     {
         int device;
         ~RestoreDevice() { (void)hipSetDevice(device); }
     } restore{caller_device};
-    // the root's own streams: copies on its device
+    std::vector<int> devices(shard_count);
+    for (uint32_t s = 0; s < shard_count; ++s)
+        devices[s] = shards[s].device;
+    if (use_rccl)
+        ctx.ensure_communicator(devices); // (cached: ncclCommInitAll runs when the list of devices changes)
+    else
+        for (uint32_t s = 0; s < shard_count; ++s)
+            if (s != root && shards[s].device != root_device)
+                enable_peer_access(root_device, shards[s].device);
     hip_check(hipSetDevice(root_device));
-    {
-        StreamGuard own;
-        for (uint64_t f = first[root]; f < first[root + 1]; ++f)
-            if (errcs[f] == CHARLS_JPEGLS_ERRC_SUCCESS && sizes[f] != 0)
-                hip_check(hipMemcpyAsync(gathered + gather->offsets[f],
-                                         static_cast<const uint8_t*>(shards[root].d_streams) + (f - first[root]) * stream_pitch_bytes,
-                                         sizes[f], hipMemcpyDeviceToDevice, own.s));
-        if (use_rccl)
+    StreamGuard own; // the root's own copies and the peer copies
+    hip_check(hipSetDevice(caller_device));
+    uint64_t at = 0;
+    bool exchange_failed = false;
+
+    auto hand_over = [&](uint32_t s) {
+        // offsets of shard s (frames that failed take no room)
+        for (uint64_t f = first[s]; f < first[s + 1]; ++f)
         {
-            const Rccl& api = rccl();
-            std::vector<int> devices(shard_count);
-            for (uint32_t s = 0; s < shard_count; ++s)
-                devices[s] = shards[s].device;
-            ctx.ensure_communicator(devices);
-            const std::vector<Rccl::Comm>& comms = ctx.comms;
-            const std::vector<hipStream_t>& streams = ctx.comm_streams;
-            bool failed = false;
-            // one grouped send / receive pair per frame, in rounds of 64 frames per peer (point-to-point over xGMI)
-            constexpr uint64_t kRound = 64;
-            for (uint64_t r0 = 0; !failed; r0 += kRound)
-            {
-                bool any = false;
-                failed = failed || api.group_start() != 0;
-                for (uint32_t s = 0; s < shard_count && !failed; ++s)
-                {
-                    if (s == root)
-                        continue;
-                    const uint64_t lo = first[s] + r0, hi = std::min<uint64_t>(first[s + 1], lo + kRound);
-                    for (uint64_t f = lo; f < hi && !failed; ++f)
-                    {
-                        any = true;
-                        if (errcs[f] != CHARLS_JPEGLS_ERRC_SUCCESS || sizes[f] == 0)
-                            continue;
-                        (void)hipSetDevice(devices[s]);
-                        failed = failed || api.send(static_cast<const uint8_t*>(shards[s].d_streams) + (f - first[s]) * stream_pitch_bytes,
-                                                    sizes[f], kNcclUint8, static_cast<int>(root), comms[s], streams[s]) != 0;
-                        (void)hipSetDevice(root_device);
-                        failed = failed || api.recv(gathered + gather->offsets[f], sizes[f], kNcclUint8, static_cast<int>(s), comms[root],
-                                                    streams[root]) != 0;
-                    }
-                }
-                failed = api.group_end() != 0 || failed;
-                if (!any)
-                    break;
-            }
-            for (uint32_t s = 0; s < shard_count; ++s)
-            {
-                (void)hipSetDevice(devices[s]);
-                failed = hipStreamSynchronize(streams[s]) != hipSuccess || failed;
-            }
-            (void)hipSetDevice(root_device);
-            if (failed)
-            {
-                ctx.drop_communicator(); // (its state after a failed group is unknown: the next call starts a new one)
-                raise(CHARLS_AMD_ERRC_DEVICE_FAILURE);
-            }
+            gather->offsets[f] = at;
+            at += errcs[f] == CHARLS_JPEGLS_ERRC_SUCCESS ? sizes[f] : 0;
+        }
+        if (at > gather->capacity_bytes)
+            raise(CHARLS_JPEGLS_ERRC_DESTINATION_TOO_SMALL);
+        hip_check(hipSetDevice(root_device));
+        auto source = [&](uint64_t f) { return static_cast<const uint8_t*>(shards[s].d_streams) + (f - first[s]) * stream_pitch_bytes; };
+        if (s == root || shards[s].device == root_device)
+        {
+            for (uint64_t f = first[s]; f < first[s + 1]; ++f)
+                if (errcs[f] == CHARLS_JPEGLS_ERRC_SUCCESS && sizes[f] != 0)
+                    hip_check(hipMemcpyAsync(gathered + gather->offsets[f], source(f), sizes[f], hipMemcpyDeviceToDevice, own.s));
+        }
+        else if (!use_rccl)
+        {
+            for (uint64_t f = first[s]; f < first[s + 1]; ++f)
+                if (errcs[f] == CHARLS_JPEGLS_ERRC_SUCCESS && sizes[f] != 0)
+                    hip_check(hipMemcpyPeerAsync(gathered + gather->offsets[f], root_device, source(f), shards[s].device, sizes[f], own.s));
         }
         else
-        {
-            for (uint32_t s = 0; s < shard_count; ++s)
+        { // one grouped send / receive pair per frame, in rounds of 64 frames (point-to-point over xGMI)
+            const Rccl& api = rccl();
+            constexpr uint64_t kRound = 64;
+            for (uint64_t lo = first[s]; lo < first[s + 1] && !exchange_failed; lo += kRound)
             {
-                if (s == root)
-                    continue;
-                for (uint64_t f = first[s]; f < first[s + 1]; ++f)
-                    if (errcs[f] == CHARLS_JPEGLS_ERRC_SUCCESS && sizes[f] != 0)
-                        hip_check(hipMemcpyPeerAsync(gathered + gather->offsets[f], root_device,
-                                                     static_cast<const uint8_t*>(shards[s].d_streams) + (f - first[s]) * stream_pitch_bytes,
-                                                     shards[s].device, sizes[f], own.s));
+                const uint64_t hi = std::min<uint64_t>(first[s + 1], lo + kRound);
+                exchange_failed = api.group_start() != 0;
+                for (uint64_t f = lo; f < hi && !exchange_failed; ++f)
+                {
+                    if (errcs[f] != CHARLS_JPEGLS_ERRC_SUCCESS || sizes[f] == 0)
+                        continue;
+                    (void)hipSetDevice(devices[s]);
+                    exchange_failed = exchange_failed || api.send(source(f), sizes[f], kNcclUint8, static_cast<int>(root), ctx.comms[s], ctx.comm_streams[s]) != 0;
+                    (void)hipSetDevice(root_device);
+                    exchange_failed = exchange_failed || api.recv(gathered + gather->offsets[f], sizes[f], kNcclUint8, static_cast<int>(s), ctx.comms[root],
+                                                                  ctx.comm_streams[root]) != 0;
+                }
+                exchange_failed = api.group_end() != 0 || exchange_failed;
             }
+            if (exchange_failed)
+                raise(CHARLS_AMD_ERRC_DEVICE_FAILURE);
         }
-        hip_check(hipStreamSynchronize(own.s));
-    }
-    if (gather->total_bytes != nullptr)
+        (void)hipSetDevice(caller_device);
+    };
+
+    charls_jpegls_errc result = on_every_shard(ctx, shard_count, shards, code_shard, hand_over);
+    // everything that was queued has to land (or be given up) before the buffers go back to the caller
+    bool sync_failed = false;
+    (void)hipSetDevice(root_device);
+    sync_failed = hipStreamSynchronize(own.s) != hipSuccess || sync_failed;
+    if (use_rccl)
+        for (uint32_t s = 0; s < shard_count; ++s)
+        {
+            (void)hipSetDevice(devices[s]);
+            sync_failed = hipStreamSynchronize(ctx.comm_streams[s]) != hipSuccess || sync_failed;
+        }
+    (void)hipSetDevice(caller_device);
+    if (use_rccl && (exchange_failed || sync_failed))
+        ctx.drop_communicator(); // (its state after a failed group is unknown: the next call starts a new one)
+    if (result == CHARLS_JPEGLS_ERRC_SUCCESS && sync_failed)
+        result = CHARLS_AMD_ERRC_DEVICE_FAILURE;
+    if (result == CHARLS_JPEGLS_ERRC_SUCCESS && gather->total_bytes != nullptr)
         *gather->total_bytes = at;
-    return CHARLS_JPEGLS_ERRC_SUCCESS;
+    return result;
 }
 catch (...)
 {

@@ -6,6 +6,9 @@
 #include <mutex>
 #include <vector>
 
+#include "../device/knobs.h"
+#include "coalescer.h"
+
 namespace jls {
 
 using dev::hip_check;
@@ -17,14 +20,20 @@ struct ResourcePool
 {
     std::mutex mutex;
     std::vector<std::unique_ptr<EngineResources>> idle;
+    size_t idle_bytes{};
 };
 ResourcePool& pool()
 {
     static ResourcePool* p = new ResourcePool;
     return *p;
 }
-constexpr size_t kMaxIdleSets = 4;
-constexpr size_t kMaxIdleBytesPerSet = size_t{512} << 20; // a drop-in library must not sit on gigabytes of the caller's HBM
+// What stays idle: a pool of threads that makes a handle per image (cli/benchmark.cpp does) gives a set back and takes one a
+// moment later, and hipFree waits for EVERY kernel on the device -- seconds, while another thread's decoder runs.  So up to
+// kMaxIdleSets sets of at most kMaxIdleBytesPerSet each stay, as long as they add up to less than kMaxIdleBytes (a 16th
+// of an MI355X); charls_amd_release_work_areas() gives them back.
+constexpr size_t kMaxIdleSets = 1024;
+constexpr size_t kMaxIdleBytesPerSet = size_t{512} << 20;
+constexpr size_t kMaxIdleBytes = size_t{18} << 30;
 
 std::unique_ptr<EngineResources> acquire_resources()
 {
@@ -38,6 +47,7 @@ std::unique_ptr<EngineResources> acquire_resources()
             {
                 std::unique_ptr<EngineResources> r = std::move(p.idle[i]);
                 p.idle.erase(p.idle.begin() + static_cast<std::ptrdiff_t>(i));
+                p.idle_bytes -= r->device_bytes();
                 return r;
             }
     }
@@ -55,8 +65,9 @@ void release_resources(std::unique_ptr<EngineResources> r) noexcept
     {
         ResourcePool& p = pool();
         std::lock_guard<std::mutex> lock(p.mutex);
-        if (p.idle.size() < kMaxIdleSets)
+        if (p.idle.size() < kMaxIdleSets && p.idle_bytes + r->device_bytes() <= kMaxIdleBytes)
         {
+            p.idle_bytes += r->device_bytes();
             p.idle.push_back(std::move(r));
             return;
         }
@@ -64,7 +75,49 @@ void release_resources(std::unique_ptr<EngineResources> r) noexcept
     // (r is destroyed here: too large to keep, or the pool is full)
 }
 
+Coalescer& coalescer()
+{
+    static Coalescer* c = new Coalescer; // never destroyed: calls may be in flight at process exit
+    return *c;
+}
+
+bool coalescing_enabled()
+{
+    return knobs::get_or(knobs::kCoalesce, 1) != 0;
+}
+
+int lane_of(int device, bool decode)
+{
+    return device * 2 + (decode ? 1 : 0);
+}
+
+// How long the leader of a batch waits for calls that announced themselves (their host -> device copies are under way).
+// What they are late by is their copy, so the wait is priced in copies: a decoder launch is one serial chain per scan
+// (0.2 us per sample: seconds for a large frame), so a quarter of that is cheap; an encoder launch of one frame takes about
+// as long as the frame's upload, so it waits for up to 64 uploads.  Never more than 200 ms / 50 ms.
+uint32_t merge_wait_us(const ScanDesc& d, bool decode)
+{
+    if (const long long knob = knobs::get(knobs::kCoalesceWaitUs); knob != knobs::kUnset)
+        return static_cast<uint32_t>(std::clamp<long long>(knob, 0, 10'000'000));
+    const double samples = static_cast<double>(d.width) * d.height * std::max(1, d.components);
+    if (decode)
+        return static_cast<uint32_t>(std::clamp(samples * 0.2 / 4, 50.0, 200e3));
+    const double upload_us = samples * (d.bits_per_sample > 8 ? 2 : 1) / 50e3; // 50 GB/s
+    return static_cast<uint32_t>(std::clamp(64 * upload_us, 200.0, 50e3));
+}
+
+constexpr uint32_t kMaxMergedScans = 16384;
+
 } // namespace
+
+void coalescer_stats(uint64_t out[4]) noexcept
+{
+    const Coalescer::Stats s = coalescer().stats();
+    out[0] = s.calls;
+    out[1] = s.launches;
+    out[2] = s.merged;
+    out[3] = s.largest;
+}
 
 EngineResources::~EngineResources()
 {
@@ -79,11 +132,13 @@ void release_idle_engine_resources() noexcept
         ResourcePool& p = pool();
         std::lock_guard<std::mutex> lock(p.mutex);
         gone.swap(p.idle);
+        p.idle_bytes = 0;
     }
 }
 
 ScanEngine::~ScanEngine()
 {
+    end_call();
     release_resources(std::move(r_));
 }
 
@@ -92,6 +147,21 @@ void ScanEngine::ensure_stream()
     dev::require_device();
     if (!r_)
         r_ = acquire_resources();
+}
+
+void ScanEngine::announce(bool decode)
+{
+    if (announced_lane_ >= 0 || !coalescing_enabled())
+        return;
+    announced_lane_ = lane_of(r_->device, decode);
+    coalescer().announce(announced_lane_);
+}
+
+void ScanEngine::end_call() noexcept
+{
+    if (announced_lane_ >= 0)
+        coalescer().retract(announced_lane_);
+    announced_lane_ = -1;
 }
 
 ScanDesc ScanEngine::make_desc(const ScanSpec& s) const
@@ -114,41 +184,68 @@ ScanDesc ScanEngine::make_desc(const ScanSpec& s) const
 
 ScanResult ScanEngine::run(const ScanDesc& desc, bool decode)
 {
-    auto* staged = static_cast<uint8_t*>(r_->staging.ensure(sizeof(ScanDesc) + sizeof(ScanResult)));
-    std::memcpy(staged, &desc, sizeof desc);
-    auto* d_desc = static_cast<ScanDesc*>(r_->desc.ensure(sizeof(ScanDesc)));
-    auto* d_result = static_cast<ScanResult*>(r_->result.ensure(sizeof(ScanResult)));
-    hip_check(hipMemcpyAsync(d_desc, staged, sizeof desc, hipMemcpyHostToDevice, r_->stream));
-    if (decode)
-        dev::launch_decode(desc, d_desc, d_result, 1, r_->stream);
-    else
-        dev::launch_encode(desc, d_desc, d_result, 1, r_->stream);
-    hip_check(hipMemcpyAsync(staged + sizeof desc, d_result, sizeof(ScanResult), hipMemcpyDeviceToHost, r_->stream));
-    hip_check(hipStreamSynchronize(r_->stream));
-    if (dev::work_area_bytes() > (size_t{1} << 30))
-        dev::release_work_areas(); // a drop-in library must not sit on gigabytes of the caller's HBM between calls
     ScanResult r;
-    std::memcpy(&r, staged + sizeof desc, sizeof r);
+    run_many(&desc, 1, decode, &r);
     return r;
 }
 
-void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, ScanResult* results)
+// One launch for descs[0, n), on this handle's stream and with this handle's staging areas.
+void ScanEngine::launch(const ScanDesc* descs, uint32_t n, bool decode, ScanResult* results)
 {
-    const size_t desc_bytes = sizeof(ScanDesc) * count, result_bytes = sizeof(ScanResult) * count;
+    const size_t desc_bytes = sizeof(ScanDesc) * n, result_bytes = sizeof(ScanResult) * n;
     auto* staged = static_cast<uint8_t*>(r_->staging.ensure(desc_bytes + result_bytes));
     std::memcpy(staged, descs, desc_bytes);
     auto* d_descs = static_cast<ScanDesc*>(r_->desc.ensure(desc_bytes));
     auto* d_results = static_cast<ScanResult*>(r_->result.ensure(result_bytes));
     hip_check(hipMemcpyAsync(d_descs, staged, desc_bytes, hipMemcpyHostToDevice, r_->stream));
+    ScanDesc proto = descs[0];
     if (decode)
-        dev::launch_decode(descs[0], d_descs, d_results, count, r_->stream);
+        dev::launch_decode(proto, d_descs, d_results, n, r_->stream);
     else
-        dev::launch_encode(descs[0], d_descs, d_results, count, r_->stream);
+    {
+        for (uint32_t i = 1; i < n; ++i) // (an upper bound of every scan's capacity: launch_encode sizes the raw streams by it)
+            proto.stream_capacity = std::max(proto.stream_capacity, descs[i].stream_capacity);
+        dev::launch_encode(proto, d_descs, d_results, n, r_->stream);
+    }
     hip_check(hipMemcpyAsync(staged + desc_bytes, d_results, result_bytes, hipMemcpyDeviceToHost, r_->stream));
     hip_check(hipStreamSynchronize(r_->stream));
-    if (dev::work_area_bytes() > (size_t{1} << 30))
-        dev::release_work_areas();
     std::memcpy(results, staged + desc_bytes, result_bytes);
+}
+
+void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, ScanResult* results)
+{
+    constexpr size_t kKeepBytes = size_t{1} << 30; // a drop-in library must not sit on gigabytes of the caller's HBM between calls
+    if (!coalescing_enabled())
+    {
+        launch(descs, count, decode, results);
+        if (dev::work_area_bytes() > kKeepBytes)
+            dev::release_work_areas();
+        return;
+    }
+    // What this call uploaded is in HBM before anybody's launch may read it.
+    hip_check(hipStreamSynchronize(r_->stream));
+    const int lane = lane_of(r_->device, decode);
+    const bool announced = announced_lane_ == lane;
+    if (announced_lane_ >= 0 && !announced)
+        end_call();
+    announced_lane_ = -1; // (submit takes the announcement back)
+    const Coalescer::Launch run_batch = [this, decode, lane](const ScanDesc* all, uint32_t n, ScanResult* out) {
+        if (decode)
+        { // decoder launches keep next to nothing between calls and run side by side
+            launch(all, n, true, out);
+            if (dev::work_area_bytes() > kKeepBytes)
+                dev::release_work_areas();
+            return;
+        }
+        // encoder launches share the device's work areas: one merged launch at a time (the coalescer's exclusive lane
+        // already sees to that; the scope also keeps charls_amd_release_work_areas() of another thread out)
+        dev::SharedAreasScope shared;
+        launch(all, n, false, out);
+        if (shared.bytes() > kKeepBytes && coalescer().idle(lane, /*but_for_the_running_batch=*/true))
+            shared.release(); // nobody on the way: give the gigabytes back (a pool of threads keeps them while it keeps calling)
+    };
+    coalescer().submit(lane, merge_key_of(descs[0]), descs, count, results, announced, /*exclusive=*/!decode, merge_wait_us(descs[0], decode),
+                       kMaxMergedScans, run_batch);
 }
 
 void ScanEngine::encode_planes(const ScanSpec& spec, uint32_t count, size_t plane_bytes, size_t stride, size_t capacity, ScanResult* results)
@@ -173,7 +270,7 @@ void ScanEngine::encode_planes(const ScanSpec& spec, uint32_t count, size_t plan
 
 void ScanEngine::fetch_encoded_scan(uint32_t index, uint8_t* destination, size_t bytes)
 {
-    hip_check(hipMemcpy(destination, r_->bits.as<uint8_t>() + plane_capacity_ * index, bytes, hipMemcpyDeviceToHost));
+    copy_out(destination, r_->bits.as<uint8_t>() + plane_capacity_ * index, bytes);
 }
 
 void ScanEngine::decode_planes(const ScanSpec& spec, const size_t* stream_offsets, uint32_t count, ScanResult* results)
@@ -199,13 +296,33 @@ void ScanEngine::decode_planes(const ScanSpec& spec, const size_t* stream_offset
 void ScanEngine::fetch_decoded_plane(const ScanSpec& spec, uint32_t index, uint8_t* destination, size_t stride)
 {
     const size_t row_bytes = static_cast<size_t>(spec.width) * bytes_per_sample(spec.bits_per_sample);
-    hip_check(hipMemcpy2D(destination, stride, r_->pixels.as<uint8_t>() + row_bytes * spec.height * index, row_bytes, row_bytes,
-                          spec.height, hipMemcpyDeviceToHost));
+    copy_rows_out(destination, stride, r_->pixels.as<uint8_t>() + row_bytes * spec.height * index, row_bytes, spec.height);
+}
+
+// Device -> host on the handle's own stream (the null stream would queue the copies of all calling threads behind each other).
+void ScanEngine::copy_out(uint8_t* destination, const uint8_t* device_source, size_t bytes)
+{
+    if (bytes == 0)
+        return;
+    hip_check(hipMemcpyAsync(destination, device_source, bytes, hipMemcpyDeviceToHost, r_->stream));
+    hip_check(hipStreamSynchronize(r_->stream));
+}
+
+void ScanEngine::copy_rows_out(uint8_t* destination, size_t stride, const uint8_t* device_source, size_t row_bytes, size_t rows)
+{
+    if (stride == row_bytes)
+    { // packed rows: one copy
+        copy_out(destination, device_source, row_bytes * rows);
+        return;
+    }
+    hip_check(hipMemcpy2DAsync(destination, stride, device_source, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, r_->stream));
+    hip_check(hipStreamSynchronize(r_->stream));
 }
 
 void ScanEngine::upload_pixels(const uint8_t* source, size_t bytes)
 {
     ensure_stream();
+    announce(false); // (before the copy: the copy is what the others of a batch wait for)
     r_->pixels.ensure(bytes);
     pixel_bytes_ = bytes;
     hip_check(hipMemcpyAsync(r_->pixels.as<uint8_t>(), source, bytes, hipMemcpyHostToDevice, r_->stream));
@@ -228,13 +345,14 @@ size_t ScanEngine::encode_scan(const ScanSpec& spec, size_t pixel_offset, size_t
     const ScanResult r = run(d, false);
     if (r.errc != kOk)
         raise(static_cast<charls_jpegls_errc>(r.errc));
-    hip_check(hipMemcpy(destination, d.stream, r.bytes, hipMemcpyDeviceToHost));
+    copy_out(destination, d.stream, r.bytes);
     return r.bytes;
 }
 
 void ScanEngine::upload_stream(const uint8_t* source, size_t bytes)
 {
     ensure_stream();
+    announce(true);
     r_->bits.ensure(bytes + 16); // the ring refill of the wave decoder reads whole 16-byte groups
     stream_bytes_ = bytes;
     hip_check(hipMemcpyAsync(r_->bits.as<uint8_t>(), source, bytes, hipMemcpyHostToDevice, r_->stream));
@@ -255,7 +373,7 @@ size_t ScanEngine::decode_scan(const ScanSpec& spec, size_t stream_offset, uint8
     const ScanResult r = run(d, true);
     if (r.errc != kOk) // the destination content after a failed decode is unspecified in the reference as well
         raise(static_cast<charls_jpegls_errc>(r.errc));
-    hip_check(hipMemcpy2D(destination, stride, d.pixels, row_bytes, row_bytes, spec.height, hipMemcpyDeviceToHost));
+    copy_rows_out(destination, stride, d.pixels, row_bytes, spec.height);
     return r.bytes;
 }
 

@@ -46,6 +46,20 @@ struct EngineResources
 
 // Frees the idle sets of the pool (charls_amd_release_work_areas calls it).
 void release_idle_engine_resources() noexcept;
+// What the coalescer of the host-pointer ABI did so far (coalescer.h): calls, launches, calls that shared a launch, scans of
+// the largest launch.
+void coalescer_stats(uint64_t out[4]) noexcept;
+
+class ScanEngine;
+// Ends the engine's part of a coding call of the facade however the call ends (ScanEngine::end_call).
+struct CallScope
+{
+    explicit CallScope(ScanEngine& e) noexcept : engine(e) {}
+    CallScope(const CallScope&) = delete;
+    CallScope& operator=(const CallScope&) = delete;
+    inline ~CallScope();
+    ScanEngine& engine;
+};
 
 class ScanEngine
 {
@@ -79,14 +93,28 @@ public:
     void decode_planes(const ScanSpec& spec, const size_t* stream_offsets, uint32_t count, ScanResult* results);
     void fetch_decoded_plane(const ScanSpec& spec, uint32_t index, uint8_t* destination, size_t stride);
 
+    // The coding call of the facade is over (normally or not): an upload that announced this call to the coalescer and
+    // was not followed by a scan is taken back.
+    void end_call() noexcept;
+
 private:
     void ensure_stream();
+    void announce(bool decode);
     ScanDesc make_desc(const ScanSpec& spec) const;
     ScanResult run(const ScanDesc& desc, bool decode);
     void run_many(const ScanDesc* descs, uint32_t count, bool decode, ScanResult* results);
+    void launch(const ScanDesc* descs, uint32_t n, bool decode, ScanResult* results);
+    void copy_out(uint8_t* destination, const uint8_t* device_source, size_t bytes);
+    void copy_rows_out(uint8_t* destination, size_t stride, const uint8_t* device_source, size_t row_bytes, size_t rows);
 
     std::unique_ptr<EngineResources> r_; // from the pool at the first device call, back to it with the handle
     size_t pixel_bytes_{}, stream_bytes_{}, plane_capacity_{};
+    int announced_lane_{-1}; // the coalescer lane this call announced itself on (-1: none)
 };
+
+inline CallScope::~CallScope()
+{
+    engine.end_call();
+}
 
 } // namespace jls

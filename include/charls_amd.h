@@ -419,19 +419,37 @@ CHARLS_AMD_API charls_jpegls_errc charls_amd_jpegls_encoder_set_restart_interval
  * kernel, 2 = force the parallel pipeline (returns invalid_argument when the scan is not eligible). Process-wide. */
 CHARLS_AMD_API charls_jpegls_errc charls_amd_set_encode_engine(int32_t engine);
 
-/* HBM kept by the library for its own work areas (the lossless encoder's per-scan work area of 10 B per sample plus the
- * unstuffed stream, the private buffers of restart intervals).  They belong to the calling thread and to the device that
- * was current when they were made (a thread that moves to another device gets new ones there), grow on demand and stay
- * allocated between calls.  The limit is process-wide: 0 (the default) = a quarter of the device's memory, and never more than what is
- * free minus 8 GiB.  A batch larger than the limit allows is coded in several passes; when not even one work area can be
- * allocated the encoder falls back to its one-wavefront-per-scan kernel, which needs none.  The host-pointer encoder /
- * decoder of part 1 release work areas above 1 GiB before they return.  Their handles share a small process-wide pool of
- * device buffers, streams and pinned staging areas (at most 4 idle sets of at most 512 MiB each: callers create a handle per
- * image, and creating these per handle costs more than coding a frame); charls_amd_release_work_areas frees the idle ones
- * too. */
+/* HBM kept by the library for its own work areas (the lossless encoder's per-scan work area of 8 B per sample of up to 8
+ * bits -- 10 B per wider sample -- plus the unstuffed stream, the private buffers of restart intervals).  The batch entry
+ * points of part 2 keep them per calling thread and device (a thread that moves to another device gets new ones there);
+ * they grow on demand and stay allocated between calls.  The limit is process-wide: 0 (the default) = a quarter of the
+ * device's memory, and never more than what is free minus 8 GiB.  A batch larger than the limit allows is coded in several
+ * passes; when not even one work area can be allocated the encoder falls back to its one-wavefront-per-scan kernel, which
+ * needs none (counted: charls_amd_engine_counters [4]).
+ *
+ * The host-pointer encoder / decoder of part 1 (THREADING, as the reference: distinct handles are independent, callers
+ * scale by threads x handles): calls that arrive together are merged into one kernel launch (charls_amd_engine_counters),
+ * and the merged encoder launches of ALL threads run on ONE set of work areas per device, within the same limit -- a pool of
+ * 256 threads holds one arena, not 256.  That set is given back above 1 GiB as soon as no further call is on its way.
+ * Handles share a process-wide pool of device buffers, streams and pinned staging areas (idle sets of at most 512 MiB each,
+ * at most 18 GiB together: callers create a handle per image, creating these per handle costs more than coding a frame,
+ * and freeing them waits for every kernel on the device); charls_amd_release_work_areas frees the calling thread's areas,
+ * the shared set and the idle pool. */
 CHARLS_AMD_API charls_jpegls_errc charls_amd_set_workspace_limit(uint64_t bytes);
-CHARLS_AMD_API charls_jpegls_errc charls_amd_release_work_areas(void); /* the calling thread's */
-CHARLS_AMD_API uint64_t charls_amd_work_area_bytes(void);              /* the calling thread's, currently allocated */
+CHARLS_AMD_API charls_jpegls_errc charls_amd_release_work_areas(void);
+CHARLS_AMD_API uint64_t charls_amd_work_area_bytes(void); /* the calling thread's + the shared set of part 1, currently allocated */
+
+/* What the engine did with the calls of part 1 since the library was loaded (process-wide): out[0] scan submissions of
+ * the host-pointer ABI, out[1] kernel launches they took, out[2] submissions that shared their launch with another call,
+ * out[3] scans of the largest launch, out[4] scans the lossless pipeline was eligible for that were coded by the
+ * one-wavefront kernel because no work area could be allocated.  Returns the number of values written (5 at most). */
+CHARLS_AMD_API int32_t charls_amd_engine_counters(uint64_t* out, int32_t capacity);
+
+/* Test and measurement knobs (charls_amd/csrc/device/knobs.h has the list: DECODE_GROUP, JOB_EVENTS, TILE_SAMPLES,
+ * COALESCE, ...).  The environment (CHARLS_AMD_<NAME>) is read ONCE, when the first knob is looked at; after that only this
+ * call changes a value.  `name` with or without the CHARLS_AMD_ prefix; `value` INT64_MIN clears the knob (the engine's own
+ * rule applies again).  Process-wide, not synchronised with calls in flight.  invalid_argument for an unknown name. */
+CHARLS_AMD_API charls_jpegls_errc charls_amd_debug_set_knob(const char* name, int64_t value);
 
 /* Milliseconds of GPU time (hipEvent) the last batch call on this thread spent in its kernels, by stage:
  * out[0] total, out[1] dominant kernel, out[2..7] stage breakdown. Returns the number of values. */

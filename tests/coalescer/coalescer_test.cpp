@@ -1,0 +1,210 @@
+// coalescer_test.cpp -- drives charls_amd/csrc/host/coalescer.h with a fake launch (no HIP, no GPU).  Built and run by
+// tests/test_coalescer_cpu.py.  Every check prints a line; the last line is "coalescer ok".
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+
+#include "host/coalescer.h"
+
+using namespace jls;
+using Clock = std::chrono::steady_clock;
+
+static int g_failures = 0;
+#define CHECK(cond, what)                                                  \
+    do                                                                     \
+    {                                                                      \
+        const bool ok_ = (cond);                                           \
+        std::printf("%s: %s\n", ok_ ? "ok" : "FAILED", what);              \
+        if (!ok_)                                                          \
+            ++g_failures;                                                  \
+    } while (0)
+
+static ScanDesc desc_of(uint32_t width, uint32_t tag)
+{
+    ScanDesc d{};
+    d.width = width;
+    d.height = 8;
+    d.components = 1;
+    d.bits_per_sample = 8;
+    d.stream_capacity = tag; // (the fake launch echoes it: every caller must get ITS result back)
+    return d;
+}
+
+static double ms_since(Clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+}
+
+int main()
+{
+    // 1. a caller that is alone launches at once, whatever the wait
+    {
+        Coalescer c;
+        int launches = 0;
+        const ScanDesc d = desc_of(64, 7);
+        ScanResult r{};
+        const auto t0 = Clock::now();
+        c.announce(1);
+        c.submit(1, merge_key_of(d), &d, 1, &r, true, false, 500000, 1024, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
+            ++launches;
+            for (uint32_t i = 0; i < n; ++i)
+                out[i] = ScanResult{0, 0, all[i].stream_capacity * 3};
+        });
+        CHECK(launches == 1 && r.bytes == 21 && ms_since(t0) < 100, "a lone call launches at once and gets its result");
+        CHECK(c.idle(1), "the lane is idle afterwards");
+    }
+    // 2. N announced calls end up in ONE launch, every caller gets its own result
+    {
+        Coalescer c;
+        constexpr int kThreads = 48;
+        std::atomic<int> launches{0}, largest{0}, wrong{0};
+        for (int i = 0; i < kThreads; ++i)
+            c.announce(3);
+        std::vector<std::thread> threads;
+        for (int i = 0; i < kThreads; ++i)
+            threads.emplace_back([&, i] {
+                std::this_thread::sleep_for(std::chrono::microseconds(200 * (i % 7))); // (uploads of different length)
+                ScanDesc d[2] = {desc_of(512, 1000 + i), desc_of(512, 2000 + i)};
+                ScanResult r[2]{};
+                c.submit(3, merge_key_of(d[0]), d, 2, r, true, false, 2000000, 1024, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
+                    ++launches;
+                    largest = std::max<int>(largest, (int)n);
+                    for (uint32_t k = 0; k < n; ++k)
+                        out[k] = ScanResult{0, 0, all[k].stream_capacity + 5};
+                });
+                if (r[0].bytes != 1005u + i || r[1].bytes != 2005u + i)
+                    ++wrong;
+            });
+        for (auto& t : threads)
+            t.join();
+        CHECK(launches == 1 && largest == 2 * kThreads && wrong == 0, "48 announced calls of two scans share one launch");
+        const Coalescer::Stats s = c.stats();
+        CHECK(s.calls == kThreads && s.launches == 1 && s.merged == kThreads && s.largest == 2 * kThreads, "the counters say so");
+    }
+    // 3. different keys never share a launch; equal keys on different lanes neither
+    {
+        Coalescer c;
+        std::atomic<int> launches{0}, mixed{0};
+        std::vector<std::thread> threads;
+        for (int i = 0; i < 24; ++i)
+            c.announce(i % 2 ? 5 : 7);
+        for (int i = 0; i < 24; ++i)
+            threads.emplace_back([&, i] {
+                const ScanDesc d = desc_of(i % 3 == 0 ? 100 : 200, (uint32_t)i);
+                ScanResult r{};
+                c.submit(i % 2 ? 5 : 7, merge_key_of(d), &d, 1, &r, true, false, 300000, 1024, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
+                    ++launches;
+                    for (uint32_t k = 0; k < n; ++k)
+                    {
+                        if (all[k].width != all[0].width || (all[k].stream_capacity % 2) != (all[0].stream_capacity % 2))
+                            ++mixed;
+                        out[k] = ScanResult{};
+                    }
+                });
+            });
+        for (auto& t : threads)
+            t.join();
+        CHECK(mixed == 0 && launches >= 4, "keys and lanes are kept apart");
+    }
+    // 4. an exclusive lane runs one batch at a time, and whoever arrives while one runs joins the NEXT one (group commit)
+    {
+        Coalescer c;
+        std::atomic<int> running{0}, overlap{0}, launches{0};
+        auto fake = [&](const ScanDesc*, uint32_t n, ScanResult* out) {
+            if (++running > 1)
+                ++overlap;
+            ++launches;
+            std::this_thread::sleep_for(std::chrono::milliseconds(60));
+            for (uint32_t k = 0; k < n; ++k)
+                out[k] = ScanResult{};
+            --running;
+        };
+        std::vector<std::thread> threads;
+        for (int i = 0; i < 12; ++i)
+            threads.emplace_back([&, i] {
+                if (i > 0)
+                    std::this_thread::sleep_for(std::chrono::milliseconds(10 + i)); // the first one is running by then
+                const ScanDesc d = desc_of(300, (uint32_t)i);
+                ScanResult r{};
+                c.submit(2, merge_key_of(d), &d, 1, &r, false, true, 0, 1024, fake);
+            });
+        for (auto& t : threads)
+            t.join();
+        CHECK(overlap == 0 && launches == 2, "exclusive: no two batches at once, 11 late calls in the second launch");
+    }
+    // 5. a launch that fails fails every call of its batch with its code
+    {
+        Coalescer c;
+        std::atomic<int> codes{0};
+        std::vector<std::thread> threads;
+        for (int i = 0; i < 6; ++i)
+            c.announce(9);
+        for (int i = 0; i < 6; ++i)
+            threads.emplace_back([&] {
+                const ScanDesc d = desc_of(77, 0);
+                ScanResult r{};
+                try
+                {
+                    c.submit(9, merge_key_of(d), &d, 1, &r, true, false, 500000, 1024,
+                             [&](const ScanDesc*, uint32_t, ScanResult*) { raise(CHARLS_JPEGLS_ERRC_NOT_ENOUGH_MEMORY); });
+                }
+                catch (const error& e)
+                {
+                    if (e.code == CHARLS_JPEGLS_ERRC_NOT_ENOUGH_MEMORY)
+                        ++codes;
+                }
+            });
+        for (auto& t : threads)
+            t.join();
+        CHECK(codes == 6, "all six calls of a failed launch report its error");
+        CHECK(c.idle(9), "and the lane is idle again");
+    }
+    // 6. retracting an announcement lets the leader go; an announced call that never comes costs at most the wait
+    {
+        Coalescer c;
+        c.announce(11);
+        std::thread quitter([&] {
+            std::this_thread::sleep_for(std::chrono::milliseconds(30));
+            c.retract(11);
+        });
+        const ScanDesc d = desc_of(10, 0);
+        ScanResult r{};
+        auto t0 = Clock::now();
+        c.announce(11);
+        c.submit(11, merge_key_of(d), &d, 1, &r, true, false, 3000000, 1024, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+        const double waited = ms_since(t0);
+        quitter.join();
+        CHECK(waited >= 20 && waited < 1500, "the leader waits for an announced call and stops waiting when it is retracted");
+        c.announce(11); // never submits
+        t0 = Clock::now();
+        c.submit(11, merge_key_of(d), &d, 1, &r, false, false, 50000, 1024, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+        const double capped = ms_since(t0);
+        CHECK(capped >= 40 && capped < 1000, "an announced call that never comes costs the wait and no more");
+        c.retract(11);
+    }
+    // 7. a batch never grows beyond max_scans
+    {
+        Coalescer c;
+        std::atomic<int> largest{0}, total{0};
+        std::vector<std::thread> threads;
+        for (int i = 0; i < 20; ++i)
+            c.announce(13);
+        for (int i = 0; i < 20; ++i)
+            threads.emplace_back([&] {
+                const ScanDesc d = desc_of(40, 0);
+                ScanResult r{};
+                c.submit(13, merge_key_of(d), &d, 1, &r, true, false, 200000, 8, [&](const ScanDesc*, uint32_t n, ScanResult* out) {
+                    largest = std::max<int>(largest, (int)n);
+                    total += (int)n;
+                    for (uint32_t k = 0; k < n; ++k)
+                        out[k] = ScanResult{};
+                });
+            });
+        for (auto& t : threads)
+            t.join();
+        CHECK(largest <= 8 && total == 20, "batches are capped at max_scans and nobody is lost");
+    }
+    std::printf(g_failures == 0 ? "coalescer ok\n" : "coalescer FAILED\n");
+    return g_failures == 0 ? 0 : 1;
+}

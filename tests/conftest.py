@@ -29,3 +29,31 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+class _Knobs:
+    """Sets the engine's knobs through charls_amd_debug_set_knob and clears every one it touched at the end of the test."""
+
+    def __init__(self):
+        self.touched = set()
+
+    def set(self, name, value):
+        from charls_amd import capi
+        name = name.replace("CHARLS_AMD_", "")
+        capi.set_knob(name, value)
+        self.touched.add(name)
+
+    def clear(self, name):
+        self.set(name, None)
+
+    def restore(self):
+        from charls_amd import capi
+        for name in self.touched:
+            capi.set_knob(name, None)
+
+
+@pytest.fixture
+def knobs():
+    k = _Knobs()
+    yield k
+    k.restore()

@@ -40,7 +40,7 @@ def _build_and_load(driver, out):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not os.path.exists(out) or os.path.getmtime(out) < newest:
             tmp = out + f".{os.getpid()}.tmp"
-            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + EMU_DIR,
+            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DJLS_KNOBS_LIVE_ENV", "-I" + EMU_DIR,
                                    "-I" + DEV, "-x", "c++", os.path.join(EMU_DIR, driver), "-o", tmp])
             os.replace(tmp, out)
     L = C.CDLL(out)
@@ -74,7 +74,7 @@ def lib():
             fcntl.flock(lock, fcntl.LOCK_EX)
             if not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
                 tmp = OUT + f".{os.getpid()}.tmp"
-                subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + EMU_DIR,
+                subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DJLS_KNOBS_LIVE_ENV", "-I" + EMU_DIR,
                                        "-I" + DEV, "-x", "c++", os.path.join(EMU_DIR, "emu_driver.cpp"), "-o", tmp])
                 os.replace(tmp, OUT)
         L = C.CDLL(OUT)

@@ -137,13 +137,13 @@ def test_config4_frames_equal_reference_hashes(torch):
     assert (errcs == 0).all() and torch.equal(out, frames)
 
 
-def test_exact_decoder_agrees_with_speed_path(torch, monkeypatch):
+def test_exact_decoder_agrees_with_speed_path(torch, knobs):
     """CHARLS_AMD_EXACT_DECODER=1 forces the reference-policy decoder; both must give the same pixels and byte counts."""
     frames = synth.frames_torch(4, 333, 77, seed0=5, kind="mixed", device="cuda:0")
     enc = batch.encode_batch(frames)
     out_fast = torch.empty_like(frames)
     batch.decode_batch(enc.streams, enc.sizes, out_fast)
-    monkeypatch.setenv("CHARLS_AMD_EXACT_DECODER", "1")
+    knobs.set("EXACT_DECODER", 1)
     out_exact = torch.empty_like(frames)
     _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out_exact)
     assert (errcs == 0).all() and torch.equal(out_fast, out_exact) and torch.equal(out_exact, frames)
@@ -278,18 +278,18 @@ def test_planar_batch_every_capacity_around_the_fit(torch, bits, near, comps):
                 assert host[f, :int(enc.sizes[f])].tobytes() == want, (pitch, f)
 
 
-def _decode_both_ways(torch, streams, sizes, like, monkeypatch):
+def _decode_both_ways(torch, streams, sizes, like, knobs):
     """The batch decoder with the component scans of planar frames in one launch, and scan by scan (CHARLS_AMD_BATCH_ROUNDS)."""
     out_a, out_b = torch.zeros_like(like), torch.zeros_like(like)
-    monkeypatch.delenv("CHARLS_AMD_BATCH_ROUNDS", raising=False)
+    knobs.clear("BATCH_ROUNDS")
     _, errcs_a, _ = batch.decode_batch(streams, sizes, out_a)
-    monkeypatch.setenv("CHARLS_AMD_BATCH_ROUNDS", "1")
+    knobs.set("BATCH_ROUNDS", 1)
     _, errcs_b, _ = batch.decode_batch(streams, sizes, out_b)
-    monkeypatch.delenv("CHARLS_AMD_BATCH_ROUNDS", raising=False)
+    knobs.clear("BATCH_ROUNDS")
     return out_a, errcs_a, out_b, errcs_b
 
 
-def test_planar_batch_decodes_all_component_scans_in_one_launch(torch, monkeypatch):
+def test_planar_batch_decodes_all_component_scans_in_one_launch(torch, knobs):
     """VERDICT round 3, item 8, the decoder's half: the scans of planar frames are found (the marker that ends a scan is
     searched for on the device, the part-1 reader parses on from there) and decoded by ONE launch.  Pixels against the
     frames, the same pixels and error codes as scan by scan, and the time against the same planes as separate frames."""
@@ -299,7 +299,7 @@ def test_planar_batch_decodes_all_component_scans_in_one_launch(torch, monkeypat
     frames = torch.from_numpy(np.stack(imgs)).cuda()
     enc = batch.encode_batch(frames, component_count=3)
     assert (enc.errcs == 0).all()
-    out_a, errcs_a, out_b, errcs_b = _decode_both_ways(torch, enc.streams, enc.sizes, frames, monkeypatch)
+    out_a, errcs_a, out_b, errcs_b = _decode_both_ways(torch, enc.streams, enc.sizes, frames, knobs)
     assert (errcs_a == 0).all() and (errcs_b == 0).all()
     assert torch.equal(out_a, frames) and torch.equal(out_b, frames)
     planes = batch.encode_batch(frames.reshape(n * 3, h, w))
@@ -316,7 +316,7 @@ def test_planar_batch_decodes_all_component_scans_in_one_launch(torch, monkeypat
 
 
 @pytest.mark.parametrize("bits,comps,near,restart", [(8, 3, 0, 0), (8, 3, 2, 0), (16, 2, 0, 0), (12, 4, 0, 0), (8, 3, 0, 7)])
-def test_planar_batch_decode_modes_and_damage(torch, monkeypatch, bits, comps, near, restart):
+def test_planar_batch_decode_modes_and_damage(torch, knobs, bits, comps, near, restart):
     """Planar frames of several widths of sample, near-lossless, with restart intervals; then the same batch with one stream
     cut short, one damaged inside its second scan, one whose end-of-image marker is gone and one with a comment segment THAT
     CONTAINS A START-OF-SCAN MARKER between two scans: pixels and error codes equal what the scan-by-scan decoder gives."""
@@ -325,7 +325,7 @@ def test_planar_batch_decode_modes_and_damage(torch, monkeypatch, bits, comps, n
     frames = torch.from_numpy(np.stack(imgs).astype(np.int16 if bits > 8 else np.uint8)).cuda()
     enc = batch.encode_batch(frames, bits_per_sample=bits, component_count=comps, near_lossless=near, restart_interval=restart)
     assert (enc.errcs == 0).all()
-    out_a, errcs_a, out_b, errcs_b = _decode_both_ways(torch, enc.streams, enc.sizes, frames, monkeypatch)
+    out_a, errcs_a, out_b, errcs_b = _decode_both_ways(torch, enc.streams, enc.sizes, frames, knobs)
     assert (errcs_a == 0).all() and (errcs_b == 0).all() and torch.equal(out_a, out_b)
     if near == 0:
         assert torch.equal(out_a, frames)
@@ -358,7 +358,7 @@ def test_planar_batch_decode_modes_and_damage(torch, monkeypatch, bits, comps, n
     bad[3, s3 + len(comment):s3 + len(comment) + len(tail)] = np.frombuffer(tail, dtype=np.uint8)
     sizes[3] += len(comment)
     streams = torch.from_numpy(bad).cuda()
-    out_a, errcs_a, out_b, errcs_b = _decode_both_ways(torch, streams, sizes, frames, monkeypatch)
+    out_a, errcs_a, out_b, errcs_b = _decode_both_ways(torch, streams, sizes, frames, knobs)
     assert list(errcs_a) == list(errcs_b), (errcs_a, errcs_b)
     assert errcs_a[0] != 0 and errcs_a[1] != 0 and errcs_a[2] != 0 and errcs_a[3] == 0 and errcs_a[4] == 0
     assert torch.equal(out_a[3], out_b[3]) and torch.equal(out_a[4], out_b[4])

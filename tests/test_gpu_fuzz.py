@@ -93,7 +93,7 @@ def test_mutated_streams_decode_like_the_oracle(lib, name):
 
 
 @pytest.mark.parametrize("restart", [0, 6])
-def test_mutated_planar_streams_through_the_batch_decoder(lib, monkeypatch, restart):
+def test_mutated_planar_streams_through_the_batch_decoder(lib, knobs, restart):
     """The batch decoder finds the component scans of planar frames by searching for the marker that ends each of them and
     decodes them by one launch; a frame for which anything is out of the ordinary is decoded again scan by scan.  Eighty
     mutated planar RGB streams in ONE batch: every frame's error code equals what part 1 (one stream through the C ABI)
@@ -115,11 +115,11 @@ def test_mutated_planar_streams_through_the_batch_decoder(lib, monkeypatch, rest
     dev = torch.from_numpy(host).cuda()
     out_a = torch.zeros((n, 3, h, w), dtype=torch.uint8, device="cuda")
     out_b = torch.zeros_like(out_a)
-    monkeypatch.delenv("CHARLS_AMD_BATCH_ROUNDS", raising=False)
+    knobs.clear("BATCH_ROUNDS")
     _, errcs_a, _ = batch.decode_batch(dev, sizes, out_a)
-    monkeypatch.setenv("CHARLS_AMD_BATCH_ROUNDS", "1")
+    knobs.set("BATCH_ROUNDS", 1)
     _, errcs_b, _ = batch.decode_batch(dev, sizes, out_b)
-    monkeypatch.delenv("CHARLS_AMD_BATCH_ROUNDS", raising=False)
+    knobs.clear("BATCH_ROUNDS")
     assert list(errcs_a) == list(errcs_b)
     assert errcs_a[0] == 0 and (errcs_a != 0).sum() > 10 and (errcs_a == 0).sum() > 3  # (the mutations do both)
     mismatches = []

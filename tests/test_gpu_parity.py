@@ -149,7 +149,7 @@ def test_random_parameters_against_oracle(lib):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("name", ["cfg2_full", "cfg3_full", "cfg4_frame0"])
+@pytest.mark.parametrize("name", ["cfg2_full", "cfg2_full_mixed", "cfg3_full", "cfg3b_full_12bit", "cfg4_frame0"])
 def test_baseline_configs_full_size_hash(lib, name):
     """BASELINE.json configs at full size: bytes identical to the reference (hash committed), decode restores the input."""
     c = next(c for c in CASES if c["name"] == name)

@@ -83,10 +83,10 @@ def test_flat_wide_frames_every_tile_looks_back(lib):
         assert lib.encode(img, **kw) == ob.encode(img, **kw)
 
 
-def test_forced_speculation_in_pixel_mode(lib, monkeypatch):
+def test_forced_speculation_in_pixel_mode(lib, knobs):
     for k, v in {"CHARLS_AMD_JOB_EVENTS": "16", "CHARLS_AMD_WARM_EVENTS": "0", "CHARLS_AMD_RUN_JOB_EVENTS": "32",
-                 "CHARLS_AMD_RUN_WARM_EVENTS": "0", "CHARLS_AMD_RUN_LONG_WARM_EVENTS": "0"}.items():
-        monkeypatch.setenv(k, v)
+                 "CHARLS_AMD_RUN_WARM_EVENTS": "0"}.items():
+        knobs.set(k, v)
     for w, h, comps, ilv in ((1024, 512, 3, 2), (12000, 40, 1, 0)):
         img = _rgb(w, h, seed=9, comps=comps) if comps > 1 else synth.frame_numpy(w, h, seed=9, kind="mixed")
         kw = dict(width=w, height=h, component_count=comps, interleave_mode=ilv)
@@ -115,7 +115,7 @@ def test_batch_of_sample_interleaved_frames(lib):
 
 
 @pytest.mark.parametrize("chunk", range(3))
-def test_random_lossless_scans_with_small_tiles(lib, monkeypatch, chunk):
+def test_random_lossless_scans_with_small_tiles(lib, knobs, chunk):
     """Random lossless scans of every interleave mode with tiles of 64 - 512 samples (CHARLS_AMD_TILE_SAMPLES, read per call):
     lines cut into segments at every phase, look-backs, runs across segments, tiles of one to sixteen lines -- and, every
     third case, every scan through pixel mode.  Bytes against the oracle."""
@@ -128,11 +128,11 @@ def test_random_lossless_scans_with_small_tiles(lib, monkeypatch, chunk):
         h = int(rng.choice([1, 2, 3, 9, 20]))
         ct = int(rng.integers(1, 4)) if (comps == 3 and bits in (8, 16) and rng.random() < 0.5) else 0
         kind = str(rng.choice(["mixed", "gradient", "hard", "zero", "noise"]))
-        monkeypatch.setenv("CHARLS_AMD_TILE_SAMPLES", str(int(rng.choice([64, 128, 192, 256, 512]))))
+        knobs.set("TILE_SAMPLES", int(rng.choice([64, 128, 192, 256, 512])))
         if it % 3 == 0:
-            monkeypatch.setenv("CHARLS_AMD_PIXEL_MODE", "1")
+            knobs.set("PIXEL_MODE", 1)
         else:
-            monkeypatch.delenv("CHARLS_AMD_PIXEL_MODE", raising=False)
+            knobs.clear("PIXEL_MODE")
         img = synth.frame_numpy(w, h, seed=1000 * chunk + it, bits=bits, components=comps, kind=kind, interleaved=True)
         if kind == "mixed" and h > 1:  # flat stretches common to all components, across segment boundaries
             x0 = int(rng.integers(0, w))

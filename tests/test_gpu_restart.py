@@ -135,17 +135,17 @@ def test_cpu_assembled_restart_streams_including_ff_terminated_intervals(lib):
     assert ff_total > 0  # the sample contains intervals whose last data byte is 0xFF (followed by a stuffed byte)
 
 
-def test_sequential_and_interval_decoders_agree(lib, monkeypatch):
+def test_sequential_and_interval_decoders_agree(lib, knobs):
     img = synth.frame_numpy(320, 240, seed=77, kind="mixed")
     jls = lib.encode(img, restart_interval=16)
     fast = lib.decode(jls)[1].tobytes()
-    monkeypatch.setenv("CHARLS_AMD_SEQUENTIAL_INTERVALS", "1")
+    knobs.set("SEQUENTIAL_INTERVALS", 1)
     slow = lib.decode(jls)[1].tobytes()
     assert fast == slow == img.tobytes()
 
 
 @pytest.mark.parametrize("damage", ["wrong_index", "missing_marker", "extra_byte", "truncated"])
-def test_damaged_restart_streams_report_the_sequential_decoders_errc(lib, damage, monkeypatch):
+def test_damaged_restart_streams_report_the_sequential_decoders_errc(lib, damage, knobs):
     img = synth.frame_numpy(96, 64, seed=5, kind="mixed")
     jls = bytearray(lib.encode(img, restart_interval=8))
     cont = jls_container.parse(bytes(jls))
@@ -171,7 +171,7 @@ def test_damaged_restart_streams_report_the_sequential_decoders_errc(lib, damage
         except JpegLSError as e:
             return ("err", e.errc)
     got = run()
-    monkeypatch.setenv("CHARLS_AMD_SEQUENTIAL_INTERVALS", "1")
+    knobs.set("SEQUENTIAL_INTERVALS", 1)
     seq = run()
     assert got == seq == want
 

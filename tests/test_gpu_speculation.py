@@ -19,7 +19,7 @@ from charls_amd import batch, capi, synth
 pytestmark = pytest.mark.gpu
 
 FORCED = {"CHARLS_AMD_JOB_EVENTS": "32", "CHARLS_AMD_WARM_EVENTS": "0", "CHARLS_AMD_RUN_JOB_EVENTS": "32",
-          "CHARLS_AMD_RUN_WARM_EVENTS": "0", "CHARLS_AMD_RUN_LONG_WARM_EVENTS": "0"}
+          "CHARLS_AMD_RUN_WARM_EVENTS": "0"}
 
 
 @pytest.fixture(scope="module")
@@ -37,16 +37,16 @@ def counters(lib):
     return np.array(list(out), dtype=np.int64)
 
 
-def force(monkeypatch, **more):
+def force(knobs, **more):
     for k, v in {**FORCED, **more}.items():
-        monkeypatch.setenv(k, v)
+        knobs.set(k, v)
 
 
 @pytest.mark.parametrize("kind,bits,w,h,seed", [("mixed", 8, 512, 512, 21), ("gradient", 8, 1024, 1024, 22),
                                                 ("hard", 8, 1024, 1024, 23), ("mixed", 16, 512, 512, 24),
                                                 ("mixed", 12, 1024, 1024, 25), ("hard", 16, 1024, 1024, 26)])
-def test_every_job_boundary_disagrees_gray(lib, monkeypatch, kind, bits, w, h, seed):
-    force(monkeypatch)
+def test_every_job_boundary_disagrees_gray(lib, knobs, kind, bits, w, h, seed):
+    force(knobs)
     img = synth.frame_numpy(w, h, seed=seed, bits=bits, kind=kind)
     before = counters(lib)
     got = lib.encode(img, width=w, height=h, bits_per_sample=bits)
@@ -59,8 +59,8 @@ def test_every_job_boundary_disagrees_gray(lib, monkeypatch, kind, bits, w, h, s
 
 
 @pytest.mark.parametrize("bits,w,h,ct", [(8, 512, 512, 0), (8, 1024, 1024, 1), (16, 512, 512, 0)])
-def test_every_job_boundary_disagrees_line_interleaved_rgb(lib, monkeypatch, bits, w, h, ct):
-    force(monkeypatch)
+def test_every_job_boundary_disagrees_line_interleaved_rgb(lib, knobs, bits, w, h, ct):
+    force(knobs)
     img = synth.frame_numpy(w, h, seed=31 + bits, bits=bits, components=3, kind="mixed", interleaved=True)
     kw = dict(width=w, height=h, bits_per_sample=bits, component_count=3, interleave_mode=1, color_transformation=ct)
     before = counters(lib)
@@ -70,9 +70,9 @@ def test_every_job_boundary_disagrees_line_interleaved_rgb(lib, monkeypatch, bit
     assert did[1] > did[0] // 4 and did[3] > 0, did
 
 
-def test_partial_warm_up_settles_some_jobs_only(lib, monkeypatch):
+def test_partial_warm_up_settles_some_jobs_only(lib, knobs):
     """A warm-up that is too short for SOME chains: right and wrong guesses in the same launch."""
-    force(monkeypatch, CHARLS_AMD_JOB_EVENTS="64", CHARLS_AMD_WARM_EVENTS="48", CHARLS_AMD_RUN_JOB_EVENTS="64",
+    force(knobs, CHARLS_AMD_JOB_EVENTS="64", CHARLS_AMD_WARM_EVENTS="48", CHARLS_AMD_RUN_JOB_EVENTS="64",
           CHARLS_AMD_RUN_WARM_EVENTS="32")
     img = synth.frame_numpy(1024, 1024, seed=41, kind="mixed")
     before = counters(lib)
@@ -115,10 +115,10 @@ def test_batch_mixing_converging_and_non_converging_frames(lib):
     assert (errcs == 0).all() and torch.equal(out, frames)
 
 
-def test_batch_with_forced_knobs_and_two_passes(lib, monkeypatch):
+def test_batch_with_forced_knobs_and_two_passes(lib, knobs):
     """Several scans per launch AND several passes (a small workspace limit) with every boundary disagreeing."""
     import torch
-    force(monkeypatch)
+    force(knobs)
     w = h = 512
     host = [synth.frame_numpy(w, h, seed=70 + i, kind="mixed" if i % 2 else "hard") for i in range(6)]
     frames = torch.from_numpy(np.stack(host)).cuda()
@@ -137,13 +137,13 @@ def test_batch_with_forced_knobs_and_two_passes(lib, monkeypatch):
 
 
 @pytest.mark.parametrize("chunk,warm", [("64", "0"), ("256", "512"), ("4096", "1024")])
-def test_speculative_stuffing_with_failing_guesses(lib, monkeypatch, chunk, warm):
+def test_speculative_stuffing_with_failing_guesses(lib, knobs, chunk, warm):
     """Stage E in its speculative form (passes of more than 8 scans; speculative_stuffing.hip) with chunks and warm-ups so small
     that entry-state guesses fail: chunks walked again by the resolving wavefront, and -- 64-byte chunks without warm-up --
     scans given up and stuffed in sequence by their first wavefront.  Bytes against the oracle."""
     import torch
-    monkeypatch.setenv("CHARLS_AMD_SPEC_CHUNK", chunk)
-    monkeypatch.setenv("CHARLS_AMD_SPEC_WARM", warm)
+    knobs.set("SPEC_CHUNK", chunk)
+    knobs.set("SPEC_WARM", warm)
     w = h = 256
     kinds = ["mixed", "noise", "gradient", "hard", "zero", "noise", "mixed", "hard", "gradient", "noise", "mixed", "zero"]
     host = [synth.frame_numpy(w, h, seed=90 + i, kind=k) for i, k in enumerate(kinds)]
@@ -164,14 +164,14 @@ def _six(lib):
 
 
 @pytest.mark.parametrize("rare_warm,serial", [(None, 0), ("0", 1), ("24", 1)])
-def test_rarer_run_context_segments_and_their_fallback(lib, monkeypatch, rare_warm, serial):
+def test_rarer_run_context_segments_and_their_fallback(lib, knobs, rare_warm, serial):
     """The exact walk of the rarer run-interruption context goes in segments of its event list from a warm-up counted in
     its own events; a wrong guess makes one lane walk the list again.  Both ways on the MI355X: the oracle's bytes, and the
     counters say which of the two ran."""
     w, h = 1536, 1024
     img = synth.frame_numpy(w, h, seed=41, kind="mixed")
     if rare_warm is not None:
-        monkeypatch.setenv("CHARLS_AMD_RARE_WARM_EVENTS", rare_warm)
+        knobs.set("RARE_WARM_EVENTS", rare_warm)
     before = _six(lib)
     got = lib.encode(img, width=w, height=h)
     did = _six(lib) - before

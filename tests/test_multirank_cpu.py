@@ -105,6 +105,17 @@ def test_bench_launcher_starts_the_ranks_itself():
     assert "nranks=2" in r.stderr
 
 
+def test_bench_cfg4_shards_256_frames_over_the_ranks():
+    """`bench.py --workload cfg4 --gpus 2`: BASELINE configs[3] as stated -- 256 frames split by batch.shard_range, every rank's
+    bitstreams handed to rank 0 from a side thread (as the timed step does it); rank 0 sees all 256, each from its owner."""
+    import json
+    r = _run_bench(["--gpus", "2", "--workload", "cfg4", "--selftest-exchange"], {"CHARLS_AMD_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert lines == [{"selftest": "exchange", "n_gpus": 2, "backend": "gloo", "ranks_seen_by_backend": 2, "ok": True,
+                      "workload": "cfg4", "frames": 256}], r.stdout
+
+
 def test_bench_refuses_to_run_fewer_ranks_than_asked_for():
     """A box with fewer GPUs than --gpus is an error, not a silent single-rank run (there is no GPU here at all)."""
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:

@@ -99,7 +99,7 @@ mpix = args.width * args.height / 1e6
 print(f"synth {t1 - t0:.1f}s encode {t2 - t1:.2f}s = {mpix * args.frames / (t2 - t1):.0f} MPix/s", flush=True)
 rows = []
 for g in [int(x) for x in args.groups.split(",")]:
-    os.environ["CHARLS_AMD_DECODE_GROUP"] = str(g)
+    capi.set_knob("DECODE_GROUP", g)
     for n in [int(x) for x in args.sizes.split(",")]:
         if n > args.frames:
             continue

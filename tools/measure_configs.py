@@ -99,9 +99,9 @@ if "5p" in only:  # planar RGB: the component scans of every frame in one launch
     for k in range(3):
         planes[:, k] = synth.frames_torch(args.rgb_frames, 4096, 4096, seed0=5 + 7919 * k, bits=8, device=dev)
     run("4096x4096 RGB planar (ILV_NONE) lossless (5p)", planes, bits=8, comps=3)
-    os.environ["CHARLS_AMD_BATCH_ROUNDS"] = "1"
+    capi.set_knob("BATCH_ROUNDS", 1)
     run("the same, scan by scan (CHARLS_AMD_BATCH_ROUNDS=1: rounds of one component scan per frame, as until round 4)", planes, bits=8, comps=3)
-    del os.environ["CHARLS_AMD_BATCH_ROUNDS"]
+    capi.set_knob("BATCH_ROUNDS", None)
     del planes
     torch.cuda.empty_cache()
     batch.release_work_areas(lib)

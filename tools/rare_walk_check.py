@@ -12,8 +12,8 @@ def enc(tag):
     print(tag, len(b), [int(after[i] - before[i]) for i in range(6)], flush=True)
     return b
 a = enc("default")
-os.environ["CHARLS_AMD_RARE_WARM_EVENTS"] = "0"
+capi.set_knob("RARE_WARM_EVENTS", 0)
 b = enc("rare warm 0")
-os.environ["CHARLS_AMD_RARE_WARM_EVENTS"] = "100000000"
+capi.set_knob("RARE_WARM_EVENTS", 100000000)
 c = enc("rare warm all")
 print("equal:", a == b == c)
