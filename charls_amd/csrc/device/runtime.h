@@ -141,6 +141,19 @@ size_t work_area_budget() noexcept; // what the calling thread's work areas may 
 // Scans the lossless pipeline was eligible for that were coded by the one-wavefront kernel because no work area could be had.
 uint64_t pipeline_fallback_scans() noexcept;
 
+// A size with room to spare for buffers that grow with the number of scans of a launch: at least 64 KB, then the next power of
+// two.  (Growing a DeviceBuffer frees the old block, and hipFree waits for every kernel that is running on the device.)
+inline size_t with_headroom(size_t bytes) noexcept
+{
+    size_t v = size_t{64} << 10;
+    while (v < bytes)
+        v <<= 1;
+    return v;
+}
+// What the shared work areas of the host-pointer ABI may keep between calls: an eighth of the device's memory, within the
+// workspace limit.
+size_t shared_areas_keep_bytes() noexcept;
+
 // The host-pointer ABI's merged launches (host/scan_engine.cpp) run on ONE set of work areas per device, shared by all
 // calling threads: while a scope is alive the calling thread's launches use that set (and nobody else does).
 class SharedAreasScope

@@ -570,8 +570,8 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
     // they are gathered on the device and decoded by one launch
     auto* d_retry_count = static_cast<uint32_t*>(interval_arena(4).ensure(sizeof(uint32_t)));
     hip_check(hipMemsetAsync(d_retry_count, 0, sizeof(uint32_t), stream));
-    auto* d_retry_index = static_cast<uint32_t*>(interval_arena(5).ensure(sizeof(uint32_t) * count));
-    auto* d_retry_descs = static_cast<ScanDesc*>(interval_arena(6).ensure(sizeof(ScanDesc) * count));
+    auto* d_retry_index = static_cast<uint32_t*>(interval_arena(5).ensure(with_headroom(sizeof(uint32_t) * count)));
+    auto* d_retry_descs = static_cast<ScanDesc*>(interval_arena(6).ensure(with_headroom(sizeof(ScanDesc) * count)));
     hipLaunchKernelGGL(gather_retries, dim3((count + 255) / 256), dim3(256), 0, stream, d_descs,
                        static_cast<const ScanResult*>(d_results), count, d_retry_descs, d_retry_index, d_retry_count);
     hip_check(hipGetLastError());
@@ -580,7 +580,7 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
     hip_check(hipStreamSynchronize(stream));
     if (retries == 0)
         return;
-    auto* d_retry_results = static_cast<ScanResult*>(interval_arena(7).ensure(sizeof(ScanResult) * retries));
+    auto* d_retry_results = static_cast<ScanResult*>(interval_arena(7).ensure(with_headroom(sizeof(ScanResult) * retries)));
     exact(d_retry_descs, d_retry_results, retries);
     hipLaunchKernelGGL(scatter_retries, dim3((retries + 255) / 256), dim3(256), 0, stream,
                        static_cast<const ScanResult*>(d_retry_results), static_cast<const uint32_t*>(d_retry_index), retries,
@@ -839,7 +839,17 @@ void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_r
     const bool over_limit = g_workspace_limit.load() != 0 && budget < per_scan;
     for (; !over_limit;)
     {
-        arena = static_cast<uint8_t*>(try_ensure(pipeline_arena(), per_scan * resident + kCounterBytes));
+        // (the shared areas of the host-pointer ABI see batches of every size: they grow in powers of two, so that they stop
+        // growing -- growing frees the old block, and hipFree waits for every kernel on the device)
+        uint32_t room = resident;
+        if (t_shared_areas != nullptr)
+        {
+            room = 1;
+            while (room < resident)
+                room *= 2;
+            room = static_cast<uint32_t>(std::max<size_t>(resident, std::min<size_t>(room, budget / per_scan)));
+        }
+        arena = static_cast<uint8_t*>(try_ensure(pipeline_arena(), per_scan * room + kCounterBytes));
         if (arena != nullptr || resident == 1)
             break;
         resident = (resident + 1) / 2;
@@ -1218,6 +1228,19 @@ DeviceBuffer& plane_arena()
 size_t work_area_budget() noexcept
 {
     return arena_budget(areas().bytes());
+}
+
+size_t shared_areas_keep_bytes() noexcept
+{
+    size_t free_bytes = 0, total_bytes = 0;
+    if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return size_t{1} << 30;
+    }
+    const uint64_t configured = g_workspace_limit.load();
+    const size_t eighth = total_bytes / 8;
+    return configured != 0 ? std::min<size_t>(static_cast<size_t>(configured), eighth) : eighth;
 }
 
 // ---- the work areas of the host-pointer ABI: one set per device, used by one merged launch at a time

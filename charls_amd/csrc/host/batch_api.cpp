@@ -517,7 +517,7 @@ try
     std::vector<uint32_t> active;
     EventTimer total(stream);
     double scan_ms = 0;
-    bool first_params = true;
+    uint32_t params_from = UINT32_MAX; // the frame params_out describes so far: the lowest-index frame that got as far as a scan
 
     // What a frame's scan needs besides its stream position: geometry and coding parameters from the reader (which stands
     // behind the scan's header), the destination of its first plane, the line scratch (an offset until run_scans places it).
@@ -546,13 +546,13 @@ try
         scratch_total = (scratch_total + 255) & ~size_t{255};
         return d;
     };
-    auto report_params = [&](Frame& x) {
-        if (params_out && first_params)
+    auto report_params = [&](Frame& x, uint32_t index) {
+        if (params_out && index < params_from)
         {
             *params_out = charls_amd_codec_params{x.reader.frame_info(), x.reader.parameters().near_lossless,
                                                   x.reader.scan_interleave_mode(), x.reader.parameters().transformation,
                                                   x.reader.preset_coding_parameters(), 0, x.reader.parameters().restart_interval};
-            first_params = false;
+            params_from = index;
         }
     };
     // Decodes descs[0, n) (tags[k] says whose scan descs[k] is; both are permuted: scans that can share a kernel
@@ -766,7 +766,7 @@ try
                 Frame& y = probe[p.frame];
                 if (y.errc != CHARLS_JPEGLS_ERRC_SUCCESS)
                     continue; // (the rounds decode it again and report this)
-                report_params(fr[p.frame]);
+                report_params(fr[p.frame], p.frame);
                 y.decoded_components = static_cast<uint32_t>(p.scans.size());
                 y.done = true;
                 fr[p.frame] = std::move(y);
@@ -788,7 +788,7 @@ try
             try
             {
                 const ScanDesc d = scan_desc(i, x, scratch_total);
-                report_params(x);
+                report_params(x, i);
                 descs.push_back(d);
                 active.push_back(i);
             }

@@ -4,17 +4,20 @@
 // builds its own codec (src/charls_jpegls_decoder.cpp:177-201), and its callers scale by threads x handles (SURVEY 8b
 // "Threading").  On this engine a scan that is launched ALONE has a whole kernel to itself -- one decoder chain on one of
 // 1024 SIMDs at 5 MPix/s, an encoder pipeline that fills the chip with one frame's tiles -- and what makes the GPU fast is
-// the number of scans in a launch (8 scans share a decoder wavefront; a pass of the encoder takes hundreds of frames).  So
-// calls that arrive together are put into ONE launch:
+// the number of scans in a launch (8 scans share a decoder wavefront; a pass of the encoder takes hundreds of frames; and the
+// hardware runs only a handful of kernels of different streams side by side).  So calls that arrive together are put into
+// ONE launch:
 //
-//  * a call ANNOUNCES itself when its host->device copy starts (ScanEngine::upload_*) and SUBMITS its scans when the copy is
-//    through;
-//  * the first submitter of a kind (lane = device x direction, key = geometry and coding parameters) becomes the leader of
-//    a batch: it waits while announced calls are still on their way (never longer than `wait_us`; a caller that is alone
-//    has nobody to wait for and launches at once), then runs the launch for everybody on its own stream and hands the
-//    results out;
-//  * an EXCLUSIVE lane (encode: the work areas of the pipeline are shared) runs one batch at a time, and the next batch
-//    stays open while the current one runs -- group commit.
+//  * a handle ANNOUNCES itself on its lane (device x direction) as soon as it is clear that a coding call is coming -- the
+//    decoder when it is given its source, the encoder its frame info -- and SUBMITS its scans when its host -> device copy is
+//    through.  An announcement is FRESH for `wait_us`; a handle that sits idle for longer no longer holds anybody up;
+//  * the first submitter of a kind (key = geometry and coding parameters) leads a batch: it waits while fresh announcements
+//    are outstanding (never longer than `wait_us`; a caller that is alone has nobody to wait for and launches at once), then
+//    runs the launch for everybody on its own stream and hands the results out;
+//  * at most `max_running` batches of a key run at a time (an encoder lane: ONE batch of any key -- the work areas of the
+//    pipeline are shared).  A batch that has to wait for its turn stays OPEN meanwhile -- group commit -- and when its turn
+//    comes it gives the callers of the batch that just finished a moment (`wait_us` / 4) to come back: threads that loop over
+//    images fall into step that way instead of taking turns.
 //
 // Pure C++ (no HIP): tests/test_coalescer_cpu.py drives it with a fake launch.
 #pragma once
@@ -58,6 +61,7 @@ inline MergeKey merge_key_of(const ScanDesc& d) noexcept
 class Coalescer
 {
 public:
+    using Clock = std::chrono::steady_clock;
     // Runs ONE launch for descs[0, n) and fills results[0, n); may raise jls::error (every call of the batch then fails
     // with that code).
     using Launch = std::function<void(const ScanDesc* descs, uint32_t n, ScanResult* results)>;
@@ -70,42 +74,54 @@ public:
         uint64_t largest;  // scans in the largest batch
     };
 
-    static constexpr int kLanes = 64; // device * 2 + (decode ? 1 : 0), devices 0..31
+    struct Policy
+    {
+        uint32_t wait_us;     // how long announcements are fresh, and the longest a leader waits for them
+        uint32_t max_scans;   // scans of a batch at most
+        uint32_t max_running; // batches of ONE key that may run at a time (0: the lane runs one batch of ANY key at a time)
+    };
 
-    void announce(int lane) noexcept
+    static constexpr int kLanes = 64; // device * 2 + (decode ? 1 : 0), devices 0..31
+    using Ticket = uint64_t;          // of an announcement; 0 = none
+
+    Ticket announce(int lane)
     {
         std::lock_guard<std::mutex> lock(mutex_);
-        ++expected_[lane % kLanes];
+        const Ticket ticket = ++last_ticket_;
+        announced_[lane % kLanes].emplace(ticket, Clock::now());
+        return ticket;
     }
 
-    // An announced call that will not submit after all (it failed before it got that far).
-    void retract(int lane) noexcept
+    // An announced call that will not submit after all (its handle went away, or the call failed before it got that far).
+    void retract(int lane, Ticket ticket) noexcept
     {
+        if (ticket == 0)
+            return;
         std::lock_guard<std::mutex> lock(mutex_);
-        if (expected_[lane % kLanes] > 0)
-            --expected_[lane % kLanes];
+        announced_[lane % kLanes].erase(ticket);
         arrival_.notify_all();
     }
 
-    // Blocks until the `count` scans are done.  `announced`: this call announced itself on the lane.  `launch` runs on
-    // the calling thread when it leads the batch, and not at all when it joined somebody else's.
-    void submit(int lane, const MergeKey& key, const ScanDesc* descs, uint32_t count, ScanResult* results, bool announced, bool exclusive,
-                uint32_t wait_us, uint32_t max_scans, const Launch& launch)
+    // Blocks until the `count` scans are done.  `ticket`: this call's announcement on the lane (0: it made none).  `launch`
+    // runs on the calling thread when it leads the batch, and not at all when it joined somebody else's.
+    void submit(int lane, const MergeKey& key, const ScanDesc* descs, uint32_t count, ScanResult* results, Ticket ticket, const Policy& policy,
+                const Launch& launch)
     {
         lane %= kLanes;
+        const auto wait = std::chrono::microseconds(policy.wait_us);
         std::unique_lock<std::mutex> lock(mutex_);
         ++stats_.calls;
-        if (announced && expected_[lane] > 0)
-            --expected_[lane];
+        if (ticket != 0)
+            announced_[lane].erase(ticket);
         const auto id = std::make_pair(lane, key);
         auto open = open_.find(id);
-        if (open != open_.end() && open->second->descs.size() + count <= max_scans)
+        if (open != open_.end() && open->second->descs.size() + count <= policy.max_scans)
         { // join
             std::shared_ptr<Batch> b = open->second;
             const size_t first = b->descs.size();
             b->descs.insert(b->descs.end(), descs, descs + count);
             ++b->calls;
-            arrival_.notify_all(); // the leader looks at `expected_` again
+            arrival_.notify_all(); // the leader looks again
             b->finished.wait(lock, [&] { return b->done; });
             if (b->failure != CHARLS_JPEGLS_ERRC_SUCCESS)
                 raise(b->failure);
@@ -118,26 +134,39 @@ public:
         b->calls = 1;
         const bool published = open == open_.end();
         if (published)
-            open_[id] = b; // (a full batch of this kind is still open: this one stays private and runs on its own)
-        else
-            arrival_.notify_all();
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us);
+            open_[id] = b; // (otherwise a full batch of this kind is still open: this one stays private and runs on its own)
+        arrival_.notify_all();
+        auto running_now = [&]() -> uint32_t& { return policy.max_running == 0 ? lane_running_[lane] : key_running_[id]; };
+        const uint32_t limit = policy.max_running == 0 ? 1u : policy.max_running;
+        auto deadline = Clock::now() + wait;
+        Clock::time_point grace{}; // set when the batch had to wait for its turn
+        bool had_to_wait = false;
         for (;;)
         {
-            const bool others_coming = published && expected_[lane] > 0 && b->descs.size() < max_scans &&
-                                       std::chrono::steady_clock::now() < deadline;
-            const bool not_my_turn = exclusive && busy_[lane];
-            if (!others_coming && !not_my_turn)
-                break;
-            if (not_my_turn) // (the batch stays open while another one runs: whoever arrives meanwhile joins it)
+            const Clock::time_point now = Clock::now();
+            const bool my_turn = running_now() < limit;
+            if (!my_turn)
+            { // (the batch stays open while another one runs: whoever arrives meanwhile joins it)
+                had_to_wait = true;
                 arrival_.wait(lock);
-            else
-                arrival_.wait_until(lock, deadline);
+                continue;
+            }
+            if (had_to_wait)
+            { // the callers of the batch that just finished get a moment to come back and join
+                had_to_wait = false;
+                grace = now + wait / 4;
+                deadline = now + wait;
+            }
+            const bool room = published && b->descs.size() < policy.max_scans;
+            const bool in_grace = room && now < grace;
+            const bool others_coming = room && now < deadline && fresh_announcements(lane, now, wait);
+            if (!in_grace && !others_coming)
+                break;
+            arrival_.wait_until(lock, in_grace && !others_coming ? grace : deadline);
         }
         if (published)
             open_.erase(id);
-        if (exclusive)
-            busy_[lane] = true;
+        ++running_now();
         ++stats_.launches;
         if (b->calls > 1)
             stats_.merged += b->calls;
@@ -154,24 +183,33 @@ public:
             failure = current_exception_to_errc();
         }
         lock.lock();
-        if (exclusive)
-            busy_[lane] = false;
+        if (--running_now() == 0 && policy.max_running != 0)
+            key_running_.erase(id);
         b->failure = failure;
         b->done = true;
         b->finished.notify_all();
-        arrival_.notify_all(); // the leader of the next batch of an exclusive lane
+        arrival_.notify_all(); // the leaders that wait for their turn
         if (failure != CHARLS_JPEGLS_ERRC_SUCCESS)
             raise(failure);
         std::memcpy(results, b->results.data(), sizeof(ScanResult) * count);
     }
 
-    // Nothing announced, open or running on the lane: whoever holds shared work areas for it may give them back.
-    bool idle(int lane, bool but_for_the_running_batch = false)
+    // No fresh announcement and no open batch on the lane (and, unless asked otherwise, nothing running): whoever holds
+    // shared work areas for it may give them back.
+    bool idle(int lane, uint32_t fresh_us, bool but_for_the_running_batch = false)
     {
         lane %= kLanes;
         std::lock_guard<std::mutex> lock(mutex_);
-        if (expected_[lane] > 0 || (busy_[lane] && !but_for_the_running_batch))
+        if (fresh_announcements(lane, Clock::now(), std::chrono::microseconds(fresh_us)))
             return false;
+        if (!but_for_the_running_batch)
+        {
+            if (lane_running_[lane] != 0)
+                return false;
+            for (const auto& entry : key_running_)
+                if (entry.first.first == lane)
+                    return false;
+        }
         for (const auto& entry : open_)
             if (entry.first.first == lane)
                 return false;
@@ -195,11 +233,21 @@ private:
         std::condition_variable finished;
     };
 
+    // Is a call on its way to this lane?  An announcement older than `wait` is stale -- a handle that was configured and then
+    // left alone -- and holds nobody up (tickets rise with time: the last one is the youngest).
+    bool fresh_announcements(int lane, Clock::time_point now, std::chrono::microseconds wait) const
+    {
+        const auto& list = announced_[lane];
+        return !list.empty() && now - list.rbegin()->second <= wait;
+    }
+
     std::mutex mutex_;
-    std::condition_variable arrival_; // an announced call submitted or retracted; a batch of an exclusive lane finished
+    std::condition_variable arrival_; // an announced call submitted or retracted; a running batch finished
     std::map<std::pair<int, MergeKey>, std::shared_ptr<Batch>> open_;
-    uint32_t expected_[kLanes]{};
-    bool busy_[kLanes]{};
+    std::map<std::pair<int, MergeKey>, uint32_t> key_running_;
+    std::map<Ticket, Clock::time_point> announced_[kLanes];
+    uint32_t lane_running_[kLanes]{};
+    Ticket last_ticket_{};
     Stats stats_{};
 };
 

@@ -266,6 +266,7 @@ charls_jpegls_errc charls_jpegls_decoder_set_source_buffer(charls_jpegls_decoder
     check_operation(d->state == D::State::initial);
     d->reader.set_source(static_cast<const uint8_t*>(source), size);
     d->state = D::State::source_set;
+    d->engine.expect_call(true); // (the read_header / decode_to_buffer calls of this thread follow: others about to launch wait for them)
     JLS_THUNK_END
 }
 

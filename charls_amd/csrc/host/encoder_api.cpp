@@ -44,6 +44,7 @@ struct charls_jpegls_encoder
         check_argument(f.component_count >= 1 && f.component_count <= kMaxComponents,
                        CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_COMPONENT_COUNT);
         frame = f;
+        engine.expect_call(false); // (the encode call of this thread follows: others about to launch wait for it)
     }
 
     bool frame_configured() const noexcept { return frame.width != 0; }

@@ -91,21 +91,25 @@ int lane_of(int device, bool decode)
     return device * 2 + (decode ? 1 : 0);
 }
 
-// How long the leader of a batch waits for calls that announced themselves (their host -> device copies are under way).
-// What they are late by is their copy, so the wait is priced in copies: a decoder launch is one serial chain per scan
-// (0.2 us per sample: seconds for a large frame), so a quarter of that is cheap; an encoder launch of one frame takes about
-// as long as the frame's upload, so it waits for up to 64 uploads.  Never more than 200 ms / 50 ms.
+// How long an announcement counts and the leader of a batch waits for announced calls at most.  What they are late by is their
+// host -> device copy (and whatever their thread does between configuring its handle and calling the coding function), so
+// the wait is priced in the work it delays: a decoder launch is one serial chain per scan (0.2 us per sample: seconds for
+// a large frame), an eighth of that is cheap; an encoder launch of one frame takes about as long as the frame's upload,
+// so it waits for up to 64 uploads.  Never more than 400 ms / 50 ms.
 uint32_t merge_wait_us(const ScanDesc& d, bool decode)
 {
     if (const long long knob = knobs::get(knobs::kCoalesceWaitUs); knob != knobs::kUnset)
-        return static_cast<uint32_t>(std::clamp<long long>(knob, 0, 10'000'000));
+        return static_cast<uint32_t>(std::clamp<long long>(knob, 0, 100'000'000));
     const double samples = static_cast<double>(d.width) * d.height * std::max(1, d.components);
     if (decode)
-        return static_cast<uint32_t>(std::clamp(samples * 0.2 / 4, 50.0, 200e3));
+        return static_cast<uint32_t>(std::clamp(samples * 0.2 / 8, 50.0, 400e3));
     const double upload_us = samples * (d.bits_per_sample > 8 ? 2 : 1) / 50e3; // 50 GB/s
     return static_cast<uint32_t>(std::clamp(64 * upload_us, 200.0, 50e3));
 }
 
+// Decoder batches of one geometry that may run side by side: the device runs kernels of a few streams at once, and a second
+// batch beside the first costs nothing while the first leaves most of the chip idle; beyond that a batch waits (and collects).
+constexpr uint32_t kDecodeBatchesAtOnce = 2;
 constexpr uint32_t kMaxMergedScans = 16384;
 
 } // namespace
@@ -149,18 +153,25 @@ void ScanEngine::ensure_stream()
         r_ = acquire_resources();
 }
 
-void ScanEngine::announce(bool decode)
+void ScanEngine::expect_call(bool decode) noexcept
 {
-    if (announced_lane_ >= 0 || !coalescing_enabled())
+    if (ticket_ != 0 || !coalescing_enabled() || dev::device_status() != CHARLS_JPEGLS_ERRC_SUCCESS)
         return;
-    announced_lane_ = lane_of(r_->device, decode);
-    coalescer().announce(announced_lane_);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return;
+    }
+    announced_lane_ = lane_of(device, decode);
+    ticket_ = coalescer().announce(announced_lane_);
 }
 
 void ScanEngine::end_call() noexcept
 {
-    if (announced_lane_ >= 0)
-        coalescer().retract(announced_lane_);
+    if (ticket_ != 0)
+        coalescer().retract(announced_lane_, ticket_);
+    ticket_ = 0;
     announced_lane_ = -1;
 }
 
@@ -193,10 +204,12 @@ ScanResult ScanEngine::run(const ScanDesc& desc, bool decode)
 void ScanEngine::launch(const ScanDesc* descs, uint32_t n, bool decode, ScanResult* results)
 {
     const size_t desc_bytes = sizeof(ScanDesc) * n, result_bytes = sizeof(ScanResult) * n;
-    auto* staged = static_cast<uint8_t*>(r_->staging.ensure(desc_bytes + result_bytes));
+    // (with room to spare: growing a buffer frees the old one, and hipFree waits for every kernel on the device -- another
+    // batch's decoder, seconds)
+    auto* staged = static_cast<uint8_t*>(r_->staging.ensure(dev::with_headroom(desc_bytes + result_bytes)));
     std::memcpy(staged, descs, desc_bytes);
-    auto* d_descs = static_cast<ScanDesc*>(r_->desc.ensure(desc_bytes));
-    auto* d_results = static_cast<ScanResult*>(r_->result.ensure(result_bytes));
+    auto* d_descs = static_cast<ScanDesc*>(r_->desc.ensure(dev::with_headroom(desc_bytes)));
+    auto* d_results = static_cast<ScanResult*>(r_->result.ensure(dev::with_headroom(result_bytes)));
     hip_check(hipMemcpyAsync(d_descs, staged, desc_bytes, hipMemcpyHostToDevice, r_->stream));
     ScanDesc proto = descs[0];
     if (decode)
@@ -225,11 +238,13 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
     // What this call uploaded is in HBM before anybody's launch may read it.
     hip_check(hipStreamSynchronize(r_->stream));
     const int lane = lane_of(r_->device, decode);
-    const bool announced = announced_lane_ == lane;
-    if (announced_lane_ >= 0 && !announced)
-        end_call();
-    announced_lane_ = -1; // (submit takes the announcement back)
-    const Coalescer::Launch run_batch = [this, decode, lane](const ScanDesc* all, uint32_t n, ScanResult* out) {
+    if (ticket_ != 0 && announced_lane_ != lane)
+        end_call(); // (announced for another device or direction: nobody waits for that any longer)
+    const Coalescer::Ticket ticket = ticket_;
+    ticket_ = 0; // (submit takes the announcement back)
+    announced_lane_ = -1;
+    const uint32_t wait_us = merge_wait_us(descs[0], decode);
+    const Coalescer::Launch run_batch = [this, decode, lane, wait_us](const ScanDesc* all, uint32_t n, ScanResult* out) {
         if (decode)
         { // decoder launches keep next to nothing between calls and run side by side
             launch(all, n, true, out);
@@ -241,11 +256,14 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
         // already sees to that; the scope also keeps charls_amd_release_work_areas() of another thread out)
         dev::SharedAreasScope shared;
         launch(all, n, false, out);
-        if (shared.bytes() > kKeepBytes && coalescer().idle(lane, /*but_for_the_running_batch=*/true))
-            shared.release(); // nobody on the way: give the gigabytes back (a pool of threads keeps them while it keeps calling)
+        // The shared areas stay while they are moderate (an eighth of the device at most: a pool of threads that codes in
+        // rounds would otherwise pay for 40 GB of hipMalloc + hipFree -- seconds -- in every round); beyond that they go back
+        // as soon as nobody is on the way.
+        if (shared.bytes() > dev::shared_areas_keep_bytes() && coalescer().idle(lane, wait_us, /*but_for_the_running_batch=*/true))
+            shared.release();
     };
-    coalescer().submit(lane, merge_key_of(descs[0]), descs, count, results, announced, /*exclusive=*/!decode, merge_wait_us(descs[0], decode),
-                       kMaxMergedScans, run_batch);
+    const Coalescer::Policy policy{wait_us, kMaxMergedScans, decode ? kDecodeBatchesAtOnce : 0u};
+    coalescer().submit(lane, merge_key_of(descs[0]), descs, count, results, ticket, policy, run_batch);
 }
 
 void ScanEngine::encode_planes(const ScanSpec& spec, uint32_t count, size_t plane_bytes, size_t stride, size_t capacity, ScanResult* results)
@@ -322,7 +340,7 @@ void ScanEngine::copy_rows_out(uint8_t* destination, size_t stride, const uint8_
 void ScanEngine::upload_pixels(const uint8_t* source, size_t bytes)
 {
     ensure_stream();
-    announce(false); // (before the copy: the copy is what the others of a batch wait for)
+    expect_call(false); // (before the copy: the copy is what the others of a batch wait for)
     r_->pixels.ensure(bytes);
     pixel_bytes_ = bytes;
     hip_check(hipMemcpyAsync(r_->pixels.as<uint8_t>(), source, bytes, hipMemcpyHostToDevice, r_->stream));
@@ -352,7 +370,7 @@ size_t ScanEngine::encode_scan(const ScanSpec& spec, size_t pixel_offset, size_t
 void ScanEngine::upload_stream(const uint8_t* source, size_t bytes)
 {
     ensure_stream();
-    announce(true);
+    expect_call(true);
     r_->bits.ensure(bytes + 16); // the ring refill of the wave decoder reads whole 16-byte groups
     stream_bytes_ = bytes;
     hip_check(hipMemcpyAsync(r_->bits.as<uint8_t>(), source, bytes, hipMemcpyHostToDevice, r_->stream));

@@ -93,13 +93,15 @@ public:
     void decode_planes(const ScanSpec& spec, const size_t* stream_offsets, uint32_t count, ScanResult* results);
     void fetch_decoded_plane(const ScanSpec& spec, uint32_t index, uint8_t* destination, size_t stride);
 
-    // The coding call of the facade is over (normally or not): an upload that announced this call to the coalescer and
-    // was not followed by a scan is taken back.
+    // A coding call is coming on this handle (the decoder was given its source, the encoder its frame info): announced to
+    // the coalescer, so that calls of other threads that are about to launch wait a moment for this one (coalescer.h).
+    void expect_call(bool decode) noexcept;
+    // The coding call of the facade is over (normally or not), or the handle goes away: an announcement that was not
+    // followed by a scan is taken back.
     void end_call() noexcept;
 
 private:
     void ensure_stream();
-    void announce(bool decode);
     ScanDesc make_desc(const ScanSpec& spec) const;
     ScanResult run(const ScanDesc& desc, bool decode);
     void run_many(const ScanDesc* descs, uint32_t count, bool decode, ScanResult* results);
@@ -109,7 +111,8 @@ private:
 
     std::unique_ptr<EngineResources> r_; // from the pool at the first device call, back to it with the handle
     size_t pixel_bytes_{}, stream_bytes_{}, plane_capacity_{};
-    int announced_lane_{-1}; // the coalescer lane this call announced itself on (-1: none)
+    int announced_lane_{-1};   // the coalescer lane this handle announced itself on (-1: none)
+    uint64_t ticket_{};        // of that announcement (0: none)
 };
 
 inline CallScope::~CallScope()

@@ -45,29 +45,30 @@ int main()
         const ScanDesc d = desc_of(64, 7);
         ScanResult r{};
         const auto t0 = Clock::now();
-        c.announce(1);
-        c.submit(1, merge_key_of(d), &d, 1, &r, true, false, 500000, 1024, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
+        const Coalescer::Ticket mine = c.announce(1);
+        c.submit(1, merge_key_of(d), &d, 1, &r, mine, Coalescer::Policy{500000, 1024, 2}, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
             ++launches;
             for (uint32_t i = 0; i < n; ++i)
                 out[i] = ScanResult{0, 0, all[i].stream_capacity * 3};
         });
         CHECK(launches == 1 && r.bytes == 21 && ms_since(t0) < 100, "a lone call launches at once and gets its result");
-        CHECK(c.idle(1), "the lane is idle afterwards");
+        CHECK(c.idle(1, 500000), "the lane is idle afterwards");
     }
     // 2. N announced calls end up in ONE launch, every caller gets its own result
     {
         Coalescer c;
         constexpr int kThreads = 48;
         std::atomic<int> launches{0}, largest{0}, wrong{0};
+        std::vector<Coalescer::Ticket> tickets;
         for (int i = 0; i < kThreads; ++i)
-            c.announce(3);
+            tickets.push_back(c.announce(3));
         std::vector<std::thread> threads;
         for (int i = 0; i < kThreads; ++i)
             threads.emplace_back([&, i] {
                 std::this_thread::sleep_for(std::chrono::microseconds(200 * (i % 7))); // (uploads of different length)
                 ScanDesc d[2] = {desc_of(512, 1000 + i), desc_of(512, 2000 + i)};
                 ScanResult r[2]{};
-                c.submit(3, merge_key_of(d[0]), d, 2, r, true, false, 2000000, 1024, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
+                c.submit(3, merge_key_of(d[0]), d, 2, r, tickets[i], Coalescer::Policy{2000000, 1024, 2}, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
                     ++launches;
                     largest = std::max<int>(largest, (int)n);
                     for (uint32_t k = 0; k < n; ++k)
@@ -87,13 +88,14 @@ int main()
         Coalescer c;
         std::atomic<int> launches{0}, mixed{0};
         std::vector<std::thread> threads;
+        std::vector<Coalescer::Ticket> tickets;
         for (int i = 0; i < 24; ++i)
-            c.announce(i % 2 ? 5 : 7);
+            tickets.push_back(c.announce(i % 2 ? 5 : 7));
         for (int i = 0; i < 24; ++i)
             threads.emplace_back([&, i] {
                 const ScanDesc d = desc_of(i % 3 == 0 ? 100 : 200, (uint32_t)i);
                 ScanResult r{};
-                c.submit(i % 2 ? 5 : 7, merge_key_of(d), &d, 1, &r, true, false, 300000, 1024, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
+                c.submit(i % 2 ? 5 : 7, merge_key_of(d), &d, 1, &r, tickets[i], Coalescer::Policy{300000, 1024, 2}, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
                     ++launches;
                     for (uint32_t k = 0; k < n; ++k)
                     {
@@ -127,7 +129,7 @@ int main()
                     std::this_thread::sleep_for(std::chrono::milliseconds(10 + i)); // the first one is running by then
                 const ScanDesc d = desc_of(300, (uint32_t)i);
                 ScanResult r{};
-                c.submit(2, merge_key_of(d), &d, 1, &r, false, true, 0, 1024, fake);
+                c.submit(2, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{0, 1024, 0}, fake);
             });
         for (auto& t : threads)
             t.join();
@@ -138,15 +140,16 @@ int main()
         Coalescer c;
         std::atomic<int> codes{0};
         std::vector<std::thread> threads;
+        std::vector<Coalescer::Ticket> tickets;
         for (int i = 0; i < 6; ++i)
-            c.announce(9);
+            tickets.push_back(c.announce(9));
         for (int i = 0; i < 6; ++i)
-            threads.emplace_back([&] {
+            threads.emplace_back([&, i] {
                 const ScanDesc d = desc_of(77, 0);
                 ScanResult r{};
                 try
                 {
-                    c.submit(9, merge_key_of(d), &d, 1, &r, true, false, 500000, 1024,
+                    c.submit(9, merge_key_of(d), &d, 1, &r, tickets[i], Coalescer::Policy{500000, 1024, 2},
                              [&](const ScanDesc*, uint32_t, ScanResult*) { raise(CHARLS_JPEGLS_ERRC_NOT_ENOUGH_MEMORY); });
                 }
                 catch (const error& e)
@@ -158,43 +161,50 @@ int main()
         for (auto& t : threads)
             t.join();
         CHECK(codes == 6, "all six calls of a failed launch report its error");
-        CHECK(c.idle(9), "and the lane is idle again");
+        CHECK(c.idle(9, 500000), "and the lane is idle again");
     }
-    // 6. retracting an announcement lets the leader go; an announced call that never comes costs at most the wait
+    // 6. retracting an announcement lets the leader go; an announced call that never comes costs at most the wait; a STALE
+    //    announcement (a handle that was configured long ago) costs nothing
     {
         Coalescer c;
-        c.announce(11);
+        const Coalescer::Ticket other = c.announce(11);
         std::thread quitter([&] {
             std::this_thread::sleep_for(std::chrono::milliseconds(30));
-            c.retract(11);
+            c.retract(11, other);
         });
         const ScanDesc d = desc_of(10, 0);
         ScanResult r{};
         auto t0 = Clock::now();
-        c.announce(11);
-        c.submit(11, merge_key_of(d), &d, 1, &r, true, false, 3000000, 1024, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+        const Coalescer::Ticket mine = c.announce(11);
+        c.submit(11, merge_key_of(d), &d, 1, &r, mine, Coalescer::Policy{3000000, 1024, 2}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
         const double waited = ms_since(t0);
         quitter.join();
         CHECK(waited >= 20 && waited < 1500, "the leader waits for an announced call and stops waiting when it is retracted");
-        c.announce(11); // never submits
+        const Coalescer::Ticket never = c.announce(11); // never submits
         t0 = Clock::now();
-        c.submit(11, merge_key_of(d), &d, 1, &r, false, false, 50000, 1024, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+        c.submit(11, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{50000, 1024, 2}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
         const double capped = ms_since(t0);
         CHECK(capped >= 40 && capped < 1000, "an announced call that never comes costs the wait and no more");
-        c.retract(11);
+        std::this_thread::sleep_for(std::chrono::milliseconds(80)); // the announcement is older than the wait of the next call
+        t0 = Clock::now();
+        c.submit(11, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{50000, 1024, 2}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+        CHECK(ms_since(t0) < 30, "a stale announcement holds nobody up");
+        CHECK(c.idle(11, 50000) && !c.idle(11, 60000000), "idle() applies the same notion of freshness");
+        c.retract(11, never);
     }
     // 7. a batch never grows beyond max_scans
     {
         Coalescer c;
         std::atomic<int> largest{0}, total{0};
         std::vector<std::thread> threads;
+        std::vector<Coalescer::Ticket> tickets;
         for (int i = 0; i < 20; ++i)
-            c.announce(13);
+            tickets.push_back(c.announce(13));
         for (int i = 0; i < 20; ++i)
-            threads.emplace_back([&] {
+            threads.emplace_back([&, i] {
                 const ScanDesc d = desc_of(40, 0);
                 ScanResult r{};
-                c.submit(13, merge_key_of(d), &d, 1, &r, true, false, 200000, 8, [&](const ScanDesc*, uint32_t n, ScanResult* out) {
+                c.submit(13, merge_key_of(d), &d, 1, &r, tickets[i], Coalescer::Policy{200000, 8, 4}, [&](const ScanDesc*, uint32_t n, ScanResult* out) {
                     largest = std::max<int>(largest, (int)n);
                     total += (int)n;
                     for (uint32_t k = 0; k < n; ++k)
@@ -204,6 +214,68 @@ int main()
         for (auto& t : threads)
             t.join();
         CHECK(largest <= 8 && total == 20, "batches are capped at max_scans and nobody is lost");
+    }
+    // 8. max_running batches of a key side by side, the next one waits and collects; other keys are not held up
+    {
+        Coalescer c;
+        std::atomic<int> running{0}, most{0}, launches{0}, other_key_ms{0};
+        auto fake = [&](const ScanDesc*, uint32_t n, ScanResult* out) {
+            const int now = ++running;
+            most = std::max<int>(most, now);
+            ++launches;
+            std::this_thread::sleep_for(std::chrono::milliseconds(80));
+            for (uint32_t k = 0; k < n; ++k)
+                out[k] = ScanResult{};
+            --running;
+        };
+        std::vector<std::thread> threads;
+        for (int i = 0; i < 10; ++i)
+            threads.emplace_back([&, i] {
+                std::this_thread::sleep_for(std::chrono::milliseconds(5 * i)); // one after the other: nobody is announced when the first two launch
+                const ScanDesc d = desc_of(300, (uint32_t)i);
+                ScanResult r{};
+                c.submit(21, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{20000, 1024, 2}, fake);
+            });
+        threads.emplace_back([&] {
+            std::this_thread::sleep_for(std::chrono::milliseconds(30)); // two batches of the other key are running
+            const ScanDesc d = desc_of(999, 0);
+            ScanResult r{};
+            const auto t0 = Clock::now();
+            c.submit(21, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{20000, 1024, 2}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+            other_key_ms = (int)ms_since(t0);
+        });
+        for (auto& t : threads)
+            t.join();
+        CHECK(most == 2 && launches == 3, "two batches of a key side by side, the eight late calls in a third");
+        CHECK(other_key_ms < 40, "a call of another key does not wait for them");
+    }
+    // 9. two threads that loop over images fall into step: after the first rounds every launch carries both
+    {
+        Coalescer c;
+        std::atomic<int> launches{0}, pairs{0};
+        auto fake = [&](const ScanDesc*, uint32_t n, ScanResult* out) {
+            ++launches;
+            if (n == 2)
+                ++pairs;
+            std::this_thread::sleep_for(std::chrono::milliseconds(40));
+            for (uint32_t k = 0; k < n; ++k)
+                out[k] = ScanResult{};
+        };
+        auto looper = [&](int offset_ms) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(offset_ms));
+            for (int round = 0; round < 8; ++round)
+            {
+                const Coalescer::Ticket t = c.announce(23);
+                std::this_thread::sleep_for(std::chrono::milliseconds(2)); // its upload
+                const ScanDesc d = desc_of(128, 0);
+                ScanResult r{};
+                c.submit(23, merge_key_of(d), &d, 1, &r, t, Coalescer::Policy{40000, 1024, 1}, fake);
+            }
+        };
+        std::thread a(looper, 0), b(looper, 17);
+        a.join();
+        b.join();
+        CHECK(pairs >= 5 && launches <= 11, "two looping threads end up sharing their launches");
     }
     std::printf(g_failures == 0 ? "coalescer ok\n" : "coalescer FAILED\n");
     return g_failures == 0 ? 0 : 1;

@@ -42,53 +42,80 @@ def _read(path):
         return None
 
 
+def my_card():
+    """The /sys/class/drm/cardN of the GPU this process sees (a box may expose the sysfs nodes of GPUs that belong to other
+    tenants: card0 is NOT necessarily ours).  Matched by PCI address; None when that cannot be told."""
+    try:
+        p = torch.cuda.get_device_properties(0)
+        want = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}"
+    except AttributeError:
+        return None, None
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+        if "-" in os.path.basename(card):
+            continue
+        try:
+            where = os.path.realpath(os.path.join(card, "device"))
+        except OSError:
+            continue
+        if os.path.basename(where).lower().startswith(want):
+            return card, want
+    return None, want
+
+
 class Telemetry:
-    """Every sysfs source this box offers, raw: which of them exist differs between kernels."""
+    """Every sysfs source of OUR card, raw (which of them exist differs between kernels); when the card cannot be identified by
+    its PCI address, all cards are sampled and the one that was busiest during the launch is reported."""
+
+    NAMES = ("freq1_input", "freq2_input", "power1_average", "power1_input", "power1_cap", "temp1_input", "temp2_input", "temp3_input")
 
     def __init__(self, hz):
         self.period = 1.0 / hz
-        self.sclk_files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.hwmon = {}
-        for name in ("freq1_input", "freq2_input", "power1_average", "power1_input", "temp1_input", "temp2_input", "temp3_input"):
-            found = sorted(glob.glob(f"/sys/class/drm/card*/device/hwmon/hwmon*/{name}"))
-            if found:
-                self.hwmon[name] = found[0]
-        self.busy = sorted(glob.glob("/sys/class/drm/card*/device/gpu_busy_percent"))
+        self.card, self.pci = my_card()
+        cards = [self.card] if self.card else [c for c in sorted(glob.glob("/sys/class/drm/card[0-9]*")) if "-" not in os.path.basename(c)]
+        self.cards = {}
+        for c in cards:
+            files = {"sclk": os.path.join(c, "device", "pp_dpm_sclk"), "busy": os.path.join(c, "device", "gpu_busy_percent")}
+            for name in self.NAMES:
+                found = sorted(glob.glob(os.path.join(c, "device", "hwmon", "hwmon*", name)))
+                if found:
+                    files[name] = found[0]
+            self.cards[os.path.basename(c)] = files
         self.samples = []
         self.stop = False
 
     def sources(self):
-        return {"pp_dpm_sclk": self.sclk_files, **self.hwmon, "gpu_busy_percent": self.busy}
+        return {"my_card": self.card, "pci": self.pci, "cards": {c: sorted(f) for c, f in self.cards.items()}}
 
-    def sample(self):
-        s = {"t": time.perf_counter()}
-        for f in self.sclk_files[:1]:
-            text = _read(f) or ""
-            for line in text.splitlines():
-                if "*" in line:
-                    try:
-                        s["sclk_mhz"] = int(line.split(":")[1].strip().lower().split("mhz")[0])
-                    except (ValueError, IndexError):
-                        pass
-        for name, path in self.hwmon.items():
-            v = _read(path)
-            if v is not None and v.lstrip("-").isdigit():
-                v = int(v)
-                if name.startswith("freq"):
-                    s[name + "_mhz"] = v // 1_000_000
-                elif name.startswith("power"):
-                    s[name + "_w"] = round(v / 1e6, 1)
-                else:
-                    s[name + "_c"] = v // 1000
-        for f in self.busy[:1]:
-            v = _read(f)
-            if v is not None and v.isdigit():
-                s["busy_pct"] = int(v)
+    def sample_card(self, files):
+        s = {}
+        text = _read(files["sclk"]) or ""
+        for line in text.splitlines():
+            if "*" in line:
+                try:
+                    s["sclk_mhz"] = int(line.split(":")[1].strip().lower().split("mhz")[0])
+                except (ValueError, IndexError):
+                    pass
+        v = _read(files["busy"])
+        if v is not None and v.isdigit():
+            s["busy_pct"] = int(v)
+        for name in self.NAMES:
+            if name not in files:
+                continue
+            v = _read(files[name])
+            if v is None or not v.lstrip("-").isdigit():
+                continue
+            v = int(v)
+            if name.startswith("freq"):
+                s[name + "_mhz"] = v // 1_000_000
+            elif name.startswith("power"):
+                s[name + "_w"] = round(v / 1e6, 1)
+            else:
+                s[name + "_c"] = v // 1000
         return s
 
     def _run(self):
         while not self.stop:
-            self.samples.append(self.sample())
+            self.samples.append({"t": time.perf_counter(), **{c: self.sample_card(f) for c, f in self.cards.items()}})
             time.sleep(self.period)
 
     def __enter__(self):
@@ -101,14 +128,29 @@ class Telemetry:
         self.stop = True
         self.thread.join()
 
+    def busiest(self):
+        best, score = None, -1.0
+        for c in self.cards:
+            vals = [s[c].get("busy_pct", 0) for s in self.samples if c in s]
+            mean = sum(vals) / len(vals) if vals else 0.0
+            if mean > score:
+                best, score = c, mean
+        return best
+
     def summary(self):
-        out = {"samples": len(self.samples)}
-        keys = sorted({k for s in self.samples for k in s if k != "t"})
+        card = os.path.basename(self.card) if self.card else self.busiest()
+        out = {"samples": len(self.samples), "card": card, "card_identified_by": "pci address" if self.card else "busiest during the launch"}
+        keys = sorted({k for s in self.samples for k in s.get(card, {})})
         for k in keys:
-            vals = [s[k] for s in self.samples if k in s]
+            vals = [s[card][k] for s in self.samples if k in s.get(card, {})]
             if vals:
                 out[k] = {"min": min(vals), "mean": round(sum(vals) / len(vals), 1), "max": max(vals)}
         return out
+
+    def series(self, t0):
+        card = os.path.basename(self.card) if self.card else self.busiest()
+        return [(round(s["t"] - t0, 2), s.get(card, {}).get("sclk_mhz", s.get(card, {}).get("freq1_input_mhz")),
+                 s.get(card, {}).get("power1_average_w", s.get(card, {}).get("power1_input_w")), s.get(card, {}).get("busy_pct")) for s in self.samples]
 
 
 def smi_snapshot(tag):
@@ -126,9 +168,56 @@ def smi_snapshot(tag):
     print(f"--- no amd-smi / rocm-smi on this box ({tag})")
 
 
+class SmiSeries:
+    """amd-smi called back to back while a launch runs (it sees the GPU of this container, whatever sysfs shows): socket power
+    and the clocks of the eight XCDs."""
+
+    def __init__(self):
+        self.exe = shutil.which("amd-smi") or ("/opt/rocm/bin/amd-smi" if os.path.exists("/opt/rocm/bin/amd-smi") else None)
+        self.rows, self.stop = [], False
+
+    def _one(self):
+        r = subprocess.run([self.exe, "metric", "-c", "-p"], capture_output=True, text=True, timeout=20)
+        power, clocks, section = None, [], None
+        for line in r.stdout.splitlines():
+            t = line.strip()
+            if t.startswith("SOCKET_POWER:"):
+                power = t.split(":", 1)[1].strip()
+            elif t.startswith("GFX_"):
+                section = "gfx"
+            elif t.endswith(":") and not t.startswith("GFX_"):
+                section = t if t in ("POWER:", "CLOCK:") else (None if not t.startswith("GFX") else section)
+            elif t.startswith("CLK:") and section == "gfx":
+                clocks.append(t.split(":", 1)[1].strip().split()[0])
+                section = None
+        return power, clocks
+
+    def _run(self, t0):
+        while not self.stop:
+            try:
+                power, clocks = self._one()
+                self.rows.append((round(time.perf_counter() - t0, 2), power, clocks))
+            except Exception as e:  # noqa: BLE001
+                self.rows.append((round(time.perf_counter() - t0, 2), repr(e), []))
+                return
+
+    def __enter__(self):
+        self.rows, self.stop = [], False
+        if self.exe:
+            self.thread = threading.Thread(target=self._run, args=(time.perf_counter(),), daemon=True)
+            self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        if self.exe:
+            self.thread.join()
+
+
 lib = capi.load_product()
 dev = torch.device("cuda:0")
 tele = Telemetry(args.hz)
+smi = SmiSeries()
 print("# decode clock / power telemetry:", json.dumps({"frames": args.frames, "kind": args.kind, "distinct": args.distinct,
                                                         "device": torch.cuda.get_device_name(0)}))
 print("# telemetry sources:", json.dumps(tele.sources()))
@@ -153,7 +242,7 @@ for rep in range(args.repeat):
         capi.set_knob("DECODE_GROUP", g)
         out.zero_()
         torch.cuda.synchronize()
-        with tele:
+        with tele, smi:
             a = time.perf_counter()
             _, errcs, gpu_ms = batch.decode_batch(enc.streams, enc.sizes, out, lib=lib)
             torch.cuda.synchronize()
@@ -164,8 +253,7 @@ for rep in range(args.repeat):
                "mpix_s": round(mpix * args.frames / (b - a), 1), "ns_per_step": round((b - a) * 1e9 / (args.width * args.height), 1),
                "ok": bool((errcs == 0).all()), **tele.summary()}
         print(json.dumps(row), flush=True)
-        series = [(round(s["t"] - a, 2), s.get("sclk_mhz", s.get("freq1_input_mhz")), s.get("power1_average_w", s.get("power1_input_w")))
-                  for s in tele.samples]
-        print("#   (t, sclk MHz, W):", " ".join(f"({t},{c},{p})" for t, c, p in series[:64]), flush=True)
+        print("#   amd-smi during the launch (t s, socket power, XCD clocks MHz):", " ".join(f"({t},{p},{'/'.join(c)})" for t, p, c in smi.rows), flush=True)
+        print("#   (t s, sclk MHz, W, busy %):", " ".join(f"({t},{c},{p},{u})" for t, c, p, u in tele.series(a)[:64]), flush=True)
 capi.set_knob("DECODE_GROUP", None)
 smi_snapshot("after")

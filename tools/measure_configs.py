@@ -70,6 +70,28 @@ if "2" in only:
     del f
     torch.cuda.empty_cache()
     batch.release_work_areas(lib)
+if "2b" in only:  # SURVEY 8(d) C3': "medical-style" 12-bit samples in 16-bit containers
+    f = synth.frames_torch(args.frames16, 4096, 4096, seed0=4, bits=12, device=dev)
+    run("config 2 as 12-bit (2b): 4096x4096 12-bit gray lossless", f, bits=12)
+    del f
+    torch.cuda.empty_cache()
+    batch.release_work_areas(lib)
+if "noise" in only:  # full-range noise: the chains' recurrences never forget (|Errval| >> N), every job is walked again by ONE lane per chain
+    import ctypes as C
+    L = lib.lib
+    L.charls_amd_speculation_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int32]
+    L.charls_amd_speculation_counters.restype = C.c_int32
+    before = (C.c_uint64 * 6)()
+    L.charls_amd_speculation_counters(before, 6)
+    f = synth.frames_torch(64, 4096, 4096, seed0=2, bits=8, kind="noise", device=dev)
+    run("full-range noise (the encoder's worst case): 4096x4096 8-bit gray, kind=noise", f, bits=8)
+    after = (C.c_uint64 * 6)()
+    L.charls_amd_speculation_counters(after, 6)
+    print("  speculation counters of its two encodes (jobs, walked again, run jobs, walked again, rare segments, rare serial): "
+          + ", ".join(str(int(a) - int(b)) for a, b in zip(after, before)), flush=True)
+    del f
+    torch.cuda.empty_cache()
+    batch.release_work_areas(lib)
 if "3" in only:
     f = synth.frames_torch(256, 2048, 2048, seed0=100, bits=8, device=dev)
     run("config 3: 256 x 2048x2048 8-bit gray lossless (one GPU)", f, bits=8)
