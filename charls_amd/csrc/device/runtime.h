@@ -137,6 +137,8 @@ DeviceBuffer& plane_arena(); // the calling thread's private stream buffers of t
 void* try_ensure(DeviceBuffer& buffer, size_t bytes) noexcept; // ensure() that reports failure (nullptr; the buffer is released) instead of raising
 void release_work_areas() noexcept;
 size_t work_area_bytes() noexcept;
+size_t thread_work_area_bytes() noexcept;   // the calling thread's own areas (not the shared set of the host-pointer ABI)
+void release_thread_work_areas() noexcept;
 size_t work_area_budget() noexcept; // what the calling thread's work areas may grow to right now (limit, free memory)
 // Scans the lossless pipeline was eligible for that were coded by the one-wavefront kernel because no work area could be had.
 uint64_t pipeline_fallback_scans() noexcept;

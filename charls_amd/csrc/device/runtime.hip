@@ -823,7 +823,10 @@ constexpr size_t kCounterBytes = 256; // tile::kCounters words behind the work a
 template <typename S>
 void run_tile_pipeline(const ScanDesc& proto, ScanDesc* d_descs, ScanResult* d_results, uint32_t count, hipStream_t stream)
 {
-    const size_t budget = arena_budget(pipeline_arena().capacity());
+    // (the shared work areas of the host-pointer ABI stay allocated between calls, so they are kept moderate: more frames than
+    // fit take more passes)
+    const size_t budget = t_shared_areas != nullptr ? std::min(arena_budget(pipeline_arena().capacity()), shared_areas_keep_bytes())
+                                                    : arena_budget(pipeline_arena().capacity());
     // the layout depends on the number of scans of a pass only through the job size: settle on it for a full pass
     TileLayout lay(proto, proto.stream_capacity, count);
     size_t per_scan = lay.bytes + 2 * (sizeof(tile::Work) + sizeof(pipe::Work));
@@ -1293,6 +1296,16 @@ size_t SharedAreasScope::bytes() const noexcept
 void SharedAreasScope::release() noexcept
 {
     shared_areas(device_).areas.release();
+}
+
+size_t thread_work_area_bytes() noexcept
+{
+    return areas().bytes();
+}
+
+void release_thread_work_areas() noexcept
+{
+    areas().release();
 }
 
 void release_work_areas() noexcept

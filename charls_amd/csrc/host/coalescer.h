@@ -16,8 +16,8 @@
 //    runs the launch for everybody on its own stream and hands the results out;
 //  * at most `max_running` batches of a key run at a time (an encoder lane: ONE batch of any key -- the work areas of the
 //    pipeline are shared).  A batch that has to wait for its turn stays OPEN meanwhile -- group commit -- and when its turn
-//    comes it gives the callers of the batch that just finished a moment (`wait_us` / 4) to come back: threads that loop over
-//    images fall into step that way instead of taking turns.
+//    comes it may give the callers of the batch that just finished a moment (`grace_us`) to come back: decoder threads that
+//    loop over images fall into step that way instead of taking turns.
 //
 // Pure C++ (no HIP): tests/test_coalescer_cpu.py drives it with a fake launch.
 #pragma once
@@ -79,6 +79,7 @@ public:
         uint32_t wait_us;     // how long announcements are fresh, and the longest a leader waits for them
         uint32_t max_scans;   // scans of a batch at most
         uint32_t max_running; // batches of ONE key that may run at a time (0: the lane runs one batch of ANY key at a time)
+        uint32_t grace_us;    // what a batch that had to wait for its turn gives the callers of the finished batch to come back
     };
 
     static constexpr int kLanes = 64; // device * 2 + (decode ? 1 : 0), devices 0..31
@@ -154,7 +155,7 @@ public:
             if (had_to_wait)
             { // the callers of the batch that just finished get a moment to come back and join
                 had_to_wait = false;
-                grace = now + wait / 4;
+                grace = now + std::chrono::microseconds(policy.grace_us);
                 deadline = now + wait;
             }
             const bool room = published && b->descs.size() < policy.max_scans;

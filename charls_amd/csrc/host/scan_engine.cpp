@@ -231,8 +231,8 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
     if (!coalescing_enabled())
     {
         launch(descs, count, decode, results);
-        if (dev::work_area_bytes() > kKeepBytes)
-            dev::release_work_areas();
+        if (dev::thread_work_area_bytes() > kKeepBytes)
+            dev::release_thread_work_areas();
         return;
     }
     // What this call uploaded is in HBM before anybody's launch may read it.
@@ -244,25 +244,25 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
     ticket_ = 0; // (submit takes the announcement back)
     announced_lane_ = -1;
     const uint32_t wait_us = merge_wait_us(descs[0], decode);
-    const Coalescer::Launch run_batch = [this, decode, lane, wait_us](const ScanDesc* all, uint32_t n, ScanResult* out) {
+    const Coalescer::Launch run_batch = [this, decode](const ScanDesc* all, uint32_t n, ScanResult* out) {
         if (decode)
         { // decoder launches keep next to nothing between calls and run side by side
             launch(all, n, true, out);
-            if (dev::work_area_bytes() > kKeepBytes)
-                dev::release_work_areas();
+            if (dev::thread_work_area_bytes() > kKeepBytes)
+                dev::release_thread_work_areas();
             return;
         }
         // encoder launches share the device's work areas: one merged launch at a time (the coalescer's exclusive lane
         // already sees to that; the scope also keeps charls_amd_release_work_areas() of another thread out)
         dev::SharedAreasScope shared;
         launch(all, n, false, out);
-        // The shared areas stay while they are moderate (an eighth of the device at most: a pool of threads that codes in
-        // rounds would otherwise pay for 40 GB of hipMalloc + hipFree -- seconds -- in every round); beyond that they go back
-        // as soon as nobody is on the way.
-        if (shared.bytes() > dev::shared_areas_keep_bytes() && coalescer().idle(lane, wait_us, /*but_for_the_running_batch=*/true))
-            shared.release();
+        // (the shared areas stay: they never grow beyond dev::shared_areas_keep_bytes(), and a pool of threads that codes in
+        // rounds would otherwise pay for gigabytes of hipMalloc + hipFree -- seconds -- in every round;
+        // charls_amd_release_work_areas() gives them back)
     };
-    const Coalescer::Policy policy{wait_us, kMaxMergedScans, decode ? kDecodeBatchesAtOnce : 0u};
+    // (the grace: a decoder batch that had to queue is seconds late already, a quarter of the wait more lets the threads of the
+    // batch before it come back and join; encoder batches are short and collect what arrives while they queue)
+    const Coalescer::Policy policy{wait_us, kMaxMergedScans, decode ? kDecodeBatchesAtOnce : 0u, decode ? wait_us / 4 : 0u};
     coalescer().submit(lane, merge_key_of(descs[0]), descs, count, results, ticket, policy, run_batch);
 }
 

@@ -429,12 +429,13 @@ CHARLS_AMD_API charls_jpegls_errc charls_amd_set_encode_engine(int32_t engine);
  *
  * The host-pointer encoder / decoder of part 1 (THREADING, as the reference: distinct handles are independent, callers
  * scale by threads x handles): calls that arrive together are merged into one kernel launch (charls_amd_engine_counters),
- * and the merged encoder launches of ALL threads run on ONE set of work areas per device, within the same limit -- a pool of
- * 256 threads holds one arena, not 256.  That set is given back above 1 GiB as soon as no further call is on its way.
- * Handles share a process-wide pool of device buffers, streams and pinned staging areas (idle sets of at most 512 MiB each,
- * at most 18 GiB together: callers create a handle per image, creating these per handle costs more than coding a frame,
- * and freeing them waits for every kernel on the device); charls_amd_release_work_areas frees the calling thread's areas,
- * the shared set and the idle pool. */
+ * and the merged encoder launches of ALL threads run on ONE set of work areas per device -- a pool of 256 threads holds
+ * one arena, not 256.  That set never grows beyond the limit nor beyond an eighth of the device's memory (larger batches
+ * take more passes) and stays allocated between calls: giving gigabytes back to the driver and asking for them again
+ * costs seconds, and hipFree waits for every kernel on the device.  Handles share a process-wide pool of device buffers,
+ * streams and pinned staging areas (idle sets of at most 512 MiB each, at most 18 GiB together: callers create a handle
+ * per image, creating these per handle costs more than coding a frame).  charls_amd_release_work_areas frees the calling
+ * thread's areas, the shared set and the idle pool. */
 CHARLS_AMD_API charls_jpegls_errc charls_amd_set_workspace_limit(uint64_t bytes);
 CHARLS_AMD_API charls_jpegls_errc charls_amd_release_work_areas(void);
 CHARLS_AMD_API uint64_t charls_amd_work_area_bytes(void); /* the calling thread's + the shared set of part 1, currently allocated */

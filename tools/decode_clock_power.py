@@ -223,9 +223,16 @@ print("# decode clock / power telemetry:", json.dumps({"frames": args.frames, "k
 print("# telemetry sources:", json.dumps(tele.sources()))
 smi_snapshot("idle, before")
 n_distinct = min(args.distinct or args.frames, args.frames)
-base = synth.frames_torch(n_distinct, args.width, args.height, seed0=2, bits=8, kind=args.kind, device=dev)
-frames = base.repeat((args.frames + n_distinct - 1) // n_distinct, 1, 1)[:args.frames].contiguous() if n_distinct < args.frames else base
-del base
+if args.kind == "tulips":  # the reference's natural test image tiled to the frame size (bench.py: data_frames)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import bench
+    bench.WIDTH, bench.HEIGHT = args.width, args.height
+    frames = torch.empty((args.frames, args.height, args.width), dtype=torch.uint8, device=dev)
+    bench.data_frames(torch, "tulips", args.frames, dev, frames)
+else:
+    base = synth.frames_torch(n_distinct, args.width, args.height, seed0=2, bits=8, kind=args.kind, device=dev)
+    frames = base.repeat((args.frames + n_distinct - 1) // n_distinct, 1, 1)[:args.frames].contiguous() if n_distinct < args.frames else base
+    del base
 out = torch.empty_like(frames)
 batch.set_workspace_limit(64 << 30, lib)
 enc = batch.encode_batch(frames, bits_per_sample=8, lib=lib)
