@@ -214,6 +214,22 @@ size_t group_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
 // as densely as it takes to stay at two wavefronts per CU, and no denser.
 // CHARLS_AMD_DECODE_GROUP overrides (0, 4, 8, 16, 32).
 constexpr long long kDecodeWavesPerCu = 2; // (DECODE_WAVES_PER_CU overrides: measurements)
+// Wavefronts per workgroup of the group decoder for a launch of `count` single-component scans at `lanes` lanes per scan
+// (scan_group_decode.hip, template parameter W).  Up to two wavefronts per CU the one-wavefront workgroups of rounds 2 - 4
+// find a SIMD each; beyond that the dispatcher doubles wavefronts up on some SIMDs while others idle, and those pairs take the
+// launch's tail with them -- so a launch that needs four wavefronts per CU makes them ONE workgroup of four, which the
+// hardware deals out one per SIMD (it takes the whole LDS of its CU: one workgroup per CU).
+int decode_workgroup_waves(const ScanDesc& d, uint32_t count, int lanes)
+{
+    if (lanes == 0 || group_lines(d) != 1)
+        return 1;
+    const uint32_t per_wave = 64u / static_cast<uint32_t>(lanes);
+    const int forced = static_cast<int>(knobs::get_or(knobs::kDecodeWorkgroupWaves, -1));
+    if ((forced == 1 || forced == 4 || forced == 8) && (lanes == 16 || lanes == 32 || forced == 1) &&
+        group_lds_bytes(d, per_wave * static_cast<uint32_t>(forced)) <= kGroupDecodeLds)
+        return forced;
+    return 1;
+}
 int decode_group_lanes(const ScanDesc& d, uint32_t count)
 {
     if (d.bits_per_sample > 8 && d.t3 > grp::kMaxTableT3)
@@ -525,16 +541,19 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
     else
     {
         const uint32_t per_wave = 64u / static_cast<uint32_t>(group);
-        const dim3 grid((count + per_wave - 1) / per_wave);
-        const size_t lds = group_lds_bytes(proto, per_wave);
-#define JLS_LAUNCH_GROUP_N(S, G, N)                                                                                      \
+        const int wg_waves = decode_workgroup_waves(proto, count, group);
+        const uint32_t per_group = per_wave * static_cast<uint32_t>(wg_waves);
+        const dim3 grid((count + per_group - 1) / per_group);
+        const size_t lds = group_lds_bytes(proto, per_group);
+#define JLS_LAUNCH_GROUP_NW(S, G, N, W)                                                                                  \
     do                                                                                                                   \
     {                                                                                                                    \
         if (lds > kMaxDynamicLds) /* more than the default limit of dynamic LDS per workgroup */                          \
-            hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_scans_group<S, G, N>),                   \
+            hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_scans_group<S, G, N, W>),                \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
-        hipLaunchKernelGGL((decode_scans_group<S, G, N>), grid, dim3(64), lds, stream, d_descs, d_results, count);       \
+        hipLaunchKernelGGL((decode_scans_group<S, G, N, W>), grid, dim3(64 * W), lds, stream, d_descs, d_results, count); \
     } while (0)
+#define JLS_LAUNCH_GROUP_N(S, G, N) JLS_LAUNCH_GROUP_NW(S, G, N, 1)
 #define JLS_LAUNCH_GROUP(S, G)                                                                                           \
     do                                                                                                                   \
     {                                                                                                                    \
@@ -545,7 +564,23 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
         else JLS_LAUNCH_GROUP_N(S, G, 4);                                                                                \
     } while (0)
         const bool wide = proto.bits_per_sample > 8;
-        if (group == 4)
+        if (wg_waves == 4 && group == 16)
+        {
+            if (wide) JLS_LAUNCH_GROUP_NW(uint16_t, 16, 1, 4); else JLS_LAUNCH_GROUP_NW(uint8_t, 16, 1, 4);
+        }
+        else if (wg_waves == 4 && group == 32)
+        {
+            if (wide) JLS_LAUNCH_GROUP_NW(uint16_t, 32, 1, 4); else JLS_LAUNCH_GROUP_NW(uint8_t, 32, 1, 4);
+        }
+        else if (wg_waves == 8 && group == 16)
+        {
+            if (wide) JLS_LAUNCH_GROUP_NW(uint16_t, 16, 1, 8); else JLS_LAUNCH_GROUP_NW(uint8_t, 16, 1, 8);
+        }
+        else if (wg_waves == 8 && group == 32)
+        {
+            if (wide) JLS_LAUNCH_GROUP_NW(uint16_t, 32, 1, 8); else JLS_LAUNCH_GROUP_NW(uint8_t, 32, 1, 8);
+        }
+        else if (group == 4)
         {
             if (wide) JLS_LAUNCH_GROUP(uint16_t, 4); else JLS_LAUNCH_GROUP(uint8_t, 4);
         }
@@ -561,6 +596,7 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
         {
             if (wide) JLS_LAUNCH_GROUP(uint16_t, 32); else JLS_LAUNCH_GROUP(uint8_t, 32);
         }
+#undef JLS_LAUNCH_GROUP_NW
 #undef JLS_LAUNCH_GROUP
 #undef JLS_LAUNCH_GROUP_N
     }

@@ -390,27 +390,37 @@ JLS_DEV int take_unary(const uint32_t* ring, uint32_t& p, int most)
 // line of its own component above it and with its own RUNindex, on the ONE set of contexts; a line is decoded exactly like
 // a line of a single-component scan, so the step loop is the same code, and what changes is which of the NL lines in LDS
 // it works on and that a finished pixel row goes to the user's row interleaved (and through the inverse colour transform).
-template <typename S, int G, int NL = 1>
-__global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restrict__ descs, ScanResult* __restrict__ results,
-                                                         uint32_t count)
+//
+// W: wavefronts of a workgroup.  The wavefronts of a kernel never talk to each other (one barrier, behind the shared gradient
+// table); W only decides WHERE they run.  A workgroup's wavefronts are dealt to the SIMDs of its CU in turn, so W = 4 with the
+// whole LDS of a CU puts exactly one wavefront on every SIMD of every CU.  Workgroups of ONE wavefront (rounds 2 - 4) are
+// placed wherever a slot is free: with four of them per CU, two often share a SIMD while another SIMD idles, and those two
+// take the launch's tail with them -- rocprofv3 counted wavefronts resident for 77 % of such a launch on average while the
+// shader engines were busy for 94 % of it, at an unchanged 2.39 GHz (profiles/r05_pmc_decode_effective_clock.txt; what
+// rounds 3 and 4 read as "the chip clocks down when every SIMD runs this kernel").
+template <typename S, int G, int NL = 1, int W = 1>
+__global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __restrict__ descs, ScanResult* __restrict__ results,
+                                                             uint32_t count)
 {
     using namespace grp;
     using L = Layout<S>;
     static_assert(G == 4 || G == 8 || G == 16 || G == 32, "lanes per scan");
     static_assert(NL >= 1 && NL <= 4, "lines per pixel row");
+    static_assert(W == 1 || W == 2 || W == 4 || W == 8, "wavefronts per workgroup");
     constexpr int kScansPerWave = 64 / G;
     constexpr bool kWide = sizeof(S) > 1;
     JLS_DYNAMIC_LDS(smem);
-    const int lane = threadIdx.x;
+    const int lane = W == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63u);
+    const int wave = W == 1 ? 0 : (int)(threadIdx.x >> 6);
     const int sid = lane / G;
     const int sub = lane % G;
-    const uint32_t scan = blockIdx.x * kScansPerWave + (uint32_t)sid;
+    const uint32_t scan = (blockIdx.x * (uint32_t)W + (uint32_t)wave) * kScansPerWave + (uint32_t)sid;
     const bool live = scan < count;
     const ScanDesc d = descs[live ? scan : count - 1];
     const Traits t = make_traits(d);
     const uint32_t width = d.width;
 
-    unsigned char* region = smem + L::kLutBytes + (size_t)sid * region_bytes<S>(width, NL);
+    unsigned char* region = smem + L::kLutBytes + (size_t)(wave * kScansPerWave + sid) * region_bytes<S>(width, NL);
     Record* records = reinterpret_cast<Record*>(region + L::kRecords);
     RunCtx* run_ctx = reinterpret_cast<RunCtx*>(region + L::kRun);
     uint32_t* ring = reinterpret_cast<uint32_t*>(region + L::kRing);
@@ -420,7 +430,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
     // built from the thresholds of the workgroup's first scan; a scan with other thresholds (batches mix them only when
     // the streams carry different LSE segments) is left to the exact decoder.
     unsigned char* lut = smem;
-    const ScanDesc& d_first = descs[blockIdx.x * kScansPerWave];
+    const ScanDesc& d_first = descs[blockIdx.x * (uint32_t)(W * kScansPerWave)]; // (always < count: every workgroup has a live first scan)
     const Traits t_first = make_traits(d_first);
     S* const line0 = reinterpret_cast<S*>(region + L::kLine);
     const uint32_t line_stride = line_stride_bytes<S>(width) / (uint32_t)sizeof(S); // samples from one component's line to the next
@@ -436,7 +446,7 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
             run_ctx[sub] = RunCtx{sub, initial_a(t), 1, 0};
         // (the host checks the thresholds of ONE scan of the launch: a scan with T3 beyond the table that leads its wavefront
         // must not write past the table's region -- it and its neighbours go to the exact decoder, see `usable`)
-        for (int q = lane; q <= 2 * cap && q < (int)L::kLutBytes; q += 64)
+        for (int q = (int)threadIdx.x; q <= 2 * cap && q < (int)L::kLutBytes; q += 64 * W)
             lut[q] = (unsigned char)(quantize(t_first, q - cap) + 4);
         for (uint32_t q = sub; q < (NL == 1 ? width + 6 : NL * line_stride); q += G)
             line0[q] = 0;
@@ -455,6 +465,8 @@ __global__ void __launch_bounds__(64) decode_scans_group(const ScanDesc* __restr
         src.prev_byte = 0;
         src.ended = d.stream_capacity == 0;
     }
+    if (W > 1)
+        __syncthreads(); // the one meeting of the workgroup's wavefronts: the gradient table they share is complete
     JLS_LOCKSTEP();
 
     enum : int { kLineStart = 0, kInLine, kDrain, kDone };

@@ -2,6 +2,8 @@
 #include "scan_engine.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -84,6 +86,16 @@ Coalescer& coalescer()
 bool coalescing_enabled()
 {
     return knobs::get_or(knobs::kCoalesce, 1) != 0;
+}
+
+bool tracing()
+{
+    return knobs::get_or(knobs::kTrace, 0) != 0;
+}
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 int lane_of(int device, bool decode)
@@ -169,6 +181,13 @@ void ScanEngine::expect_call(bool decode) noexcept
 
 void ScanEngine::end_call() noexcept
 {
+    if (trace_.begin_ms != 0 && tracing())
+    { // (CHARLS_AMD_TRACE: where the call's time went; submit = waiting for / leading the shared launch, launch = this thread ran it)
+        std::fprintf(stderr, "charls_amd trace %s begin=%.1f total=%.1f upload=%.1f sync=%.1f submit=%.1f (launch=%.1f of %u scans) copy_out=%.1f ms\n",
+                     trace_.decode ? "decode" : "encode", trace_.begin_ms, now_ms() - trace_.begin_ms, trace_.upload_ms, trace_.sync_ms,
+                     trace_.submit_ms, trace_.launch_ms, trace_.launched_scans, trace_.copy_out_ms);
+    }
+    trace_ = Trace{};
     if (ticket_ != 0)
         coalescer().retract(announced_lane_, ticket_);
     ticket_ = 0;
@@ -236,7 +255,10 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
         return;
     }
     // What this call uploaded is in HBM before anybody's launch may read it.
+    const double t_sync = tracing() ? now_ms() : 0;
     hip_check(hipStreamSynchronize(r_->stream));
+    if (tracing())
+        trace_.sync_ms += now_ms() - t_sync;
     const int lane = lane_of(r_->device, decode);
     if (ticket_ != 0 && announced_lane_ != lane)
         end_call(); // (announced for another device or direction: nobody waits for that any longer)
@@ -245,6 +267,18 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
     announced_lane_ = -1;
     const uint32_t wait_us = merge_wait_us(descs[0], decode);
     const Coalescer::Launch run_batch = [this, decode](const ScanDesc* all, uint32_t n, ScanResult* out) {
+        const double t_launch = tracing() ? now_ms() : 0;
+        struct Note
+        {
+            ScanEngine& e;
+            double t0;
+            uint32_t n;
+            ~Note()
+            {
+                if (tracing())
+                    e.trace_.launch_ms += now_ms() - t0, e.trace_.launched_scans = n;
+            }
+        } note{*this, t_launch, n};
         if (decode)
         { // decoder launches keep next to nothing between calls and run side by side
             launch(all, n, true, out);
@@ -263,6 +297,18 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
     // (the grace: a decoder batch that had to queue is seconds late already, a quarter of the wait more lets the threads of the
     // batch before it come back and join; encoder batches are short and collect what arrives while they queue)
     const Coalescer::Policy policy{wait_us, kMaxMergedScans, decode ? kDecodeBatchesAtOnce : 0u, decode ? wait_us / 4 : 0u};
+    const double t_submit = tracing() ? now_ms() : 0;
+    struct Queued
+    {
+        ScanEngine& e;
+        double t0;
+        ~Queued()
+        {
+            if (tracing())
+                e.trace_.submit_ms += now_ms() - t0;
+        }
+    } queued{*this, t_submit};
+    trace_.decode = decode;
     coalescer().submit(lane, merge_key_of(descs[0]), descs, count, results, ticket, policy, run_batch);
 }
 
@@ -322,8 +368,11 @@ void ScanEngine::copy_out(uint8_t* destination, const uint8_t* device_source, si
 {
     if (bytes == 0)
         return;
+    const double t0 = tracing() ? now_ms() : 0;
     hip_check(hipMemcpyAsync(destination, device_source, bytes, hipMemcpyDeviceToHost, r_->stream));
     hip_check(hipStreamSynchronize(r_->stream));
+    if (tracing())
+        trace_.copy_out_ms += now_ms() - t0;
 }
 
 void ScanEngine::copy_rows_out(uint8_t* destination, size_t stride, const uint8_t* device_source, size_t row_bytes, size_t rows)
@@ -341,9 +390,12 @@ void ScanEngine::upload_pixels(const uint8_t* source, size_t bytes)
 {
     ensure_stream();
     expect_call(false); // (before the copy: the copy is what the others of a batch wait for)
+    const double t0 = tracing() ? now_ms() : 0;
     r_->pixels.ensure(bytes);
     pixel_bytes_ = bytes;
     hip_check(hipMemcpyAsync(r_->pixels.as<uint8_t>(), source, bytes, hipMemcpyHostToDevice, r_->stream));
+    if (tracing())
+        trace_.upload_ms += now_ms() - t0, trace_.begin_ms = trace_.begin_ms == 0 ? t0 : trace_.begin_ms;
 }
 
 size_t ScanEngine::encode_scan(const ScanSpec& spec, size_t pixel_offset, size_t stride, uint8_t* destination,
@@ -371,9 +423,12 @@ void ScanEngine::upload_stream(const uint8_t* source, size_t bytes)
 {
     ensure_stream();
     expect_call(true);
+    const double t0 = tracing() ? now_ms() : 0;
     r_->bits.ensure(bytes + 16); // the ring refill of the wave decoder reads whole 16-byte groups
     stream_bytes_ = bytes;
     hip_check(hipMemcpyAsync(r_->bits.as<uint8_t>(), source, bytes, hipMemcpyHostToDevice, r_->stream));
+    if (tracing())
+        trace_.upload_ms += now_ms() - t0, trace_.begin_ms = trace_.begin_ms == 0 ? t0 : trace_.begin_ms;
 }
 
 size_t ScanEngine::decode_scan(const ScanSpec& spec, size_t stream_offset, uint8_t* destination, size_t stride)

@@ -111,6 +111,12 @@ private:
 
     std::unique_ptr<EngineResources> r_; // from the pool at the first device call, back to it with the handle
     size_t pixel_bytes_{}, stream_bytes_{}, plane_capacity_{};
+    struct Trace // CHARLS_AMD_TRACE: the phases of the current coding call, in ms
+    {
+        double begin_ms{}, upload_ms{}, sync_ms{}, submit_ms{}, launch_ms{}, copy_out_ms{};
+        uint32_t launched_scans{};
+        bool decode{};
+    } trace_;
     int announced_lane_{-1};   // the coalescer lane this handle announced itself on (-1: none)
     uint64_t ticket_{};        // of that announcement (0: none)
 };

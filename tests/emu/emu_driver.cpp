@@ -155,6 +155,37 @@ int emu_decode_scans_group(const jls::ScanDesc* descs, jls::ScanResult* results,
     return 0;
 }
 
+// The same kernel with W wavefronts per workgroup (one workgroup per CU, a wavefront per SIMD: the launches of big batches).
+int emu_decode_scans_group_waves(const jls::ScanDesc* descs, jls::ScanResult* results, int count, int group, int waves)
+{
+    const jls::ScanDesc& d = descs[0];
+    const bool wide = d.bits_per_sample > 8;
+    if ((group != 16 && group != 32) || (waves != 4 && waves != 8) || d.interleave_mode == 1)
+        return -1;
+    const int per_group = 64 / group * waves;
+    const size_t lds = wide ? jls::grp::workgroup_lds_bytes<uint16_t>(d.width, per_group, 1) : jls::grp::workgroup_lds_bytes<uint8_t>(d.width, per_group, 1);
+    const dim3 grid((count + per_group - 1) / per_group);
+#define EMU_GROUP_W(S, G, W) emu::launch(jls::decode_scans_group<S, G, 1, W>, grid, dim3(64 * W), lds, descs, results, (uint32_t)count)
+    if (group == 16 && waves == 4)
+    {
+        if (wide) EMU_GROUP_W(uint16_t, 16, 4); else EMU_GROUP_W(uint8_t, 16, 4);
+    }
+    else if (group == 32 && waves == 4)
+    {
+        if (wide) EMU_GROUP_W(uint16_t, 32, 4); else EMU_GROUP_W(uint8_t, 32, 4);
+    }
+    else if (group == 16)
+    {
+        if (wide) EMU_GROUP_W(uint16_t, 16, 8); else EMU_GROUP_W(uint8_t, 16, 8);
+    }
+    else
+    {
+        if (wide) EMU_GROUP_W(uint16_t, 32, 8); else EMU_GROUP_W(uint8_t, 32, 8);
+    }
+#undef EMU_GROUP_W
+    return 0;
+}
+
 // scan_group_pixels.hip: sample-interleaved scans, `group` lanes per scan.
 int emu_decode_pixels_group(const jls::ScanDesc* descs, jls::ScanResult* results, int count, int group)
 {

@@ -59,6 +59,32 @@ def test_group_decoder_matches_reference_pixels(c):
     assert common.sha(b"".join(o.tobytes() for o in outs)) == c["decoded_sha256"]
 
 
+@pytest.mark.parametrize("group,waves,w,h,bits,kind,count", [(16, 4, 70, 9, 8, "mixed", 37), (32, 4, 130, 6, 8, "hard", 5), (32, 8, 64, 7, 16, "mixed", 19),
+                                                              (16, 8, 33, 5, 12, "noise", 70), (16, 4, 40, 4, 8, "zero", 1)])
+def test_group_decoder_with_several_wavefronts_per_workgroup(group, waves, w, h, bits, kind, count):
+    """decode_scans_group<S, G, 1, W>: W wavefronts per workgroup share the gradient table and nothing else (the launches of
+    big batches: one workgroup per CU, a wavefront per SIMD).  Counts that leave whole wavefronts of the last workgroup
+    without a scan, and a single scan."""
+    L = emu_bind.lib()
+    bps = 1 if bits <= 8 else 2
+    keep, outs, descs, imgs = [], [], [], []
+    for f in range(count):
+        img = synth.frame_numpy(w, h, seed=7 * f + bits + waves, bits=bits, kind=kind)
+        jls = ob.encode(img, width=w, height=h, bits_per_sample=bits)
+        cont = jls_container.parse(jls)
+        pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+        pix = np.zeros(w * h * bps, dtype=np.uint8)
+        descs.append(emu_bind.make_desc(w, h, 1, 0, bits, 0, 0, pc, 0, pix, w * bps, _stream_copy(jls, cont.scans[0].data_start), keep))
+        outs.append(pix)
+        imgs.append((img, cont.scans[0].data_end - cont.scans[0].data_start))
+    arr = (emu_bind.ScanDesc * count)(*descs)
+    res = (emu_bind.ScanResult * count)()
+    assert L.emu_decode_scans_group_waves(arr, res, count, group, waves) == 0
+    for r, o, (img, nbytes) in zip(res, outs, imgs):
+        assert (r.errc, r.flags, r.bytes) == (0, 0, nbytes)
+        assert o.tobytes() == img.tobytes()
+
+
 @pytest.mark.parametrize("group,w,h,bits,kind,count", _rotating(GROUPS, [(64, 20, 8, "mixed", 7), (300, 5, 8, "noise", 5), (33, 9, 16, "mixed", 5),
                                                  (41, 7, 12, "hard", 3), (1, 9, 8, "mixed", 3), (520, 3, 2, "noise", 9),
                                                  (70, 6, 8, "zero", 4)]))

@@ -17,7 +17,7 @@ ap.add_argument("--frames", type=int, default=4096)
 ap.add_argument("--width", type=int, default=4096)
 ap.add_argument("--height", type=int, default=4096)
 ap.add_argument("--bits", type=int, default=8)
-ap.add_argument("--groups", default="0,16")
+ap.add_argument("--groups", default="0,16", help="lanes per scan, optionally with the wavefronts per workgroup: 8,16:4,32:8")
 ap.add_argument("--sizes", default="64,256,1024,4096")
 ap.add_argument("--repeat", type=int, default=1)
 ap.add_argument("--distinct", type=int, default=0,
@@ -98,8 +98,10 @@ batch.release_work_areas(lib)
 mpix = args.width * args.height / 1e6
 print(f"synth {t1 - t0:.1f}s encode {t2 - t1:.2f}s = {mpix * args.frames / (t2 - t1):.0f} MPix/s", flush=True)
 rows = []
-for g in [int(x) for x in args.groups.split(",")]:
+for spec in args.groups.split(","):
+    g, wg = (int(x) for x in (spec.split(":") + ["1"])[:2])
     capi.set_knob("DECODE_GROUP", g)
+    capi.set_knob("DECODE_WORKGROUP_WAVES", wg)
     for n in [int(x) for x in args.sizes.split(",")]:
         if n > args.frames:
             continue
@@ -116,6 +118,6 @@ for g in [int(x) for x in args.groups.split(",")]:
         ok = bool((errcs == 0).all())
         for f0 in range(0, n, 64):  # compare in pieces: torch.equal materialises a mask of the operands' size
             ok = ok and torch.equal(out[f0:min(n, f0 + 64)], frames[f0:min(n, f0 + 64)])
-        rows.append({"group": g, "frames": n, "decode_s": round(best, 4), "mpix_s": round(mpix * n / best, 1),
+        rows.append({"group": g, "workgroup_waves": wg, "frames": n, "decode_s": round(best, 4), "mpix_s": round(mpix * n / best, 1),
                      "kernel_ms": round(gpu_ms[0], 2), "sclk_mhz": clocks.mean(), "ok": ok})
         print(json.dumps(rows[-1]), flush=True)
