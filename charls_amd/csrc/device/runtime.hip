@@ -213,32 +213,43 @@ size_t group_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
 // every run: 4096 frames with 4 scans per wavefront took 3.94 s in one sweep and 5.01 s in the next), so the scans are packed
 // as densely as it takes to stay at two wavefronts per CU, and no denser.
 // CHARLS_AMD_DECODE_GROUP overrides (0, 4, 8, 16, 32).
-constexpr long long kDecodeWavesPerCu = 2; // (DECODE_WAVES_PER_CU overrides: measurements)
-// Wavefronts per workgroup of the group decoder for a launch of `count` single-component scans at `lanes` lanes per scan
-// (scan_group_decode.hip, template parameter W).  Up to two wavefronts per CU the one-wavefront workgroups of rounds 2 - 4
-// find a SIMD each; beyond that the dispatcher doubles wavefronts up on some SIMDs while others idle, and those pairs take the
-// launch's tail with them -- so a launch that needs four wavefronts per CU makes them ONE workgroup of four, which the
-// hardware deals out one per SIMD (it takes the whole LDS of its CU: one workgroup per CU).
-int decode_workgroup_waves(const ScanDesc& d, uint32_t count, int lanes)
+// Lanes per scan (G) and wavefronts per workgroup (W) of the speed path (scan_group_decode.hip) for a launch of `count` scans;
+// lanes 0 = the one-scan-per-wavefront kernel (scan_fast_decode.hip).
+//
+// What a sample costs: a wavefront stops for every event of every one of its scans (run mode, end of line, refill), so the
+// fewer scans share a wavefront the less a step takes -- 206 ns with 2 scans per wavefront, 217 with 4, 232 with 8 -- as long
+// as the wavefront has a SIMD TO ITSELF: two wavefronts of this kernel on one SIMD take a third longer each (4.8 s instead of
+// 3.6 s for a frame's 16.8 M samples: profiles/r05_decode_wavefronts_per_workgroup.txt).  So the rule is one wavefront per
+// SIMD, and the fewest scans per wavefront that allows:
+//  * up to two wavefronts per CU, one-wavefront workgroups find a SIMD each (W = 1: rounds 2 - 4);
+//  * beyond that the dispatcher doubles one-wavefront workgroups up on some SIMDs while others idle -- not in every launch:
+//    1024 of them decoded 4096 frames in 3.67 s in one call and in 4.89 s in others, at an unchanged 2.39 GHz
+//    (profiles/r05_pmc_decode_effective_clock.txt; rounds 3 and 4 took the slow launches for the chip clocking down and never
+//    went beyond two wavefronts per CU).  A workgroup of FOUR wavefronts that takes the whole LDS of its CU is dealt out one
+//    wavefront per SIMD by construction: 4096 frames at 16 lanes per scan in 3.76 s, every time (8 lanes, W = 1: 4.05 s).
+// DECODE_GROUP / DECODE_WORKGROUP_WAVES override (0, 4, 8, 16, 32 lanes; 1, 4, 8 wavefronts).
+struct GroupPlan
 {
-    if (lanes == 0 || group_lines(d) != 1)
-        return 1;
-    const uint32_t per_wave = 64u / static_cast<uint32_t>(lanes);
-    const int forced = static_cast<int>(knobs::get_or(knobs::kDecodeWorkgroupWaves, -1));
-    if ((forced == 1 || forced == 4 || forced == 8) && (lanes == 16 || lanes == 32 || forced == 1) &&
-        group_lds_bytes(d, per_wave * static_cast<uint32_t>(forced)) <= kGroupDecodeLds)
-        return forced;
-    return 1;
-}
-int decode_group_lanes(const ScanDesc& d, uint32_t count)
+    int lanes, waves;
+};
+GroupPlan decode_group_plan(const ScanDesc& d, uint32_t count)
 {
     if (d.bits_per_sample > 8 && d.t3 > grp::kMaxTableT3)
-        return 0;
+        return {0, 1};
+    const bool one_line = group_lines(d) == 1; // (the W > 1 instantiations exist for single-component scans)
     const int forced = static_cast<int>(knobs::get_or(knobs::kDecodeGroup, -1));
+    const int forced_waves = static_cast<int>(knobs::get_or(knobs::kDecodeWorkgroupWaves, -1));
     if (forced == 0)
-        return 0;
-    if ((forced == 4 || forced == 8 || forced == 16 || forced == 32) && group_lds_bytes(d, 64u / forced) <= kGroupDecodeLds)
-        return forced;
+        return {0, 1};
+    if (forced == 4 || forced == 8 || forced == 16 || forced == 32)
+    {
+        const uint32_t per_wave = 64u / static_cast<uint32_t>(forced);
+        if ((forced_waves == 4 || forced_waves == 8) && one_line && (forced == 16 || forced == 32) &&
+            group_lds_bytes(d, per_wave * static_cast<uint32_t>(forced_waves)) <= kGroupDecodeLds)
+            return {forced, forced_waves};
+        if (group_lds_bytes(d, per_wave) <= kGroupDecodeLds)
+            return {forced, 1};
+    }
     static const uint32_t cus = [] {
         hipDeviceProp_t prop;
         int device = 0;
@@ -246,18 +257,27 @@ int decode_group_lanes(const ScanDesc& d, uint32_t count)
             return 256u;
         return static_cast<uint32_t>(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     }();
-    const uint32_t waves_per_cu = static_cast<uint32_t>(std::clamp<long long>(knobs::get_or(knobs::kDecodeWavesPerCu, kDecodeWavesPerCu), 1, 16));
-    int best = 0;
+    const uint32_t waves_per_cu = static_cast<uint32_t>(std::clamp<long long>(knobs::get_or(knobs::kDecodeWavesPerCu, 2), 1, 16));
+    const bool allow_workgroups = one_line && forced_waves != 1;
+    int fallback = 0;
     for (int lanes = 32; lanes >= 8; lanes /= 2)
     {
         const uint32_t per_wave = 64u / static_cast<uint32_t>(lanes);
         if (group_lds_bytes(d, per_wave) > kGroupDecodeLds)
             break;
-        best = lanes;
+        fallback = lanes;
         if ((count + per_wave - 1) / per_wave <= waves_per_cu * cus)
-            break;
+            return {lanes, 1};
+        // four wavefronts per CU as ONE workgroup (it must be the only one its CU can hold: more than half of the LDS)
+        const uint32_t per_group = 4 * per_wave;
+        if (allow_workgroups && lanes >= 16 && group_lds_bytes(d, per_group) <= kGroupDecodeLds && (count + per_group - 1) / per_group <= cus)
+            return {lanes, 4};
     }
-    return best;
+    return {fallback, 1};
+}
+int decode_group_lanes(const ScanDesc& d, uint32_t count)
+{
+    return decode_group_plan(d, count).lanes;
 }
 
 // Lanes per scan of the speed path of sample-interleaved scans, lossless or near-lossless, and of near-lossless
@@ -541,10 +561,12 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
     else
     {
         const uint32_t per_wave = 64u / static_cast<uint32_t>(group);
-        const int wg_waves = decode_workgroup_waves(proto, count, group);
+        const int wg_waves = decode_group_plan(proto, count).waves;
         const uint32_t per_group = per_wave * static_cast<uint32_t>(wg_waves);
         const dim3 grid((count + per_group - 1) / per_group);
-        const size_t lds = group_lds_bytes(proto, per_group);
+        // (a workgroup of several wavefronts is to have its CU to itself -- one wavefront per SIMD: it asks for more than half
+        // of the CU's LDS whatever its scans need)
+        const size_t lds = wg_waves > 1 ? std::max<size_t>(group_lds_bytes(proto, per_group), kGroupDecodeLds / 2 + 1024) : group_lds_bytes(proto, per_group);
 #define JLS_LAUNCH_GROUP_NW(S, G, N, W)                                                                                  \
     do                                                                                                                   \
     {                                                                                                                    \

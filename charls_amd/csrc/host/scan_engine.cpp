@@ -77,6 +77,70 @@ void release_resources(std::unique_ptr<EngineResources> r) noexcept
     // (r is destroyed here: too large to keep, or the pool is full)
 }
 
+// ---- the streams the shared launches run on.  The device runs the kernels of only a few hardware queues side by side, and
+// the runtime deals its queues out per stream PRIORITY: a decoder launch is ONE kernel that runs for seconds (a serial chain
+// per scan), and on the handles' own streams it shared its hardware queue with whatever stream came next -- an encoder batch
+// of 250 frames that should take 0.1 s waited 3.4 s behind an unrelated decoder kernel (profiles/r05_threads_call_trace.txt).
+// So decoder launches run on a few streams of the LOWEST priority (their own queues; they leave most of every CU idle and
+// give way), encoder launches on one stream of the HIGHEST priority per device; the handles' streams only carry copies.
+constexpr int kMaxDevices = 32;
+struct LaunchStreams
+{
+    std::mutex guard;
+    std::vector<hipStream_t> idle_decode; // lowest priority; made on demand, kept
+    hipStream_t encode{};                 // highest priority (the encoder lane runs one batch at a time)
+};
+LaunchStreams& launch_streams(int device)
+{
+    static LaunchStreams* all = new LaunchStreams[kMaxDevices]; // never destroyed: the HIP runtime may be gone at exit
+    return all[device >= 0 && device < kMaxDevices ? device : 0];
+}
+void priority_range(int& lowest, int& highest)
+{
+    lowest = highest = 0;
+    if (hipDeviceGetStreamPriorityRange(&lowest, &highest) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        lowest = highest = 0;
+    }
+}
+hipStream_t take_decode_stream(int device)
+{
+    LaunchStreams& ls = launch_streams(device);
+    {
+        std::lock_guard<std::mutex> lock(ls.guard);
+        if (!ls.idle_decode.empty())
+        {
+            hipStream_t s = ls.idle_decode.back();
+            ls.idle_decode.pop_back();
+            return s;
+        }
+    }
+    int lowest = 0, highest = 0;
+    priority_range(lowest, highest);
+    hipStream_t s{};
+    hip_check(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lowest));
+    return s;
+}
+void give_back_decode_stream(int device, hipStream_t s) noexcept
+{
+    LaunchStreams& ls = launch_streams(device);
+    std::lock_guard<std::mutex> lock(ls.guard);
+    ls.idle_decode.push_back(s);
+}
+hipStream_t encode_stream(int device)
+{
+    LaunchStreams& ls = launch_streams(device);
+    std::lock_guard<std::mutex> lock(ls.guard);
+    if (ls.encode == nullptr)
+    {
+        int lowest = 0, highest = 0;
+        priority_range(lowest, highest);
+        hip_check(hipStreamCreateWithPriority(&ls.encode, hipStreamNonBlocking, highest));
+    }
+    return ls.encode;
+}
+
 Coalescer& coalescer()
 {
     static Coalescer* c = new Coalescer; // never destroyed: calls may be in flight at process exit
@@ -121,7 +185,7 @@ uint32_t merge_wait_us(const ScanDesc& d, bool decode)
 
 // Decoder batches of one geometry that may run side by side: the device runs kernels of a few streams at once, and a second
 // batch beside the first costs nothing while the first leaves most of the chip idle; beyond that a batch waits (and collects).
-constexpr uint32_t kDecodeBatchesAtOnce = 2;
+constexpr uint32_t kDecodeBatchesAtOnce = 3;
 constexpr uint32_t kMaxMergedScans = 16384;
 
 } // namespace
@@ -219,8 +283,8 @@ ScanResult ScanEngine::run(const ScanDesc& desc, bool decode)
     return r;
 }
 
-// One launch for descs[0, n), on this handle's stream and with this handle's staging areas.
-void ScanEngine::launch(const ScanDesc* descs, uint32_t n, bool decode, ScanResult* results)
+// One launch for descs[0, n) on `stream`, with this handle's staging areas.
+void ScanEngine::launch(const ScanDesc* descs, uint32_t n, bool decode, ScanResult* results, hipStream_t stream)
 {
     const size_t desc_bytes = sizeof(ScanDesc) * n, result_bytes = sizeof(ScanResult) * n;
     // (with room to spare: growing a buffer frees the old one, and hipFree waits for every kernel on the device -- another
@@ -229,18 +293,18 @@ void ScanEngine::launch(const ScanDesc* descs, uint32_t n, bool decode, ScanResu
     std::memcpy(staged, descs, desc_bytes);
     auto* d_descs = static_cast<ScanDesc*>(r_->desc.ensure(dev::with_headroom(desc_bytes)));
     auto* d_results = static_cast<ScanResult*>(r_->result.ensure(dev::with_headroom(result_bytes)));
-    hip_check(hipMemcpyAsync(d_descs, staged, desc_bytes, hipMemcpyHostToDevice, r_->stream));
+    hip_check(hipMemcpyAsync(d_descs, staged, desc_bytes, hipMemcpyHostToDevice, stream));
     ScanDesc proto = descs[0];
     if (decode)
-        dev::launch_decode(proto, d_descs, d_results, n, r_->stream);
+        dev::launch_decode(proto, d_descs, d_results, n, stream);
     else
     {
         for (uint32_t i = 1; i < n; ++i) // (an upper bound of every scan's capacity: launch_encode sizes the raw streams by it)
             proto.stream_capacity = std::max(proto.stream_capacity, descs[i].stream_capacity);
-        dev::launch_encode(proto, d_descs, d_results, n, r_->stream);
+        dev::launch_encode(proto, d_descs, d_results, n, stream);
     }
-    hip_check(hipMemcpyAsync(staged + desc_bytes, d_results, result_bytes, hipMemcpyDeviceToHost, r_->stream));
-    hip_check(hipStreamSynchronize(r_->stream));
+    hip_check(hipMemcpyAsync(staged + desc_bytes, d_results, result_bytes, hipMemcpyDeviceToHost, stream));
+    hip_check(hipStreamSynchronize(stream));
     std::memcpy(results, staged + desc_bytes, result_bytes);
 }
 
@@ -249,7 +313,7 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
     constexpr size_t kKeepBytes = size_t{1} << 30; // a drop-in library must not sit on gigabytes of the caller's HBM between calls
     if (!coalescing_enabled())
     {
-        launch(descs, count, decode, results);
+        launch(descs, count, decode, results, r_->stream);
         if (dev::thread_work_area_bytes() > kKeepBytes)
             dev::release_thread_work_areas();
         return;
@@ -281,7 +345,13 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
         } note{*this, t_launch, n};
         if (decode)
         { // decoder launches keep next to nothing between calls and run side by side
-            launch(all, n, true, out);
+            struct Borrowed
+            {
+                int device;
+                hipStream_t s;
+                ~Borrowed() { give_back_decode_stream(device, s); }
+            } borrowed{r_->device, take_decode_stream(r_->device)};
+            launch(all, n, true, out, borrowed.s);
             if (dev::thread_work_area_bytes() > kKeepBytes)
                 dev::release_thread_work_areas();
             return;
@@ -289,7 +359,7 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
         // encoder launches share the device's work areas: one merged launch at a time (the coalescer's exclusive lane
         // already sees to that; the scope also keeps charls_amd_release_work_areas() of another thread out)
         dev::SharedAreasScope shared;
-        launch(all, n, false, out);
+        launch(all, n, false, out, encode_stream(r_->device));
         // (the shared areas stay: they never grow beyond dev::shared_areas_keep_bytes(), and a pool of threads that codes in
         // rounds would otherwise pay for gigabytes of hipMalloc + hipFree -- seconds -- in every round;
         // charls_amd_release_work_areas() gives them back)

@@ -105,7 +105,7 @@ private:
     ScanDesc make_desc(const ScanSpec& spec) const;
     ScanResult run(const ScanDesc& desc, bool decode);
     void run_many(const ScanDesc* descs, uint32_t count, bool decode, ScanResult* results);
-    void launch(const ScanDesc* descs, uint32_t n, bool decode, ScanResult* results);
+    void launch(const ScanDesc* descs, uint32_t n, bool decode, ScanResult* results, hipStream_t stream);
     void copy_out(uint8_t* destination, const uint8_t* device_source, size_t bytes);
     void copy_rows_out(uint8_t* destination, size_t stride, const uint8_t* device_source, size_t row_bytes, size_t rows);
 

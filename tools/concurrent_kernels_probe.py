@@ -50,3 +50,30 @@ for coalesce in (0, 1):
         "{k: after[k] - before[k] for k in ('calls', 'launches', 'merged_calls')}",
         str({k: after[k] - before[k] for k in ("calls", "launches", "merged_calls")})), flush=True)
 capi.set_knob("COALESCE", None)
+
+# ---- does a decoder kernel that runs for seconds hold up an encoder call of another thread?  (It did, for as long as it ran,
+# while both were launched on the handles' own streams: the device runs the kernels of few hardware queues side by side.)
+big = synth.frame_numpy(4096, 4096, seed=2)
+big_jls = lib.encode(big, width=4096, height=4096)
+lat = []
+
+
+def long_decode():
+    lib.decode(big_jls)
+
+
+t = threading.Thread(target=long_decode)
+t0 = time.perf_counter()
+t.start()
+time.sleep(0.5)
+for _ in range(5):
+    a = time.perf_counter()
+    lib.encode(big, width=4096, height=4096)
+    lat.append((time.perf_counter() - a) * 1e3)
+small = frames[0]
+a = time.perf_counter()
+lib.decode(streams[0])
+small_decode_ms = (time.perf_counter() - a) * 1e3
+t.join()
+print(f"one 4096x4096 decode running ({time.perf_counter() - t0:.2f} s); meanwhile on another thread: 4096x4096 encodes "
+      f"{', '.join(f'{v:.1f}' for v in lat)} ms, one 1024x1024 decode {small_decode_ms:.1f} ms", flush=True)

@@ -246,7 +246,7 @@ print("# idle:", json.dumps(tele.summary()))
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 for rep in range(args.repeat):
     for g in [int(x) for x in args.groups.split(",")]:
-        capi.set_knob("DECODE_GROUP", g)
+        capi.set_knob("DECODE_GROUP", g if g >= 0 else None)  # (-1: the library's own rule)
         out.zero_()
         torch.cuda.synchronize()
         with tele, smi:
@@ -254,7 +254,7 @@ for rep in range(args.repeat):
             _, errcs, gpu_ms = batch.decode_batch(enc.streams, enc.sizes, out, lib=lib)
             torch.cuda.synchronize()
             b = time.perf_counter()
-        waves = (args.frames + 64 // g - 1) // (64 // g)
+        waves = (args.frames + 64 // g - 1) // (64 // g) if g > 0 else 0
         row = {"round": rep, "lanes_per_scan": g, "wavefronts": waves, "wavefronts_per_cu": round(waves / cus, 2),
                "decode_s": round(b - a, 3), "kernel_ms": round(gpu_ms[1] if len(gpu_ms) > 1 else gpu_ms[0], 1),
                "mpix_s": round(mpix * args.frames / (b - a), 1), "ns_per_step": round((b - a) * 1e9 / (args.width * args.height), 1),

@@ -33,7 +33,13 @@ L = emu_bind.profile_lib()
 count = 64 // args.group  # one wavefront
 keep, outs, descs, imgs = [], [], [], []
 for f in range(count):
-    img = synth.frame_numpy(args.width, args.lines, seed=1000 + f, bits=8, kind=args.kind)
+    if args.kind == "tulips":  # the reference's natural test image, tiled to the width, a different band of lines per scan
+        import common
+        tile, _ = common.read_pnm("tulips-gray-8bit-512-512.pgm")
+        band = np.roll(tile, shift=(-(37 * f) % 512, 29 * f), axis=(0, 1))[:args.lines]
+        img = np.ascontiguousarray(np.tile(band, (1, (args.width + 511) // 512))[:, :args.width])
+    else:
+        img = synth.frame_numpy(args.width, args.lines, seed=1000 + f, bits=8, kind=args.kind)
     jls = ob.encode(img, width=args.width, height=args.lines, bits_per_sample=8)
     cont = jls_container.parse(jls)
     pc = jls_container.validated_pc(cont.pc, cont.bits, 0)

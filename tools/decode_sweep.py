@@ -100,6 +100,8 @@ print(f"synth {t1 - t0:.1f}s encode {t2 - t1:.2f}s = {mpix * args.frames / (t2 -
 rows = []
 for spec in args.groups.split(","):
     g, wg = (int(x) for x in (spec.split(":") + ["1"])[:2])
+    if g < 0:  # the library's own rule
+        g = wg = None
     capi.set_knob("DECODE_GROUP", g)
     capi.set_knob("DECODE_WORKGROUP_WAVES", wg)
     for n in [int(x) for x in args.sizes.split(",")]:
