@@ -64,6 +64,13 @@ private:
     size_t cap_{};
 };
 
+// A launch that runs for seconds is in flight (a decoder launch of the host-pointer ABI): until it ends, DeviceBuffers that
+// give a block up set it aside instead of calling hipFree (which would wait for that launch); reap_deferred_frees() frees what
+// was set aside once no such launch is running.
+void long_kernel_begins() noexcept;
+void long_kernel_ends() noexcept;
+void reap_deferred_frees() noexcept;
+
 enum class EncodeEngine : int32_t
 {
     automatic = 0,

@@ -78,10 +78,51 @@ void* DeviceBuffer::ensure(size_t bytes)
     return ptr_;
 }
 
+// hipFree waits for every kernel that is running on the device.  While one of this library's decoder launches of the
+// host-pointer ABI is in flight -- ONE kernel that runs for seconds -- a block that is given up (a buffer that grows) is not
+// freed but set aside, and freed once no such launch is running (profiles/r05_concurrent_kernels.txt: an encoder call that grew
+// the shared work areas beside a running decoder took 2.9 s instead of 2 ms).
+namespace {
+std::atomic<int> g_long_kernels{0};
+std::mutex g_deferred_guard;
+std::vector<void*> g_deferred;
+} // namespace
+
+void reap_deferred_frees() noexcept
+{
+    if (g_long_kernels.load() > 0)
+        return;
+    std::vector<void*> gone;
+    {
+        std::lock_guard<std::mutex> lock(g_deferred_guard);
+        gone.swap(g_deferred);
+    }
+    for (void* p : gone)
+        (void)hipFree(p);
+}
+
+void long_kernel_begins() noexcept
+{
+    g_long_kernels.fetch_add(1);
+}
+
+void long_kernel_ends() noexcept
+{
+    g_long_kernels.fetch_sub(1);
+}
+
 void DeviceBuffer::release() noexcept
 {
     if (ptr_)
-        (void)hipFree(ptr_);
+    {
+        if (g_long_kernels.load() > 0)
+        {
+            std::lock_guard<std::mutex> lock(g_deferred_guard);
+            g_deferred.push_back(ptr_);
+        }
+        else
+            (void)hipFree(ptr_);
+    }
     ptr_ = nullptr;
     cap_ = 0;
 }

@@ -14,6 +14,10 @@
 //  * the first submitter of a kind (key = geometry and coding parameters) leads a batch: it waits while fresh announcements
 //    are outstanding (never longer than `wait_us`; a caller that is alone has nobody to wait for and launches at once), then
 //    runs the launch for everybody on its own stream and hands the results out;
+//  * on a lane that is visibly shared (somebody joined the batch already, or another batch of the lane is running) the leader
+//    also waits while calls KEEP JOINING -- the batch goes when none has joined for `gap_us`: a pool of threads that comes out
+//    of its encoder calls over a few hundred milliseconds decodes as one batch, not as three small ones and a big one that
+//    waits for them (profiles/r05_threads_call_trace.txt);
 //  * at most `max_running` batches of a key run at a time (an encoder lane: ONE batch of any key -- the work areas of the
 //    pipeline are shared).  A batch that has to wait for its turn stays OPEN meanwhile -- group commit -- and when its turn
 //    comes it may give the callers of the batch that just finished a moment (`grace_us`) to come back: decoder threads that
@@ -80,6 +84,7 @@ public:
         uint32_t max_scans;   // scans of a batch at most
         uint32_t max_running; // batches of ONE key that may run at a time (0: the lane runs one batch of ANY key at a time)
         uint32_t grace_us;    // what a batch that had to wait for its turn gives the callers of the finished batch to come back
+        uint32_t gap_us;      // on a lane that is visibly shared: the batch goes when no call has joined for this long
     };
 
     static constexpr int kLanes = 64; // device * 2 + (decode ? 1 : 0), devices 0..31
@@ -122,6 +127,7 @@ public:
             const size_t first = b->descs.size();
             b->descs.insert(b->descs.end(), descs, descs + count);
             ++b->calls;
+            b->last_join = Clock::now();
             arrival_.notify_all(); // the leader looks again
             b->finished.wait(lock, [&] { return b->done; });
             if (b->failure != CHARLS_JPEGLS_ERRC_SUCCESS)
@@ -133,6 +139,7 @@ public:
         auto b = std::make_shared<Batch>();
         b->descs.assign(descs, descs + count);
         b->calls = 1;
+        b->last_join = Clock::now();
         const bool published = open == open_.end();
         if (published)
             open_[id] = b; // (otherwise a full batch of this kind is still open: this one stays private and runs on its own)
@@ -160,10 +167,21 @@ public:
             }
             const bool room = published && b->descs.size() < policy.max_scans;
             const bool in_grace = room && now < grace;
-            const bool others_coming = room && now < deadline && fresh_announcements(lane, now, wait);
+            // Others are on their way while an announcement is fresh -- or, where the lane is visibly shared (somebody joined
+            // this batch already, or another batch of the lane is running), while calls keep joining: the batch goes when
+            // none has joined for `gap_us`.  (A caller that is alone sees neither and launches at once.)
+            const bool shared = b->calls > 1 || lane_busy(lane);
+            const Clock::time_point quiet = b->last_join + std::chrono::microseconds(policy.gap_us);
+            const bool still_joining = shared && now < quiet;
+            const bool others_coming = room && now < deadline && (fresh_announcements(lane, now, wait) || still_joining);
             if (!in_grace && !others_coming)
                 break;
-            arrival_.wait_until(lock, in_grace && !others_coming ? grace : deadline);
+            Clock::time_point until = deadline;
+            if (in_grace && !others_coming)
+                until = grace;
+            else if (!fresh_announcements(lane, now, wait) && still_joining)
+                until = std::min(deadline, quiet);
+            arrival_.wait_until(lock, until);
         }
         if (published)
             open_.erase(id);
@@ -229,10 +247,21 @@ private:
         std::vector<ScanDesc> descs;
         std::vector<ScanResult> results;
         uint32_t calls{};
+        Clock::time_point last_join{}; // when the latest call joined (the leader counts)
         bool done{};
         charls_jpegls_errc failure{CHARLS_JPEGLS_ERRC_SUCCESS};
         std::condition_variable finished;
     };
+
+    bool lane_busy(int lane) const
+    {
+        if (lane_running_[lane] != 0)
+            return true;
+        for (const auto& entry : key_running_)
+            if (entry.first.first == lane && entry.second != 0)
+                return true;
+        return false;
+    }
 
     // Is a call on its way to this lane?  An announcement older than `wait` is stale -- a handle that was configured and then
     // left alone -- and holds nobody up (tickets rise with time: the last one is the youngest).

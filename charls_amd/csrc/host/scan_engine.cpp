@@ -252,6 +252,7 @@ void ScanEngine::end_call() noexcept
                      trace_.submit_ms, trace_.launch_ms, trace_.launched_scans, trace_.copy_out_ms);
     }
     trace_ = Trace{};
+    dev::reap_deferred_frees(); // (blocks that were given up while a decoder launch ran; nothing to do as a rule)
     if (ticket_ != 0)
         coalescer().retract(announced_lane_, ticket_);
     ticket_ = 0;
@@ -351,6 +352,11 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
                 hipStream_t s;
                 ~Borrowed() { give_back_decode_stream(device, s); }
             } borrowed{r_->device, take_decode_stream(r_->device)};
+            struct Running
+            { // (hipFree of any thread would wait for this launch: frees are set aside while it runs, runtime.hip)
+                Running() { dev::long_kernel_begins(); }
+                ~Running() { dev::long_kernel_ends(); }
+            } running;
             launch(all, n, true, out, borrowed.s);
             if (dev::thread_work_area_bytes() > kKeepBytes)
                 dev::release_thread_work_areas();
@@ -365,8 +371,9 @@ void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, Sc
         // charls_amd_release_work_areas() gives them back)
     };
     // (the grace: a decoder batch that had to queue is seconds late already, a quarter of the wait more lets the threads of the
-    // batch before it come back and join; encoder batches are short and collect what arrives while they queue)
-    const Coalescer::Policy policy{wait_us, kMaxMergedScans, decode ? kDecodeBatchesAtOnce : 0u, decode ? wait_us / 4 : 0u};
+    // batch before it come back and join; the gap: on a lane that several threads are seen to use a decoder batch goes when no
+    // call has joined for a quarter of the wait; encoder batches are short and collect what arrives while they queue)
+    const Coalescer::Policy policy{wait_us, kMaxMergedScans, decode ? kDecodeBatchesAtOnce : 0u, decode ? wait_us / 4 : 0u, decode ? wait_us / 4 : 0u};
     const double t_submit = tracing() ? now_ms() : 0;
     struct Queued
     {

@@ -46,7 +46,7 @@ int main()
         ScanResult r{};
         const auto t0 = Clock::now();
         const Coalescer::Ticket mine = c.announce(1);
-        c.submit(1, merge_key_of(d), &d, 1, &r, mine, Coalescer::Policy{500000, 1024, 2, 125000}, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
+        c.submit(1, merge_key_of(d), &d, 1, &r, mine, Coalescer::Policy{500000, 1024, 2, 125000, 0}, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
             ++launches;
             for (uint32_t i = 0; i < n; ++i)
                 out[i] = ScanResult{0, 0, all[i].stream_capacity * 3};
@@ -68,7 +68,7 @@ int main()
                 std::this_thread::sleep_for(std::chrono::microseconds(200 * (i % 7))); // (uploads of different length)
                 ScanDesc d[2] = {desc_of(512, 1000 + i), desc_of(512, 2000 + i)};
                 ScanResult r[2]{};
-                c.submit(3, merge_key_of(d[0]), d, 2, r, tickets[i], Coalescer::Policy{2000000, 1024, 2, 500000}, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
+                c.submit(3, merge_key_of(d[0]), d, 2, r, tickets[i], Coalescer::Policy{2000000, 1024, 2, 500000, 0}, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
                     ++launches;
                     largest = std::max<int>(largest, (int)n);
                     for (uint32_t k = 0; k < n; ++k)
@@ -95,7 +95,7 @@ int main()
             threads.emplace_back([&, i] {
                 const ScanDesc d = desc_of(i % 3 == 0 ? 100 : 200, (uint32_t)i);
                 ScanResult r{};
-                c.submit(i % 2 ? 5 : 7, merge_key_of(d), &d, 1, &r, tickets[i], Coalescer::Policy{300000, 1024, 2, 75000}, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
+                c.submit(i % 2 ? 5 : 7, merge_key_of(d), &d, 1, &r, tickets[i], Coalescer::Policy{300000, 1024, 2, 75000, 0}, [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
                     ++launches;
                     for (uint32_t k = 0; k < n; ++k)
                     {
@@ -129,7 +129,7 @@ int main()
                     std::this_thread::sleep_for(std::chrono::milliseconds(10 + i)); // the first one is running by then
                 const ScanDesc d = desc_of(300, (uint32_t)i);
                 ScanResult r{};
-                c.submit(2, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{0, 1024, 0, 0}, fake);
+                c.submit(2, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{0, 1024, 0, 0, 0}, fake);
             });
         for (auto& t : threads)
             t.join();
@@ -149,7 +149,7 @@ int main()
                 ScanResult r{};
                 try
                 {
-                    c.submit(9, merge_key_of(d), &d, 1, &r, tickets[i], Coalescer::Policy{500000, 1024, 2, 125000},
+                    c.submit(9, merge_key_of(d), &d, 1, &r, tickets[i], Coalescer::Policy{500000, 1024, 2, 125000, 0},
                              [&](const ScanDesc*, uint32_t, ScanResult*) { raise(CHARLS_JPEGLS_ERRC_NOT_ENOUGH_MEMORY); });
                 }
                 catch (const error& e)
@@ -176,18 +176,18 @@ int main()
         ScanResult r{};
         auto t0 = Clock::now();
         const Coalescer::Ticket mine = c.announce(11);
-        c.submit(11, merge_key_of(d), &d, 1, &r, mine, Coalescer::Policy{3000000, 1024, 2, 750000}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+        c.submit(11, merge_key_of(d), &d, 1, &r, mine, Coalescer::Policy{3000000, 1024, 2, 750000, 0}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
         const double waited = ms_since(t0);
         quitter.join();
         CHECK(waited >= 20 && waited < 1500, "the leader waits for an announced call and stops waiting when it is retracted");
         const Coalescer::Ticket never = c.announce(11); // never submits
         t0 = Clock::now();
-        c.submit(11, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{50000, 1024, 2, 12500}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+        c.submit(11, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{50000, 1024, 2, 12500, 0}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
         const double capped = ms_since(t0);
         CHECK(capped >= 40 && capped < 1000, "an announced call that never comes costs the wait and no more");
         std::this_thread::sleep_for(std::chrono::milliseconds(80)); // the announcement is older than the wait of the next call
         t0 = Clock::now();
-        c.submit(11, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{50000, 1024, 2, 12500}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+        c.submit(11, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{50000, 1024, 2, 12500, 0}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
         CHECK(ms_since(t0) < 30, "a stale announcement holds nobody up");
         CHECK(c.idle(11, 50000) && !c.idle(11, 60000000), "idle() applies the same notion of freshness");
         c.retract(11, never);
@@ -204,7 +204,7 @@ int main()
             threads.emplace_back([&, i] {
                 const ScanDesc d = desc_of(40, 0);
                 ScanResult r{};
-                c.submit(13, merge_key_of(d), &d, 1, &r, tickets[i], Coalescer::Policy{200000, 8, 4, 50000}, [&](const ScanDesc*, uint32_t n, ScanResult* out) {
+                c.submit(13, merge_key_of(d), &d, 1, &r, tickets[i], Coalescer::Policy{200000, 8, 4, 50000, 0}, [&](const ScanDesc*, uint32_t n, ScanResult* out) {
                     largest = std::max<int>(largest, (int)n);
                     total += (int)n;
                     for (uint32_t k = 0; k < n; ++k)
@@ -234,14 +234,14 @@ int main()
                 std::this_thread::sleep_for(std::chrono::milliseconds(5 * i)); // one after the other: nobody is announced when the first two launch
                 const ScanDesc d = desc_of(300, (uint32_t)i);
                 ScanResult r{};
-                c.submit(21, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{20000, 1024, 2, 5000}, fake);
+                c.submit(21, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{20000, 1024, 2, 5000, 0}, fake);
             });
         threads.emplace_back([&] {
             std::this_thread::sleep_for(std::chrono::milliseconds(30)); // two batches of the other key are running
             const ScanDesc d = desc_of(999, 0);
             ScanResult r{};
             const auto t0 = Clock::now();
-            c.submit(21, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{20000, 1024, 2, 5000}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+            c.submit(21, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{20000, 1024, 2, 5000, 0}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
             other_key_ms = (int)ms_since(t0);
         });
         for (auto& t : threads)
@@ -269,13 +269,43 @@ int main()
                 std::this_thread::sleep_for(std::chrono::milliseconds(2)); // its upload
                 const ScanDesc d = desc_of(128, 0);
                 ScanResult r{};
-                c.submit(23, merge_key_of(d), &d, 1, &r, t, Coalescer::Policy{40000, 1024, 1, 10000}, fake);
+                c.submit(23, merge_key_of(d), &d, 1, &r, t, Coalescer::Policy{40000, 1024, 1, 10000, 0}, fake);
             }
         };
         std::thread a(looper, 0), b(looper, 17);
         a.join();
         b.join();
         CHECK(pairs >= 5 && launches <= 11, "two looping threads end up sharing their launches");
+    }
+    // 10. a shared lane: calls that trickle in without announcing themselves still end up in one batch while they keep coming
+    {
+        Coalescer c;
+        std::atomic<int> launches{0}, largest{0};
+        auto fake = [&](const ScanDesc*, uint32_t n, ScanResult* out) {
+            ++launches;
+            largest = std::max<int>(largest, (int)n);
+            std::this_thread::sleep_for(std::chrono::milliseconds(30));
+            for (uint32_t k = 0; k < n; ++k)
+                out[k] = ScanResult{};
+        };
+        std::vector<std::thread> threads;
+        for (int i = 0; i < 20; ++i)
+            threads.emplace_back([&, i] {
+                std::this_thread::sleep_for(std::chrono::milliseconds(i == 0 ? 0 : 5 + 8 * i)); // 8 ms apart, after a first pair
+                const ScanDesc d = desc_of(222, (uint32_t)i);
+                ScanResult r{};
+                const Coalescer::Ticket t = i < 2 ? c.announce(25) : 0; // (the first two overlap: the lane is seen to be shared)
+                c.submit(25, merge_key_of(d), &d, 1, &r, t, Coalescer::Policy{400000, 1024, 3, 0, 40000}, fake);
+            });
+        for (auto& t : threads)
+            t.join();
+        CHECK(launches <= 2 && largest >= 19, "calls that keep joining a shared lane's batch go in one launch");
+        // and a caller that is alone still launches at once
+        const ScanDesc d = desc_of(222, 0);
+        ScanResult r{};
+        const auto t0 = Clock::now();
+        c.submit(25, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{400000, 1024, 3, 0, 40000}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+        CHECK(ms_since(t0) < 20, "a caller that is alone does not wait for joiners");
     }
     std::printf(g_failures == 0 ? "coalescer ok\n" : "coalescer FAILED\n");
     return g_failures == 0 ? 0 : 1;
