@@ -85,20 +85,23 @@ void* DeviceBuffer::ensure(size_t bytes)
 namespace {
 std::atomic<int> g_long_kernels{0};
 std::mutex g_deferred_guard;
-std::vector<void*> g_deferred;
+std::vector<void*> g_deferred, g_deferred_host;
 } // namespace
 
 void reap_deferred_frees() noexcept
 {
     if (g_long_kernels.load() > 0)
         return;
-    std::vector<void*> gone;
+    std::vector<void*> gone, gone_host;
     {
         std::lock_guard<std::mutex> lock(g_deferred_guard);
         gone.swap(g_deferred);
+        gone_host.swap(g_deferred_host);
     }
     for (void* p : gone)
         (void)hipFree(p);
+    for (void* p : gone_host)
+        (void)hipHostFree(p);
 }
 
 void long_kernel_begins() noexcept
@@ -129,18 +132,30 @@ void DeviceBuffer::release() noexcept
 
 PinnedBuffer::~PinnedBuffer()
 {
+    release();
+}
+
+void PinnedBuffer::release() noexcept
+{
     if (ptr_)
-        (void)hipHostFree(ptr_);
+    {
+        if (g_long_kernels.load() > 0)
+        { // (hipHostFree waits for the device like hipFree does)
+            std::lock_guard<std::mutex> lock(g_deferred_guard);
+            g_deferred_host.push_back(ptr_);
+        }
+        else
+            (void)hipHostFree(ptr_);
+    }
+    ptr_ = nullptr;
+    cap_ = 0;
 }
 
 void* PinnedBuffer::ensure(size_t bytes)
 {
     if (bytes <= cap_ && ptr_)
         return ptr_;
-    if (ptr_)
-        (void)hipHostFree(ptr_);
-    ptr_ = nullptr;
-    cap_ = 0;
+    release();
     hip_check(hipHostMalloc(&ptr_, bytes < 256 ? 256 : bytes, hipHostMallocDefault));
     cap_ = bytes < 256 ? 256 : bytes;
     return ptr_;
