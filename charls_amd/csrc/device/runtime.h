@@ -53,8 +53,6 @@ public:
     PinnedBuffer& operator=(const PinnedBuffer&) = delete;
     ~PinnedBuffer();
     void* ensure(size_t bytes);
-    void release() noexcept;
-    size_t capacity() const noexcept { return cap_; }
     template <typename T>
     T* as() const noexcept
     {

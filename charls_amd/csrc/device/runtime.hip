@@ -85,23 +85,20 @@ void* DeviceBuffer::ensure(size_t bytes)
 namespace {
 std::atomic<int> g_long_kernels{0};
 std::mutex g_deferred_guard;
-std::vector<void*> g_deferred, g_deferred_host;
+std::vector<void*> g_deferred;
 } // namespace
 
 void reap_deferred_frees() noexcept
 {
     if (g_long_kernels.load() > 0)
         return;
-    std::vector<void*> gone, gone_host;
+    std::vector<void*> gone;
     {
         std::lock_guard<std::mutex> lock(g_deferred_guard);
         gone.swap(g_deferred);
-        gone_host.swap(g_deferred_host);
     }
     for (void* p : gone)
         (void)hipFree(p);
-    for (void* p : gone_host)
-        (void)hipHostFree(p);
 }
 
 void long_kernel_begins() noexcept
@@ -132,30 +129,18 @@ void DeviceBuffer::release() noexcept
 
 PinnedBuffer::~PinnedBuffer()
 {
-    release();
-}
-
-void PinnedBuffer::release() noexcept
-{
     if (ptr_)
-    {
-        if (g_long_kernels.load() > 0)
-        { // (hipHostFree waits for the device like hipFree does)
-            std::lock_guard<std::mutex> lock(g_deferred_guard);
-            g_deferred_host.push_back(ptr_);
-        }
-        else
-            (void)hipHostFree(ptr_);
-    }
-    ptr_ = nullptr;
-    cap_ = 0;
+        (void)hipHostFree(ptr_);
 }
 
 void* PinnedBuffer::ensure(size_t bytes)
 {
     if (bytes <= cap_ && ptr_)
         return ptr_;
-    release();
+    if (ptr_)
+        (void)hipHostFree(ptr_);
+    ptr_ = nullptr;
+    cap_ = 0;
     hip_check(hipHostMalloc(&ptr_, bytes < 256 ? 256 : bytes, hipHostMallocDefault));
     cap_ = bytes < 256 ? 256 : bytes;
     return ptr_;

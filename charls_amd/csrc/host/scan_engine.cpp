@@ -2,7 +2,6 @@
 #include "scan_engine.h"
 
 #include <algorithm>
-#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -142,19 +141,6 @@ hipStream_t encode_stream(int device)
     return ls.encode;
 }
 
-// ---- host copies under contention.  The callers' buffers are ordinary pageable memory; the runtime pins them in place for
-// the duration of a copy, which is as fast as pinned memory for ONE caller (profiles/r04_copy_probe.txt: 54 GB/s either way) --
-// and serialises in the kernel's memory-management locks when 256 threads do it at once: the last of 256 downloads of a
-// decoded 16.8 MB frame arrived 0.7 s after the first (profiles/r05_threads_call_trace.txt).  From kBounceFrom calls in flight
-// a handle copies through a pinned buffer of its own (kept with its pooled resources; the CPU copies of the threads run in
-// parallel); a lone caller keeps the direct path, which is faster for it.  Pinned memory is bounded: kBounceBudget for all
-// handles together.
-std::atomic<int> g_calls_in_flight{0};
-std::atomic<size_t> g_bounce_bytes{0};
-constexpr int kBounceFrom = 8;
-constexpr size_t kBounceMin = size_t{1} << 20;
-constexpr size_t kBounceBudget = size_t{24} << 30;
-
 Coalescer& coalescer()
 {
     static Coalescer* c = new Coalescer; // never destroyed: calls may be in flight at process exit
@@ -215,7 +201,6 @@ void coalescer_stats(uint64_t out[4]) noexcept
 
 EngineResources::~EngineResources()
 {
-    g_bounce_bytes.fetch_sub(bounce.capacity());
     if (stream)
         (void)hipStreamDestroy(stream);
 }
@@ -242,11 +227,6 @@ void ScanEngine::ensure_stream()
     dev::require_device();
     if (!r_)
         r_ = acquire_resources();
-    if (!counted_)
-    { // (until end_call)
-        counted_ = true;
-        g_calls_in_flight.fetch_add(1, std::memory_order_relaxed);
-    }
 }
 
 void ScanEngine::expect_call(bool decode) noexcept
@@ -272,11 +252,6 @@ void ScanEngine::end_call() noexcept
                      trace_.submit_ms, trace_.launch_ms, trace_.launched_scans, trace_.copy_out_ms);
     }
     trace_ = Trace{};
-    if (counted_)
-    {
-        counted_ = false;
-        g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed);
-    }
     dev::reap_deferred_frees(); // (blocks that were given up while a decoder launch ran; nothing to do as a rule)
     if (ticket_ != 0)
         coalescer().retract(announced_lane_, ticket_);
@@ -465,62 +440,14 @@ void ScanEngine::fetch_decoded_plane(const ScanSpec& spec, uint32_t index, uint8
     copy_rows_out(destination, stride, r_->pixels.as<uint8_t>() + row_bytes * spec.height * index, row_bytes, spec.height);
 }
 
-// The handle's pinned bounce buffer for a copy of `bytes`, or nullptr: the copy goes straight to / from the caller's memory.
-uint8_t* ScanEngine::bounce_for(size_t bytes)
-{
-    if (bytes < kBounceMin || g_calls_in_flight.load(std::memory_order_relaxed) < kBounceFrom)
-        return nullptr;
-    if (r_->bounce.capacity() < bytes)
-    {
-        const size_t want = (bytes + kBounceMin - 1) / kBounceMin * kBounceMin, had = r_->bounce.capacity();
-        if (g_bounce_bytes.load() + want - had > kBounceBudget)
-            return nullptr;
-        try
-        {
-            r_->bounce.ensure(want);
-        }
-        catch (const error&)
-        { // (no pinned memory to be had: the direct path needs none)
-            (void)hipGetLastError();
-            g_bounce_bytes.fetch_sub(had);
-            return nullptr;
-        }
-        g_bounce_bytes.fetch_add(want - had);
-    }
-    return r_->bounce.as<uint8_t>();
-}
-
-// Host -> device on the handle's own stream; complete (for the device) when the stream has been synchronised.
-void ScanEngine::copy_in(uint8_t* device_destination, const uint8_t* source, size_t bytes)
-{
-    if (bytes == 0)
-        return;
-    if (uint8_t* pinned = bounce_for(bytes))
-    {
-        hip_check(hipStreamSynchronize(r_->stream)); // (an earlier upload of this call may still read the bounce buffer)
-        std::memcpy(pinned, source, bytes);
-        source = pinned;
-    }
-    hip_check(hipMemcpyAsync(device_destination, source, bytes, hipMemcpyHostToDevice, r_->stream));
-}
-
 // Device -> host on the handle's own stream (the null stream would queue the copies of all calling threads behind each other).
 void ScanEngine::copy_out(uint8_t* destination, const uint8_t* device_source, size_t bytes)
 {
     if (bytes == 0)
         return;
     const double t0 = tracing() ? now_ms() : 0;
-    if (uint8_t* pinned = bounce_for(bytes))
-    {
-        hip_check(hipMemcpyAsync(pinned, device_source, bytes, hipMemcpyDeviceToHost, r_->stream));
-        hip_check(hipStreamSynchronize(r_->stream));
-        std::memcpy(destination, pinned, bytes);
-    }
-    else
-    {
-        hip_check(hipMemcpyAsync(destination, device_source, bytes, hipMemcpyDeviceToHost, r_->stream));
-        hip_check(hipStreamSynchronize(r_->stream));
-    }
+    hip_check(hipMemcpyAsync(destination, device_source, bytes, hipMemcpyDeviceToHost, r_->stream));
+    hip_check(hipStreamSynchronize(r_->stream));
     if (tracing())
         trace_.copy_out_ms += now_ms() - t0;
 }
@@ -543,7 +470,7 @@ void ScanEngine::upload_pixels(const uint8_t* source, size_t bytes)
     const double t0 = tracing() ? now_ms() : 0;
     r_->pixels.ensure(bytes);
     pixel_bytes_ = bytes;
-    copy_in(r_->pixels.as<uint8_t>(), source, bytes);
+    hip_check(hipMemcpyAsync(r_->pixels.as<uint8_t>(), source, bytes, hipMemcpyHostToDevice, r_->stream));
     if (tracing())
         trace_.upload_ms += now_ms() - t0, trace_.begin_ms = trace_.begin_ms == 0 ? t0 : trace_.begin_ms;
 }
@@ -576,7 +503,7 @@ void ScanEngine::upload_stream(const uint8_t* source, size_t bytes)
     const double t0 = tracing() ? now_ms() : 0;
     r_->bits.ensure(bytes + 16); // the ring refill of the wave decoder reads whole 16-byte groups
     stream_bytes_ = bytes;
-    copy_in(r_->bits.as<uint8_t>(), source, bytes);
+    hip_check(hipMemcpyAsync(r_->bits.as<uint8_t>(), source, bytes, hipMemcpyHostToDevice, r_->stream));
     if (tracing())
         trace_.upload_ms += now_ms() - t0, trace_.begin_ms = trace_.begin_ms == 0 ? t0 : trace_.begin_ms;
 }

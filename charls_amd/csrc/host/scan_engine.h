@@ -34,7 +34,6 @@ struct EngineResources
     int device{-1};
     dev::DeviceBuffer pixels, bits, scratch, desc, result;
     dev::PinnedBuffer staging;
-    dev::PinnedBuffer bounce; // pinned stand-in for the caller's pageable buffer when many calls copy at once (scan_engine.cpp: bounce_for)
     EngineResources() = default;
     EngineResources(const EngineResources&) = delete;
     EngineResources& operator=(const EngineResources&) = delete;
@@ -107,9 +106,7 @@ private:
     ScanResult run(const ScanDesc& desc, bool decode);
     void run_many(const ScanDesc* descs, uint32_t count, bool decode, ScanResult* results);
     void launch(const ScanDesc* descs, uint32_t n, bool decode, ScanResult* results, hipStream_t stream);
-    void copy_in(uint8_t* device_destination, const uint8_t* source, size_t bytes);
     void copy_out(uint8_t* destination, const uint8_t* device_source, size_t bytes);
-    uint8_t* bounce_for(size_t bytes);
     void copy_rows_out(uint8_t* destination, size_t stride, const uint8_t* device_source, size_t row_bytes, size_t rows);
 
     std::unique_ptr<EngineResources> r_; // from the pool at the first device call, back to it with the handle
@@ -122,7 +119,6 @@ private:
     } trace_;
     int announced_lane_{-1};   // the coalescer lane this handle announced itself on (-1: none)
     uint64_t ticket_{};        // of that announcement (0: none)
-    bool counted_{};           // this handle is counted among the calls in flight (bounce_for)
 };
 
 inline CallScope::~CallScope()
