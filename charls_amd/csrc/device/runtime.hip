@@ -321,6 +321,8 @@ int decode_group_lanes(const ScanDesc& d, uint32_t count)
     return decode_group_plan(d, count).lanes;
 }
 
+constexpr uint32_t kPixelWaves = 512; // wavefronts a launch of the pixel kernels (scan_group_pixels.hip, scan_group_encode.hip) aims at: two per CU
+
 // Lanes per scan of the speed path of sample-interleaved scans, lossless or near-lossless, and of near-lossless
 // single-component scans (scan_group_pixels.hip); 0 = the exact decoder.  Packing as in decode_group_lanes.
 int pixel_group_lanes(const ScanDesc& d, uint32_t count)
@@ -346,7 +348,7 @@ int pixel_group_lanes(const ScanDesc& d, uint32_t count)
         if (pixel_group_lds_bytes(d, per_wave) > kGroupDecodeLds)
             break;
         best = lanes;
-        if ((count + per_wave - 1) / per_wave <= 256u)
+        if ((count + per_wave - 1) / per_wave <= kPixelWaves) // (two one-wavefront workgroups per CU find a SIMD each, see decode_group_plan)
             break;
     }
     return best;
@@ -1277,7 +1279,7 @@ int group_encode_lanes(const ScanDesc& d, uint32_t count)
         if (group_encode_lds_bytes(d, per_wave) > kGroupDecodeLds)
             break;
         best = lanes;
-        if ((count + per_wave - 1) / per_wave <= 256u)
+        if ((count + per_wave - 1) / per_wave <= kPixelWaves) // (two one-wavefront workgroups per CU find a SIMD each, see decode_group_plan)
             break;
     }
     return best;

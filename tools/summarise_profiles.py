@@ -12,6 +12,9 @@ SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "fi
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 PMC_FRAMES = 64
+# the instantiation of the headline decoder that the bench's 4096-frame launch uses (runtime.hip: decode_group_plan)
+DOMINANT = os.environ.get("CHARLS_AMD_DOMINANT_INSTANTIATION", "<unsigned char, 16, 1, 4>")
+DOMINANT_KNOBS = "CHARLS_AMD_DECODE_GROUP=16 CHARLS_AMD_DECODE_WORKGROUP_WAVES=4"
 
 
 def short(name):
@@ -77,10 +80,10 @@ def main():
     write_big, _ = counters("pmc4096_WRITE_SIZE")
     inst8, l8 = counters("pmc_inst_g8")
     dom_pmc = {"kernel": dom, "frames": frames}
-    big = [k for k in fetch_big if dom in k and "<unsigned char, 8, 1>" in k and k in write_big]
+    big = [k for k in fetch_big if dom in k and DOMINANT in k and k in write_big]
     fetch_g8, lg = counters("pmc_g8_FETCH_SIZE")
     write_g8, _ = counters("pmc_g8_WRITE_SIZE")
-    small = [k for k in fetch_g8 if dom in k and "<unsigned char, 8, 1>" in k and k in write_g8]
+    small = [k for k in fetch_g8 if dom in k and DOMINANT in k and k in write_g8]
     if big:
         k = big[0]
         per_launch = (2 * fetch_big[k]["FETCH_SIZE"] + write_big[k]["WRITE_SIZE"]) * 1024 / max(1, lb[k])
@@ -95,19 +98,19 @@ def main():
         dom_pmc["hbm_bytes_per_frame_at_64_frames"] = per_frame
         if not big:  # the 4096-frame PMC pass did not survive: the same instantiation with 64 frames stands in, and says so
             dom_pmc.update({"instantiation": k, "hbm_bytes_per_frame": per_frame, "frames": frames, "measured_with_frames": PMC_FRAMES,
-                            "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `CHARLS_AMD_DECODE_GROUP=8 python bench.py --frames "
-                                      f"{PMC_FRAMES} --steps 1 --warmup 0` (the bench's instantiation, eight scans per wavefront, with "
+                            "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{DOMINANT_KNOBS} python bench.py --frames "
+                                      f"{PMC_FRAMES} --steps 1 --warmup 0` (the bench's instantiation, with "
                                       f"{PMC_FRAMES} frames: the PMC pass with {frames} frames crashed in rocprofv3), per frame"})
-    g8 = [k for k in inst8 if dom in k and "<unsigned char, 8, 1>" in k]
+    g8 = [k for k in inst8 if dom in k and DOMINANT in k]
     if g8:
         k = g8[0]
         samples = PMC_FRAMES * 4096 * 4096 * max(1, l8[k])
         dom_pmc.update({"valu_wave_instructions_per_sample": round(inst8[k]["SQ_INSTS_VALU"] / samples, 3),
                         "salu_wave_instructions_per_sample": round(inst8[k]["SQ_INSTS_SALU"] / samples, 3),
                         "lds_wave_instructions_per_sample": round(inst8[k]["SQ_INSTS_LDS"] / samples, 3),
-                        "instruction_source": "rocprofv3 --pmc SQ_INSTS_* of `CHARLS_AMD_DECODE_GROUP=8 python bench.py --frames 64 --steps 1 "
-                                              "--warmup 0` (eight scans per wavefront, as in the 4096-frame launch; per-sample counts do "
-                                              "not depend on the number of wavefronts)"})
+                        "instruction_source": f"rocprofv3 --pmc SQ_INSTS_* of `{DOMINANT_KNOBS} python bench.py --frames 64 --steps 1 "
+                                              "--warmup 0` (the instantiation of the 4096-frame launch: four scans per wavefront, four wavefronts "
+                                              "per workgroup; per-sample counts do not depend on the number of wavefronts)"})
     with open(os.path.join(DST, f"{TAG}_dominant_kernel_pmc.json"), "w") as f:
         json.dump(dom_pmc, f, indent=1)
         f.write("\n")
@@ -128,7 +131,8 @@ def main():
     # ---- the rest of the collection run, as it is
     import shutil
     for src, dst in (("other_configs.txt", "other_configs.txt"), ("one_frame_latency.txt", "one_frame_latency.txt"),
-                     ("copy_probe.txt", "copy_probe.txt"), ("pytest_gpu.log", "pytest_gpu.log")):
+                     ("copy_probe.txt", "copy_probe.txt"), ("pytest_gpu.log", "pytest_gpu.log"), ("decode_tulips.txt", "decode_natural_image_4096_frames.txt"),
+                     ("bench_cfg4.json", "bench_cfg4_1gpu.json")):
         if os.path.exists(os.path.join(SRC, src)):
             shutil.copyfile(os.path.join(SRC, src), os.path.join(DST, f"{TAG}_{dst}"))
     one = os.path.join(SRC, "one", "one_kernel_stats.csv")
