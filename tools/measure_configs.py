@@ -17,10 +17,12 @@ dev = torch.device("cuda:0")
 batch.set_workspace_limit(int(os.environ.get("CHARLS_AMD_MEASURE_WORKSPACE_GIB", "160")) << 30, lib)
 
 
-def run(name, frames, *, bits, comps=1, ilv=0, near=0, xform=0, restart=0):
+def run(name, frames, *, bits, comps=1, ilv=0, near=0, xform=0, restart=0, slot_factor=None):
     torch.cuda.synchronize()
     kw = dict(bits_per_sample=bits, component_count=comps, interleave_mode=ilv, near_lossless=near,
               color_transformation=xform, restart_interval=restart, lib=lib)
+    if slot_factor:  # data that does not compress needs more room than charls_jpegls_encoder_get_estimated_destination_size gives it
+        kw["streams"] = torch.empty((frames.shape[0], int(frames[0].numel() * frames.element_size() * slot_factor) & ~255), dtype=torch.uint8, device=dev)
     batch.encode_batch(frames, **kw)  # warm-up with the whole batch: the work arena is sized by the call that needs it
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -84,7 +86,7 @@ if "noise" in only:  # full-range noise: the chains' recurrences never forget (|
     before = (C.c_uint64 * 6)()
     L.charls_amd_speculation_counters(before, 6)
     f = synth.frames_torch(64, 4096, 4096, seed0=2, bits=8, kind="noise", device=dev)
-    run("full-range noise (the encoder's worst case): 4096x4096 8-bit gray, kind=noise", f, bits=8)
+    run("full-range noise (the encoder's worst case): 4096x4096 8-bit gray, kind=noise", f, bits=8, slot_factor=1.3)
     after = (C.c_uint64 * 6)()
     L.charls_amd_speculation_counters(after, 6)
     print("  speculation counters of its two encodes (jobs, walked again, run jobs, walked again, rare segments, rare serial): "
