@@ -487,9 +487,11 @@ def main():
                          "kernel_ms_per_launch": round(dom_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes)},
             "issue_roofline": issue,
         }
-        if not args.no_extras and args.restart_interval == 0 and args.workload == "cfg2":
+        # (context for `value` and the CPU baseline: at N = 1 only -- the other ranks of a multi-GPU run would sit in the process
+        # group for minutes while rank 0 measures them)
+        if not args.no_extras and args.restart_interval == 0 and args.workload == "cfg2" and world == 1:
             line.update(extras(lib, batch, torch, frames, streams, out, enc, dev, mpix, pitch, args))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         # ---- context, never `value`: SURVEY 8(d)'s methodology (host buffer in -> host buffer out) and the whole host CPU
         if "batch_api_host_buffers" in line:

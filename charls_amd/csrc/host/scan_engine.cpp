@@ -152,6 +152,14 @@ bool coalescing_enabled()
     return knobs::get_or(knobs::kCoalesce, 1) != 0;
 }
 
+// The coalescer's lanes and the launch streams are tables over devices 0 .. kMaxDevices - 1; a device beyond them (no such box
+// exists) codes every call for itself.
+static_assert(2 * kMaxDevices <= Coalescer::kLanes, "a lane per device and direction");
+bool coalescing_enabled_on(int device)
+{
+    return coalescing_enabled() && device >= 0 && device < kMaxDevices;
+}
+
 bool tracing()
 {
     return knobs::get_or(knobs::kTrace, 0) != 0;
@@ -239,6 +247,8 @@ void ScanEngine::expect_call(bool decode) noexcept
         (void)hipGetLastError();
         return;
     }
+    if (!coalescing_enabled_on(device))
+        return;
     announced_lane_ = lane_of(device, decode);
     ticket_ = coalescer().announce(announced_lane_);
 }
@@ -312,8 +322,10 @@ void ScanEngine::launch(const ScanDesc* descs, uint32_t n, bool decode, ScanResu
 void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, ScanResult* results)
 {
     constexpr size_t kKeepBytes = size_t{1} << 30; // a drop-in library must not sit on gigabytes of the caller's HBM between calls
-    if (!coalescing_enabled())
+    if (!coalescing_enabled_on(r_->device))
     {
+        if (ticket_ != 0)
+            end_call();
         launch(descs, count, decode, results, r_->stream);
         if (dev::thread_work_area_bytes() > kKeepBytes)
             dev::release_thread_work_areas();
