@@ -149,6 +149,36 @@ def test_exact_decoder_agrees_with_speed_path(torch, knobs):
     assert (errcs == 0).all() and torch.equal(out_fast, out_exact) and torch.equal(out_exact, frames)
 
 
+@pytest.mark.parametrize("group,waves,bits,count,w,h", [(16, 4, 8, 37, 300, 40), (32, 4, 8, 5, 4096, 6), (32, 8, 16, 19, 129, 33), (16, 8, 12, 70, 64, 20),
+                                                        (16, 4, 8, 1, 50, 50), (32, 4, 16, 64, 640, 24)])
+def test_decoder_workgroups_of_several_wavefronts(torch, knobs, group, waves, bits, count, w, h):
+    """decode_scans_group<S, G, 1, W>: the launch shape of big batches (one workgroup per CU, a wavefront per SIMD: runtime.hip,
+    decode_group_plan), forced here on small ones -- counts that leave wavefronts of the last workgroup without a scan, a single
+    scan, a 4096-sample line -- and compared with the one-wavefront workgroups and the source frames."""
+    frames = synth.frames_torch(count, w, h, seed0=90, bits=bits, kind="mixed", device="cuda:0")
+    enc = batch.encode_batch(frames, bits_per_sample=bits)
+    assert (enc.errcs == 0).all()
+    knobs.set("DECODE_GROUP", group)
+    knobs.set("DECODE_WORKGROUP_WAVES", waves)
+    out = torch.zeros_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+    assert (errcs == 0).all() and torch.equal(out, frames)
+    knobs.set("DECODE_WORKGROUP_WAVES", 1)
+    again = torch.zeros_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, again)
+    assert (errcs == 0).all() and torch.equal(again, frames)
+
+
+def test_the_launch_rule_takes_workgroups_for_big_batches(torch):
+    """More scans than two one-wavefront workgroups per CU can take at 32 lanes per scan (1024 on an MI355X): the library's own
+    rule switches to workgroups of four wavefronts.  3000 small frames, every one compared."""
+    frames = synth.frames_torch(24, 96, 16, seed0=7, kind="mixed", device="cuda:0").repeat(125, 1, 1).contiguous()
+    enc = batch.encode_batch(frames)
+    out = torch.zeros_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+    assert (errcs == 0).all() and torch.equal(out, frames)
+
+
 def test_serial_and_pipeline_encoders_agree(torch):
     frames = synth.frames_torch(3, 257, 65, seed0=8, kind="mixed", device="cuda:0")
     batch.set_encode_engine(1)
