@@ -512,10 +512,13 @@ def main():
         dist.destroy_process_group()
 
 
-def threads_abi(lib, host_frames, pitch, threads, seconds):
+def threads_abi(lib, host_frames, pitch, threads, seconds, stagger=0.0):
     """The product under the harness `cpu_baseline.all_cores` uses for CharLS: `threads` host threads, one encoder / decoder
     handle per call (created inside the clock, as cli/benchmark.cpp does), host buffers in and out, every thread coding its
-    own frame in a loop until the deadline.  Through the 48-symbol ABI only."""
+    own frame in a loop until the deadline.  Through the 48-symbol ABI only.  stagger > 0 (tools/threads_abi_probe.py, not the
+    bench line): the threads start up to that many seconds apart and idle a random while between their calls -- arrival without
+    any alignment."""
+    import random
     from concurrent.futures import ThreadPoolExecutor
     from charls_amd import capi
     mpix = WIDTH * HEIGHT / 1e6
@@ -530,6 +533,9 @@ def threads_abi(lib, host_frames, pitch, threads, seconds):
         t_e = t_d = 0.0
         ok = True
         start_line.wait()
+        rng = random.Random(t)
+        if stagger:
+            time.sleep(rng.uniform(0, stagger))
         deadline = time.perf_counter() + seconds
         while time.perf_counter() < deadline or n == 0:
             a = time.perf_counter()
@@ -537,6 +543,8 @@ def threads_abi(lib, host_frames, pitch, threads, seconds):
             b = time.perf_counter()
             lib.decode(data, out=pxs[t])
             c = time.perf_counter()
+            if stagger:
+                time.sleep(rng.uniform(0, stagger / 10))
             t_e += b - a
             t_d += c - b
             n += 1

@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--threads", default="256,512")
 ap.add_argument("--seconds", type=float, default=12.0)
 ap.add_argument("--distinct", type=int, default=256)
+ap.add_argument("--stagger", type=float, default=0.0, help="threads start up to this many seconds apart and idle a random while between calls")
 ap.add_argument("--workspace-gib", type=int, default=96)
 args = ap.parse_args()
 
@@ -31,7 +32,9 @@ torch.cuda.empty_cache()
 host_list = [host[i] for i in range(args.distinct)]
 pitch = (batch.estimated_destination_size(bench.WIDTH, bench.HEIGHT, 8, 1) + 255) & ~255
 for t in [int(x) for x in args.threads.split(",")]:
-    row = bench.threads_abi(lib, host_list, pitch, t, args.seconds)
+    row = bench.threads_abi(lib, host_list, pitch, t, args.seconds, stagger=args.stagger)
+    if args.stagger:
+        row["stagger_s"] = args.stagger
     print(json.dumps(row), flush=True)
     print(f"# work areas held after the run: {batch.work_area_bytes(lib) / 2**30:.1f} GiB", flush=True)
 batch.release_work_areas(lib)
