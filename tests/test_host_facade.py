@@ -163,3 +163,19 @@ def test_every_symbol_the_header_declares_is_exported():
     lib = ctypes.CDLL(os.path.join(root, "charls_amd", "lib", "libcharls_amd.so"))
     missing = [name for name in sorted(declared) if not hasattr(lib, name)]
     assert not missing, missing
+
+
+def test_knobs_and_engine_counters_are_plain_host_calls(lib):
+    """charls_amd_debug_set_knob / charls_amd_engine_counters (include/charls_amd.h part 2): a table and a few counters, usable
+    without a GPU.  Unknown names are refused; a cleared knob can be set again; the counters come back as five values."""
+    from charls_amd import capi
+    L = lib.lib
+    L.charls_amd_debug_set_knob.argtypes = [C.c_char_p, C.c_int64]
+    L.charls_amd_debug_set_knob.restype = C.c_int32
+    assert L.charls_amd_debug_set_knob(b"TILE_SAMPLES", 256) == 0
+    assert L.charls_amd_debug_set_knob(b"CHARLS_AMD_TILE_SAMPLES", capi.KNOB_UNSET) == 0  # (with the prefix too; cleared)
+    assert L.charls_amd_debug_set_knob(b"NO_SUCH_KNOB", 1) == 101
+    assert L.charls_amd_debug_set_knob(None, 1) == 101
+    counters = capi.engine_counters(lib)
+    assert set(counters) == {"calls", "launches", "merged_calls", "largest_launch", "pipeline_fallback_scans"}
+    assert all(v >= 0 for v in counters.values())
