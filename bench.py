@@ -434,14 +434,17 @@ def main():
                 traffic = int(tj["hbm_bytes_per_frame"] * frames_n)
                 traffic_source = tj.get("source")
             if tj.get("kernel") == dom_name and dom_ms > 0:
-                # instruction-issue roofline: the SIMDs of CDNA4 are 32 lanes wide, a wave64 vector instruction issues over TWO
-                # cycles (MI355X_MICROARCH.md, "Wave scheduling"): 1024 SIMDs x 2.4 GHz / 2 = 1228.8 G wave-instructions/s.
-                # (Round 3 divided by 4 -- the GCN figure -- and reported twice the fraction.)
+                # instruction-issue roofline.  Every wave64 vector instruction of this kernel keeps its SIMD's vector ALU for one
+                # QUAD-cycle (PMC: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU, both in quad-cycles; two wavefronts of the kernel on one
+                # SIMD reach 83 % ALU-busy and take a third longer each: profiles/r05_pmc_decode_valu_busy.txt), so the ceiling is
+                # 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s -- round 3's ruler.  (Round 4 took 2 cycles per
+                # instruction from the guide's "Wave scheduling" paragraph and reported half the fraction.)
                 valu = float(tj["valu_wave_instructions_per_sample"]) * frames_n * pixels
-                peak = 1024 * 2.4e9 / 2
+                peak = 1024 * 2.4e9 / 4
                 issue = {"bound": "valu_issue", "achieved": round(valu / (dom_ms * 1e-3) / 1e9, 2), "peak": round(peak / 1e9, 1),
                          "unit": "G wave-instructions/s", "frac": round(valu / (dom_ms * 1e-3) / peak, 4),
                          "valu_wave_instructions_per_sample": tj["valu_wave_instructions_per_sample"],
+                         "peak_is": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 vector instruction (profiles/r05_pmc_decode_valu_busy.txt)",
                          "source": tj.get("instruction_source")}
         except (OSError, ValueError, KeyError, StopIteration):
             pass
