@@ -433,7 +433,7 @@ def main():
             if tj.get("kernel") == dom_name and int(tj.get("frames", -1)) == frames_n:
                 traffic = int(tj["hbm_bytes_per_frame"] * frames_n)
                 traffic_source = tj.get("source")
-            if tj.get("kernel") == dom_name and dom_ms > 0:
+            if tj.get("kernel") == dom_name and dom_ms > 0 and int(tj.get("frames", -1)) == frames_n:  # (instructions per sample are those of the launch shape of that many frames)
                 # instruction-issue roofline.  Every wave64 vector instruction of this kernel keeps its SIMD's vector ALU for one
                 # QUAD-cycle (PMC: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU, both in quad-cycles; two wavefronts of the kernel on one
                 # SIMD reach 83 % ALU-busy and take a third longer each: profiles/r05_pmc_decode_valu_busy.txt), so the ceiling is
