@@ -1428,6 +1428,7 @@ void release_work_areas() noexcept
     }
     if (have_device)
         (void)hipSetDevice(current);
+    reap_deferred_frees(); // (blocks that were set aside while a decoder launch of the host-pointer ABI ran)
 }
 
 size_t work_area_bytes() noexcept
