@@ -29,6 +29,9 @@
 
 #include "scan_model.h"
 #include "scan_fast_decode.hip"
+#ifndef JLS_EMULATED
+#include "scan_group_step.inc"
+#endif
 
 namespace jls {
 namespace grp {
@@ -38,6 +41,13 @@ constexpr uint32_t kRingBits = kRingWords * 32;
 constexpr int kStepsPerCheck = 64;                 // regular-mode steps between two looks at the producer
 constexpr uint32_t kMarginBits = kStepsPerCheck * 32 + 320; // dense bits the step loop and one event handler may consume
 constexpr int kMaxTableT3 = 1023;                  // widest gradient table (2 * T3 + 1 entries) for samples wider than 8 bits
+// What a step needs of the previous line is prepared ahead of the step loop, 64 samples at a time and by all lanes of the group
+// (prepare_line): one 8-byte entry per sample, in a ring of 128 entries whose first 64 are mirrored behind its end, so that a
+// step loop of up to 63 steps reads its entries at consecutive addresses wherever in the ring it starts.
+constexpr uint32_t kPrepRing = 128;
+constexpr uint32_t kPrepSlots = kPrepRing + 64;
+constexpr uint32_t kPrepChunk = 64;                // samples prepared per call
+constexpr int kStepsPerLoop = 63;                  // the step loop never consumes the last prepared sample (see prepare_line)
 
 // LDS of a workgroup (one wavefront): the gradient table shared by its scans, then one region per scan.  A scan's line
 // starts one sample before a 16-byte boundary so that sample 1 (the first of the row) is aligned for the 16-byte row stores.
@@ -48,7 +58,9 @@ struct Layout
     static constexpr uint32_t kRecords = 0;                        // 365 x 8 B (+ an unused slot)
     static constexpr uint32_t kRun = 2928;                         // 2 x RunCtx
     static constexpr uint32_t kRing = kRun + 32;                   // kRingWords + 2 words
-    static constexpr uint32_t kLine = kRing + kRingWords * 4 + 16 + 16 - sizeof(S);
+    static constexpr uint32_t kPrep = kRing + kRingWords * 4 + 8;  // kPrepSlots x 8 B: what a step needs of the previous line
+    static constexpr uint32_t kLine = kPrep + kPrepSlots * 8 + 24 + 16 - sizeof(S);
+    static_assert(kPrep % 8 == 0 && (kLine + sizeof(S)) % 16 == 0, "alignment of the prepared entries and of sample 1 of the line");
 };
 
 // Regions follow each other at a stride of 16 bytes more than a multiple of 128: the scans of a wavefront run in step and
@@ -86,6 +98,35 @@ struct Record
     uint32_t a;
     uint32_t ncb;
 };
+
+// One prepared entry of the previous line (the kernel's `prepare`) / one 8-byte LDS word.
+struct PrepEntry
+{
+    uint32_t x, y;
+};
+JLS_DEV PrepEntry load_pair(uint32_t address) // (8-byte aligned)
+{
+    const uint64_t w = lds_load<uint64_t>(address);
+    return PrepEntry{(uint32_t)w, (uint32_t)(w >> 32)};
+}
+JLS_DEV void store_pair(uint32_t address, const PrepEntry& e)
+{
+    lds_store<uint64_t>(address, ((uint64_t)e.y << 32) | e.x);
+}
+
+#ifndef JLS_EMULATED
+JLS_DEV uint32_t abs_difference_plus(uint32_t a, uint32_t b, uint32_t c) // |a - b| + c in one instruction
+{
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#else
+JLS_DEV uint32_t abs_difference_plus(uint32_t a, uint32_t b, uint32_t c)
+{
+    return (a > b ? a - b : b - a) + c;
+}
+#endif
 
 // The dense bit ring is LSB first: stream bit j is bit (j & 31) of word (j >> 5), so that the next 32 bits of the stream are
 // one funnel shift (v_alignbit_b32) of two neighbouring words, the unary prefix is a count of TRAILING zeros, and a
@@ -447,7 +488,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
         // (the host checks the thresholds of ONE scan of the launch: a scan with T3 beyond the table that leads its wavefront
         // must not write past the table's region -- it and its neighbours go to the exact decoder, see `usable`)
         for (int q = (int)threadIdx.x; q <= 2 * cap && q < (int)L::kLutBytes; q += 64 * W)
-            lut[q] = (unsigned char)(quantize(t_first, q - cap) + 4);
+            lut[q] = (unsigned char)((quantize(t_first, q - cap) + 4) * 8); // (premultiplied: a context record has 8 bytes)
         for (uint32_t q = sub; q < (NL == 1 ? width + 6 : NL * line_stride); q += G)
             line0[q] = 0;
         for (uint32_t q = sub; q <= kRingWords + 1; q += G)
@@ -482,39 +523,62 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
 #pragma unroll
     for (int c = 0; c < NL; ++c)
         corner_of[c] = run_index_of[c] = 0;
-    // Window of the previous line around sample i: prev[i - 1], prev[i], prev[i + 1], prev[i + 2] = Rc, Rb, Rd and the
-    // sample after it.  8-bit samples: one byte each in w0; wider samples: two halves each in w0 (Rc, Rb) and w1.
-    uint32_t w0 = 0, w1 = 0;
     int a = 0;           // Ra
-    int q1 = 0, t9 = 0;  // Q1 + 4 = quantised (Rd - Rb) + 4 and T = 9 (Q1 + 4) + (Q2 + 4) of sample i
     uint32_t a_seen = 0; // OR of every updated A (samples wider than 8 bits): 2^24 overflow test
     const int maxval = t.maxval, reset = t.reset;
     const uint32_t limit_m = (uint32_t)(t.limit - t.qbpp - 1);
+    const uint32_t records_address = lds_address(records);
+    const uint32_t prep_address = lds_address(region + L::kPrep);
+    // What the steps need of the previous line is prepared ahead of them (prepare): the entries of samples up to prepped_end
+    // exist.  An entry is made while the previous line still holds ALL its samples around it, i.e. before sample j - 1 of
+    // the current line is stored; the one exception is the first sample behind an event that jumped ahead of the prepared
+    // entries (a line start, a long run): its Rc = prev[i - 1] is kept in rc_over by whoever moved i.
+    uint32_t prepped_end = 0;
+    int rc_over = 0;
 
-    // quantised gradient + 4 (0..8): the three of a context then combine without sign extensions, and
-    // Q = 81 Q1 + 9 Q2 + Q3 = 9 (9 (Q1 + 4) + (Q2 + 4)) + (Q3 + 4) - 364
+    // (quantised gradient + 4) * 8, 0..64: the three of a context then combine without sign extensions, and the byte offset of
+    // a context's record is |8 (81 Q1 + 9 Q2 + Q3)| = |9 (9 q1 + q2) + q3 - 8 * 364| with q = 8 (Q + 4)
     auto quantised = [&](int diff) -> int {
         if (kWide)
             diff = med3(diff, -cap, cap);
         return (int)lds_load<unsigned char>((uint32_t)(diff + cap)); // the table is at LDS address 0
     };
-    auto rc_of = [&]() -> int { return kWide ? (int)(w0 & 0xFFFFu) : (int)(w0 & 0xFFu); };
-    auto rb_of = [&]() -> int { return kWide ? (int)(w0 >> 16) : (int)((w0 >> 8) & 0xFFu); };
-    auto rd_of = [&]() -> int { return kWide ? (int)(w1 & 0xFFFFu) : (int)((w0 >> 16) & 0xFFu); };
-    auto rd2_of = [&]() -> int { return kWide ? (int)(w1 >> 16) : (int)(w0 >> 24); };
-    // (re)loads the window of the previous line for sample i; rc = prev[i - 1] is the caller's (that slot of the line
-    // already holds the current line)
-    auto prime = [&](int rc) {
-        const uint32_t rb = line[i], rd = line[i + 1], rd2 = line[i + 2];
-        if (kWide)
+    // Entries of samples from .. from + kPrepChunk - 1 (those of the line): {Rc | T << 16, Rb} with T = 9 (9 q1 + q2), q1 of
+    // Rd - Rb, q2 of Rb - Rc.  Every lane of the group takes kPrepChunk / G consecutive samples: their kPer + 2 samples of the
+    // previous line, kPer + 1 gradients (q2 of a sample is q1 of its left neighbour).
+    auto prepare = [&](bool want, uint32_t from, bool first_is_over) {
+        constexpr uint32_t kPer = kPrepChunk / G;
+        const uint32_t j0 = from + (uint32_t)sub * kPer;
+        const uint32_t last = width + 1; // (prev[width + 1] = prev[width], set at the start of the line)
+        int v[kPer + 2];
+#pragma unroll
+        for (uint32_t c = 0; c < kPer + 2; ++c)
         {
-            w0 = (uint32_t)rc | (rb << 16);
-            w1 = rd | (rd2 << 16);
+            const uint32_t at = j0 - 1 + c;
+            v[c] = (int)line[at < last ? at : last];
         }
-        else
-            w0 = (uint32_t)rc | (rb << 8) | (rd << 16) | (rd2 << 24);
-        q1 = quantised((int)rd - (int)rb);
-        t9 = 9 * q1 + quantised((int)rb - rc);
+        if (first_is_over && sub == 0)
+            v[0] = rc_over;
+        int g[kPer + 1];
+#pragma unroll
+        for (uint32_t c = 0; c < kPer + 1; ++c)
+            g[c] = quantised(v[c + 1] - v[c]);
+        JLS_LOCKSTEP();
+#pragma unroll
+        for (uint32_t c = 0; c < kPer; ++c)
+        {
+            const uint32_t j = j0 + c;
+            const uint32_t tt = (uint32_t)mad24(g[c + 1], 81, 9 * g[c]);
+            const uint32_t slot = j & (kPrepRing - 1);
+            const PrepEntry entry{(uint32_t)v[c] | (tt << 16), (uint32_t)v[c + 1]};
+            if (want && j <= width)
+            {
+                store_pair(prep_address + slot * 8u, entry);
+                if (slot < kPrepSlots - kPrepRing)
+                    store_pair(prep_address + (slot + kPrepRing) * 8u, entry);
+            }
+        }
+        JLS_LOCKSTEP();
     };
 
     for (;;)
@@ -555,26 +619,41 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 if (starting)
                 {
                     i = 1;
-                    prime(corner);       // Rc = prev[0]
-                    a = rb_of();         // cur[0] = prev[1]
+                    prepped_end = 0;
+                    rc_over = corner;    // Rc = prev[0]
+                    a = (int)line[1];    // cur[0] = prev[1]
                     first = a;
                     phase = kInLine;
                 }
+            }
+        }
+        // ---- the previous line, prepared for the next steps: every scan inside a line has the entries of samples i .. i + 63
+        // (or to the end of its line) before the step loop; a call makes 64 of them
+        {
+            const uint32_t reach = i + (uint32_t)kStepsPerLoop < width ? i + (uint32_t)kStepsPerLoop : width;
+            const bool need = phase == kInLine && prepped_end < reach;
+            if (__any(need))
+            {
+                JLS_PATH(14); // calls of prepare
+                const uint32_t from = prepped_end + 1 > i ? prepped_end + 1 : i;
+                prepare(need, from, from == i);
+                if (need)
+                    prepped_end = from + kPrepChunk - 1;
             }
         }
         // ---- step loop: one regular-mode sample per scan and step
         const bool in_line = phase == kInLine; // i <= width: the end of a line is handled as soon as it is reached
         const LaneMask in_line_m = lanes_where(in_line);
         LaneMask ok_m = ~0ull; // lanes whose last step decoded a sample
-        int qsu = 364;         // Q + 364 of the last step
+        uint32_t qsu8 = 2912;  // 8 (Q + 364) of the last step
         // what the last step of a lane that could not decode its sample had in its registers (the run handler starts from it)
-        uint32_t win_stopped = 0, t_next_stopped = 0;
-        int q1n_stopped = 0;
+        uint32_t win_stopped = 0;
+        PrepEntry entry_stopped{0, 0};
         if (in_line_m != 0)
         {
             // no scan may step past the end of its line: the wavefront takes as many steps as the shortest rest allows
             const uint32_t rest_of_line = width + 1 - i;
-            uint32_t steps = kStepsPerCheck;
+            uint32_t steps = kStepsPerLoop;
             for (;;)
             { // (one trip per scan that is close to the end of its line, at most)
                 const LaneMask closer = lanes_where(in_line && rest_of_line < steps);
@@ -584,175 +663,163 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 steps = value_of_lowest_lane(closer, rest_of_line);
             }
             JLS_PATH(3); // step loops
-            uint64_t ticker = 1ull << (steps - 1); // one-hot step counter, 1 <= steps <= kStepsPerCheck
             // lanes outside their line never pass the `u < limit` test below
             const uint32_t limit_v = opaque(in_line ? limit_m : 0u);
-            // The loop is rotated.  An iteration first does the bookkeeping the PREVIOUS step left behind -- Ra, bit position,
-            // window and line pointer advance, its A.12 / A.13 context update and the two stores -- and then decodes its own
-            // sample; the four LDS reads of the new step are issued before the update arithmetic and the context read
-            // before the prefix / predictor arithmetic, so the wavefront finds every LDS result waiting.  Nothing in the
-            // loop is predicated: when a lane cannot decode its sample the loop ends before that lane's next bookkeeping,
-            // and the lanes that did decode theirs get it after the loop.  The first iteration does the bookkeeping of a
-            // step that changes nothing (it rewrites cur[i - 1] and an unused context record); scans that are not inside
-            // a line (finished or waiting for their marker: their contexts and line are dead) run along on their own dead
-            // state without advancing.
+            // The loop is rotated.  An iteration first does the bookkeeping the PREVIOUS step left behind -- bit position,
+            // line and entry pointers, the second half of its context update (A.13, k and the error correction of the new
+            // state) and the two stores -- and then decodes its own sample; the LDS reads of the new step are issued before
+            // the update arithmetic and the context read before the prefix / predictor arithmetic, so the wavefront finds
+            // every LDS result waiting.  Nothing in the loop is predicated: when a lane cannot decode its sample the loop
+            // ends before that lane's next bookkeeping, and the lanes that did decode theirs get it after the loop.  The
+            // first iteration does the bookkeeping of a step that changes nothing (it rewrites cur[i - 1] and an unused
+            // context record); scans that are not inside a line (finished or waiting for their marker: their contexts and
+            // line are dead) run along on their own dead state without advancing.
             const uint32_t p_kept = p;
-            S* lp = in_line ? line + i - 1 : line + width + 2; // slot of the previous step's sample
-            const uint32_t lp_step = in_line ? 1u : 0u;
-            Record* where = records + 365;      // the previous step's context record (an unused slot at first)
+            constexpr uint32_t kSz = (uint32_t)sizeof(S);
+            const uint32_t line_address = lds_address(line);
+            // lm: LDS address of the slot of the sample BEFORE the previous step's sample (a step adds one slot and then
+            // stores Ra = the previous step's sample at lm); pp: entry of the previous step's sample
+            uint32_t lm = in_line ? line_address + (i - 2) * kSz : line_address + (width + 1) * kSz;
+            uint32_t pp = prep_address + ((i & (kPrepRing - 1)) << 3) - (in_line ? 8u : 0u);
+            uint32_t where = records_address + 365u * 8u; // the previous step's context record (an unused slot at first)
             // what the previous step leaves for its context update: A + |Errval|, N, B + Errval (all three already halved
-            // when N had reached RESET) and the record's other word, for C
-            int u_a = 0, u_n1 = 2, u_tb = 0; // u_n1 = N + 1
-            uint32_t t_ncb = 0, t_adv = 0, t_mm = 0;
-            int q1n = q1; // Q1 + 4 of the next sample
-            uint32_t t_next; // the sample of the previous line that slides into the window
-            if (kWide)
-            {
-                t_next = w1 >> 16;
-                w1 = (w0 >> 16) | (w1 << 16);
-                w0 <<= 16;
-            }
-            else
-            {
-                t_next = w0 >> 24;
-                w0 <<= 8;
-            }
+            // when N had reached RESET) and C
+            int u_a = 0, u_n1 = 2, u_tb = 0, u_cc = 0; // u_n1 = N + 1
+            uint32_t u1 = 0, k_last = 0, t_mm = 0;    // the previous step's code: prefix + 1, k, mapped error
             uint32_t k_seen = 0, mm_seen = 0, a_seen_now = 0;
-            uint32_t win_now;
+            uint32_t win_now = 0;
+#if defined(JLS_EMULATED) || defined(JLS_CXX_STEP_LOOP)
+            // (the rendering the CPU harness runs, and the specification of the assembly below)
+            const uint32_t lm_step = in_line ? kSz : 0u;
+            const uint32_t pp_step = in_line ? 8u : 0u;
+            uint64_t ticker = 1ull << (steps - 1); // one-hot step counter, 1 <= steps <= kStepsPerLoop
             do
             {
                 JLS_PATH(5); // steps
                 // -- bookkeeping of the previous step, part 1: registers (Ra was set when the sample was decoded)
-                p += t_adv;
+                p += u1 + k_last;
                 if (kWide)
-                {
-                    w0 = (w0 >> 16) | (w1 << 16);
-                    w1 = (w1 >> 16) | (t_next << 16);
                     mm_seen |= t_mm;
-                }
-                else
-                    w0 = (w0 >> 8) | (t_next << 24);
-                lp += lp_step; // now the slot of this step's sample; lp[1..] still hold the previous line
-                q1 = q1n;
-                // -- this step's LDS reads: next sample of the previous line, bit window, Q1 of the next sample, Q3
-                t_next = lp[3];
+                lm += lm_step; // now the slot of the previous step's sample; the slots behind it still hold the previous line
+                pp += pp_step;
+                // -- this step's LDS reads: the prepared entry {Rc | T << 16, Rb}, the bit window, Q3
+                const PrepEntry entry = load_pair(pp);
                 const uint64_t ring_words = ring_words_at(ring_address, p);
-                q1n = quantised(rd2_of() - rd_of());
-                const int rc = rc_of(), rb = rb_of();
+                const int rc = kWide ? (int)(entry.x & 0xFFFFu) : (int)(entry.x & 0xFFu);
+                const int rb = (int)entry.y;
                 const int q3 = quantised(rc - a);
                 // -- bookkeeping, part 2: A.12 / A.13, src/regular_mode_context.hpp:45-93 (|B| cannot overflow in lossless
                 // mode).  With N' the new N and tb = B + Errval (halved at a reset): delta = (tb > 0) - (tb + N' <= 0),
                 // B' = median(tb - delta * N', 1 - N', 0), C' = median(C + delta, -128, 127).
                 Record updated;
                 {
-                    const int cc = (int)(signed char)(t_ncb >> 8);
                     const int n_new = u_n1;
                     const int minus_delta = 1 - med3(u_tb, 0, 1) - med3(u_tb + n_new, 0, 1);
                     const int b_new = med3(mad24(minus_delta, n_new, u_tb), 1 - n_new, 0);
-                    const int c_new = med3(cc - minus_delta, -128, 127);
+                    const int c_new = med3(u_cc - minus_delta, -128, 127);
                     updated = Record{(uint32_t)u_a, ((uint32_t)b_new << 16) | pack_bytes((uint32_t)c_new, (uint32_t)n_new)};
                 }
-                JLS_SCHEDULE_FENCE(); // the arithmetic above covers the latency of the four reads
                 const uint32_t win = (uint32_t)(ring_words >> (p & 31)); // the next 32 bits of the stream
                 win_now = win;
                 // -- the chain: Ra -> Q3 -> context -> k -> code -> Errval -> sample
-                qsu = mad24(t9, 9, q3); // Q + 364 (the three gradients come with + 4 each)
-                t9 = mad24(q1n, 9, q1); // T of the next sample (a lane that cannot decode this one rebuilds its T and Q1)
-                const int sgn = qsu < 364 ? -1 : 1;
-                const int idx = (int)abs_difference((uint32_t)qsu, 364u);
+                qsu8 = (entry.x >> 16) + (uint32_t)q3; // 8 (Q + 364)
+                const uint32_t here = abs_difference_plus(qsu8, 2912u, records_address); // the record of |Q|; Q = 0 (run mode): an unused one
+                const int sgn = qsu8 < 2912u ? -1 : 1;
                 JLS_LOCKSTEP();
-                *where = updated;      // bookkeeping, part 3: the stores
-                lp[-1] = (S)a;
+                store_pair(where, PrepEntry{updated.a, updated.ncb}); // bookkeeping, part 3: the stores
+                lds_store<S>(lm, (S)a);
                 JLS_LOCKSTEP();
-                where = records + idx; // idx 0 (run mode) reads a valid, unused record
-                const Record rec = *where;
+                where = here;
+                const PrepEntry rec = load_pair(here); // {A, N | C << 8 | B << 16}
                 const uint32_t u = lowest_one(win); // length of the unary prefix; 0xFFFFFFFF for an all-zero window
-                const uint32_t u1 = u + 1u; // the window beyond the prefix: u1 = 32 only with k = 0, where no field is read
+                u1 = u + 1u; // the window beyond the prefix: u1 = 32 only with k = 0, where no field is read
                 const uint32_t beyond = bit_reverse(win >> (u1 & 31u));
                 const int px0 = med3(a + (rb - rc), a, rb); // MED predictor = median(Ra, Rb, Ra + Rb - Rc), src/jpegls_algorithm.hpp:143-161
                 // A regular-mode sample whose code lies inside the 32-bit window.  8-bit samples: valid streams keep
                 // A / N < 2^9, so k <= 9, and u < LIMIT - qbpp - 1 <= 23 then bounds the code by 32 bits and |Errval| by
                 // 5888; k (and, for wider samples, the mapped error) are only accumulated here and examined after the
                 // loop: a stream that breaks those bounds is invalid and goes to the exact decoder as a whole.
-                ok_m = lanes_where(qsu != 364) & lanes_where(u < limit_v);
-                JLS_SCHEDULE_FENCE(); // the arithmetic above covers the latency of the context read
-                t_ncb = rec.ncb;
-                const int n = (int)(rec.ncb & 0xFFu);
-                const int cc = (int)(signed char)(rec.ncb >> 8);
-                const int bb = (int)rec.ncb >> 16;
+                ok_m = lanes_where(qsu8 != 2912u) & lanes_where(u < limit_v);
+                const int n = (int)(rec.y & 0xFFu);
+                const int cc = (int)(signed char)(rec.y >> 8);
+                const int bb = (int)rec.y >> 16;
                 // k = min{k : N << k >= A} (N >= 1; A may be 0, then k = 0).  Scaling a float by 2^k adds k << 23 to its bit
                 // pattern and positive floats order like their bit patterns, so N * 2^k >= A <=> k << 23 >= bits(A) - bits(N):
                 // k = max(0, ceil((bits(A) - bits(N)) / 2^23)).  A < 2^24 and N <= 255 convert exactly.
-                const int k_raw = ((int)(float_bits(rec.a) - float_bits((uint32_t)n)) + 0x7FFFFF) >> 23;
+                const int k_raw = ((int)(float_bits(rec.x) - float_bits((uint32_t)n)) + 0x7FFFFF) >> 23;
                 const int k = k_raw < 0 ? 0 : k_raw;
                 if (kWide)
                     ok_m &= lanes_where(u + (uint32_t)k < 32u);
-                // Golomb code -> mapped error -> Errval (src/scan_decoder_core.hpp:38-69)
-                const int mm = (int)((u << k) | (uint32_t)(((uint64_t)beyond << k) >> 32));
+                // Golomb code -> mapped error -> Errval (src/scan_decoder_core.hpp:38-69): prefix and remainder are ONE 64-bit
+                // number {u : the window beyond the prefix}, and the mapped error its upper half after a shift by k
+                const int mm = (int)(uint32_t)(((((uint64_t)u << 32) | beyond) << (k & 63)) >> 32);
                 // Errval = unmap(mm), complemented when k = 0 and 2B + N - 1 < 0 (src/regular_mode_context.hpp:36-42):
                 // e = (mm >> 1) ^ -odd and |e| = (mm >> 1) + odd with odd = the low bit of mm, flipped by the correction
-                const int half = mm >> 1;
-                const int odd = (mm ^ (((k - 1) & (2 * bb + n - 1)) >> 31)) & 1;
+                const int half = (int)((uint32_t)mm >> 1);
+                const int odd = (mm ^ (int)((uint32_t)((k - 1) & (2 * bb + n - 1)) >> 31)) & 1;
                 const int e = half ^ -odd;
                 const int px = med3(mad24(cc, sgn, px0), 0, maxval); // plus the bias C
                 a = mad24(e, sgn, px) & maxval; // every lane: a lane that could not decode reloads its Ra after the loop
-                t_adv = u1 + (uint32_t)k;
+                k_last = (uint32_t)k;
                 t_mm = (uint32_t)mm;
                 // first half of A.12 / A.13 for this step (the rest is the next iteration's): A += |Errval|, B += Errval, and
                 // the halving of A, B and N once N has reached RESET
-                u_a = (int)rec.a + half + odd;
+                u_a = (int)rec.x + half + odd;
                 if (kWide)
                     a_seen_now |= (uint32_t)u_a;
                 u_n1 = n + 1;
                 u_tb = bb + e;
-                const LaneMask halve_m = lanes_where(n == reset);
-                if (__builtin_expect(halve_m != 0, 0))
+                u_cc = cc;
+                if (n == reset)
                 { // once per RESET samples of a context
-                    JLS_RARE_BLOCK();
-                    if (lane_of(halve_m))
-                    {
-                        u_a >>= 1;
-                        u_n1 = (n >> 1) + 1;
-                        u_tb >>= 1;
-                    }
+                    u_a >>= 1;
+                    u_n1 = (n >> 1) + 1;
+                    u_tb >>= 1;
                 }
-                // (keeps the compiler from carrying these two as bytes and widening them again in every iteration)
-                t_next = opaque(t_next);
-                q1n = (int)opaque((uint32_t)q1n);
                 k_seen |= (uint32_t)k; // of every lane: a lane that cannot decode still looked at a real context
-                // one exit (the compiler unifies loop exits anyway): a one-hot counter that an event clears
+                // one exit: a one-hot counter that an event clears
                 ticker = tick(ticker, in_line_m, ok_m);
             } while (ticker != 0);
+#else
+            // The same loop, written out for gfx950: 73 instructions per step for 8-bit samples (the compiler's rendering of the
+            // C++ above: 88), scheduled by hand so that the three LDS round trips of the chain (Q3 <- the gradient table,
+            // the context record, and before them the prepared entry, which is requested one step ahead) are covered by the
+            // previous step's context update, the bit window and the predictor.  Lanes outside their line are switched off
+            // (EXEC) for the whole loop.  Hazards kept by hand: two instructions between a v_cmp and the VALU that reads its mask.
+            {
+                LaneMask fail_m;
+                uint32_t count = steps - 1;
+                const int reset_v = reset, cap_v = cap;
+                const int maxval_s = (int)uniform((uint32_t)maxval); // (the scans of a wavefront that are inside a line share their sample precision: `usable`)
+                if constexpr (kWide)
+                    JLS_STEP_LOOP_ASM_WIDE();
+                else
+                    JLS_STEP_LOOP_ASM_NARROW();
+                (void)cap_v;
+                ok_m = in_line_m & ~fail_m;
+            }
+#endif
             win_stopped = win_now;
-            t_next_stopped = t_next;
-            q1n_stopped = q1n;
             // the bookkeeping owed to the lanes whose last step decoded a sample
             bool owed_last;
             int ra_stopped;
             {
-                RegCtx ctx{u_a, u_tb, (int)(signed char)(t_ncb >> 8), u_n1};
+                RegCtx ctx{u_a, u_tb, u_cc, u_n1};
                 const int minus_delta = 1 - med3(ctx.b, 0, 1) - med3(ctx.b + ctx.n, 0, 1);
                 ctx.b = med3(ctx.b + minus_delta * ctx.n, 1 - ctx.n, 0);
                 ctx.c = med3(ctx.c - minus_delta, -128, 127);
                 const bool owed = in_line && lane_of(ok_m);
                 owed_last = owed;
                 JLS_LOCKSTEP();
-                ra_stopped = (int)lp[-1]; // Ra of a lane whose last step did not decode: stored by that step
+                ra_stopped = (int)lds_load<S>(lm); // Ra of a lane whose last step did not decode: stored by that step
                 if (owed)
                 {
-                    *where = Record{(uint32_t)ctx.a, ((uint32_t)ctx.b << 16) | pack_bytes((uint32_t)ctx.c, (uint32_t)ctx.n)};
-                    lp[0] = (S)a;
-                    p += t_adv;
+                    store_pair(where, PrepEntry{(uint32_t)ctx.a, ((uint32_t)ctx.b << 16) | pack_bytes((uint32_t)ctx.c, (uint32_t)ctx.n)});
+                    lm += kSz;
+                    lds_store<S>(lm, (S)a);
+                    p += u1 + k_last;
                     if (kWide)
-                    {
-                        w0 = (w0 >> 16) | (w1 << 16);
-                        w1 = (w1 >> 16) | (t_next << 16);
                         mm_seen |= t_mm;
-                    }
-                    else
-                        w0 = (w0 >> 8) | (t_next << 24);
-                    ++lp;
-                    q1 = q1n;
                 }
                 JLS_LOCKSTEP();
             }
@@ -760,7 +827,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
             {
                 if (!owed_last)
                     a = ra_stopped;
-                i = (uint32_t)(lp - line);
+                i = (lm - line_address) / kSz + 1;
                 a_seen |= a_seen_now;
                 // the reference raises invalid_data for k >= 16 and for |Errval| > 65535
                 // (src/regular_mode_context.hpp:99-111, src/scan_decoder_core.hpp:38-69)
@@ -769,20 +836,22 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
             }
             else
                 p = p_kept;
+            // the entry of the sample a lane stopped at (its Rb is what the run handler needs first)
+            if (in_line && !owed_last)
+                entry_stopped = load_pair(pp);
         }
         // what stopped a scan that is still inside its line: Q = 0 is run mode, anything else an unusual code
-        const int qs = qsu - 364;
+        const int qs8 = (int)qsu8 - 2912;
         const bool stopped = in_line && !lane_of(ok_m);
-        const bool in_run = stopped && qs == 0 && !retry;
-        const bool slow = stopped && qs != 0 && !retry;
+        const bool in_run = stopped && qs8 == 0 && !retry;
+        const bool slow = stopped && qs8 != 0 && !retry;
 
         // ---- run mode: reference src/scan_decoder_impl.hpp:264-337, src/scan_decoder_core.hpp:72-100
         // Three run events in four are a run of length 0 -- the single bit 0 (and J zero bits) -- followed by its interruption
         // sample, and everything such an event needs is in the registers its lane left the step loop with: the bit window
-        // (the lane consumed nothing in its last step), Rb = the sample above the interruption sample, and the window of the
-        // previous line, which slides on by one sample exactly as a regular step would slide it.  What is left to fetch is
-        // the run context (both are read, ahead of knowing which) and one gradient for the next sample.  The general handler
-        // below takes every other case, and all of them when the codes of one lane do not fit its window.
+        // (the lane consumed nothing in its last step) and Rb = the sample above the interruption sample.  What is left to
+        // fetch is the run context (both are read, ahead of knowing which).  The general handler below takes every other
+        // case, and all of them when the codes of one lane do not fit its window.
         bool empty_runs = false;
         if (__any(in_run))
         {
@@ -790,7 +859,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
             const int j = run_j(run_index);
             const uint32_t w2 = j >= 31 ? 0u : win_stopped >> (1 + j); // the bits behind the run-length code
             const uint32_t avail = 31u - (uint32_t)j;
-            const int b_at = rb_of(); // prev[i]
+            const int b_at = (int)entry_stopped.y; // prev[i]
             const int which = a == b_at ? 1 : 0;
             RunCtx ctx = which ? ctx1 : ctx0;
             const uint32_t goal = (uint32_t)ctx.a + (uint32_t)(ctx.n >> 1) * (uint32_t)ctx.ritype;
@@ -815,8 +884,6 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 const int e = run_error_value(ctx, em + ctx.ritype, k);
                 run_update(ctx, e, em, t.reset);
                 const int x = which ? ((a + e) & t.maxval) : ((b_at + e * ((b_at - a) < 0 ? -1 : 1)) & t.maxval);
-                // Q2 of the next sample: its Rb is this one's Rd, its Rc this one's Rb
-                const int q2n = quantised(rd_of() - b_at);
                 JLS_LOCKSTEP();
                 if (in_run)
                 {
@@ -827,15 +894,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                         --run_index;
                     ++i;
                     p += 1u + (uint32_t)j + code_bits;
-                    if (kWide)
-                    {
-                        w0 = (w0 >> 16) | (w1 << 16);
-                        w1 = (w1 >> 16) | (t_next_stopped << 16);
-                    }
-                    else
-                        w0 = (w0 >> 8) | (t_next_stopped << 24);
-                    q1 = q1n_stopped;
-                    t9 = 9 * q1 + q2n;
+                    rc_over = b_at; // prev[i - 1] of the next sample, should it have no entry yet
                 }
                 JLS_LOCKSTEP();
             }
@@ -990,21 +1049,20 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 if (run_index > 0)
                     --run_index;
                 i = at + 1;
+                rc_over = b_at; // prev[at] is Rc of the next sample, should it have no entry yet
             }
             else if (in_run && !retry)
                 i = width + 1; // the run reached the end of the line
             JLS_LOCKSTEP();
-            if (interrupted && i <= width)
-                prime(b_at); // prev[at] becomes Rc of the next sample
         }
 
         // ---- one regular-mode sample with every case the step loop leaves out (escape codes, long prefixes)
         if (__any(slow))
         {
             JLS_PATH(9); // unusual codes
-            const int rc = rc_of(), rb = rb_of();
-            const int s = qs >> 31;
-            const int idx = (qs ^ s) - s;
+            const int rc = kWide ? (int)(entry_stopped.x & 0xFFFFu) : (int)(entry_stopped.x & 0xFFu), rb = (int)entry_stopped.y;
+            const int s = qs8 >> 31;
+            const int idx = ((qs8 ^ s) - s) >> 3;
             const Record rec = records[idx];
             RegCtx ctx{(int)rec.a, (int)rec.ncb >> 16, (int)(signed char)(rec.ncb >> 8), (int)(rec.ncb & 0xFFu)};
             const int k = regular_k(ctx);
@@ -1039,12 +1097,11 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 line[i] = (S)x;
                 a = x;
                 ++i;
+                rc_over = rb; // prev[i - 1] of the next sample, should it have no entry yet
             }
             else if (slow)
                 retry = true;
             JLS_LOCKSTEP();
-            if (good && i <= width)
-                prime(rb); // prev[i - 1] of the next sample
         }
 
         if (kWide && a_seen >= (1u << 24))

@@ -1,0 +1,147 @@
+// The decoder's step loop (charls_amd/csrc/device/scan_group_step.inc) alone, on synthetic LDS contents that keep every lane
+// decoding: cycles per step of the product's text and of edited copies (tools/microbench/steploop_variants.py), with the
+// product's launch shape -- four wavefronts per workgroup (one per SIMD), four scans per wavefront, the product's LDS layout.
+// Not part of the product.  Build: see steploop_variants.py.  Run: tools/microbench/build/steploop [workgroups]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define JLS_SDWA(s0, s1) " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" s0 " src1_sel:" s1 "\n"
+#include "build/steploop_variants.inc"
+
+#define CLOBBERS                                                                                                                  \
+    "memory", "vcc", "scc", "s96", "s97", "s98", "s99", "v100", "v101", "v102", "v103", "v104", "v105", "v108", "v109", "v110", "v111",  \
+        "v112", "v113", "v114", "v115", "v116", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+
+constexpr uint32_t kRegion = 9744, kRecords = 0, kRing = 2960, kPrep = 3992, kLine = 5568, kLut = 512;
+constexpr int kBurst = 60;
+
+__device__ __forceinline__ uint64_t now()
+{
+    uint64_t t;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+__device__ int quantize(int d)
+{
+    const int pos = (d > 0) + (d >= 3) + (d >= 7) + (d >= 21), neg = (d < 0) + (d <= -3) + (d <= -7) + (d <= -21);
+    return pos - neg;
+}
+
+#define KERNEL(V)                                                                                                                 \
+    __global__ void __launch_bounds__(256) steploop_##V(uint64_t* out, uint32_t* sink, int repeats)                              \
+    {                                                                                                                             \
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                                      \
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sid = lane / 16, sub = lane % 16;                             \
+        unsigned char* region = smem + kLut + (size_t)(wave * 4 + sid) * kRegion;                                                 \
+        for (int q = threadIdx.x; q < 511; q += 256)                                                                              \
+            smem[q] = (unsigned char)((quantize(q - 255) + 4) * 8);                                                               \
+        uint32_t* records = reinterpret_cast<uint32_t*>(region + kRecords);                                                       \
+        for (int q = sub; q < 366; q += 16)                                                                                       \
+        {                                                                                                                         \
+            records[2 * q] = 4;                                                                                                   \
+            records[2 * q + 1] = 1;                                                                                               \
+        }                                                                                                                         \
+        uint32_t* ring = reinterpret_cast<uint32_t*>(region + kRing);                                                             \
+        uint32_t seed = 12345u + 977u * (blockIdx.x * 16 + wave * 4 + sid);                                                       \
+        for (int q = sub; q < 258; q += 16)                                                                                       \
+        {                                                                                                                         \
+            uint32_t x = seed + 2654435761u * (uint32_t)q;                                                                        \
+            x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;                                                                         \
+            ring[q] = x | 0x00010001u; /* a one bit in every 16: no prefix is longer than 15 */                                   \
+        }                                                                                                                         \
+        uint32_t* prep = reinterpret_cast<uint32_t*>(region + kPrep);                                                             \
+        for (int e = sub; e < 192; e += 16)                                                                                       \
+        {                                                                                                                         \
+            const uint32_t q1 = (e % 2) ? 24 : 40, q2 = 24 + 8 * (uint32_t)((e / 2) % 3); /* never the run-mode context */        \
+            prep[2 * e] = (100u + (uint32_t)(e % 3)) | ((9u * (9u * q1 + q2)) << 16);                                             \
+            prep[2 * e + 1] = 101;                                                                                                \
+        }                                                                                                                         \
+        __syncthreads();                                                                                                          \
+        const uint32_t ring_address = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(region + kRing);             \
+        const uint32_t records_address = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(region + kRecords);       \
+        const uint32_t prep_address = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(region + kPrep);             \
+        const uint32_t line_address = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(region + kLine);             \
+        int a = 100, u_a = 0, u_n1 = 2, u_tb = 0, u_cc = 0;                                                                       \
+        uint32_t p = 0, u1 = 0, k_last = 0, k_seen = 0, qsu8 = 0, win_now = 0, where = records_address + 365 * 8;                 \
+        const uint32_t limit_v = 23, reset_v = 64;                                                                                \
+        const int maxval_s = 255;                                                                                                 \
+        const unsigned long long in_line_m = ~0ull;                                                                               \
+        unsigned long long fail_m = 0, failed = 0;                                                                                \
+        const uint64_t t0 = now();                                                                                                \
+        for (int r = 0; r < repeats; ++r)                                                                                         \
+        {                                                                                                                         \
+            uint32_t lm = line_address + ((uint32_t)(r * 64) & 2047u);                                                            \
+            uint32_t pp = prep_address + (((uint32_t)r * 24u) & 127u) * 8u - 8u;                                                  \
+            uint32_t count = kBurst - 1;                                                                                          \
+            asm volatile(STEPLOOP_TEXT_##V                                                                                        \
+                         : [a] "+v"(a), [p] "+v"(p), [lm] "+v"(lm), [pp] "+v"(pp), [where] "+v"(where), [ua] "+v"(u_a),            \
+                           [un1] "+v"(u_n1), [utb] "+v"(u_tb), [cc] "+v"(u_cc), [u1] "+v"(u1), [k] "+v"(k_last),                   \
+                           [kseen] "+v"(k_seen), [qsu] "+v"(qsu8), [win] "+v"(win_now), [cnt] "+s"(count), [fail] "=&s"(fail_m)     \
+                         : [ring] "v"(ring_address), [recbase] "v"(records_address), [limitv] "v"(limit_v), [vreset] "v"(reset_v), \
+                           [inl] "s"(in_line_m), [smax] "s"(maxval_s)                                                              \
+                         : CLOBBERS);                                                                                             \
+            failed |= fail_m;                                                                                                     \
+        }                                                                                                                         \
+        const uint64_t t1 = now();                                                                                                \
+        if (lane == 0)                                                                                                            \
+        {                                                                                                                         \
+            out[2 * (blockIdx.x * 4 + wave)] = t1 - t0;                                                                           \
+            out[2 * (blockIdx.x * 4 + wave) + 1] = failed;                                                                        \
+        }                                                                                                                         \
+        sink[threadIdx.x] = (uint32_t)a + p + k_seen + qsu8 + win_now + (uint32_t)u_a;                                            \
+    }
+
+KERNEL(0) KERNEL(1) KERNEL(2) KERNEL(3) KERNEL(4) KERNEL(5) KERNEL(6) KERNEL(7) KERNEL(8)
+static_assert(STEPLOOP_VARIANTS == 9, "one KERNEL() per variant");
+
+typedef void (*Kernel)(uint64_t*, uint32_t*, int);
+
+int main(int argc, char** argv)
+{
+    const int groups = argc > 1 ? atoi(argv[1]) : 256;
+    const int repeats = 2000;
+    const Kernel kernels[] = {steploop_0, steploop_1, steploop_2, steploop_3, steploop_4, steploop_5, steploop_6, steploop_7, steploop_8};
+    const char* names[] = {STEPLOOP_NAME_0, STEPLOOP_NAME_1, STEPLOOP_NAME_2, STEPLOOP_NAME_3, STEPLOOP_NAME_4,
+                           STEPLOOP_NAME_5, STEPLOOP_NAME_6, STEPLOOP_NAME_7, STEPLOOP_NAME_8};
+    uint64_t* d_out;
+    uint32_t* d_sink;
+    (void)hipMalloc(&d_out, sizeof(uint64_t) * 2 * 4 * groups);
+    (void)hipMalloc(&d_sink, 4096);
+    const size_t lds = kLut + 16 * kRegion;
+    printf("step loop alone: %d workgroups of 4 wavefronts (one per SIMD), 4 scans per wavefront, %zu bytes of LDS, %d bursts of %d steps\n",
+           groups, lds, repeats, kBurst);
+    printf("%-44s %12s %12s %12s %s\n", "variant", "cyc/step min", "median", "max", "lanes that stopped");
+    for (int v = 0; v < STEPLOOP_VARIANTS; ++v)
+    {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[v]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        std::vector<double> per;
+        unsigned long long failed = 0;
+        for (int r = 0; r < 2; ++r)
+        {
+            hipLaunchKernelGGL(kernels[v], dim3(groups), dim3(256), lds, 0, d_out, d_sink, repeats);
+            std::vector<uint64_t> h(2 * 4 * groups);
+            if (hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            {
+                printf("%s: launch failed: %s\n", names[v], hipGetErrorString(hipGetLastError()));
+                break;
+            }
+            per.clear();
+            failed = 0;
+            for (int w = 0; w < 4 * groups; ++w)
+            {
+                per.push_back((double)h[2 * w] / ((double)repeats * kBurst));
+                failed |= h[2 * w + 1];
+            }
+        }
+        if (per.empty())
+            continue;
+        std::sort(per.begin(), per.end());
+        printf("%-44s %12.1f %12.1f %12.1f %016llx\n", names[v], per.front(), per[per.size() / 2], per.back(), failed);
+    }
+    return 0;
+}
