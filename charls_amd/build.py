@@ -108,9 +108,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
               *os.environ.get("CHARLS_AMD_CXXFLAGS", "").split()]  # (e.g. -DJLS_PHASE_CLOCKS, tools/phase_clocks.py)
     objs = []
     procs = []
+    # An object is compiled again when anything it can include is newer: the device units include device/ only, the host
+    # units host/, the headers of device/ and the public header (a change to a kernel does not recompile the facade, a change
+    # to the facade not the kernels -- the five device units take minutes).  CHARLS_AMD_CXXFLAGS always recompile.
+    def newest(paths):
+        return max(os.path.getmtime(f) for f in paths if os.path.isfile(f))
+    device_files = glob.glob(os.path.join(CSRC, "device", "*"))
+    host_deps = glob.glob(os.path.join(CSRC, "host", "*")) + [f for f in device_files if f.endswith(".h")] + \
+        [os.path.join(ROOT, "include", "charls_amd.h"), __file__]
+    device_newest, host_newest = newest(device_files + [__file__]), newest(host_deps)
+    flags_given = bool(os.environ.get("CHARLS_AMD_CXXFLAGS", "").split())
     for src in SOURCES:
         obj = os.path.join(obj_dir, src.replace("/", "_") + ".o")
         objs.append(obj)
+        stale_after = device_newest if src.startswith("device/") else host_newest
+        if not flags_given and os.path.exists(obj) and os.path.getmtime(obj) >= stale_after:
+            continue
         cmd = [HIPCC, *common, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

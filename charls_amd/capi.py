@@ -309,7 +309,9 @@ def engine_counters(lib: CharLSLibrary | None = None) -> dict:
     L = (lib or load_product()).lib
     L.charls_amd_engine_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int32]
     L.charls_amd_engine_counters.restype = C.c_int32
-    out = (C.c_uint64 * 5)()
-    n = L.charls_amd_engine_counters(out, 5)
-    assert n == 5
-    return dict(zip(("calls", "launches", "merged_calls", "largest_launch", "pipeline_fallback_scans"), (int(v) for v in out)))
+    out = (C.c_uint64 * 10)()
+    n = L.charls_amd_engine_counters(out, 10)
+    assert n >= 5
+    names = ("calls", "launches", "merged_calls", "largest_launch", "pipeline_fallback_scans", "split_launches", "idle_pool_bytes",
+             "deferred_free_bytes", "idle_releases", "exact_retry_scans")
+    return dict(zip(names[:n], (int(v) for v in out[:n])))

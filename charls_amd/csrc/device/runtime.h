@@ -67,9 +67,12 @@ private:
 // A launch that runs for seconds is in flight (a decoder launch of the host-pointer ABI): until it ends, DeviceBuffers that
 // give a block up set it aside instead of calling hipFree (which would wait for that launch); reap_deferred_frees() frees what
 // was set aside once no such launch is running.
+// (The counter is per device, and so is what is set aside: at most 4 GiB per device -- a block beyond that is freed on the spot --
+// and an allocation that fails frees everything that was set aside on its device, waiting for the running launch, and retries.)
 void long_kernel_begins() noexcept;
 void long_kernel_ends() noexcept;
 void reap_deferred_frees() noexcept;
+uint64_t deferred_free_bytes() noexcept; // what is set aside right now, all devices
 
 enum class EncodeEngine : int32_t
 {
@@ -140,6 +143,9 @@ void launch_place_epilogue(uint8_t* slots, uint64_t slot_pitch, FrameCursorPod* 
 // The limit is process-wide (0 = a quarter of the device's memory); the areas themselves belong to the calling thread,
 // grow on demand up to the limit and stay allocated between calls until released.
 void set_workspace_limit(uint64_t bytes) noexcept;
+uint64_t workspace_limit() noexcept;          // as set (0: the default rule)
+void release_shared_work_areas() noexcept;    // the shared sets of the host-pointer ABI's merged launches, all devices (a launch that runs finishes first)
+size_t shared_work_area_bytes() noexcept;     // what they hold
 DeviceBuffer& plane_arena(); // the calling thread's private stream buffers of the planar batch encoder (a work area)
 void* try_ensure(DeviceBuffer& buffer, size_t bytes) noexcept; // ensure() that reports failure (nullptr; the buffer is released) instead of raising
 void release_work_areas() noexcept;
@@ -149,6 +155,7 @@ void release_thread_work_areas() noexcept;
 size_t work_area_budget() noexcept; // what the calling thread's work areas may grow to right now (limit, free memory)
 // Scans the lossless pipeline was eligible for that were coded by the one-wavefront kernel because no work area could be had.
 uint64_t pipeline_fallback_scans() noexcept;
+uint64_t exact_retry_scans() noexcept; // scans the speed-path decoders handed to the exact decoder since the library was loaded
 
 // A size with room to spare for buffers that grow with the number of scans of a launch: at least 64 KB, then the next power of
 // two.  (Growing a DeviceBuffer frees the old block, and hipFree waits for every kernel that is running on the device.)

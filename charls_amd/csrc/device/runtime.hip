@@ -62,6 +62,67 @@ void require_device()
         raise(CHARLS_AMD_ERRC_DEVICE_UNAVAILABLE);
 }
 
+// hipFree waits for every kernel that is running on the device.  While one of this library's decoder launches of the
+// host-pointer ABI is in flight on a device -- ONE kernel that runs for seconds -- a block of that device that is given up (a
+// buffer that grows) is not freed but set aside, and freed once no such launch is running there (profiles/r05_concurrent_kernels.txt:
+// an encoder call that grew the shared work areas beside a running decoder took 2.9 s instead of 2 ms).  What is set aside is
+// invisible HBM, so it is bounded: beyond kMaxDeferredBytes per device a block is freed on the spot (and waits), and an
+// allocation that fails frees everything that was set aside -- waiting for the running launch if it has to -- and tries again.
+namespace {
+constexpr int kMaxDevices = 32;
+constexpr size_t kMaxDeferredBytes = size_t{4} << 30;
+struct DeferredFrees
+{
+    std::mutex guard;
+    std::vector<std::pair<void*, size_t>> blocks[kMaxDevices];
+    size_t bytes[kMaxDevices]{};
+    std::atomic<int> long_kernels[kMaxDevices]{};
+};
+DeferredFrees& deferred()
+{
+    static DeferredFrees* d = new DeferredFrees; // never destroyed: a thread may give a buffer up while the process exits
+    return *d;
+}
+int slot_of(int device) noexcept
+{
+    return device >= 0 && device < kMaxDevices ? device : 0;
+}
+int current_device() noexcept
+{
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        device = 0;
+    }
+    return device;
+}
+// Frees what was set aside on `device` (the calling thread's current device is restored).  `even_while_running`: the caller
+// needs the memory now and waits for the launch that is in flight.
+void reap_device(int device, bool even_while_running) noexcept
+{
+    DeferredFrees& d = deferred();
+    const int slot = slot_of(device);
+    if (!even_while_running && d.long_kernels[slot].load() > 0)
+        return;
+    std::vector<std::pair<void*, size_t>> gone;
+    {
+        std::lock_guard<std::mutex> lock(d.guard);
+        gone.swap(d.blocks[slot]);
+        d.bytes[slot] = 0;
+    }
+    if (gone.empty())
+        return;
+    const int before = current_device();
+    if (before != device)
+        (void)hipSetDevice(device);
+    for (const auto& block : gone)
+        (void)hipFree(block.first);
+    if (before != device)
+        (void)hipSetDevice(before);
+}
+} // namespace
+
 void* DeviceBuffer::ensure(size_t bytes)
 {
     int device = 0;
@@ -72,56 +133,75 @@ void* DeviceBuffer::ensure(size_t bytes)
         return ptr_;
     release();
     const size_t want = bytes < 256 ? 256 : bytes;
-    hip_check(hipMalloc(&ptr_, want));
+    hipError_t e = hipMalloc(&ptr_, want);
+    if (e == hipErrorOutOfMemory)
+    { // what this library set aside is memory too
+        (void)hipGetLastError();
+        ptr_ = nullptr;
+        reap_device(device, true);
+        e = hipMalloc(&ptr_, want);
+    }
+    if (e != hipSuccess)
+        ptr_ = nullptr;
+    hip_check(e);
     cap_ = want;
     device_ = device;
     return ptr_;
 }
 
-// hipFree waits for every kernel that is running on the device.  While one of this library's decoder launches of the
-// host-pointer ABI is in flight -- ONE kernel that runs for seconds -- a block that is given up (a buffer that grows) is not
-// freed but set aside, and freed once no such launch is running (profiles/r05_concurrent_kernels.txt: an encoder call that grew
-// the shared work areas beside a running decoder took 2.9 s instead of 2 ms).
-namespace {
-std::atomic<int> g_long_kernels{0};
-std::mutex g_deferred_guard;
-std::vector<void*> g_deferred;
-} // namespace
-
 void reap_deferred_frees() noexcept
 {
-    if (g_long_kernels.load() > 0)
-        return;
-    std::vector<void*> gone;
-    {
-        std::lock_guard<std::mutex> lock(g_deferred_guard);
-        gone.swap(g_deferred);
-    }
-    for (void* p : gone)
-        (void)hipFree(p);
+    for (int device = 0; device < kMaxDevices; ++device)
+        if (deferred().bytes[device] != 0) // (a racy look is fine: whoever set a block aside reaps again when its call ends)
+            reap_device(device, false);
+}
+
+uint64_t deferred_free_bytes() noexcept
+{
+    DeferredFrees& d = deferred();
+    std::lock_guard<std::mutex> lock(d.guard);
+    uint64_t total = 0;
+    for (int device = 0; device < kMaxDevices; ++device)
+        total += d.bytes[device];
+    return total;
 }
 
 void long_kernel_begins() noexcept
 {
-    g_long_kernels.fetch_add(1);
+    deferred().long_kernels[slot_of(current_device())].fetch_add(1);
 }
 
 void long_kernel_ends() noexcept
 {
-    g_long_kernels.fetch_sub(1);
+    deferred().long_kernels[slot_of(current_device())].fetch_sub(1);
 }
 
 void DeviceBuffer::release() noexcept
 {
     if (ptr_)
     {
-        if (g_long_kernels.load() > 0)
+        DeferredFrees& d = deferred();
+        const int slot = slot_of(device_);
+        bool set_aside = false;
+        if (d.long_kernels[slot].load() > 0)
         {
-            std::lock_guard<std::mutex> lock(g_deferred_guard);
-            g_deferred.push_back(ptr_);
+            std::lock_guard<std::mutex> lock(d.guard);
+            if (d.bytes[slot] + cap_ <= kMaxDeferredBytes)
+            {
+                d.blocks[slot].emplace_back(ptr_, cap_);
+                d.bytes[slot] += cap_;
+                set_aside = true;
+            }
         }
-        else
+        if (!set_aside)
+        { // (the block may live on another device than the thread's current one: a handle that moved on)
+            const int before = current_device();
+            if (device_ >= 0 && before != device_)
+                (void)hipSetDevice(device_);
             (void)hipFree(ptr_);
+            if (device_ >= 0 && before != device_)
+                (void)hipSetDevice(before);
+        }
     }
     ptr_ = nullptr;
     cap_ = 0;
@@ -161,6 +241,11 @@ void set_workspace_limit(uint64_t bytes) noexcept
     g_workspace_limit.store(bytes);
 }
 
+uint64_t workspace_limit() noexcept
+{
+    return g_workspace_limit.load();
+}
+
 Timings& last_timings() noexcept
 {
     static thread_local Timings t{};
@@ -169,6 +254,7 @@ Timings& last_timings() noexcept
 
 namespace {
 std::atomic<uint64_t> g_speculation[tile_counter_count]{};
+std::atomic<uint64_t> g_exact_retry_scans{0}; // scans a speed-path decoder handed to the exact decoder (it did not end cleanly there)
 std::atomic<uint64_t> g_serial_fallback_scans{0}; // scans the tile pipeline was eligible for that ran on the one-wavefront kernel: no work area
 void note_pipeline_fallback(uint32_t scans) noexcept
 {
@@ -178,6 +264,10 @@ void note_pipeline_fallback(uint32_t scans) noexcept
 uint64_t pipeline_fallback_scans() noexcept
 {
     return g_serial_fallback_scans.load();
+}
+uint64_t exact_retry_scans() noexcept
+{
+    return g_exact_retry_scans.load();
 }
 void speculation_counters(uint64_t out[tile_counter_count]) noexcept
 {
@@ -681,6 +771,7 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
     hip_check(hipStreamSynchronize(stream));
     if (retries == 0)
         return;
+    g_exact_retry_scans.fetch_add(retries); // (charls_amd_engine_counters [9]: a valid stream that lands here is a lost speed path)
     auto* d_retry_results = static_cast<ScanResult*>(interval_arena(7).ensure(with_headroom(sizeof(ScanResult) * retries)));
     exact(d_retry_descs, d_retry_results, retries);
     hipLaunchKernelGGL(scatter_retries, dim3((retries + 255) / 256), dim3(256), 0, stream,
@@ -1349,7 +1440,6 @@ size_t shared_areas_keep_bytes() noexcept
 
 // ---- the work areas of the host-pointer ABI: one set per device, used by one merged launch at a time
 namespace {
-constexpr int kMaxDevices = 32;
 struct SharedAreas
 {
     std::mutex turn;
@@ -1409,11 +1499,10 @@ void release_thread_work_areas() noexcept
     areas().release();
 }
 
-void release_work_areas() noexcept
+void release_shared_work_areas() noexcept
 {
-    areas().release();
     if (t_shared_areas != nullptr)
-        return; // (called from inside a merged launch: its areas are the ones just released)
+        return; // (called from inside a merged launch)
     int current = 0;
     const bool have_device = hipGetDevice(&current) == hipSuccess;
     for (int device = 0; device < kMaxDevices; ++device)
@@ -1422,12 +1511,30 @@ void release_work_areas() noexcept
         if (s == nullptr)
             continue;
         std::lock_guard<std::mutex> turn(s->turn); // (a merged launch that is running finishes first)
+        (void)hipSetDevice(device);
         s->areas.lanes.destroy();
         s->areas.release();
         s->held.store(0, std::memory_order_relaxed);
     }
     if (have_device)
         (void)hipSetDevice(current);
+}
+
+size_t shared_work_area_bytes() noexcept
+{
+    size_t total = 0;
+    for (int device = 0; device < kMaxDevices; ++device)
+        if (SharedAreas* s = g_shared[device].load(std::memory_order_acquire))
+            total += s->held.load(std::memory_order_relaxed);
+    return total;
+}
+
+void release_work_areas() noexcept
+{
+    areas().release();
+    if (t_shared_areas != nullptr)
+        return; // (called from inside a merged launch: its areas are the ones just released)
+    release_shared_work_areas();
     reap_deferred_frees(); // (blocks that were set aside while a decoder launch of the host-pointer ABI ran)
 }
 

@@ -394,6 +394,17 @@ JLS_DEV void refill(Producer& s, uint32_t* ring, bool want, int lane, int sub)
     }
 }
 
+// Samples of the first r blocks of a run-length code, sum of 2^J[q] for q < r (0 <= r <= 32; J: reference src/scan_codec.hpp:18-19
+// = {0 x 4, 1 x 4, 2 x 4, 3 x 4, 4, 4, 5, 5, 6, 6, 7, 7, 8, 9, ..., 15}), in closed form: 0 .. 16 by fours, 16 .. 24 by twos, then
+// single blocks.
+JLS_DEV uint32_t run_prefix(uint32_t r)
+{
+    const uint32_t fours = ((4u + (r & 3u)) << (r >> 2)) - 4u;                          // r <= 16
+    const uint32_t twos = 28u + ((2u + (r & 1u)) << (4u + (((r - 16u) >> 1) & 7u)));    // 16 <= r <= 24
+    const uint32_t ones = 284u + (1u << ((r - 16u) & 31u));                             // 24 <= r <= 32
+    return r <= 16u ? fours : (r <= 24u ? twos : ones);
+}
+
 // Number of zero bits before the next one bit, which is consumed as well; -1 when it exceeds `most`.  Per lane.
 JLS_DEV int take_unary(const uint32_t* ring, uint32_t& p, int most)
 {
@@ -481,8 +492,10 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
 
     {
         const Record fresh{(uint32_t)initial_a(t), 1u};
+        // (record 0 belongs to no context -- Q = 0 is run mode -- and is what a step in run mode reads: its N is preset to RESET,
+        // so that the step loop's ONE test for "anything rare" -- N has reached RESET -- catches run mode as well)
         for (int q = sub; q < 366; q += G)
-            records[q] = fresh;
+            records[q] = q == 0 ? Record{fresh.a, (uint32_t)t.reset} : fresh;
         if (sub < 2)
             run_ctx[sub] = RunCtx{sub, initial_a(t), 1, 0};
         // (the host checks the thresholds of ONE scan of the launch: a scan with T3 beyond the table that leads its wavefront
@@ -755,7 +768,9 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 const int mm = (int)(uint32_t)(((((uint64_t)u << 32) | beyond) << (k & 63)) >> 32);
                 // Errval = unmap(mm), complemented when k = 0 and 2B + N - 1 < 0 (src/regular_mode_context.hpp:36-42):
                 // e = (mm >> 1) ^ -odd and |e| = (mm >> 1) + odd with odd = the low bit of mm, flipped by the correction
-                const int half = (int)((uint32_t)mm >> 1);
+                // (17 bits of it: a mapped error beyond 131071 is invalid data and examined after the loop; what a lane that cannot
+                // decode its sample -- an empty window: u = 0xFFFFFFFF -- computes here must not look like an overflow of A)
+                const int half = (int)(((uint32_t)mm >> 1) & 0x1FFFFu);
                 const int odd = (mm ^ (int)((uint32_t)((k - 1) & (2 * bb + n - 1)) >> 31)) & 1;
                 const int e = half ^ -odd;
                 const int px = med3(mad24(cc, sgn, px0), 0, maxval); // plus the bias C
@@ -899,7 +914,83 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 JLS_LOCKSTEP();
             }
         }
+        // A run of any length that is interrupted inside its line, with codes that fit 64 bits of the stream: ONE request for the
+        // bits (three ring words), both run contexts read ahead of knowing which, the length of the run from the number of
+        // leading ones in closed form (run_prefix) instead of bit by bit, and one dependent LDS trip -- the sample above the
+        // interruption sample.  What does not fit -- a run that reaches the end of its line, RUNindex beyond the table, a code
+        // longer than the window -- takes the handler below, bit by bit (round 3's).
+        bool windowed_runs = false;
         if (!empty_runs && __any(in_run))
+        {
+            const uint32_t remaining = width - (i - 1);
+            const uint32_t wi = (p >> 5) & (kRingWords - 1);
+            const uint32_t r0 = ring[wi], r1 = ring[wi + 1], r2 = ring[wi + 2]; // (words kRingWords, kRingWords + 1 mirror words 0, 1)
+            const RunCtx ctx0 = run_ctx[0], ctx1 = run_ctx[1];
+            const uint32_t lo = funnel_shift(r1, r0, p), hi = funnel_shift(r2, r1, p);
+            const uint64_t w = ((uint64_t)hi << 32) | lo; // the next 64 bits of the stream
+            const uint32_t ones = lowest_one(~lo);        // blocks of the run-length code (0xFFFFFFFF: no zero among 32 bits)
+            const uint32_t ri_after = (uint32_t)run_index + ones;
+            const bool counted = ones < 32u && ri_after <= 31u;
+            const uint32_t ri2 = counted ? ri_after : 0u;
+            const uint32_t blocks = run_prefix(ri2) - run_prefix((uint32_t)run_index);
+            const int j = run_j((int)ri2);
+            const uint32_t after_zero = (uint32_t)(w >> ((ones + 1u) & 63u));
+            const uint32_t run = blocks + field(after_zero, j);
+            const uint32_t used = ones + 1u + (uint32_t)j; // bits of the run-length code (<= 47)
+            const bool inside = counted && blocks < remaining && run < remaining; // (every block complete, interrupted before the end of the line)
+            const uint32_t at = inside ? i + run : i;
+            JLS_LOCKSTEP();
+            const int b_at = (int)line[at]; // prev[at]: not overwritten yet
+            const int which = a == b_at ? 1 : 0;
+            RunCtx ctx = which ? ctx1 : ctx0;
+            const uint32_t goal = (uint32_t)ctx.a + (uint32_t)(ctx.n >> 1) * (uint32_t)ctx.ritype;
+            int k = 0;
+            if (goal > (uint32_t)ctx.n)
+            {
+                k = (int)leading_zeros((uint32_t)ctx.n) - (int)leading_zeros(goal);
+                k += (((uint64_t)(uint32_t)ctx.n << k) < goal) ? 1 : 0;
+            }
+            const uint32_t w3 = (uint32_t)(w >> (used & 63u)); // the bits behind the run-length code
+            const uint32_t zeros = lowest_one(w3);
+            const int escape_from = t.limit - j - 1 - t.qbpp - 1;
+            const int tail_bits = (int)zeros < escape_from ? k : t.qbpp;
+            const uint32_t code_bits = zeros + 1u + (uint32_t)tail_bits;
+            const bool fits = inside && k <= 24 && zeros < 32u && used + code_bits <= 64u;
+            windowed_runs = __all(!in_run || fits);
+            if (windowed_runs)
+            {
+                JLS_PATH(15); // run handlers out of one 64-bit window
+                const uint32_t tail = field((uint32_t)(w >> ((used + zeros + 1u) & 63u)), tail_bits);
+                const int em = (int)zeros < escape_from ? ((int)zeros << k) + (int)tail : (int)tail + 1;
+                const int e = run_error_value(ctx, em + ctx.ritype, k);
+                run_update(ctx, e, em, t.reset);
+                const int x = which ? ((a + e) & t.maxval) : ((b_at + e * ((b_at - a) < 0 ? -1 : 1)) & t.maxval);
+                JLS_LOCKSTEP();
+                {
+                    uint32_t r = (uint32_t)sub;
+                    while (__any(in_run && r < run))
+                    {
+                        JLS_PATH(8); // trips of the run fill
+                        if (in_run && r < run)
+                            line[i + r] = (S)a;
+                        r += G;
+                    }
+                }
+                JLS_LOCKSTEP();
+                if (in_run)
+                {
+                    run_ctx[which] = ctx;
+                    line[at] = (S)x;
+                    a = x;
+                    run_index = ri2 > 0 ? (int)ri2 - 1 : 0;
+                    i = at + 1;
+                    p += used + code_bits;
+                    rc_over = b_at; // prev[at] is Rc of the next sample, should it have no entry yet
+                }
+                JLS_LOCKSTEP();
+            }
+        }
+        if (!empty_runs && !windowed_runs && __any(in_run))
         {
             JLS_PATH(6); // run handler
             const uint32_t remaining = width - (i - 1);

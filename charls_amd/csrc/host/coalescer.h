@@ -10,7 +10,12 @@
 //
 //  * a handle ANNOUNCES itself on its lane (device x direction) as soon as it is clear that a coding call is coming -- the
 //    decoder when it is given its source, the encoder its frame info -- and SUBMITS its scans when its host -> device copy is
-//    through.  An announcement is FRESH for `wait_us`; a handle that sits idle for longer no longer holds anybody up;
+//    through.  An announcement says WHAT is coming as far as the handle knows (a hash of the frame's geometry; 0 = not known
+//    yet) and for how long it counts: one made before the coding call (the caller may only want the header) is FRESH for a
+//    millisecond, one made inside the coding call -- its upload is on the way -- for the leader's `wait_us`.  A leader only
+//    waits for announcements that can join ITS batch (same geometry, or not known yet): in a pool that codes images of mixed
+//    sizes there is almost always a fresh announcement of SOME kind, and waiting for those made every call wait its full
+//    `wait_us` and still launch alone;
 //  * the first submitter of a kind (key = geometry and coding parameters) leads a batch: it waits while fresh announcements
 //    are outstanding (never longer than `wait_us`; a caller that is alone has nobody to wait for and launches at once), then
 //    runs the launch for everybody on its own stream and hands the results out;
@@ -18,6 +23,9 @@
 //    also waits while calls KEEP JOINING -- the batch goes when none has joined for `gap_us`: a pool of threads that comes out
 //    of its encoder calls over a few hundred milliseconds decodes as one batch, not as three small ones and a big one that
 //    waits for them (profiles/r05_threads_call_trace.txt);
+//  * a launch-level failure of a merged batch that each call could have survived alone (out of memory: the staging areas
+//    of 16384 merged scans) is not everybody's failure: the leader runs the calls of the batch one by one and every caller gets
+//    the outcome of ITS scans;
 //  * at most `max_running` batches of a key run at a time (an encoder lane: ONE batch of any key -- the work areas of the
 //    pipeline are shared).  A batch that has to wait for its turn stays OPEN meanwhile -- group commit -- and when its turn
 //    comes it may give the callers of the batch that just finished a moment (`grace_us`) to come back: decoder threads that
@@ -76,6 +84,7 @@ public:
         uint64_t launches; // batches run
         uint64_t merged;   // submissions that shared their launch with another one
         uint64_t largest;  // scans in the largest batch
+        uint64_t split;    // merged batches whose launch ran out of memory and whose calls were then run one by one
     };
 
     struct Policy
@@ -89,13 +98,44 @@ public:
 
     static constexpr int kLanes = 64; // device * 2 + (decode ? 1 : 0), devices 0..31
     using Ticket = uint64_t;          // of an announcement; 0 = none
+    static constexpr uint32_t kForever = 0xFFFFFFFFu;
 
-    Ticket announce(int lane)
+    // `hint`: what kind of call is coming (geometry_hint; 0 = not known yet: it may join anything); `fresh_us`: for how long the
+    // announcement holds anybody up at most (kForever: as long as the leader's own wait).  announce(lane) is the announcement
+    // of a call whose upload is on the way.
+    Ticket announce(int lane, uint64_t hint = 0, uint32_t fresh_us = kForever)
     {
         std::lock_guard<std::mutex> lock(mutex_);
         const Ticket ticket = ++last_ticket_;
-        announced_[lane % kLanes].emplace(ticket, Clock::now());
+        const Clock::time_point now = Clock::now();
+        announced_[lane % kLanes].emplace(ticket, Announcement{now, fresh_us == kForever ? Clock::time_point::max() : now + std::chrono::microseconds(fresh_us), hint});
         return ticket;
+    }
+
+    // The announced call knows more now (its geometry) or has got further (into its coding call: fresh from now on).
+    void renew(int lane, Ticket ticket, uint64_t hint, uint32_t fresh_us = kForever) noexcept
+    {
+        if (ticket == 0)
+            return;
+        std::lock_guard<std::mutex> lock(mutex_);
+        auto& list = announced_[lane % kLanes];
+        const auto it = list.find(ticket);
+        if (it == list.end())
+            return;
+        const Clock::time_point now = Clock::now();
+        it->second = Announcement{now, fresh_us == kForever ? Clock::time_point::max() : now + std::chrono::microseconds(fresh_us), hint};
+        arrival_.notify_all();
+    }
+
+    // What an announcement tells about the kind of call: width, height and sample width of the frame (calls that differ in more
+    // than that -- components per scan, coding parameters -- still wait for each other; they are rare).
+    static uint64_t geometry_hint(uint32_t width, uint32_t height, int bits_per_sample) noexcept
+    {
+        uint64_t h = (static_cast<uint64_t>(width) << 32) ^ height ^ (static_cast<uint64_t>(static_cast<uint32_t>(bits_per_sample)) << 56);
+        h ^= h >> 29;
+        h *= 0x9E3779B97F4A7C15ull;
+        h ^= h >> 32;
+        return h == 0 ? 1 : h;
     }
 
     // An announced call that will not submit after all (its handle went away, or the call failed before it got that far).
@@ -125,20 +165,26 @@ public:
         { // join
             std::shared_ptr<Batch> b = open->second;
             const size_t first = b->descs.size();
+            const size_t call = b->call_first.size();
             b->descs.insert(b->descs.end(), descs, descs + count);
+            b->call_first.push_back(static_cast<uint32_t>(first));
+            b->call_failure.push_back(CHARLS_JPEGLS_ERRC_SUCCESS);
             ++b->calls;
             b->last_join = Clock::now();
             arrival_.notify_all(); // the leader looks again
             b->finished.wait(lock, [&] { return b->done; });
-            if (b->failure != CHARLS_JPEGLS_ERRC_SUCCESS)
-                raise(b->failure);
+            if (b->call_failure[call] != CHARLS_JPEGLS_ERRC_SUCCESS)
+                raise(b->call_failure[call]);
             std::memcpy(results, b->results.data() + first, sizeof(ScanResult) * count);
             return;
         }
         // lead
         auto b = std::make_shared<Batch>();
         b->descs.assign(descs, descs + count);
+        b->call_first.push_back(0);
+        b->call_failure.push_back(CHARLS_JPEGLS_ERRC_SUCCESS);
         b->calls = 1;
+        const uint64_t hint = descs[0].width == 0 ? 0 : geometry_hint(descs[0].width, descs[0].height, descs[0].bits_per_sample);
         b->last_join = Clock::now();
         const bool published = open == open_.end();
         if (published)
@@ -173,43 +219,77 @@ public:
             const bool shared = b->calls > 1 || lane_busy(lane);
             const Clock::time_point quiet = b->last_join + std::chrono::microseconds(policy.gap_us);
             const bool still_joining = shared && now < quiet;
-            const bool others_coming = room && now < deadline && (fresh_announcements(lane, now, wait) || still_joining);
+            const bool others_coming = room && now < deadline && (fresh_announcements(lane, now, wait, hint) || still_joining);
             if (!in_grace && !others_coming)
                 break;
             Clock::time_point until = deadline;
             if (in_grace && !others_coming)
                 until = grace;
-            else if (!fresh_announcements(lane, now, wait) && still_joining)
+            else if (!fresh_announcements(lane, now, wait, hint) && still_joining)
                 until = std::min(deadline, quiet);
-            arrival_.wait_until(lock, until);
+            else
+                until = std::min(until, next_expiry(lane, now, hint)); // (an announcement that goes stale wakes nobody by itself)
+            wait_until(lock, until);
         }
         if (published)
             open_.erase(id);
         ++running_now();
-        ++stats_.launches;
-        if (b->calls > 1)
-            stats_.merged += b->calls;
-        stats_.largest = std::max<uint64_t>(stats_.largest, b->descs.size());
-        b->results.resize(b->descs.size());
-        lock.unlock();
+        // From here on whatever happens -- an allocation that fails, a launch that throws -- the running count goes down again
+        // and everybody who joined is told: a count that leaks blocks the lane for good, a batch that is never `done` its callers.
         charls_jpegls_errc failure = CHARLS_JPEGLS_ERRC_SUCCESS;
+        bool was_split = false;
         try
         {
-            launch(b->descs.data(), static_cast<uint32_t>(b->descs.size()), b->results.data());
+            ++stats_.launches;
+            if (b->calls > 1)
+                stats_.merged += b->calls;
+            stats_.largest = std::max<uint64_t>(stats_.largest, b->descs.size());
+            b->results.resize(b->descs.size());
+            lock.unlock();
+            try
+            {
+                launch(b->descs.data(), static_cast<uint32_t>(b->descs.size()), b->results.data());
+            }
+            catch (...)
+            {
+                failure = current_exception_to_errc();
+            }
+            if (failure == CHARLS_JPEGLS_ERRC_NOT_ENOUGH_MEMORY && b->calls > 1)
+            { // what a call could have survived alone is not everybody's failure: the calls of the batch one by one
+                failure = CHARLS_JPEGLS_ERRC_SUCCESS;
+                for (size_t call = 0; call < b->call_first.size(); ++call)
+                {
+                    const uint32_t first = b->call_first[call];
+                    const uint32_t end = call + 1 < b->call_first.size() ? b->call_first[call + 1] : static_cast<uint32_t>(b->descs.size());
+                    try
+                    {
+                        launch(b->descs.data() + first, end - first, b->results.data() + first);
+                    }
+                    catch (...)
+                    {
+                        b->call_failure[call] = current_exception_to_errc();
+                    }
+                }
+                was_split = true;
+            }
         }
         catch (...)
         {
             failure = current_exception_to_errc();
         }
-        lock.lock();
+        if (!lock.owns_lock())
+            lock.lock();
+        if (was_split)
+            ++stats_.split;
         if (--running_now() == 0 && policy.max_running != 0)
             key_running_.erase(id);
-        b->failure = failure;
+        if (failure != CHARLS_JPEGLS_ERRC_SUCCESS)
+            std::fill(b->call_failure.begin(), b->call_failure.end(), failure);
         b->done = true;
         b->finished.notify_all();
         arrival_.notify_all(); // the leaders that wait for their turn
-        if (failure != CHARLS_JPEGLS_ERRC_SUCCESS)
-            raise(failure);
+        if (b->call_failure[0] != CHARLS_JPEGLS_ERRC_SUCCESS)
+            raise(b->call_failure[0]);
         std::memcpy(results, b->results.data(), sizeof(ScanResult) * count);
     }
 
@@ -219,7 +299,7 @@ public:
     {
         lane %= kLanes;
         std::lock_guard<std::mutex> lock(mutex_);
-        if (fresh_announcements(lane, Clock::now(), std::chrono::microseconds(fresh_us)))
+        if (fresh_announcements(lane, Clock::now(), std::chrono::microseconds(fresh_us), 0))
             return false;
         if (!but_for_the_running_batch)
         {
@@ -246,12 +326,33 @@ private:
     {
         std::vector<ScanDesc> descs;
         std::vector<ScanResult> results;
+        std::vector<uint32_t> call_first;               // first scan of every call of the batch (call 0: the leader)
+        std::vector<charls_jpegls_errc> call_failure;   // what every call is told
         uint32_t calls{};
         Clock::time_point last_join{}; // when the latest call joined (the leader counts)
         bool done{};
-        charls_jpegls_errc failure{CHARLS_JPEGLS_ERRC_SUCCESS};
         std::condition_variable finished;
     };
+
+    struct Announcement
+    {
+        Clock::time_point at;      // when it was made or renewed
+        Clock::time_point expires; // its own freshness (a handle that was configured and then left alone holds nobody up)
+        uint64_t hint;             // geometry_hint of the call that is coming; 0 = not known yet
+    };
+
+    // std::condition_variable::wait_until on a steady clock is pthread_cond_clockwait, which gcc's ThreadSanitizer does not
+    // intercept (it then reports every access under the mutex as a race); the sanitizer build waits on the system clock.
+    void wait_until(std::unique_lock<std::mutex>& lock, Clock::time_point until)
+    {
+#ifdef JLS_TSAN
+        const auto left = until - Clock::now();
+        if (left > Clock::duration::zero())
+            arrival_.wait_until(lock, std::chrono::system_clock::now() + std::chrono::duration_cast<std::chrono::system_clock::duration>(left));
+#else
+        arrival_.wait_until(lock, until);
+#endif
+    }
 
     bool lane_busy(int lane) const
     {
@@ -263,19 +364,37 @@ private:
         return false;
     }
 
-    // Is a call on its way to this lane?  An announcement older than `wait` is stale -- a handle that was configured and then
-    // left alone -- and holds nobody up (tickets rise with time: the last one is the youngest).
-    bool fresh_announcements(int lane, Clock::time_point now, std::chrono::microseconds wait) const
+    // Is a call on its way to this lane that could join a batch of kind `hint` (0: of any kind)?  An announcement older than
+    // `wait`, or past its own freshness, is stale -- a handle that was configured and then left alone -- and holds nobody up.
+    bool fresh_announcements(int lane, Clock::time_point now, std::chrono::microseconds wait, uint64_t hint) const
     {
-        const auto& list = announced_[lane];
-        return !list.empty() && now - list.rbegin()->second <= wait;
+        for (const auto& entry : announced_[lane])
+        {
+            const Announcement& a = entry.second;
+            if (now - a.at <= wait && now < a.expires && (hint == 0 || a.hint == 0 || a.hint == hint))
+                return true;
+        }
+        return false;
+    }
+
+    // When the first of the announcements a leader of kind `hint` waits for stops being fresh by its own clock.
+    Clock::time_point next_expiry(int lane, Clock::time_point now, uint64_t hint) const
+    {
+        Clock::time_point first = Clock::time_point::max();
+        for (const auto& entry : announced_[lane])
+        {
+            const Announcement& a = entry.second;
+            if (now < a.expires && (hint == 0 || a.hint == 0 || a.hint == hint))
+                first = std::min(first, a.expires);
+        }
+        return first;
     }
 
     std::mutex mutex_;
     std::condition_variable arrival_; // an announced call submitted or retracted; a running batch finished
     std::map<std::pair<int, MergeKey>, std::shared_ptr<Batch>> open_;
     std::map<std::pair<int, MergeKey>, uint32_t> key_running_;
-    std::map<Ticket, Clock::time_point> announced_[kLanes];
+    std::map<Ticket, Announcement> announced_[kLanes];
     uint32_t lane_running_[kLanes]{};
     Ticket last_ticket_{};
     Stats stats_{};

@@ -127,7 +127,7 @@ struct charls_jpegls_decoder
                 a.restart_interval != b.restart_interval || std::memcmp(&a.pc, &b.pc, sizeof a.pc) != 0)
                 return false;
         }
-        engine.upload_stream(base, reader.remaining());
+        engine.upload_stream(base, reader.remaining(), frame_hint(f.width, f.height, f.bits_per_sample));
         uploaded = true;
         std::vector<ScanResult> results(count);
         try
@@ -213,7 +213,7 @@ struct charls_jpegls_decoder
                                 reader.parameters().restart_interval};
             if (!uploaded)
             { // everything from the first entropy-coded byte to the end of the source goes to the device once
-                engine.upload_stream(base, reader.remaining());
+                engine.upload_stream(base, reader.remaining(), frame_hint(f.width, f.height, f.bits_per_sample));
                 uploaded = true;
             }
             const size_t used = engine.decode_scan(spec, static_cast<size_t>(reader.position() - base), dst, stride);

@@ -44,7 +44,8 @@ struct charls_jpegls_encoder
         check_argument(f.component_count >= 1 && f.component_count <= kMaxComponents,
                        CHARLS_JPEGLS_ERRC_INVALID_ARGUMENT_COMPONENT_COUNT);
         frame = f;
-        engine.expect_call(false); // (the encode call of this thread follows: others about to launch wait for it)
+        // (the encode call of this thread follows: others about to launch a batch of this geometry wait a moment for it)
+        engine.expect_call(false, frame_hint(f.width, f.height, f.bits_per_sample));
     }
 
     bool frame_configured() const noexcept { return frame.width != 0; }
@@ -154,7 +155,7 @@ struct charls_jpegls_encoder
         }
 
         const CallScope call(engine);
-        engine.upload_pixels(static_cast<const uint8_t*>(source), min_size);
+        engine.upload_pixels(static_cast<const uint8_t*>(source), min_size, frame_hint(frame.width, frame.height, frame.bits_per_sample));
         ScanSpec spec{frame.width, frame.height, 1, interleave, frame.bits_per_sample, near, transformation, pc, restart_interval};
         if (interleave == 0)
         {

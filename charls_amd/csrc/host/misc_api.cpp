@@ -183,11 +183,18 @@ int32_t charls_amd_speculation_counters(uint64_t* out, int32_t capacity)
 
 int32_t charls_amd_engine_counters(uint64_t* out, int32_t capacity)
 {
-    uint64_t v[5];
-    coalescer_stats(v);
+    uint64_t stats[5], v[10];
+    coalescer_stats(stats);
+    for (int i = 0; i < 4; ++i)
+        v[i] = stats[i];
     v[4] = dev::pipeline_fallback_scans();
+    v[5] = stats[4];
+    v[6] = idle_engine_resource_bytes();
+    v[7] = dev::deferred_free_bytes();
+    v[8] = idle_releases();
+    v[9] = dev::exact_retry_scans();
     int32_t n = 0;
-    for (; out != nullptr && n < capacity && n < 5; ++n)
+    for (; out != nullptr && n < capacity && n < 10; ++n)
         out[n] = v[n];
     return n;
 }

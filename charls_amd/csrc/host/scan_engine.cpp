@@ -2,10 +2,14 @@
 #include "scan_engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../device/knobs.h"
@@ -17,12 +21,18 @@ using dev::hip_check;
 
 namespace {
 
+constexpr int kMaxDevices = 32;
+int slot_of(int device) noexcept
+{
+    return device >= 0 && device < kMaxDevices ? device : 0;
+}
+
 // Idle resource sets.  Never destroyed: at process exit the HIP runtime may already be gone.
 struct ResourcePool
 {
     std::mutex mutex;
     std::vector<std::unique_ptr<EngineResources>> idle;
-    size_t idle_bytes{};
+    size_t idle_bytes[kMaxDevices]{}; // per device
 };
 ResourcePool& pool()
 {
@@ -31,11 +41,123 @@ ResourcePool& pool()
 }
 // What stays idle: a pool of threads that makes a handle per image (cli/benchmark.cpp does) gives a set back and takes one a
 // moment later, and hipFree waits for EVERY kernel on the device -- seconds, while another thread's decoder runs.  So up to
-// kMaxIdleSets sets of at most kMaxIdleBytesPerSet each stay, as long as they add up to less than kMaxIdleBytes (a 16th
-// of an MI355X); charls_amd_release_work_areas() gives them back.
+// kMaxIdleSets sets of at most kMaxIdleBytesPerSet each stay, as long as those of a DEVICE add up to less than kMaxIdleBytes (a
+// 16th of an MI355X; never more than charls_amd_set_workspace_limit allows).  They do not stay for long: what the host-pointer
+// ABI keeps between calls -- these sets, the shared work areas of the merged encoder launches, blocks whose hipFree was put off --
+// is given back once no call has come for kIdleReleaseMs (the janitor below), and charls_amd_release_work_areas() gives it back
+// at once.  A drop-in library is a guest in the caller's HBM.
 constexpr size_t kMaxIdleSets = 1024;
 constexpr size_t kMaxIdleBytesPerSet = size_t{512} << 20;
 constexpr size_t kMaxIdleBytes = size_t{18} << 30;
+constexpr long long kIdleReleaseMs = 2000;
+
+size_t idle_cap() noexcept
+{
+    const uint64_t limit = dev::workspace_limit();
+    return limit != 0 ? std::min<size_t>(kMaxIdleBytes, static_cast<size_t>(limit)) : kMaxIdleBytes;
+}
+
+// ---- the janitor: one thread per process, started by the first coding call of the host-pointer ABI.  It wakes a few times a
+// second; when no coding call is running and none has ended for kIdleReleaseMs it frees what the calls left behind.
+struct Janitor
+{
+    std::mutex guard;
+    std::condition_variable wake;
+    std::thread thread;
+    bool started{}, stop{};
+    std::atomic<long long> last_activity_ms{0};
+    std::atomic<int> calls_running{0};
+    std::atomic<uint64_t> releases{0};
+};
+Janitor& janitor()
+{
+    static Janitor* j = new Janitor; // never destroyed (its thread is joined by an atexit handler)
+    return *j;
+}
+long long steady_ms() noexcept
+{
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+bool anything_held() noexcept
+{
+    {
+        ResourcePool& p = pool();
+        std::lock_guard<std::mutex> lock(p.mutex);
+        if (!p.idle.empty())
+            return true;
+    }
+    return dev::shared_work_area_bytes() != 0 || dev::deferred_free_bytes() != 0;
+}
+void janitor_loop()
+{
+    Janitor& j = janitor();
+    std::unique_lock<std::mutex> lock(j.guard);
+    while (!j.stop)
+    {
+        j.wake.wait_for(lock, std::chrono::milliseconds(250));
+        if (j.stop)
+            break;
+        const long long quiet_ms = knobs::get_or(knobs::kIdleReleaseMs, kIdleReleaseMs);
+        if (quiet_ms <= 0 || j.calls_running.load() != 0 || steady_ms() - j.last_activity_ms.load() < quiet_ms)
+            continue;
+        lock.unlock();
+        if (anything_held())
+        {
+            release_idle_engine_resources();
+            dev::release_shared_work_areas();
+            dev::reap_deferred_frees();
+            j.releases.fetch_add(1);
+        }
+        lock.lock();
+    }
+}
+void stop_janitor() noexcept
+{
+    Janitor& j = janitor();
+    {
+        std::lock_guard<std::mutex> lock(j.guard);
+        if (!j.started)
+            return;
+        j.stop = true;
+    }
+    j.wake.notify_all();
+    if (j.thread.joinable())
+        j.thread.join();
+}
+// A coding call of the host-pointer ABI begins / ends.
+struct Activity
+{
+    Activity() noexcept
+    {
+        Janitor& j = janitor();
+        j.calls_running.fetch_add(1);
+        j.last_activity_ms.store(steady_ms());
+        if (!j.started) // (racy look; decided under the lock)
+        {
+            std::lock_guard<std::mutex> lock(j.guard);
+            if (!j.started && !j.stop)
+            {
+                try
+                {
+                    j.thread = std::thread(janitor_loop);
+                    j.started = true;
+                    std::atexit(stop_janitor);
+                }
+                catch (...)
+                { // (no thread to be had: nothing decays, charls_amd_release_work_areas() still works)
+                }
+            }
+        }
+    }
+    ~Activity()
+    {
+        Janitor& j = janitor();
+        j.last_activity_ms.store(steady_ms());
+        j.calls_running.fetch_sub(1);
+    }
+    Activity(const Activity&) = delete;
+    Activity& operator=(const Activity&) = delete;
+};
 
 std::unique_ptr<EngineResources> acquire_resources()
 {
@@ -49,7 +171,7 @@ std::unique_ptr<EngineResources> acquire_resources()
             {
                 std::unique_ptr<EngineResources> r = std::move(p.idle[i]);
                 p.idle.erase(p.idle.begin() + static_cast<std::ptrdiff_t>(i));
-                p.idle_bytes -= r->device_bytes();
+                p.idle_bytes[slot_of(device)] -= std::min(p.idle_bytes[slot_of(device)], r->pooled_bytes);
                 return r;
             }
     }
@@ -67,10 +189,13 @@ void release_resources(std::unique_ptr<EngineResources> r) noexcept
     {
         ResourcePool& p = pool();
         std::lock_guard<std::mutex> lock(p.mutex);
-        if (p.idle.size() < kMaxIdleSets && p.idle_bytes + r->device_bytes() <= kMaxIdleBytes)
+        size_t& held = p.idle_bytes[slot_of(r->device)];
+        if (p.idle.size() < kMaxIdleSets && held + r->device_bytes() <= idle_cap())
         {
-            p.idle_bytes += r->device_bytes();
+            r->pooled_bytes = r->device_bytes();
+            held += r->pooled_bytes;
             p.idle.push_back(std::move(r));
+            janitor().last_activity_ms.store(steady_ms()); // (what has just come back is not old yet)
             return;
         }
     }
@@ -83,7 +208,6 @@ void release_resources(std::unique_ptr<EngineResources> r) noexcept
 // of 250 frames that should take 0.1 s waited 3.4 s behind an unrelated decoder kernel (profiles/r05_threads_call_trace.txt).
 // So decoder launches run on a few streams of the LOWEST priority (their own queues; they leave most of every CU idle and
 // give way), encoder launches on one stream of the HIGHEST priority per device; the handles' streams only carry copies.
-constexpr int kMaxDevices = 32;
 struct LaunchStreams
 {
     std::mutex guard;
@@ -198,13 +322,19 @@ constexpr uint32_t kMaxMergedScans = 16384;
 
 } // namespace
 
-void coalescer_stats(uint64_t out[4]) noexcept
+void coalescer_stats(uint64_t out[5]) noexcept
 {
     const Coalescer::Stats s = coalescer().stats();
     out[0] = s.calls;
     out[1] = s.launches;
     out[2] = s.merged;
     out[3] = s.largest;
+    out[4] = s.split;
+}
+
+uint64_t frame_hint(uint32_t width, uint32_t height, int bits_per_sample) noexcept
+{
+    return Coalescer::geometry_hint(width, height, bits_per_sample);
 }
 
 EngineResources::~EngineResources()
@@ -220,8 +350,24 @@ void release_idle_engine_resources() noexcept
         ResourcePool& p = pool();
         std::lock_guard<std::mutex> lock(p.mutex);
         gone.swap(p.idle);
-        p.idle_bytes = 0;
+        for (size_t& bytes : p.idle_bytes)
+            bytes = 0;
     }
+}
+
+uint64_t idle_engine_resource_bytes() noexcept
+{
+    ResourcePool& p = pool();
+    std::lock_guard<std::mutex> lock(p.mutex);
+    uint64_t total = 0;
+    for (const size_t bytes : p.idle_bytes)
+        total += bytes;
+    return total;
+}
+
+uint64_t idle_releases() noexcept
+{
+    return janitor().releases.load();
 }
 
 ScanEngine::~ScanEngine()
@@ -237,10 +383,21 @@ void ScanEngine::ensure_stream()
         r_ = acquire_resources();
 }
 
-void ScanEngine::expect_call(bool decode) noexcept
+// How long an announcement made BEFORE the coding call holds a leader up at most: the threads of a pool go from configuring
+// their handle to the coding call in microseconds; a caller that only wanted the header costs nobody more than this.
+constexpr uint32_t kEarlyAnnouncementUs = 1000;
+
+void ScanEngine::expect_call(bool decode, uint64_t hint, bool uploading) noexcept
 {
-    if (ticket_ != 0 || !coalescing_enabled() || dev::device_status() != CHARLS_JPEGLS_ERRC_SUCCESS)
+    if (!coalescing_enabled() || dev::device_status() != CHARLS_JPEGLS_ERRC_SUCCESS)
         return;
+    const uint32_t fresh_us = uploading ? Coalescer::kForever : kEarlyAnnouncementUs;
+    if (ticket_ != 0)
+    { // (announced before: the call has got further, or knows its geometry now)
+        if (uploading || hint != 0)
+            coalescer().renew(announced_lane_, ticket_, hint, fresh_us);
+        return;
+    }
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess)
     {
@@ -250,7 +407,7 @@ void ScanEngine::expect_call(bool decode) noexcept
     if (!coalescing_enabled_on(device))
         return;
     announced_lane_ = lane_of(device, decode);
-    ticket_ = coalescer().announce(announced_lane_);
+    ticket_ = coalescer().announce(announced_lane_, hint, fresh_us);
 }
 
 void ScanEngine::end_call() noexcept
@@ -321,6 +478,7 @@ void ScanEngine::launch(const ScanDesc* descs, uint32_t n, bool decode, ScanResu
 
 void ScanEngine::run_many(const ScanDesc* descs, uint32_t count, bool decode, ScanResult* results)
 {
+    const Activity activity; // (the janitor keeps its hands off while a call runs, and counts the quiet time from its end)
     constexpr size_t kKeepBytes = size_t{1} << 30; // a drop-in library must not sit on gigabytes of the caller's HBM between calls
     if (!coalescing_enabled_on(r_->device))
     {
@@ -475,10 +633,10 @@ void ScanEngine::copy_rows_out(uint8_t* destination, size_t stride, const uint8_
     hip_check(hipStreamSynchronize(r_->stream));
 }
 
-void ScanEngine::upload_pixels(const uint8_t* source, size_t bytes)
+void ScanEngine::upload_pixels(const uint8_t* source, size_t bytes, uint64_t hint)
 {
     ensure_stream();
-    expect_call(false); // (before the copy: the copy is what the others of a batch wait for)
+    expect_call(false, hint, true); // (before the copy: the copy is what the others of a batch wait for)
     const double t0 = tracing() ? now_ms() : 0;
     r_->pixels.ensure(bytes);
     pixel_bytes_ = bytes;
@@ -508,10 +666,10 @@ size_t ScanEngine::encode_scan(const ScanSpec& spec, size_t pixel_offset, size_t
     return r.bytes;
 }
 
-void ScanEngine::upload_stream(const uint8_t* source, size_t bytes)
+void ScanEngine::upload_stream(const uint8_t* source, size_t bytes, uint64_t hint)
 {
     ensure_stream();
-    expect_call(true);
+    expect_call(true, hint, true);
     const double t0 = tracing() ? now_ms() : 0;
     r_->bits.ensure(bytes + 16); // the ring refill of the wave decoder reads whole 16-byte groups
     stream_bytes_ = bytes;

@@ -38,17 +38,22 @@ struct EngineResources
     EngineResources(const EngineResources&) = delete;
     EngineResources& operator=(const EngineResources&) = delete;
     ~EngineResources();
+    size_t pooled_bytes{}; // what the pool counted for this set when it came back
     size_t device_bytes() const noexcept
     {
         return pixels.capacity() + bits.capacity() + scratch.capacity() + desc.capacity() + result.capacity();
     }
 };
 
-// Frees the idle sets of the pool (charls_amd_release_work_areas calls it).
+// Frees the idle sets of the pool (charls_amd_release_work_areas calls it, and the janitor after two quiet seconds).
 void release_idle_engine_resources() noexcept;
+uint64_t idle_engine_resource_bytes() noexcept; // device memory of the idle sets
+uint64_t idle_releases() noexcept;              // how often the janitor gave memory back
 // What the coalescer of the host-pointer ABI did so far (coalescer.h): calls, launches, calls that shared a launch, scans of
-// the largest launch.
-void coalescer_stats(uint64_t out[4]) noexcept;
+// the largest launch, merged batches that ran out of memory and were run call by call.
+void coalescer_stats(uint64_t out[5]) noexcept;
+// The frame's Coalescer::geometry_hint (scan_engine.cpp keeps coalescer.h to itself).
+uint64_t frame_hint(uint32_t width, uint32_t height, int bits_per_sample) noexcept;
 
 class ScanEngine;
 // Ends the engine's part of a coding call of the facade however the call ends (ScanEngine::end_call).
@@ -70,7 +75,8 @@ public:
     ~ScanEngine();
 
     // ---- encode: the frame's pixels are uploaded once, then one call per scan
-    void upload_pixels(const uint8_t* source, size_t bytes);
+    // (`hint`: Coalescer::geometry_hint of the frame -- what kind of call the upload belongs to)
+    void upload_pixels(const uint8_t* source, size_t bytes, uint64_t hint = 0);
     // Encodes the scan whose first row starts `pixel_offset` bytes into the uploaded pixels; writes the entropy-coded
     // segment to `destination` (host) and returns its size.  Raises what scan_encoder::encode_scan would throw.
     size_t encode_scan(const ScanSpec& spec, size_t pixel_offset, size_t stride, uint8_t* destination,
@@ -83,7 +89,7 @@ public:
     void fetch_encoded_scan(uint32_t index, uint8_t* destination, size_t bytes);
 
     // ---- decode: the remaining source bytes are uploaded once, then one call per scan
-    void upload_stream(const uint8_t* source, size_t bytes);
+    void upload_stream(const uint8_t* source, size_t bytes, uint64_t hint = 0);
     // Decodes the scan that starts `stream_offset` bytes into the uploaded stream into `destination` (host, rows
     // `stride` apart); returns the number of source bytes consumed.  Raises what scan_decoder::decode_scan would throw.
     size_t decode_scan(const ScanSpec& spec, size_t stream_offset, uint8_t* destination, size_t stride);
@@ -93,9 +99,12 @@ public:
     void decode_planes(const ScanSpec& spec, const size_t* stream_offsets, uint32_t count, ScanResult* results);
     void fetch_decoded_plane(const ScanSpec& spec, uint32_t index, uint8_t* destination, size_t stride);
 
-    // A coding call is coming on this handle (the decoder was given its source, the encoder its frame info): announced to
-    // the coalescer, so that calls of other threads that are about to launch wait a moment for this one (coalescer.h).
-    void expect_call(bool decode) noexcept;
+    // A coding call is coming on this handle: announced to the coalescer, so that calls of other threads that are about to
+    // launch a batch this one can join wait for it (coalescer.h).  Before the coding call (the decoder was given its source,
+    // the encoder its frame info -- the caller may never code anything) the announcement counts for a millisecond; inside it
+    // (`uploading`: the host -> device copy is on its way) for as long as a leader is prepared to wait.  `hint`: the frame's
+    // Coalescer::geometry_hint, 0 while it is not known.
+    void expect_call(bool decode, uint64_t hint = 0, bool uploading = false) noexcept;
     // The coding call of the facade is over (normally or not), or the handle goes away: an announcement that was not
     // followed by a scan is taken back.
     void end_call() noexcept;

@@ -431,11 +431,14 @@ CHARLS_AMD_API charls_jpegls_errc charls_amd_set_encode_engine(int32_t engine);
  * scale by threads x handles): calls that arrive together are merged into one kernel launch (charls_amd_engine_counters),
  * and the merged encoder launches of ALL threads run on ONE set of work areas per device -- a pool of 256 threads holds
  * one arena, not 256.  That set never grows beyond the limit nor beyond an eighth of the device's memory (larger batches
- * take more passes) and stays allocated between calls: giving gigabytes back to the driver and asking for them again
- * costs seconds, and hipFree waits for every kernel on the device.  Handles share a process-wide pool of device buffers,
- * streams and pinned staging areas (idle sets of at most 512 MiB each, at most 18 GiB together: callers create a handle
- * per image, creating these per handle costs more than coding a frame).  charls_amd_release_work_areas frees the calling
- * thread's areas, the shared set and the idle pool. */
+ * take more passes) and stays allocated between calls that follow each other: giving gigabytes back to the driver and
+ * asking for them again costs seconds, and hipFree waits for every kernel on the device.  Handles share a process-wide pool
+ * of device buffers, streams and pinned staging areas (idle sets of at most 512 MiB each, per device at most 18 GiB or the
+ * limit, whichever is less: callers create a handle per image, creating these per handle costs more than coding a frame).
+ * None of it stays for long: once no coding call of part 1 has run for two seconds (CHARLS_AMD_IDLE_RELEASE_MS; 0 = keep) the
+ * shared set, the idle pool and every block whose hipFree had been put off are given back by a housekeeping thread of the
+ * library (charls_amd_engine_counters [6] - [8]).  charls_amd_release_work_areas frees the calling thread's areas, the shared
+ * set and the idle pool at once. */
 CHARLS_AMD_API charls_jpegls_errc charls_amd_set_workspace_limit(uint64_t bytes);
 CHARLS_AMD_API charls_jpegls_errc charls_amd_release_work_areas(void);
 CHARLS_AMD_API uint64_t charls_amd_work_area_bytes(void); /* the calling thread's + the shared set of part 1, currently allocated */
@@ -443,7 +446,11 @@ CHARLS_AMD_API uint64_t charls_amd_work_area_bytes(void); /* the calling thread'
 /* What the engine did with the calls of part 1 since the library was loaded (process-wide): out[0] scan submissions of
  * the host-pointer ABI, out[1] kernel launches they took, out[2] submissions that shared their launch with another call,
  * out[3] scans of the largest launch, out[4] scans the lossless pipeline was eligible for that were coded by the
- * one-wavefront kernel because no work area could be allocated.  Returns the number of values written (5 at most). */
+ * one-wavefront kernel because no work area could be allocated, out[5] merged launches that ran out of memory and whose
+ * calls were then run one by one, out[6] bytes of device memory in the idle pool of handle resources, out[7] bytes whose
+ * hipFree has been put off (a decoder launch is running), out[8] how often the housekeeping thread gave memory back,
+ * out[9] scans a speed-path decoder handed to the exact decoder (streams that are damaged or that end unusually; a valid
+ * stream that is counted here lost its speed path).  Returns the number of values written (10 at most). */
 CHARLS_AMD_API int32_t charls_amd_engine_counters(uint64_t* out, int32_t capacity);
 
 /* Test and measurement knobs (charls_amd/csrc/device/knobs.h has the list: DECODE_GROUP, JOB_EVENTS, TILE_SAMPLES,

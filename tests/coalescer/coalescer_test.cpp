@@ -307,6 +307,106 @@ int main()
         c.submit(25, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{400000, 1024, 3, 0, 40000}, [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
         CHECK(ms_since(t0) < 20, "a caller that is alone does not wait for joiners");
     }
+    // 11. announcements say what is coming: a leader does not wait for announcements that can never join its batch (a pool that
+    //     codes images of mixed sizes), but it does wait for those that can, and for those that do not know yet
+    {
+        Coalescer c;
+        const uint64_t small = Coalescer::geometry_hint(64, 8, 8), large = Coalescer::geometry_hint(4096, 8, 8);
+        auto fake = [&](const ScanDesc*, uint32_t n, ScanResult* out) {
+            for (uint32_t k = 0; k < n; ++k)
+                out[k] = ScanResult{};
+        };
+        const Coalescer::Policy policy{300000, 1024, 2, 0, 0};
+        const Coalescer::Ticket other = c.announce(27, large); // somebody is uploading a LARGE frame
+        {
+            const ScanDesc d = desc_of(64, 1);
+            ScanResult r{};
+            const auto t0 = Clock::now();
+            c.submit(27, merge_key_of(d), &d, 1, &r, c.announce(27, small), policy, fake);
+            CHECK(ms_since(t0) < 50, "a leader does not wait for an announcement of another geometry");
+        }
+        {
+            const ScanDesc d = desc_of(4096, 2);
+            ScanResult r{};
+            const auto t0 = Clock::now();
+            std::thread late([&] {
+                std::this_thread::sleep_for(std::chrono::milliseconds(80));
+                c.retract(27, other);
+            });
+            c.submit(27, merge_key_of(d), &d, 1, &r, c.announce(27, large), policy, fake);
+            late.join();
+            const double waited = ms_since(t0);
+            CHECK(waited >= 60 && waited < 250, "it waits for one of its own geometry (until that is retracted)");
+        }
+        {
+            const Coalescer::Ticket unknown = c.announce(27); // (a decoder that has not read its header yet)
+            const ScanDesc d = desc_of(64, 3);
+            ScanResult r{};
+            const auto t0 = Clock::now();
+            std::thread late([&] {
+                std::this_thread::sleep_for(std::chrono::milliseconds(60));
+                c.renew(27, unknown, large); // now it knows: not ours
+            });
+            c.submit(27, merge_key_of(d), &d, 1, &r, c.announce(27, small), policy, fake);
+            late.join();
+            const double waited = ms_since(t0);
+            CHECK(waited >= 40 && waited < 200, "an announcement of unknown geometry holds a leader up until it is known to be another's");
+            c.retract(27, unknown);
+        }
+    }
+    // 12. an announcement made before the coding call (the caller may only want the header) is fresh for as long as it says:
+    //     a lone read-header-only handle costs another thread's call a millisecond, not the leader's whole wait
+    {
+        Coalescer c;
+        const Coalescer::Ticket idle_handle = c.announce(29, 0, 1000); // set_source_buffer, and then nothing
+        const ScanDesc d = desc_of(512, 1);
+        ScanResult r{};
+        const auto t0 = Clock::now();
+        c.submit(29, merge_key_of(d), &d, 1, &r, 0, Coalescer::Policy{400000, 1024, 3, 100000, 100000},
+                 [&](const ScanDesc*, uint32_t, ScanResult* out) { out[0] = ScanResult{}; });
+        const double waited = ms_since(t0);
+        CHECK(waited < 20, "an early announcement holds a call up for a millisecond at most");
+        std::printf("   (waited %.2f ms)\n", waited);
+        c.retract(29, idle_handle);
+    }
+    // 13. a merged launch that runs out of memory is run again call by call: every caller gets the outcome of ITS scans
+    {
+        Coalescer c;
+        std::atomic<int> launches{0}, failed_calls{0}, good_calls{0};
+        auto fake = [&](const ScanDesc* all, uint32_t n, ScanResult* out) {
+            ++launches;
+            if (n > 2)
+                raise(CHARLS_JPEGLS_ERRC_NOT_ENOUGH_MEMORY); // (the merged launch does not fit)
+            if (all[0].stream_capacity == 5)
+                raise(CHARLS_JPEGLS_ERRC_INVALID_DATA); // (one call is bad on its own account)
+            for (uint32_t k = 0; k < n; ++k)
+                out[k] = ScanResult{0, 0, all[k].stream_capacity + 1000};
+        };
+        std::vector<Coalescer::Ticket> tickets;
+        for (int i = 0; i < 8; ++i)
+            tickets.push_back(c.announce(31));
+        std::vector<std::thread> threads;
+        for (int i = 0; i < 8; ++i)
+            threads.emplace_back([&, i] {
+                const ScanDesc d = desc_of(640, (uint32_t)i);
+                ScanResult r{};
+                try
+                {
+                    c.submit(31, merge_key_of(d), &d, 1, &r, tickets[i], Coalescer::Policy{500000, 1024, 2, 0, 0}, fake);
+                    if (r.bytes == 1000u + i)
+                        ++good_calls;
+                }
+                catch (const error& e)
+                {
+                    if (i == 5 && e.code == CHARLS_JPEGLS_ERRC_INVALID_DATA)
+                        ++failed_calls;
+                }
+            });
+        for (auto& t : threads)
+            t.join();
+        CHECK(good_calls == 7 && failed_calls == 1 && launches == 9 && c.stats().split == 1,
+              "out of memory in a merged launch: the calls run one by one, only the bad one fails");
+    }
     std::printf(g_failures == 0 ? "coalescer ok\n" : "coalescer FAILED\n");
     return g_failures == 0 ? 0 : 1;
 }

@@ -20,7 +20,17 @@ def cases():
         return json.load(f)
 
 
+def tulips_tiled(width, height, roll):
+    """The reference's natural test image (refdata/tulips-gray-8bit-512-512.pgm) tiled to width x height and rolled by
+    (17 roll, 29 roll) -- frame `roll` of bench.py's `tulips` data (bench.py: data_frames)."""
+    tile, _ = read_pnm("tulips-gray-8bit-512-512.pgm")
+    big = np.tile(tile, (height // tile.shape[0], width // tile.shape[1]))
+    return np.ascontiguousarray(np.roll(big, shift=(17 * roll, 29 * roll), axis=(0, 1)))
+
+
 def case_input(c):
+    if c["kind"] == "tulips_tiled":
+        return tulips_tiled(c["width"], c["height"], c["seed"])
     return synth.frame_numpy(c["width"], c["height"], seed=c["seed"], bits=c["bits_per_sample"],
                              components=c["component_count"], kind=c["kind"],
                              interleaved=(c["interleave_mode"] != 0))

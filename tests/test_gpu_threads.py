@@ -217,3 +217,60 @@ def test_failed_calls_do_not_stall_the_others(lib, knobs):
     assert not any(t.is_alive() for t in pool), "a thread is still waiting"
     assert not results, results
     assert time.perf_counter() - t0 < 30, "somebody waited for a call that had failed"
+
+
+def test_what_the_library_keeps_between_calls_decays(lib, knobs):
+    """A drop-in library is a guest in the caller's HBM: after a burst of calls the shared work areas, the idle pool of handle
+    resources and every block whose hipFree was put off are given back once no call has come for CHARLS_AMD_IDLE_RELEASE_MS
+    (two seconds by default; the test asks for half a second) -- without anybody calling charls_amd_release_work_areas()."""
+    import time
+    knobs.set("IDLE_RELEASE_MS", 500)
+    cases = _cases(2, lib)
+    before = capi.engine_counters(lib)
+    failures, _ = _run_threads(lib, cases, 64, 2)
+    assert not failures, failures[:8]
+    held_now = capi.engine_counters(lib)
+    assert held_now["idle_pool_bytes"] > 0 or batch.work_area_bytes(lib) > 0, "nothing was kept: the test would prove nothing"
+    deadline = time.time() + 5.0
+    while time.time() < deadline:
+        c = capi.engine_counters(lib)
+        if batch.work_area_bytes(lib) <= (1 << 30) and c["idle_pool_bytes"] == 0 and c["deferred_free_bytes"] == 0:
+            break
+        time.sleep(0.1)
+    c = capi.engine_counters(lib)
+    assert batch.work_area_bytes(lib) <= (1 << 30), batch.work_area_bytes(lib)
+    assert c["idle_pool_bytes"] == 0 and c["deferred_free_bytes"] == 0, c
+    assert c["idle_releases"] > before["idle_releases"]
+    # and the next call simply allocates again
+    name, img, kw, want = cases[0]
+    assert lib.encode(img, **kw) == want
+
+
+def test_a_handle_that_only_reads_its_header_holds_nobody_up(lib):
+    """A decoder that was given its source and read the header -- and then codes nothing -- announced a call that never comes.
+    Its announcement counts for a millisecond: another thread's decode beside it takes what it takes alone (+ 1 ms at most;
+    the leader's full wait would be 400 ms for a large frame)."""
+    import time
+    img = synth.frame_numpy(2048, 2048, seed=77, kind="gradient")
+    stream = lib.encode(img, width=2048, height=2048)
+
+    def timed_decode():
+        t0 = time.perf_counter()
+        _, px = lib.decode(stream)
+        dt = time.perf_counter() - t0
+        assert px.tobytes() == img.tobytes()
+        return dt
+
+    timed_decode()
+    alone = min(timed_decode() for _ in range(3))
+    beside = []
+    for _ in range(3):
+        L = lib.lib
+        idle_handle = L.charls_jpegls_decoder_create()  # set_source_buffer + read_header, nothing else
+        ptr, n, keep = lib._buf(stream)
+        assert L.charls_jpegls_decoder_set_source_buffer(idle_handle, ptr, n) == 0
+        assert L.charls_jpegls_decoder_read_header(idle_handle) == 0
+        beside.append(timed_decode())
+        L.charls_jpegls_decoder_destroy(idle_handle)
+        del keep
+    assert min(beside) <= alone + 0.010, (alone, beside)  # (10 ms of slack for the clock of a 0.85 s decode; the old wait was 100+ ms)

@@ -167,7 +167,7 @@ def test_every_symbol_the_header_declares_is_exported():
 
 def test_knobs_and_engine_counters_are_plain_host_calls(lib):
     """charls_amd_debug_set_knob / charls_amd_engine_counters (include/charls_amd.h part 2): a table and a few counters, usable
-    without a GPU.  Unknown names are refused; a cleared knob can be set again; the counters come back as five values."""
+    without a GPU.  Unknown names are refused; a cleared knob can be set again; the counters come back as ten values."""
     from charls_amd import capi
     L = lib.lib
     L.charls_amd_debug_set_knob.argtypes = [C.c_char_p, C.c_int64]
@@ -177,5 +177,7 @@ def test_knobs_and_engine_counters_are_plain_host_calls(lib):
     assert L.charls_amd_debug_set_knob(b"NO_SUCH_KNOB", 1) == 101
     assert L.charls_amd_debug_set_knob(None, 1) == 101
     counters = capi.engine_counters(lib)
-    assert set(counters) == {"calls", "launches", "merged_calls", "largest_launch", "pipeline_fallback_scans"}
+    assert set(counters) == {"calls", "launches", "merged_calls", "largest_launch", "pipeline_fallback_scans", "split_launches",
+                             "idle_pool_bytes", "deferred_free_bytes", "idle_releases", "exact_retry_scans"}
+    assert L.charls_amd_debug_set_knob(b"IDLE_RELEASE_MS", 500) == 0 and L.charls_amd_debug_set_knob(b"IDLE_RELEASE_MS", capi.KNOB_UNSET) == 0
     assert all(v >= 0 for v in counters.values())

@@ -1,5 +1,6 @@
 """N > 1 path on the CPU: frames are sharded over ranks with no exchange, the only collective is the final gather of the
-variable-length bitstreams (charls_amd/batch.py).  world_size 2, gloo backend, spawned processes."""
+variable-length bitstreams (charls_amd/batch.py).  world_size 2 -- and 8, the size of the node the driver's scaling run uses:
+the first 8-GPU run must not be the first 8-rank run --, gloo backend, spawned processes."""
 import os
 import socket
 
@@ -79,6 +80,33 @@ def test_gather_streams_world_size_2(total_frames):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) == "ok"
+
+
+def test_gather_streams_world_size_8():
+    """Eight ranks, as on the 8-GPU node: 256 frames -- BASELINE configs[3] -- and a count that does not divide (rank shards of
+    different sizes, two of them empty with 6 frames)."""
+    for total_frames in (256, 6):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 8, port, total_frames, q)) for r in range(8)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(240)
+            assert p.exitcode == 0
+        assert q.get(timeout=5) == "ok"
+
+
+def test_bench_cfg4_over_eight_ranks():
+    """`bench.py --workload cfg4 --gpus 8 --selftest-exchange`: the launcher starts eight ranks, 256 frames are split 32 a rank,
+    rank 0 sees all of them, each from its owner."""
+    import json
+    r = _run_bench(["--gpus", "8", "--workload", "cfg4", "--selftest-exchange"], {"CHARLS_AMD_BENCH_BACKEND": "gloo"}, timeout=480)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert lines == [{"selftest": "exchange", "n_gpus": 8, "backend": "gloo", "ranks_seen_by_backend": 8, "ok": True,
+                      "workload": "cfg4", "frames": 256}], r.stdout
 
 
 def _run_bench(args, extra_env, timeout=240):

@@ -1,5 +1,7 @@
 // The decoder's step loop (charls_amd/csrc/device/scan_group_step.inc) alone, on synthetic LDS contents that keep every lane
-// decoding: cycles per step of the product's text and of edited copies (tools/microbench/steploop_variants.py), with the
+// decoding: cycles per step of the product's text and of other compositions of its pieces (stores by all lanes, one step per
+// trip, ...; round 6's first form and its ablations: tools/microbench/steploop_variants.py at commit 2de007a,
+// profiles/r06_steploop_v1_ablation.txt), with the
 // product's launch shape -- four wavefronts per workgroup (one per SIMD), four scans per wavefront, the product's LDS layout.
 // Not part of the product.  Build: see steploop_variants.py.  Run: tools/microbench/build/steploop [workgroups]
 #include <hip/hip_runtime.h>
@@ -9,12 +11,30 @@
 #include <cstdio>
 #include <vector>
 
-#define JLS_SDWA(s0, s1) " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" s0 " src1_sel:" s1 "\n"
-#include "build/steploop_variants.inc"
+#include "../../charls_amd/csrc/device/scan_group_step.inc"
 
-#define CLOBBERS                                                                                                                  \
-    "memory", "vcc", "scc", "s96", "s97", "s98", "s99", "v100", "v101", "v102", "v103", "v104", "v105", "v108", "v109", "v110", "v111",  \
-        "v112", "v113", "v114", "v115", "v116", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define LOOP1(STORES, KSEEN)                                                                                                      \
+    JLS_STEP_PROLOGUE JLS_STEP_BODY("a", "s_branch L_stepa%=\n", "BYTE_0", "1", STORES, "", " offset:255", "", "", "", KSEEN)     \
+        JLS_STEP_RARE("a") JLS_STEP_EPILOGUE("")
+#define LOOP2(STORES, KSEEN)                                                                                                      \
+    JLS_STEP_PROLOGUE JLS_STEP_BODY("a", "", "BYTE_0", "1", STORES, "", " offset:255", "", "", "", KSEEN)                          \
+        JLS_STEP_BODY("b", "s_branch L_stepa%=\n", "BYTE_0", "1", STORES, "", " offset:255", "", "", "", KSEEN) JLS_STEP_RARE("a")  \
+            JLS_STEP_RARE("b") JLS_STEP_EPILOGUE("")
+#define NO_STORES "", "1", "", "0"
+
+#define STEPLOOP_NAME_0 "one step per trip, both stores early"
+#define STEPLOOP_TEXT_0 LOOP1(JLS_STEP_STORES_EARLY("ds_write_b8"), JLS_STEP_KSEEN)
+#define STEPLOOP_NAME_1 "one step per trip, sample store late"
+#define STEPLOOP_TEXT_1 LOOP1(JLS_STEP_STORES_LATE("ds_write_b8"), JLS_STEP_KSEEN)
+#define STEPLOOP_NAME_2 "two steps per trip, both stores early"
+#define STEPLOOP_TEXT_2 LOOP2(JLS_STEP_STORES_EARLY("ds_write_b8"), JLS_STEP_KSEEN)
+#define STEPLOOP_NAME_3 "PRODUCT: two steps per trip, sample late"
+#define STEPLOOP_TEXT_3 LOOP2(JLS_STEP_STORES_LATE("ds_write_b8"), JLS_STEP_KSEEN)
+#define STEPLOOP_NAME_4 "product without k_seen"
+#define STEPLOOP_TEXT_4 LOOP2(JLS_STEP_STORES_LATE("ds_write_b8"), "")
+#define STEPLOOP_NAME_5 "product without the two stores"
+#define STEPLOOP_TEXT_5 LOOP2(NO_STORES, JLS_STEP_KSEEN)
+#define STEPLOOP_VARIANTS 6
 
 constexpr uint32_t kRegion = 9744, kRecords = 0, kRing = 2960, kPrep = 3992, kLine = 5568, kLut = 512;
 constexpr int kBurst = 60;
@@ -44,7 +64,7 @@ __device__ int quantize(int d)
         for (int q = sub; q < 366; q += 16)                                                                                       \
         {                                                                                                                         \
             records[2 * q] = 4;                                                                                                   \
-            records[2 * q + 1] = 1;                                                                                               \
+            records[2 * q + 1] = q == 0 ? 64 : 1; /* record 0: run mode, N preset to RESET */                                     \
         }                                                                                                                         \
         uint32_t* ring = reinterpret_cast<uint32_t*>(region + kRing);                                                             \
         uint32_t seed = 12345u + 977u * (blockIdx.x * 16 + wave * 4 + sid);                                                       \
@@ -83,8 +103,8 @@ __device__ int quantize(int d)
                            [un1] "+v"(u_n1), [utb] "+v"(u_tb), [cc] "+v"(u_cc), [u1] "+v"(u1), [k] "+v"(k_last),                   \
                            [kseen] "+v"(k_seen), [qsu] "+v"(qsu8), [win] "+v"(win_now), [cnt] "+s"(count), [fail] "=&s"(fail_m)     \
                          : [ring] "v"(ring_address), [recbase] "v"(records_address), [limitv] "v"(limit_v), [vreset] "v"(reset_v), \
-                           [inl] "s"(in_line_m), [smax] "s"(maxval_s)                                                              \
-                         : CLOBBERS);                                                                                             \
+                           [inl] "s"(in_line_m), [smax] "s"(maxval_s)                                          \
+                         : JLS_STEP_LOOP_CLOBBERS);                                                                                             \
             failed |= fail_m;                                                                                                     \
         }                                                                                                                         \
         const uint64_t t1 = now();                                                                                                \
@@ -96,8 +116,8 @@ __device__ int quantize(int d)
         sink[threadIdx.x] = (uint32_t)a + p + k_seen + qsu8 + win_now + (uint32_t)u_a;                                            \
     }
 
-KERNEL(0) KERNEL(1) KERNEL(2) KERNEL(3) KERNEL(4) KERNEL(5) KERNEL(6) KERNEL(7) KERNEL(8)
-static_assert(STEPLOOP_VARIANTS == 9, "one KERNEL() per variant");
+KERNEL(0) KERNEL(1) KERNEL(2) KERNEL(3) KERNEL(4) KERNEL(5)
+static_assert(STEPLOOP_VARIANTS == 6, "one KERNEL() per variant");
 
 typedef void (*Kernel)(uint64_t*, uint32_t*, int);
 
@@ -105,9 +125,8 @@ int main(int argc, char** argv)
 {
     const int groups = argc > 1 ? atoi(argv[1]) : 256;
     const int repeats = 2000;
-    const Kernel kernels[] = {steploop_0, steploop_1, steploop_2, steploop_3, steploop_4, steploop_5, steploop_6, steploop_7, steploop_8};
-    const char* names[] = {STEPLOOP_NAME_0, STEPLOOP_NAME_1, STEPLOOP_NAME_2, STEPLOOP_NAME_3, STEPLOOP_NAME_4,
-                           STEPLOOP_NAME_5, STEPLOOP_NAME_6, STEPLOOP_NAME_7, STEPLOOP_NAME_8};
+    const Kernel kernels[] = {steploop_0, steploop_1, steploop_2, steploop_3, steploop_4, steploop_5};
+    const char* names[] = {STEPLOOP_NAME_0, STEPLOOP_NAME_1, STEPLOOP_NAME_2, STEPLOOP_NAME_3, STEPLOOP_NAME_4, STEPLOOP_NAME_5};
     uint64_t* d_out;
     uint32_t* d_sink;
     (void)hipMalloc(&d_out, sizeof(uint64_t) * 2 * 4 * groups);
