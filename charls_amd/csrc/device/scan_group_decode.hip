@@ -805,6 +805,8 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 LaneMask fail_m;
                 uint32_t count = steps - 1;
                 const int reset_v = reset, cap_v = cap;
+                const uint32_t run_ctx_address = lds_address(run_ctx);
+                const int escape_base = t.limit - t.qbpp - 2, qbpp_v = t.qbpp; // (an event's escape prefix: escape_base - J)
                 const int maxval_s = (int)uniform((uint32_t)maxval); // (the scans of a wavefront that are inside a line share their sample precision: `usable`)
                 if constexpr (kWide)
                     JLS_STEP_LOOP_ASM_WIDE();

@@ -64,7 +64,8 @@ struct Janitor
     std::mutex guard;
     std::condition_variable wake;
     std::thread thread;
-    bool started{}, stop{};
+    std::atomic<bool> started{false};
+    bool stop{};
     std::atomic<long long> last_activity_ms{0};
     std::atomic<int> calls_running{0};
     std::atomic<uint64_t> releases{0};
@@ -94,7 +95,11 @@ void janitor_loop()
     std::unique_lock<std::mutex> lock(j.guard);
     while (!j.stop)
     {
+#ifdef JLS_TSAN // (gcc's ThreadSanitizer does not intercept the steady-clock wait: coalescer.h)
+        j.wake.wait_until(lock, std::chrono::system_clock::now() + std::chrono::milliseconds(250));
+#else
         j.wake.wait_for(lock, std::chrono::milliseconds(250));
+#endif
         if (j.stop)
             break;
         const long long quiet_ms = knobs::get_or(knobs::kIdleReleaseMs, kIdleReleaseMs);
@@ -116,7 +121,7 @@ void stop_janitor() noexcept
     Janitor& j = janitor();
     {
         std::lock_guard<std::mutex> lock(j.guard);
-        if (!j.started)
+        if (!j.started.load(std::memory_order_relaxed))
             return;
         j.stop = true;
     }
@@ -132,15 +137,15 @@ struct Activity
         Janitor& j = janitor();
         j.calls_running.fetch_add(1);
         j.last_activity_ms.store(steady_ms());
-        if (!j.started) // (racy look; decided under the lock)
+        if (!j.started.load(std::memory_order_acquire))
         {
             std::lock_guard<std::mutex> lock(j.guard);
-            if (!j.started && !j.stop)
+            if (!j.started.load(std::memory_order_relaxed) && !j.stop)
             {
                 try
                 {
                     j.thread = std::thread(janitor_loop);
-                    j.started = true;
+                    j.started.store(true, std::memory_order_release);
                     std::atexit(stop_janitor);
                 }
                 catch (...)

@@ -11,4 +11,6 @@ for lib in "$@"; do
     python tools/decode_sweep.py --frames 1024 --sizes 64,256,1024 --groups -1 --repeat 1 $arg >> "$out" 2>&1
     echo "=== $lib: 4096 frames in flight (64 distinct)" >> "$out"
     python tools/decode_sweep.py --frames 4096 --distinct 64 --sizes 4096 --groups -1 --repeat 1 $arg >> "$out" 2>&1
+    echo "=== $lib: natural image (tulips tiled), 1024 and 4096 frames in flight" >> "$out"
+    python tools/decode_sweep.py --frames 4096 --kind tulips --sizes 1024,4096 --groups -1 --repeat 1 $arg >> "$out" 2>&1
 done

@@ -25,6 +25,7 @@ ap.add_argument("--distinct", type=int, default=0,
                      "torch's synthesis kernels when thousands of them run under it)")
 ap.add_argument("--encode-repeat", type=int, default=0, help="time this many further encodes of the batch (best is printed)")
 ap.add_argument("--lib", default=None, help="another build of the product library (A/B runs of kernel variants)")
+ap.add_argument("--kind", default="gradient", help="gradient (the bench's frames), mixed, hard, zero, or tulips (the reference's natural image tiled, bench.py: data_frames)")
 args = ap.parse_args()
 if args.lib:
     capi.PRODUCT_LIB = os.path.abspath(args.lib)
@@ -68,12 +69,17 @@ class ClockSampler:
 lib = capi.load_product()
 dev = torch.device("cuda:0")
 t0 = time.perf_counter()
-if args.distinct and args.distinct < args.frames:
-    base = synth.frames_torch(args.distinct, args.width, args.height, seed0=2, bits=args.bits, device=dev)
+if args.kind == "tulips":
+    import bench
+    bench.WIDTH, bench.HEIGHT = args.width, args.height
+    frames = torch.empty((args.frames, args.height, args.width), dtype=torch.uint8, device=dev)
+    bench.data_frames(torch, "tulips", args.frames, dev, frames)
+elif args.distinct and args.distinct < args.frames:
+    base = synth.frames_torch(args.distinct, args.width, args.height, seed0=2, bits=args.bits, kind=args.kind, device=dev)
     frames = base.repeat((args.frames + args.distinct - 1) // args.distinct, 1, 1)[:args.frames].contiguous()
     del base
 else:
-    frames = synth.frames_torch(args.frames, args.width, args.height, seed0=2, bits=args.bits, device=dev)
+    frames = synth.frames_torch(args.frames, args.width, args.height, seed0=2, bits=args.bits, kind=args.kind, device=dev)
 torch.cuda.synchronize()
 out = torch.empty_like(frames)
 batch.set_workspace_limit(64 << 30, lib)

@@ -15,11 +15,11 @@
 
 #define LOOP1(STORES, KSEEN)                                                                                                      \
     JLS_STEP_PROLOGUE JLS_STEP_BODY("a", "s_branch L_stepa%=\n", "BYTE_0", "1", STORES, "", " offset:255", "", "", "", KSEEN)     \
-        JLS_STEP_RARE("a") JLS_STEP_EPILOGUE("")
+        JLS_STEP_RARE("a", "ds_read_u8", "1") JLS_STEP_EPILOGUE("")
 #define LOOP2(STORES, KSEEN)                                                                                                      \
     JLS_STEP_PROLOGUE JLS_STEP_BODY("a", "", "BYTE_0", "1", STORES, "", " offset:255", "", "", "", KSEEN)                          \
-        JLS_STEP_BODY("b", "s_branch L_stepa%=\n", "BYTE_0", "1", STORES, "", " offset:255", "", "", "", KSEEN) JLS_STEP_RARE("a")  \
-            JLS_STEP_RARE("b") JLS_STEP_EPILOGUE("")
+        JLS_STEP_BODY("b", "s_branch L_stepa%=\n", "BYTE_0", "1", STORES, "", " offset:255", "", "", "", KSEEN) JLS_STEP_RARE("a", "ds_read_u8", "1")  \
+            JLS_STEP_RARE("b", "ds_read_u8", "1") JLS_STEP_EPILOGUE("")
 #define NO_STORES "", "1", "", "0"
 
 #define STEPLOOP_NAME_0 "one step per trip, both stores early"
@@ -90,6 +90,7 @@ __device__ int quantize(int d)
         uint32_t p = 0, u1 = 0, k_last = 0, k_seen = 0, qsu8 = 0, win_now = 0, where = records_address + 365 * 8;                 \
         const uint32_t limit_v = 23, reset_v = 64;                                                                                \
         const int maxval_s = 255;                                                                                                 \
+        int run_index = 0;                                                                                                        \
         const unsigned long long in_line_m = ~0ull;                                                                               \
         unsigned long long fail_m = 0, failed = 0;                                                                                \
         const uint64_t t0 = now();                                                                                                \
@@ -101,9 +102,11 @@ __device__ int quantize(int d)
             asm volatile(STEPLOOP_TEXT_##V                                                                                        \
                          : [a] "+v"(a), [p] "+v"(p), [lm] "+v"(lm), [pp] "+v"(pp), [where] "+v"(where), [ua] "+v"(u_a),            \
                            [un1] "+v"(u_n1), [utb] "+v"(u_tb), [cc] "+v"(u_cc), [u1] "+v"(u1), [k] "+v"(k_last),                   \
-                           [kseen] "+v"(k_seen), [qsu] "+v"(qsu8), [win] "+v"(win_now), [cnt] "+s"(count), [fail] "=&s"(fail_m)     \
+                           [kseen] "+v"(k_seen), [qsu] "+v"(qsu8), [win] "+v"(win_now), [cnt] "+s"(count), [fail] "=&s"(fail_m),    \
+                           [ri] "+v"(run_index)                                                                                   \
                          : [ring] "v"(ring_address), [recbase] "v"(records_address), [limitv] "v"(limit_v), [vreset] "v"(reset_v), \
-                           [inl] "s"(in_line_m), [smax] "s"(maxval_s)                                          \
+                           [inl] "s"(in_line_m), [smax] "s"(maxval_s), [rctx] "v"(records_address), [esc] "v"(limit_v),           \
+                           [qbpp] "v"(reset_v)                                                                                     \
                          : JLS_STEP_LOOP_CLOBBERS);                                                                                             \
             failed |= fail_m;                                                                                                     \
         }                                                                                                                         \
