@@ -427,24 +427,30 @@ def main():
         # profiles/README.md); they are used only when they were taken for THIS kernel instantiation and batch size
         traffic, traffic_source, issue = None, None, None
         try:
-            pmc_file = next(p for p in (os.path.join(ROOT, "profiles", f"r0{r}_dominant_kernel_pmc.json") for r in (5, 4, 3)) if os.path.exists(p))
+            pmc_file = next(p for p in (os.path.join(ROOT, "profiles", f"r0{r}_dominant_kernel_pmc.json") for r in (6, 5, 4, 3)) if os.path.exists(p))
             with open(pmc_file) as f:
                 tj = json.load(f)
             if tj.get("kernel") == dom_name and int(tj.get("frames", -1)) == frames_n:
                 traffic = int(tj["hbm_bytes_per_frame"] * frames_n)
                 traffic_source = tj.get("source")
             if tj.get("kernel") == dom_name and dom_ms > 0 and int(tj.get("frames", -1)) == frames_n:  # (instructions per sample are those of the launch shape of that many frames)
-                # instruction-issue roofline.  Every wave64 vector instruction of this kernel keeps its SIMD's vector ALU for one
-                # QUAD-cycle (PMC: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU, both in quad-cycles; two wavefronts of the kernel on one
-                # SIMD reach 83 % ALU-busy and take a third longer each: profiles/r05_pmc_decode_valu_busy.txt), so the ceiling is
-                # 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s -- round 3's ruler.  (Round 4 took 2 cycles per
-                # instruction from the guide's "Wave scheduling" paragraph and reported half the fraction.)
+                # instruction-issue roofline.  The ruler is MEASURED (tools/microbench/issue_ceiling.hip, profiles/r06_valu_issue_ceiling.txt):
+                # the decoder's instruction mix issues 0.243 wave64 vector instructions per SIMD-cycle with one wavefront per SIMD
+                # (the launch shape of this kernel), 0.250 with two, 0.336 with four -- the saturated figure a workgroup can reach;
+                # plain two-operand instructions saturate at 0.5, the guide's "2 cycles per wave64 VALU instruction".  `frac` is
+                # against the saturated mix; the guide's figure is given beside it.  (Rounds 3 - 5 changed this ruler every round:
+                # 4, 2, 4 cycles per instruction.)
                 valu = float(tj["valu_wave_instructions_per_sample"]) * frames_n * pixels
-                peak = 1024 * 2.4e9 / 4
+                simd_cycles = 1024 * 2.4e9
+                peak = simd_cycles * 0.336
                 issue = {"bound": "valu_issue", "achieved": round(valu / (dom_ms * 1e-3) / 1e9, 2), "peak": round(peak / 1e9, 1),
                          "unit": "G wave-instructions/s", "frac": round(valu / (dom_ms * 1e-3) / peak, 4),
                          "valu_wave_instructions_per_sample": tj["valu_wave_instructions_per_sample"],
-                         "peak_is": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 vector instruction (profiles/r05_pmc_decode_valu_busy.txt)",
+                         "peak_is": "1024 SIMDs x 2.4 GHz x 0.336 wave64 vector instructions per SIMD-cycle: the decoder's instruction mix "
+                                    "with four wavefronts per SIMD (profiles/r06_valu_issue_ceiling.txt); one wavefront per SIMD -- this "
+                                    "kernel's launch shape -- issues 0.243",
+                         "frac_of_one_wavefront_per_simd": round(valu / (dom_ms * 1e-3) / (simd_cycles * 0.243), 4),
+                         "frac_of_guide_2_cycles_per_instruction": round(valu / (dom_ms * 1e-3) / (simd_cycles * 0.5), 4),
                          "source": tj.get("instruction_source")}
         except (OSError, ValueError, KeyError, StopIteration):
             pass
@@ -779,6 +785,33 @@ def extras(lib, batch, torch, frames, streams, out, enc, dev, mpix, pitch, args)
                                          "shared launches by the library (engine_counters)"}
     except Exception as e:  # noqa: BLE001
         result["threads_abi"] = {"error": repr(e)}
+    # ---- `value` on a natural image: the bench's own batch (all frames in flight) of the reference's test image tiled to the frame
+    # size -- the synthetic frames are the decoder's friendly case (a run event every 80 samples; the natural image: every 9).
+    # Last of the extras: the frames buffer becomes the destination of the decode.
+    try:
+        n = frames.shape[0]
+        batch.release_work_areas(lib)
+        note = data_frames(torch, "tulips", n, dev, out)
+        torch.cuda.synchronize()
+        best_e = best_d = None
+        for _ in range(2):
+            a = time.perf_counter()
+            e = batch.encode_batch(out, bits_per_sample=BITS, streams=streams, lib=lib)
+            torch.cuda.synchronize()
+            b = time.perf_counter()
+            _, errcs, _ = batch.decode_batch(e.streams, e.sizes, frames, lib=lib)
+            torch.cuda.synchronize()
+            c = time.perf_counter()
+            best_e = b - a if best_e is None else min(best_e, b - a)
+            best_d = c - b if best_d is None else min(best_d, c - b)
+        assert (e.errcs == 0).all() and (errcs == 0).all()
+        for f0 in range(0, n, 128):
+            assert torch.equal(frames[f0:f0 + 128], out[f0:f0 + 128]), "natural image: round trip is not lossless"
+        result["value_natural_image"] = {"value": round(n * mpix / (best_e + best_d), 1), "unit": "MPixels/s encode+decode", "frames": n,
+                                         "encode_mpix_s": round(n * mpix / best_e, 1), "decode_mpix_s": round(n * mpix / best_d, 1),
+                                         "jls_bytes_per_frame": int(np.mean(e.sizes.astype(np.float64))), "data": note}
+    except Exception as e:  # noqa: BLE001
+        result["value_natural_image"] = {"error": repr(e)}
     return result
 
 

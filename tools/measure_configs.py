@@ -54,8 +54,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="2,3,5a,5b", help="which configurations to measure")
 ap.add_argument("--frames16", type=int, default=1024)
 ap.add_argument("--rgb-frames", type=int, default=256)
+ap.add_argument("--lib", default=None, help="another build of the product library (A/B runs)")
 args = ap.parse_args()
 only = set(args.only.split(","))
+if args.lib:
+    capi.PRODUCT_LIB = os.path.abspath(args.lib)
 
 
 def rgb_frames(count, size, seed0, bits=8):
