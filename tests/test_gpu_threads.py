@@ -225,6 +225,7 @@ def test_what_the_library_keeps_between_calls_decays(lib, knobs):
     (two seconds by default; the test asks for half a second) -- without anybody calling charls_amd_release_work_areas()."""
     import time
     knobs.set("IDLE_RELEASE_MS", 500)
+    batch.release_work_areas(lib)  # (what earlier tests left in THIS thread's own areas is not the housekeeping thread's business)
     cases = _cases(2, lib)
     before = capi.engine_counters(lib)
     failures, _ = _run_threads(lib, cases, 64, 2)

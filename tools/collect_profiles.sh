@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): the bench line, the rocprofv3 kernel statistics of the same command and the PMC
 # passes that DESIGN.md / bench.py quote.  Everything lands in gpurun_out/<dir>/; tools/summarise_profiles.py turns it
 # into the files committed under profiles/.  The HBM traffic of the encoder is taken at 64 frames (all kernels of the tile
-# pipeline), traffic and instruction counts of the dominant kernel -- since round 5 decode_scans_group<uchar, 16, 1, 4>: four
+# pipeline), traffic and instruction counts of the dominant kernel -- since round 5 decode_scans_group<uchar, 16, 1, 4> (round 6: its step loop in assembly): four
 # scans per wavefront, four wavefronts per workgroup -- with the bench's own 4096 frames (decode is one launch: the counters
 # are per launch).
 set -u

@@ -13,28 +13,39 @@
 
 #include "../../charls_amd/csrc/device/scan_group_step.inc"
 
-#define LOOP1(STORES, KSEEN)                                                                                                      \
-    JLS_STEP_PROLOGUE JLS_STEP_BODY("a", "s_branch L_stepa%=\n", "BYTE_0", "1", STORES, "", " offset:255", "", "", "", KSEEN)     \
+#define WINDOW_FIRST JLS_STEP_ORDER_WINDOW_FIRST
+#define UPDATE_FIRST JLS_STEP_ORDER_UPDATE_FIRST
+#define PREDICTOR_LATE JLS_STEP_ORDER_PREDICTOR_LATE
+// one step per trip: the one copy requests the next entry into its own pair (the predictor has to come before the request)
+#define LOOP1(ORDER, STORES, KSEEN)                                                                                               \
+    JLS_STEP_PROLOGUE JLS_STEP_BODY_X("a", "s_branch L_stepa%=\n", "v118", "v119", "v[118:119]", "BYTE_0", "1",                   \
+                                      ORDER("BYTE_0", "1", "", "v118", "v119"), STORES, "", " offset:255", "", "", "", KSEEN)        \
         JLS_STEP_RARE("a", "ds_read_u8", "1") JLS_STEP_EPILOGUE("")
-#define LOOP2(STORES, KSEEN)                                                                                                      \
-    JLS_STEP_PROLOGUE JLS_STEP_BODY("a", "", "BYTE_0", "1", STORES, "", " offset:255", "", "", "", KSEEN)                          \
-        JLS_STEP_BODY("b", "s_branch L_stepa%=\n", "BYTE_0", "1", STORES, "", " offset:255", "", "", "", KSEEN) JLS_STEP_RARE("a", "ds_read_u8", "1")  \
-            JLS_STEP_RARE("b", "ds_read_u8", "1") JLS_STEP_EPILOGUE("")
+#define LOOP2(ORDER, STORES, KSEEN)                                                                                               \
+    JLS_STEP_PROLOGUE JLS_STEP_BODY_X("a", "", "v118", "v119", "v[106:107]", "BYTE_0", "1", ORDER("BYTE_0", "1", "", "v118", "v119"), \
+                                      STORES, "", " offset:255", "", "", "", KSEEN)                                                 \
+        JLS_STEP_BODY_X("b", "s_branch L_stepa%=\n", "v106", "v107", "v[118:119]", "BYTE_0", "1",                                  \
+                        ORDER("BYTE_0", "1", "", "v106", "v107"), STORES, "", " offset:255", "", "", "", KSEEN)                      \
+            JLS_STEP_RARE("a", "ds_read_u8", "1") JLS_STEP_RARE("b", "ds_read_u8", "1") JLS_STEP_EPILOGUE("")
 #define NO_STORES "", "1", "", "0"
 
 #define STEPLOOP_NAME_0 "one step per trip, both stores early"
-#define STEPLOOP_TEXT_0 LOOP1(JLS_STEP_STORES_EARLY("ds_write_b8"), JLS_STEP_KSEEN)
+#define STEPLOOP_TEXT_0 LOOP1(WINDOW_FIRST, JLS_STEP_STORES_EARLY("ds_write_b8"), JLS_STEP_KSEEN)
 #define STEPLOOP_NAME_1 "one step per trip, sample store late"
-#define STEPLOOP_TEXT_1 LOOP1(JLS_STEP_STORES_LATE("ds_write_b8"), JLS_STEP_KSEEN)
+#define STEPLOOP_TEXT_1 LOOP1(WINDOW_FIRST, JLS_STEP_STORES_LATE("ds_write_b8"), JLS_STEP_KSEEN)
 #define STEPLOOP_NAME_2 "two steps per trip, both stores early"
-#define STEPLOOP_TEXT_2 LOOP2(JLS_STEP_STORES_EARLY("ds_write_b8"), JLS_STEP_KSEEN)
+#define STEPLOOP_TEXT_2 LOOP2(WINDOW_FIRST, JLS_STEP_STORES_EARLY("ds_write_b8"), JLS_STEP_KSEEN)
 #define STEPLOOP_NAME_3 "PRODUCT: two steps per trip, sample late"
-#define STEPLOOP_TEXT_3 LOOP2(JLS_STEP_STORES_LATE("ds_write_b8"), JLS_STEP_KSEEN)
+#define STEPLOOP_TEXT_3 LOOP2(WINDOW_FIRST, JLS_STEP_STORES_LATE("ds_write_b8"), JLS_STEP_KSEEN)
 #define STEPLOOP_NAME_4 "product without k_seen"
-#define STEPLOOP_TEXT_4 LOOP2(JLS_STEP_STORES_LATE("ds_write_b8"), "")
+#define STEPLOOP_TEXT_4 LOOP2(WINDOW_FIRST, JLS_STEP_STORES_LATE("ds_write_b8"), "")
 #define STEPLOOP_NAME_5 "product without the two stores"
-#define STEPLOOP_TEXT_5 LOOP2(NO_STORES, JLS_STEP_KSEEN)
-#define STEPLOOP_VARIANTS 6
+#define STEPLOOP_TEXT_5 LOOP2(WINDOW_FIRST, NO_STORES, JLS_STEP_KSEEN)
+#define STEPLOOP_NAME_6 "A.13 and the record store first"
+#define STEPLOOP_TEXT_6 LOOP2(UPDATE_FIRST, JLS_STEP_STORES_SAMPLE_LATE("ds_write_b8"), JLS_STEP_KSEEN)
+#define STEPLOOP_NAME_7 "predictor behind the record request"
+#define STEPLOOP_TEXT_7 LOOP2(PREDICTOR_LATE, JLS_STEP_STORES_LATE("ds_write_b8"), JLS_STEP_KSEEN)
+#define STEPLOOP_VARIANTS 8
 
 constexpr uint32_t kRegion = 9744, kRecords = 0, kRing = 2960, kPrep = 3992, kLine = 5568, kLut = 512;
 constexpr int kBurst = 60;
@@ -119,8 +130,8 @@ __device__ int quantize(int d)
         sink[threadIdx.x] = (uint32_t)a + p + k_seen + qsu8 + win_now + (uint32_t)u_a;                                            \
     }
 
-KERNEL(0) KERNEL(1) KERNEL(2) KERNEL(3) KERNEL(4) KERNEL(5)
-static_assert(STEPLOOP_VARIANTS == 6, "one KERNEL() per variant");
+KERNEL(0) KERNEL(1) KERNEL(2) KERNEL(3) KERNEL(4) KERNEL(5) KERNEL(6) KERNEL(7)
+static_assert(STEPLOOP_VARIANTS == 8, "one KERNEL() per variant");
 
 typedef void (*Kernel)(uint64_t*, uint32_t*, int);
 
@@ -128,8 +139,9 @@ int main(int argc, char** argv)
 {
     const int groups = argc > 1 ? atoi(argv[1]) : 256;
     const int repeats = 2000;
-    const Kernel kernels[] = {steploop_0, steploop_1, steploop_2, steploop_3, steploop_4, steploop_5};
-    const char* names[] = {STEPLOOP_NAME_0, STEPLOOP_NAME_1, STEPLOOP_NAME_2, STEPLOOP_NAME_3, STEPLOOP_NAME_4, STEPLOOP_NAME_5};
+    const Kernel kernels[] = {steploop_0, steploop_1, steploop_2, steploop_3, steploop_4, steploop_5, steploop_6, steploop_7};
+    const char* names[] = {STEPLOOP_NAME_0, STEPLOOP_NAME_1, STEPLOOP_NAME_2, STEPLOOP_NAME_3, STEPLOOP_NAME_4, STEPLOOP_NAME_5, STEPLOOP_NAME_6,
+                           STEPLOOP_NAME_7};
     uint64_t* d_out;
     uint32_t* d_sink;
     (void)hipMalloc(&d_out, sizeof(uint64_t) * 2 * 4 * groups);
