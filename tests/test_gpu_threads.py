@@ -235,7 +235,8 @@ def test_what_the_library_keeps_between_calls_decays(lib, knobs):
     deadline = time.time() + 5.0
     while time.time() < deadline:
         c = capi.engine_counters(lib)
-        if batch.work_area_bytes(lib) <= (1 << 30) and c["idle_pool_bytes"] == 0 and c["deferred_free_bytes"] == 0:
+        if (batch.work_area_bytes(lib) <= (1 << 30) and c["idle_pool_bytes"] == 0 and c["deferred_free_bytes"] == 0
+                and c["idle_releases"] > before["idle_releases"]):  # (counted when the release is through, a moment after the bytes are gone)
             break
         time.sleep(0.1)
     c = capi.engine_counters(lib)
