@@ -40,6 +40,7 @@ enum Knob : int
     kDecodeWorkgroupWaves,  // CHARLS_AMD_DECODE_WORKGROUP_WAVES: wavefronts per workgroup of the group decoder (1, 4, 8; with DECODE_GROUP)
     kTrace,                 // CHARLS_AMD_TRACE: one line on stderr per coding call of the host-pointer ABI (where its time went)
     kIdleReleaseMs,         // CHARLS_AMD_IDLE_RELEASE_MS: what the host-pointer ABI keeps between calls is freed after this long without a call (0 = kept)
+    kNearDecodePixels,      // CHARLS_AMD_NEAR_DECODE_PIXELS: 1 = near-lossless single-component / line-interleaved scans on the pixel kernels (until round 6)
     kCount
 };
 
@@ -50,7 +51,7 @@ inline const char* name_of(int k)
     static const char* const names[kCount] = {"DECODE_GROUP", "EXACT_DECODER", "SEQUENTIAL_INTERVALS", "BLOCK_STUFFING", "SPEC_STUFFING",
                                               "JOB_EVENTS", "WARM_EVENTS", "RUN_JOB_EVENTS", "RUN_WARM_EVENTS", "RARE_WARM_EVENTS",
                                               "TILE_SAMPLES", "PIXEL_MODE", "SPEC_CHUNK", "SPEC_WARM", "BATCH_ROUNDS", "COALESCE",
-                                              "COALESCE_WAIT_US", "DECODE_WAVES_PER_CU", "DECODE_WORKGROUP_WAVES", "TRACE", "IDLE_RELEASE_MS"};
+                                              "COALESCE_WAIT_US", "DECODE_WAVES_PER_CU", "DECODE_WORKGROUP_WAVES", "TRACE", "IDLE_RELEASE_MS", "NEAR_DECODE_PIXELS"};
     return k >= 0 && k < kCount ? names[k] : nullptr;
 }
 

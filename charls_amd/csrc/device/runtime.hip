@@ -368,8 +368,13 @@ GroupPlan decode_group_plan(const ScanDesc& d, uint32_t count)
     if (d.bits_per_sample > 8 && d.t3 > grp::kMaxTableT3)
         return {0, 1};
     const bool one_line = group_lines(d) == 1; // (the W > 1 instantiations exist for single-component scans)
-    const int forced = static_cast<int>(knobs::get_or(knobs::kDecodeGroup, -1));
-    const int forced_waves = static_cast<int>(knobs::get_or(knobs::kDecodeWorkgroupWaves, -1));
+    int forced = static_cast<int>(knobs::get_or(knobs::kDecodeGroup, -1));
+    int forced_waves = static_cast<int>(knobs::get_or(knobs::kDecodeWorkgroupWaves, -1));
+    if (d.near_lossless != 0)
+    { // (the near-lossless instantiations: 8 / 16 / 32 lanes, workgroups of one or four wavefronts)
+        forced = forced == 4 ? -1 : forced;
+        forced_waves = forced_waves == 8 ? -1 : forced_waves;
+    }
     if (forced == 0)
         return {0, 1};
     if (forced == 4 || forced == 8 || forced == 16 || forced == 32)
@@ -418,8 +423,12 @@ constexpr uint32_t kPixelWaves = 512; // wavefronts a launch of the pixel kernel
 int pixel_group_lanes(const ScanDesc& d, uint32_t count)
 {
     const bool by_sample = d.interleave_mode == 2 && d.components >= 2 && d.components <= 4;
-    const bool near_planar = d.interleave_mode == 0 && d.components == 1 && d.near_lossless != 0;
-    const bool near_by_line = d.interleave_mode == 1 && d.components >= 2 && d.components <= 4 && d.near_lossless != 0;
+    // (near-lossless single-component scans and line-interleaved scans of three components have decode_scans_group<.., kNear>
+    // since round 6; NEAR_DECODE_PIXELS=1 brings them back here: the A/B)
+    const bool near_here = knobs::get_or(knobs::kNearDecodePixels, 0) != 0;
+    const bool near_planar = d.interleave_mode == 0 && d.components == 1 && d.near_lossless != 0 && near_here;
+    const bool near_by_line = d.interleave_mode == 1 && d.components >= 2 && d.components <= 4 && d.near_lossless != 0 &&
+                              (near_here || d.components != 3);
     if ((!by_sample && !near_planar && !near_by_line) || !wave_decode_eligible(d))
         return 0;
     if (by_sample && d.bits_per_sample > 8 && ((reinterpret_cast<uintptr_t>(d.pixels) | d.pixel_stride) & 1u) != 0)
@@ -450,7 +459,10 @@ bool fast_decode_eligible(const ScanDesc& d)
 {
     const bool planar = d.interleave_mode == 0 && d.components == 1;
     const bool by_line = d.interleave_mode == 1 && d.components >= 2 && d.components <= 4; // group kernel only
-    return wave_decode_eligible(d) && d.near_lossless == 0 && (planar || by_line) &&
+    // (near-lossless scans: the group kernel only)
+    const bool near_ok = d.near_lossless == 0 ||
+                         (knobs::get_or(knobs::kNearDecodePixels, 0) == 0 && (planar || d.components == 3) && decode_group_lanes(d, 1) != 0);
+    return wave_decode_eligible(d) && near_ok && (planar || by_line) &&
            ((planar && fast_decode_lds(d) <= kMaxDynamicLds) || decode_group_lanes(d, 1) != 0) &&
            knobs::get_or(knobs::kExactDecoder, 0) == 0;
 }
@@ -700,14 +712,15 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
         // (a workgroup of several wavefronts is to have its CU to itself -- one wavefront per SIMD: it asks for more than half
         // of the CU's LDS whatever its scans need)
         const size_t lds = wg_waves > 1 ? std::max<size_t>(group_lds_bytes(proto, per_group), kGroupDecodeLds / 2 + 1024) : group_lds_bytes(proto, per_group);
-#define JLS_LAUNCH_GROUP_NW(S, G, N, W)                                                                                  \
-    do                                                                                                                   \
-    {                                                                                                                    \
-        if (lds > kMaxDynamicLds) /* more than the default limit of dynamic LDS per workgroup */                          \
-            hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_scans_group<S, G, N, W>),                \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
-        hipLaunchKernelGGL((decode_scans_group<S, G, N, W>), grid, dim3(64 * W), lds, stream, d_descs, d_results, count); \
+#define JLS_LAUNCH_GROUP_NWK(S, G, N, W, K)                                                                                  \
+    do                                                                                                                       \
+    {                                                                                                                        \
+        if (lds > kMaxDynamicLds) /* more than the default limit of dynamic LDS per workgroup */                              \
+            hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_scans_group<S, G, N, W, K>),                 \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));               \
+        hipLaunchKernelGGL((decode_scans_group<S, G, N, W, K>), grid, dim3(64 * W), lds, stream, d_descs, d_results, count); \
     } while (0)
+#define JLS_LAUNCH_GROUP_NW(S, G, N, W) JLS_LAUNCH_GROUP_NWK(S, G, N, W, false)
 #define JLS_LAUNCH_GROUP_N(S, G, N) JLS_LAUNCH_GROUP_NW(S, G, N, 1)
 #define JLS_LAUNCH_GROUP(S, G)                                                                                           \
     do                                                                                                                   \
@@ -719,7 +732,38 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
         else JLS_LAUNCH_GROUP_N(S, G, 4);                                                                                \
     } while (0)
         const bool wide = proto.bits_per_sample > 8;
-        if (wg_waves == 4 && group == 16)
+        if (proto.near_lossless != 0)
+        { // near-lossless: single-component scans or three lines per pixel row (fast_decode_eligible), 8 / 16 / 32 lanes
+            const uint32_t nl = group_lines(proto);
+#define JLS_LAUNCH_NEAR(S, G, W)                                                                                         \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        if (nl == 1) JLS_LAUNCH_GROUP_NWK(S, G, 1, W, true);                                                             \
+        else JLS_LAUNCH_GROUP_NWK(S, G, 3, 1, true);                                                                     \
+    } while (0)
+            if (wg_waves == 4 && group == 16)
+            {
+                if (wide) JLS_LAUNCH_NEAR(uint16_t, 16, 4); else JLS_LAUNCH_NEAR(uint8_t, 16, 4);
+            }
+            else if (wg_waves == 4 && group == 32)
+            {
+                if (wide) JLS_LAUNCH_NEAR(uint16_t, 32, 4); else JLS_LAUNCH_NEAR(uint8_t, 32, 4);
+            }
+            else if (group == 8)
+            {
+                if (wide) JLS_LAUNCH_NEAR(uint16_t, 8, 1); else JLS_LAUNCH_NEAR(uint8_t, 8, 1);
+            }
+            else if (group == 16)
+            {
+                if (wide) JLS_LAUNCH_NEAR(uint16_t, 16, 1); else JLS_LAUNCH_NEAR(uint8_t, 16, 1);
+            }
+            else
+            {
+                if (wide) JLS_LAUNCH_NEAR(uint16_t, 32, 1); else JLS_LAUNCH_NEAR(uint8_t, 32, 1);
+            }
+#undef JLS_LAUNCH_NEAR
+        }
+        else if (wg_waves == 4 && group == 16)
         {
             if (wide) JLS_LAUNCH_GROUP_NW(uint16_t, 16, 1, 4); else JLS_LAUNCH_GROUP_NW(uint8_t, 16, 1, 4);
         }
@@ -752,6 +796,7 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
             if (wide) JLS_LAUNCH_GROUP(uint16_t, 32); else JLS_LAUNCH_GROUP(uint8_t, 32);
         }
 #undef JLS_LAUNCH_GROUP_NW
+#undef JLS_LAUNCH_GROUP_NWK
 #undef JLS_LAUNCH_GROUP
 #undef JLS_LAUNCH_GROUP_N
     }

@@ -450,7 +450,12 @@ JLS_DEV int take_unary(const uint32_t* ring, uint32_t& p, int most)
 // take the launch's tail with them -- rocprofv3 counted wavefronts resident for 77 % of such a launch on average while the
 // shader engines were busy for 94 % of it, at an unchanged 2.39 GHz (profiles/r05_pmc_decode_effective_clock.txt; what
 // rounds 3 and 4 read as "the chip clocks down when every SIMD runs this kernel").
-template <typename S, int G, int NL = 1, int W = 1>
+//
+// kNear: near-lossless scans (NEAR > 0; src/default_traits.hpp).  The chain is the same -- the line holds RECONSTRUCTED samples,
+// which is what the decoder works on anyway -- and what differs is local: gradients within +-NEAR quantise to 0 (the table), no
+// error correction, Rx = Px + sign Errval (2 NEAR + 1) brought back into range and clamped instead of reduced modulo 2^bpp, B
+// moves by Errval (2 NEAR + 1), and a run is interrupted into the context of |Ra - Rb| <= NEAR.
+template <typename S, int G, int NL = 1, int W = 1, bool kNear = false>
 __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __restrict__ descs, ScanResult* __restrict__ results,
                                                              uint32_t count)
 {
@@ -461,6 +466,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
     static_assert(W == 1 || W == 2 || W == 4 || W == 8, "wavefronts per workgroup");
     constexpr int kScansPerWave = 64 / G;
     constexpr bool kWide = sizeof(S) > 1;
+    constexpr bool kChecked = kWide || kNear; // codes may exceed the 32-bit window, |Errval| 65535, A 2^24: looked at
     JLS_DYNAMIC_LDS(smem);
     const int lane = W == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63u);
     const int wave = W == 1 ? 0 : (int)(threadIdx.x >> 6);
@@ -488,7 +494,8 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
     const uint32_t line_stride = line_stride_bytes<S>(width) / (uint32_t)sizeof(S); // samples from one component's line to the next
     S* line = line0; // the line being decoded
     const int cap = kWide ? t_first.t3 : 255;
-    const bool own_table = t.t1 == t_first.t1 && t.t2 == t_first.t2 && t.t3 == t_first.t3 && t.bpp == t_first.bpp;
+    const bool own_table = t.t1 == t_first.t1 && t.t2 == t_first.t2 && t.t3 == t_first.t3 && t.bpp == t_first.bpp && t.near == t_first.near &&
+                           (t.near != 0) == kNear;
 
     {
         const Record fresh{(uint32_t)initial_a(t), 1u};
@@ -540,6 +547,23 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
     uint32_t a_seen = 0; // OR of every updated A (samples wider than 8 bits): 2^24 overflow test
     const int maxval = t.maxval, reset = t.reset;
     const uint32_t limit_m = (uint32_t)(t.limit - t.qbpp - 1);
+    // the longest unary prefix the out-of-line readers follow: LIMIT - qbpp - 1 zeros announce the escape code -- 47 for lossless
+    // 16-bit samples, more when NEAR makes qbpp small (LIMIT = 64) -- and anything longer is left to the exact decoder
+    constexpr int kLongestPrefix = kNear ? 62 : 47;
+    const int near = kNear ? t.near : 0, near_step = 2 * near + 1, range_step = t.range * near_step;
+    // the sample a run is interrupted by (src/scan_decoder_impl.hpp:300-337): in the context of RItype 1 -- Ra and Rb within
+    // NEAR of each other -- Ra + Errval, else Rb + Errval sign(Rb - Ra); reconstructed as every sample is
+    auto same_level = [&](int ra, int rb) -> bool { return kNear ? abs_difference((uint32_t)ra, (uint32_t)rb) <= (uint32_t)near : ra == rb; };
+    auto reconstructed = [&](int predicted, int e) -> int {
+        if (!kNear)
+            return (predicted + e) & maxval;
+        int v = mad24(e, near_step, predicted);
+        v += v < -near ? range_step : (v > maxval + near ? -range_step : 0);
+        return med3(v, 0, maxval);
+    };
+    auto interruption_sample = [&](bool which, int ra, int rb, int e) -> int {
+        return which ? reconstructed(ra, e) : reconstructed(rb, (rb - ra) < 0 ? -e : e);
+    };
     const uint32_t records_address = lds_address(records);
     const uint32_t prep_address = lds_address(region + L::kPrep);
     // What the steps need of the previous line is prepared ahead of them (prepare): the entries of samples up to prepped_end
@@ -711,7 +735,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 JLS_PATH(5); // steps
                 // -- bookkeeping of the previous step, part 1: registers (Ra was set when the sample was decoded)
                 p += u1 + k_last;
-                if (kWide)
+                if (kChecked)
                     mm_seen |= t_mm;
                 lm += lm_step; // now the slot of the previous step's sample; the slots behind it still hold the previous line
                 pp += pp_step;
@@ -761,7 +785,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 // k = max(0, ceil((bits(A) - bits(N)) / 2^23)).  A < 2^24 and N <= 255 convert exactly.
                 const int k_raw = ((int)(float_bits(rec.x) - float_bits((uint32_t)n)) + 0x7FFFFF) >> 23;
                 const int k = k_raw < 0 ? 0 : k_raw;
-                if (kWide)
+                if (kChecked)
                     ok_m &= lanes_where(u + (uint32_t)k < 32u);
                 // Golomb code -> mapped error -> Errval (src/scan_decoder_core.hpp:38-69): prefix and remainder are ONE 64-bit
                 // number {u : the window beyond the prefix}, and the mapped error its upper half after a shift by k
@@ -771,19 +795,28 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 // (17 bits of it: a mapped error beyond 131071 is invalid data and examined after the loop; what a lane that cannot
                 // decode its sample -- an empty window: u = 0xFFFFFFFF -- computes here must not look like an overflow of A)
                 const int half = (int)(((uint32_t)mm >> 1) & 0x1FFFFu);
-                const int odd = (mm ^ (int)((uint32_t)((k - 1) & (2 * bb + n - 1)) >> 31)) & 1;
+                const int odd = kNear ? (mm & 1) : ((mm ^ (int)((uint32_t)((k - 1) & (2 * bb + n - 1)) >> 31)) & 1);
                 const int e = half ^ -odd;
                 const int px = med3(mad24(cc, sgn, px0), 0, maxval); // plus the bias C
-                a = mad24(e, sgn, px) & maxval; // every lane: a lane that could not decode reloads its Ra after the loop
+                int e_scaled = e; // what B moves by
+                if (kNear)
+                { // Rx = Px + sign Errval (2 NEAR + 1), brought back into -NEAR .. MAXVAL + NEAR, clamped (src/default_traits.hpp:172-184)
+                    e_scaled = mad24(e, near_step, 0);
+                    int v = mad24(e, sgn < 0 ? -near_step : near_step, px);
+                    v += v < -near ? range_step : (v > maxval + near ? -range_step : 0);
+                    a = med3(v, 0, maxval);
+                }
+                else
+                    a = mad24(e, sgn, px) & maxval; // every lane: a lane that could not decode reloads its Ra after the loop
                 k_last = (uint32_t)k;
                 t_mm = (uint32_t)mm;
                 // first half of A.12 / A.13 for this step (the rest is the next iteration's): A += |Errval|, B += Errval, and
                 // the halving of A, B and N once N has reached RESET
                 u_a = (int)rec.x + half + odd;
-                if (kWide)
+                if (kChecked)
                     a_seen_now |= (uint32_t)u_a;
                 u_n1 = n + 1;
-                u_tb = bb + e;
+                u_tb = bb + e_scaled;
                 u_cc = cc;
                 if (n == reset)
                 { // once per RESET samples of a context
@@ -808,11 +841,19 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 const uint32_t run_ctx_address = lds_address(run_ctx);
                 const int escape_base = t.limit - t.qbpp - 2, qbpp_v = t.qbpp; // (an event's escape prefix: escape_base - J)
                 const int maxval_s = (int)uniform((uint32_t)maxval); // (the scans of a wavefront that are inside a line share their sample precision: `usable`)
-                if constexpr (kWide)
+                [[maybe_unused]] const int near_s = (int)uniform((uint32_t)near), rstep_s = (int)uniform((uint32_t)range_step);
+                if constexpr (kNear && kWide)
+                    JLS_STEP_LOOP_ASM_WIDE_NEAR();
+                else if constexpr (kNear)
+                    JLS_STEP_LOOP_ASM_NARROW_NEAR();
+                else if constexpr (kWide)
                     JLS_STEP_LOOP_ASM_WIDE();
                 else
                     JLS_STEP_LOOP_ASM_NARROW();
                 (void)cap_v;
+                (void)run_ctx_address;
+                (void)escape_base;
+                (void)qbpp_v;
                 ok_m = in_line_m & ~fail_m;
             }
 #endif
@@ -835,7 +876,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                     lm += kSz;
                     lds_store<S>(lm, (S)a);
                     p += u1 + k_last;
-                    if (kWide)
+                    if (kChecked)
                         mm_seen |= t_mm;
                 }
                 JLS_LOCKSTEP();
@@ -848,7 +889,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 a_seen |= a_seen_now;
                 // the reference raises invalid_data for k >= 16 and for |Errval| > 65535
                 // (src/regular_mode_context.hpp:99-111, src/scan_decoder_core.hpp:38-69)
-                if (k_seen >= (kWide ? 16u : 10u) || (kWide && mm_seen > 131071u))
+                if (k_seen >= (kChecked ? 16u : 10u) || (kChecked && mm_seen > 131071u))
                     retry = true;
             }
             else
@@ -877,7 +918,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
             const uint32_t w2 = j >= 31 ? 0u : win_stopped >> (1 + j); // the bits behind the run-length code
             const uint32_t avail = 31u - (uint32_t)j;
             const int b_at = (int)entry_stopped.y; // prev[i]
-            const int which = a == b_at ? 1 : 0;
+            const int which = same_level(a, b_at) ? 1 : 0;
             RunCtx ctx = which ? ctx1 : ctx0;
             const uint32_t goal = (uint32_t)ctx.a + (uint32_t)(ctx.n >> 1) * (uint32_t)ctx.ritype;
             int k = 0;
@@ -900,7 +941,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 const int em = (int)zeros < escape_from ? ((int)zeros << k) + (int)tail : (int)tail + 1;
                 const int e = run_error_value(ctx, em + ctx.ritype, k);
                 run_update(ctx, e, em, t.reset);
-                const int x = which ? ((a + e) & t.maxval) : ((b_at + e * ((b_at - a) < 0 ? -1 : 1)) & t.maxval);
+                const int x = interruption_sample(which != 0, a, b_at, e);
                 JLS_LOCKSTEP();
                 if (in_run)
                 {
@@ -943,7 +984,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
             const uint32_t at = inside ? i + run : i;
             JLS_LOCKSTEP();
             const int b_at = (int)line[at]; // prev[at]: not overwritten yet
-            const int which = a == b_at ? 1 : 0;
+            const int which = same_level(a, b_at) ? 1 : 0;
             RunCtx ctx = which ? ctx1 : ctx0;
             const uint32_t goal = (uint32_t)ctx.a + (uint32_t)(ctx.n >> 1) * (uint32_t)ctx.ritype;
             int k = 0;
@@ -966,7 +1007,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 const int em = (int)zeros < escape_from ? ((int)zeros << k) + (int)tail : (int)tail + 1;
                 const int e = run_error_value(ctx, em + ctx.ritype, k);
                 run_update(ctx, e, em, t.reset);
-                const int x = which ? ((a + e) & t.maxval) : ((b_at + e * ((b_at - a) < 0 ? -1 : 1)) & t.maxval);
+                const int x = interruption_sample(which != 0, a, b_at, e);
                 JLS_LOCKSTEP();
                 {
                     uint32_t r = (uint32_t)sub;
@@ -1074,7 +1115,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
             const uint32_t at = i + run;
             JLS_LOCKSTEP();
             const int b_at = (int)line[interrupted ? at : 0]; // prev[at]: not overwritten yet
-            const int which = a == b_at ? 1 : 0;
+            const int which = same_level(a, b_at) ? 1 : 0;
             RunCtx ctx = run_ctx[which];
             int x = 0;
             if (interrupted)
@@ -1111,8 +1152,8 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                     em = u < limit - t.qbpp - 1 ? (u << k) + (int)tail : (int)tail + 1;
                 }
                 else if (k <= 24)
-                { // a prefix of 32 zeros or more: the general reader (anything beyond 47: let the exact decoder classify it)
-                    u = take_unary(ring, p, 47);
+                { // a prefix of 32 zeros or more: the general reader (anything beyond kLongestPrefix: let the exact decoder classify it)
+                    u = take_unary(ring, p, kLongestPrefix);
                     if (u >= 0)
                     {
                         if (u < limit - t.qbpp - 1)
@@ -1130,7 +1171,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 {
                     const int e = run_error_value(ctx, em + ctx.ritype, k);
                     run_update(ctx, e, em, t.reset);
-                    x = which ? ((a + e) & t.maxval) : ((b_at + e * ((b_at - a) < 0 ? -1 : 1)) & t.maxval);
+                    x = interruption_sample(which != 0, a, b_at, e);
                 }
             }
             JLS_LOCKSTEP();
@@ -1164,7 +1205,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
             bool good = slow && k < 16;
             if (good)
             {
-                const int u = take_unary(ring, p, 47);
+                const int u = take_unary(ring, p, kLongestPrefix);
                 if (u < 0)
                     good = false;
                 else
@@ -1176,10 +1217,10 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                         mm = (int)take_bits(ring, p, t.qbpp) + 1;
                     int e = unmap_error(mm);
                     if (k == 0)
-                        e ^= error_correction(ctx, 0);
-                    if (!regular_update(ctx, e, 0, t.reset))
+                        e ^= error_correction(ctx, near);
+                    if (!regular_update(ctx, e, near, t.reset))
                         good = false;
-                    x = (px + ((e ^ s) - s)) & t.maxval;
+                    x = reconstructed(px, (e ^ s) - s);
                 }
             }
             JLS_LOCKSTEP();
@@ -1197,7 +1238,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
             JLS_LOCKSTEP();
         }
 
-        if (kWide && a_seen >= (1u << 24))
+        if (kChecked && a_seen >= (1u << 24))
             retry = true;
         if (retry)
             phase = kDone;

@@ -132,7 +132,33 @@ int emu_decode_scans_group(const jls::ScanDesc* descs, jls::ScanResult* results,
         else if (nl == 3) EMU_GROUP_N(S, G, 3);             \
         else EMU_GROUP_N(S, G, 4);                          \
     } while (0)
-    if (group == 4)
+    if (d.near_lossless != 0)
+    { // decode_scans_group<S, G, NL, 1, true>: the product's near-lossless instantiations (runtime.hip: launch_decode_plain)
+#define EMU_GROUP_NEAR(S, G)                                                                                                              \
+    do                                                                                                                                    \
+    {                                                                                                                                     \
+        if (nl == 1) emu::launch(jls::decode_scans_group<S, G, 1, 1, true>, grid, dim3(64), lds, descs, results, (uint32_t)count);        \
+        else emu::launch(jls::decode_scans_group<S, G, 3, 1, true>, grid, dim3(64), lds, descs, results, (uint32_t)count);                \
+    } while (0)
+        if (nl != 1 && nl != 3)
+            return -1;
+        if (group == 8)
+        {
+            if (wide) EMU_GROUP_NEAR(uint16_t, 8); else EMU_GROUP_NEAR(uint8_t, 8);
+        }
+        else if (group == 16)
+        {
+            if (wide) EMU_GROUP_NEAR(uint16_t, 16); else EMU_GROUP_NEAR(uint8_t, 16);
+        }
+        else if (group == 32)
+        {
+            if (wide) EMU_GROUP_NEAR(uint16_t, 32); else EMU_GROUP_NEAR(uint8_t, 32);
+        }
+        else
+            return -1;
+#undef EMU_GROUP_NEAR
+    }
+    else if (group == 4)
     {
         if (wide) EMU_GROUP(uint16_t, 4); else EMU_GROUP(uint8_t, 4);
     }
@@ -166,7 +192,21 @@ int emu_decode_scans_group_waves(const jls::ScanDesc* descs, jls::ScanResult* re
     const size_t lds = wide ? jls::grp::workgroup_lds_bytes<uint16_t>(d.width, per_group, 1) : jls::grp::workgroup_lds_bytes<uint8_t>(d.width, per_group, 1);
     const dim3 grid((count + per_group - 1) / per_group);
 #define EMU_GROUP_W(S, G, W) emu::launch(jls::decode_scans_group<S, G, 1, W>, grid, dim3(64 * W), lds, descs, results, (uint32_t)count)
-    if (group == 16 && waves == 4)
+#define EMU_GROUP_W_NEAR(S, G) emu::launch(jls::decode_scans_group<S, G, 1, 4, true>, grid, dim3(64 * 4), lds, descs, results, (uint32_t)count)
+    if (d.near_lossless != 0)
+    {
+        if (waves != 4)
+            return -1;
+        if (group == 16)
+        {
+            if (wide) EMU_GROUP_W_NEAR(uint16_t, 16); else EMU_GROUP_W_NEAR(uint8_t, 16);
+        }
+        else
+        {
+            if (wide) EMU_GROUP_W_NEAR(uint16_t, 32); else EMU_GROUP_W_NEAR(uint8_t, 32);
+        }
+    }
+    else if (group == 16 && waves == 4)
     {
         if (wide) EMU_GROUP_W(uint16_t, 16, 4); else EMU_GROUP_W(uint8_t, 16, 4);
     }
@@ -183,6 +223,7 @@ int emu_decode_scans_group_waves(const jls::ScanDesc* descs, jls::ScanResult* re
         if (wide) EMU_GROUP_W(uint16_t, 32, 8); else EMU_GROUP_W(uint8_t, 32, 8);
     }
 #undef EMU_GROUP_W
+#undef EMU_GROUP_W_NEAR
     return 0;
 }
 

@@ -29,7 +29,12 @@ int emu_profile_decode_group(const jls::ScanDesc* descs, jls::ScanResult* result
     const size_t lds = jls::grp::workgroup_lds_bytes<uint8_t>(d.width, per_wave, 1);
     const dim3 grid((count + per_wave - 1) / per_wave);
     std::memset(jls_path_counts, 0, sizeof jls_path_counts);
-#define EMU_PROFILE(G) emu::launch(jls::decode_scans_group<uint8_t, G, 1>, grid, dim3(64), lds, descs, results, (uint32_t)count)
+#define EMU_PROFILE(G)                                                                                                                   \
+    do                                                                                                                                   \
+    {                                                                                                                                    \
+        if (d.near_lossless != 0) emu::launch(jls::decode_scans_group<uint8_t, G, 1, 1, true>, grid, dim3(64), lds, descs, results, (uint32_t)count); \
+        else emu::launch(jls::decode_scans_group<uint8_t, G, 1>, grid, dim3(64), lds, descs, results, (uint32_t)count);                  \
+    } while (0)
     if (group == 8)
         EMU_PROFILE(8);
     else if (group == 16)

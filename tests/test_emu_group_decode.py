@@ -297,6 +297,169 @@ def test_group_decoder_random_parameters(chunk):
     assert done >= 15
 
 
+# ---- decode_scans_group<.., kNear = true>: near-lossless single-component and line-interleaved scans (round 6) ----------
+NEAR_GROUPS = [8, 16, 32]
+
+
+def _near_descs(frames, w, h, bits, near, comps=1, ilv=0, preset=None):
+    """(descs, outs, wants, ends, keep) of one launch: the oracle's stream of every frame and what the oracle decodes from it."""
+    bps = 1 if bits <= 8 else 2
+    keep, descs, outs, wants, ends = [], [], [], [], []
+    for img in frames:
+        jls = ob.encode(img, width=w, height=h, bits_per_sample=bits, component_count=comps, interleave_mode=ilv, near_lossless=near,
+                        preset=preset)
+        cont = jls_container.parse(jls)
+        pc = jls_container.validated_pc(cont.pc, cont.bits, near)
+        pix = np.zeros(w * h * comps * bps, dtype=np.uint8)
+        scan = cont.scans[0]
+        descs.append(emu_bind.make_desc(w, h, comps, ilv, bits, near, 0, pc, 0, pix, w * comps * bps, _stream_copy(jls, scan.data_start), keep))
+        outs.append(pix)
+        wants.append(ob.decode(jls)[1].tobytes())
+        ends.append(scan.data_end - scan.data_start)
+    return descs, outs, wants, ends, keep
+
+
+@pytest.mark.parametrize("group,w,h,bits,near,kind,count", _rotating(NEAR_GROUPS, [
+    (64, 20, 8, 2, "mixed", 7), (300, 5, 8, 1, "noise", 5), (33, 9, 16, 3, "mixed", 5), (41, 7, 12, 7, "hard", 3), (1, 9, 8, 2, "mixed", 3),
+    (520, 3, 8, 40, "noise", 5), (70, 6, 8, 3, "zero", 4), (130, 10, 8, 2, "gradient", 6), (90, 8, 16, 100, "mixed", 3), (77, 6, 8, 127, "hard", 3),
+    (200, 4, 4, 1, "noise", 4), (150, 9, 8, 5, "smooth", 5)]))
+def test_group_decoder_near_lossless_batches(group, w, h, bits, near, kind, count):
+    """Near-lossless single-component frames, `count` different ones per launch: reconstruction, runs interrupted into the context
+    of |Ra - Rb| <= NEAR, small qbpp (long limited-length codes) -- the oracle's reconstruction, no scan handed to the exact decoder."""
+    L = emu_bind.lib()
+    frames = [synth.frame_numpy(w, h, seed=17 * f + bits + near, bits=bits, kind=kind) for f in range(count)]
+    descs, outs, wants, ends, keep = _near_descs(frames, w, h, bits, near)
+    res = _launch(L, descs, group)
+    for f in range(count):
+        assert (res[f].errc, res[f].flags, res[f].bytes) == (0, 0, ends[f]), f
+        assert outs[f].tobytes() == wants[f], f
+
+
+@pytest.mark.parametrize("group,w,h,bits,near,kind,count", _rotating(NEAR_GROUPS, [(40, 12, 8, 2, "mixed", 5), (300, 4, 8, 3, "noise", 3),
+                                                                                    (33, 7, 16, 5, "mixed", 3), (64, 6, 8, 1, "gradient", 3)]))
+def test_group_decoder_near_lossless_line_interleaved(group, w, h, bits, near, kind, count):
+    """Three lines per pixel row (ILV_LINE) of near-lossless components on the ONE set of contexts."""
+    L = emu_bind.lib()
+    frames = [synth.frame_numpy(w, h, seed=19 * f + bits + near, bits=bits, components=3, kind=kind, interleaved=True) for f in range(count)]
+    descs, outs, wants, ends, keep = _near_descs(frames, w, h, bits, near, comps=3, ilv=1)
+    res = _launch(L, descs, group)
+    for f in range(count):
+        assert (res[f].errc, res[f].flags, res[f].bytes) == (0, 0, ends[f]), f
+        assert outs[f].tobytes() == wants[f], f
+
+
+@pytest.mark.parametrize("group,bits,near,count", [(16, 8, 2, 21), (32, 12, 3, 9)])
+def test_group_decoder_near_lossless_with_four_wavefronts_per_workgroup(group, bits, near, count):
+    L = emu_bind.lib()
+    w, h = 70, 8
+    frames = [synth.frame_numpy(w, h, seed=23 * f + bits, bits=bits, kind="mixed") for f in range(count)]
+    descs, outs, wants, ends, keep = _near_descs(frames, w, h, bits, near)
+    arr = (emu_bind.ScanDesc * count)(*descs)
+    res = (emu_bind.ScanResult * count)()
+    assert L.emu_decode_scans_group_waves(arr, res, count, group, 4) == 0
+    for f in range(count):
+        assert (res[f].errc, res[f].flags, res[f].bytes) == (0, 0, ends[f]), f
+        assert outs[f].tobytes() == wants[f], f
+
+
+def test_group_decoder_near_lossless_kernel_leaves_lossless_scans_alone_and_the_other_way_round():
+    """The instantiation is chosen from the launch's first scan: a scan of the other kind reports kFastRetry."""
+    L = emu_bind.lib()
+    w, h = 40, 10
+    imgs = [synth.frame_numpy(w, h, seed=f + 5, bits=8, kind="mixed") for f in range(3)]
+    for nears in ([2, 0, 2], [0, 2, 0]):
+        keep, descs, outs, wants = [], [], [], []
+        for img, near in zip(imgs, nears):
+            d, o, wnt, _, k = _near_descs([img], w, h, 8, near)
+            descs += d; outs += o; wants += wnt; keep += k
+        res = _launch(L, descs, 8)
+        for f, near in enumerate(nears):
+            if near == nears[0]:
+                assert (res[f].errc, res[f].flags) == (0, 0) and outs[f].tobytes() == wants[f], (nears, f)
+            else:
+                assert (res[f].errc, res[f].flags) == (0, 4), (nears, f)
+
+
+@pytest.mark.parametrize("bits,near,kind", [(8, 2, "mixed"), (8, 9, "zero"), (16, 3, "mixed"), (12, 1, "hard")])
+def test_group_dispatch_on_mutated_near_lossless_scan_data_matches_the_oracle(bits, near, kind):
+    L = emu_bind.lib()
+    w, h = 48, 12
+    img = synth.frame_numpy(w, h, seed=bits + near, bits=bits, kind=kind)
+    base = ob.encode(img, width=w, height=h, bits_per_sample=bits, near_lossless=near)
+    cont = jls_container.parse(base)
+    scan = cont.scans[0]
+    pc = jls_container.validated_pc(cont.pc, cont.bits, near)
+    bps = 1 if bits <= 8 else 2
+    rng = np.random.default_rng(bits * 17 + near)
+    keep, descs, outs, wants = [], [], [], []
+    for k in range(36):
+        b = bytearray(base)
+        how = int(rng.integers(0, 5))
+        i = int(rng.integers(scan.data_start, len(b) - 2))
+        if how == 0:
+            b[i] ^= 1 << int(rng.integers(0, 8))
+        elif how == 1:
+            b[i] = int(rng.choice([0x00, 0xFF, 0x7F, 0x80]))
+        elif how == 2:
+            del b[i:i + int(rng.integers(1, 4))]
+        elif how == 3:
+            b[i:i] = bytes([int(rng.choice([0x00, 0xFF, 0x55]))])
+        data = bytes(b)
+        try:
+            wants.append((0, ob.decode(data)[1].tobytes()))
+        except ob.OracleError as e:
+            wants.append((e.errc, None))
+        pix = np.zeros(w * h * bps, dtype=np.uint8)
+        outs.append(pix)
+        descs.append(emu_bind.make_desc(w, h, 1, 0, bits, near, 0, pc, 0, pix, w * bps, _stream_copy(data, scan.data_start), keep))
+    res = _launch(L, descs, 16)
+    retry = [k for k in range(len(descs)) if res[k].flags & 4]
+    for k in retry:
+        one = (emu_bind.ScanResult * 1)()
+        L.emu_decode_scans_wave((emu_bind.ScanDesc * 1)(descs[k]), one, 1)
+        res[k].errc, res[k].flags, res[k].bytes = one[0].errc, one[0].flags, one[0].bytes
+    for k, want in enumerate(wants):
+        if want[0] == 0:
+            assert res[k].errc == 0 and outs[k].tobytes() == want[1], k
+        else:
+            assert res[k].errc == want[0], (k, res[k].errc, want[0])
+
+
+def test_group_decoder_near_lossless_random_parameters():
+    """Random near-lossless single-component parameter sets (bits 2..16, NEAR up to its maximum, custom thresholds / RESET)."""
+    from test_oracle_vs_reference import _image
+    L = emu_bind.lib()
+    rng = np.random.default_rng(977)
+    done = 0
+    for it in range(50):
+        bits = int(rng.integers(2, 17))
+        w, h = int(rng.choice([1, 2, 5, 17, 64, 65, 130])), int(rng.choice([1, 2, 3, 8, 21]))
+        maxval = (1 << bits) - 1
+        near = int(rng.integers(1, min(255, maxval // 2) + 1))
+        if rng.random() < 0.5:
+            near = min(near, int(rng.integers(1, 8)))
+        kind = str(rng.choice(["rand", "smooth", "gradient", "mixed", "zero", "hard"]))
+        preset = None
+        if rng.random() < 0.3:
+            t1 = int(rng.integers(near + 1, maxval + 1))
+            t2 = int(rng.integers(t1, maxval + 1))
+            t3 = int(rng.integers(t2, maxval + 1))
+            preset = (0, t1, t2, t3, int(rng.integers(3, max(255, maxval) + 1)))
+        pc = jls_container.validated_pc(preset or (0,) * 5, bits, near)
+        if not _group_eligible(bits, pc):
+            continue
+        count = int(rng.integers(1, 6))
+        frames = [np.ascontiguousarray(_image(rng, w, h, bits, 1, 0, kind, it + f)) for f in range(count)]
+        descs, outs, wants, ends, keep = _near_descs(frames, w, h, bits, near, preset=preset)
+        group = int(rng.choice(NEAR_GROUPS))
+        res = _launch(L, descs, group)
+        for f in range(count):
+            tag = (it, f, bits, near, w, h, kind, preset, group)
+            assert (res[f].errc, res[f].flags) == (0, 0) and outs[f].tobytes() == wants[f], tag
+        done += 1
+    assert done >= 20
+
+
 # ---- scan_group_pixels.hip: sample-interleaved scans (2..4 components per pixel), lossless and near-lossless ----------
 PIXEL_CASES = [c for c in common.cases() if c["errc"] == 0 and "file" in c and c["interleave_mode"] == 2 and
                c["width"] * c["height"] <= 128 * 128]

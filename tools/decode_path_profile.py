@@ -28,6 +28,7 @@ ap.add_argument("--width", type=int, default=4096)
 ap.add_argument("--lines", type=int, default=24)
 ap.add_argument("--group", type=int, default=8)
 ap.add_argument("--kind", default="gradient")
+ap.add_argument("--near", type=int, default=0, help="NEAR of the scans (decode_scans_group<.., kNear = true>)")
 args = ap.parse_args()
 
 L = emu_bind.profile_lib()
@@ -41,11 +42,13 @@ for f in range(count):
         img = np.ascontiguousarray(np.tile(band, (1, (args.width + 511) // 512))[:, :args.width])
     else:
         img = synth.frame_numpy(args.width, args.lines, seed=1000 + f, bits=8, kind=args.kind)
-    jls = ob.encode(img, width=args.width, height=args.lines, bits_per_sample=8)
+    jls = ob.encode(img, width=args.width, height=args.lines, bits_per_sample=8, near_lossless=args.near)
     cont = jls_container.parse(jls)
-    pc = jls_container.validated_pc(cont.pc, cont.bits, 0)
+    pc = jls_container.validated_pc(cont.pc, cont.bits, args.near)
+    if args.near:
+        img = ob.decode(jls)[1].reshape(img.shape)  # what a decoder has to produce
     pix = np.zeros(args.width * args.lines, dtype=np.uint8)
-    descs.append(emu_bind.make_desc(args.width, args.lines, 1, 0, 8, 0, 0, pc, 0, pix, args.width,
+    descs.append(emu_bind.make_desc(args.width, args.lines, 1, 0, 8, args.near, 0, pc, 0, pix, args.width,
                                     _stream_copy(jls, cont.scans[0].data_start), keep))
     outs.append(pix)
     imgs.append(img)
