@@ -56,8 +56,8 @@ struct Layout
 {
     static constexpr uint32_t kLutBytes = sizeof(S) == 1 ? 512 : 2 * kMaxTableT3 + 2; // quantised gradient + 4 for -cap .. cap
     static constexpr uint32_t kRecords = 0;                        // 365 x 8 B (+ an unused slot)
-    static constexpr uint32_t kRun = 2928;                         // 2 x RunCtx
-    static constexpr uint32_t kRing = kRun + 32;                   // kRingWords + 2 words
+    static constexpr uint32_t kRun = 2928;                         // 2 x RunCtx, then what the step loop's run service needs of its call (16 B)
+    static constexpr uint32_t kRing = kRun + 48;                   // kRingWords + 2 words
     static constexpr uint32_t kPrep = kRing + kRingWords * 4 + 8;  // kPrepSlots x 8 B: what a step needs of the previous line
     static constexpr uint32_t kLine = kPrep + kPrepSlots * 8 + 24 + 16 - sizeof(S);
     static_assert(kPrep % 8 == 0 && (kLine + sizeof(S)) % 16 == 0, "alignment of the prepared entries and of sample 1 of the line");
@@ -837,11 +837,15 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
             {
                 LaneMask fail_m;
                 uint32_t count = steps - 1;
-                const int reset_v = reset, cap_v = cap;
+                const int cap_v = cap;
                 const uint32_t run_ctx_address = lds_address(run_ctx);
-                const int escape_base = t.limit - t.qbpp - 2, qbpp_v = t.qbpp; // (an event's escape prefix: escape_base - J)
+                // (an event's escape prefix: escape_base - J; RESET <= 255: the records keep N in a byte)
+                const uint32_t cfg_v = (uint32_t)(t.limit - t.qbpp - 2) | ((uint32_t)t.qbpp << 8) | ((uint32_t)reset << 16);
                 const int maxval_s = (int)uniform((uint32_t)maxval); // (the scans of a wavefront that are inside a line share their sample precision: `usable`)
-                [[maybe_unused]] const int near_s = (int)uniform((uint32_t)near), rstep_s = (int)uniform((uint32_t)range_step);
+                // what the loop's run service needs of this call: the entry of the call's first sample and the samples left in
+                // its line (the count of steps is a count of samples per scan: scan_group_step.inc)
+                lds_store<uint64_t>(run_ctx_address + 32u, ((uint64_t)rest_of_line << 32) | (uint64_t)(pp + 8u));
+                [[maybe_unused]] const int near_range_s = (int)uniform((uint32_t)near | ((uint32_t)range_step << 8));
                 if constexpr (kNear && kWide)
                     JLS_STEP_LOOP_ASM_WIDE_NEAR();
                 else if constexpr (kNear)
@@ -851,9 +855,6 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 else
                     JLS_STEP_LOOP_ASM_NARROW();
                 (void)cap_v;
-                (void)run_ctx_address;
-                (void)escape_base;
-                (void)qbpp_v;
                 ok_m = in_line_m & ~fail_m;
             }
 #endif
@@ -910,8 +911,13 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
         // (the lane consumed nothing in its last step) and Rb = the sample above the interruption sample.  What is left to
         // fetch is the run context (both are read, ahead of knowing which).  The general handler below takes every other
         // case, and all of them when the codes of one lane do not fit its window.
+#if defined(JLS_EMULATED) || defined(JLS_CXX_STEP_LOOP)
+        constexpr bool kEmptyRunsLeaveTheLoop = true;
+#else
+        constexpr bool kEmptyRunsLeaveTheLoop = false; // (the assembly loop serves them; what it leaves is rarely one: the handler below)
+#endif
         bool empty_runs = false;
-        if (__any(in_run))
+        if (kEmptyRunsLeaveTheLoop && __any(in_run))
         {
             const RunCtx ctx0 = run_ctx[0], ctx1 = run_ctx[1];
             const int j = run_j(run_index);

@@ -397,3 +397,54 @@ def test_planar_batch_decode_modes_and_damage(torch, knobs, bits, comps, near, r
     # the reference decodes the frame with the comment to the same pixels
     _, want = ob.decode(bytes(bad[3, :int(sizes[3])]))
     assert out_a[3].cpu().numpy().tobytes() == want.tobytes()
+
+
+def _runs_frames(torch, count, w, h, bits, seed, longest):
+    """Piecewise-constant lines with a little noise on some segments: run mode every few samples, runs of 0 .. `longest` samples,
+    RUNindex moving up and down -- what the step loop's run service (scan_group_step.inc: JLS_STEP_RARE) lives on."""
+    rng = np.random.default_rng(seed)
+    maxval = (1 << bits) - 1
+    frames = np.zeros((count, h, w), dtype=np.uint16 if bits > 8 else np.uint8)
+    for f in range(count):
+        for y in range(h):
+            x = 0
+            level = int(rng.integers(0, maxval + 1))
+            while x < w:
+                n = int(rng.integers(1, longest + 2))
+                if rng.random() < 0.5:
+                    level = int(np.clip(level + rng.integers(-maxval // 8 - 1, maxval // 8 + 2), 0, maxval))
+                seg = np.full(min(n, w - x), level, dtype=np.int64)
+                if rng.random() < 0.3:
+                    seg = np.clip(seg + rng.integers(-3, 4, size=seg.size), 0, maxval)
+                frames[f, y, x:x + seg.size] = seg
+                x += seg.size
+        if f % 3 == 2 and h > 1:  # every third frame: lines that repeat the line above (runs in the context of RItype 1)
+            frames[f, 1::2] = frames[f, 0:-1:2][:frames[f, 1::2].shape[0]]
+    t = torch.from_numpy(frames.view(np.int16) if bits > 8 else frames).to("cuda:0")
+    return t, frames
+
+
+@pytest.mark.parametrize("group", [8, 16, 32])
+@pytest.mark.parametrize("bits,near,w,h,longest", [(8, 0, 257, 24, 6), (8, 0, 64, 40, 40), (8, 2, 300, 16, 9), (8, 0, 5, 30, 3), (12, 0, 130, 20, 12),
+                                                    (16, 3, 96, 18, 5), (8, 1, 1000, 6, 20), (8, 0, 4096, 3, 17)])
+def test_run_service_of_the_step_loop_against_the_exact_decoder(torch, knobs, group, bits, near, w, h, longest):
+    """The assembly step loop serves short runs itself (a run of at most G samples that is interrupted inside its line, with its
+    codes inside the 32-bit window): the CPU harness runs the C++ rendering, which does not -- so this path is pinned here, on
+    frames made of short runs, for every lanes-per-scan setting, lossless and near-lossless, against the exact decoder
+    (decode_scans_wave: the reference's reader) and the source."""
+    count = 2 * (64 // group) + 1
+    frames, host = _runs_frames(torch, count, w, h, bits, seed=group + bits + near + w, longest=longest)
+    enc = batch.encode_batch(frames, bits_per_sample=bits, near_lossless=near)
+    assert (enc.errcs == 0).all()
+    knobs.set("DECODE_GROUP", group)
+    before = capi.engine_counters().get("exact_retry_scans", 0)
+    out = torch.zeros_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+    assert (errcs == 0).all()
+    assert capi.engine_counters().get("exact_retry_scans", 0) == before, "a valid stream was handed to the exact decoder"
+    knobs.set("EXACT_DECODER", 1)
+    exact = torch.zeros_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, exact)
+    assert (errcs == 0).all() and torch.equal(out, exact)
+    got = out.cpu().numpy().view(host.dtype).astype(np.int64)
+    assert np.abs(got - host.astype(np.int64)).max() <= near  # tolerance = NEAR, per ISO 14495-1 (0: lossless)
