@@ -730,6 +730,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
             const uint32_t lm_step = in_line ? kSz : 0u;
             const uint32_t pp_step = in_line ? 8u : 0u;
             uint64_t ticker = 1ull << (steps - 1); // one-hot step counter, 1 <= steps <= kStepsPerLoop
+            const uint32_t pp_first = pp + 8u;     // the entry of the call's first sample
             do
             {
                 JLS_PATH(5); // steps
@@ -825,6 +826,85 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                     u_tb >>= 1;
                 }
                 k_seen |= (uint32_t)k; // of every lane: a lane that cannot decode still looked at a real context
+                // -- run mode inside the loop (the rare path of the assembly: scan_group_step.inc, JLS_STEP_RARE): when the lanes that
+                // stopped are all in run mode, a run of at most G samples that is interrupted inside its line, with RUNindex <= 16 behind
+                // its complete blocks and all its bits inside this step's window, is served here; its lane then looks like one that
+                // decoded a regular sample at the end of the run.  The count of steps is a count of SAMPLES per scan -- the entries
+                // prepared for the call reach 63 ahead and a line ends: a run that would take its scan beyond either is not served,
+                // and the count shrinks to what the scan that is furthest ahead may still take.
+                {
+                    const LaneMask run_m = in_line_m & lanes_where(qsu8 == 2912u);
+                    const LaneMask unusual_m = in_line_m & ~(lanes_where(u < limit_v) & (kChecked ? lanes_where(u + (uint32_t)k < 32u) : ~0ull));
+                    if (run_m != 0 && unusual_m == 0)
+                    {
+                        const bool mine = lane_of(run_m);
+                        const RunCtx ctx0 = run_ctx[0], ctx1 = run_ctx[1];
+                        const int ra = (int)lds_load<S>(lm);
+                        const uint32_t ones = lowest_one(~win); // complete blocks of the run-length code
+                        const uint32_t ri2 = (uint32_t)run_index + ones;
+                        bool fits = mine && ones <= 16u && ri2 <= 16u;
+                        const uint32_t j = fits ? ri2 >> 2 : 0u; // J[RUNindex] = RUNindex >> 2 up to 16
+                        const uint32_t blocks = fits ? ((4u + (ri2 & 3u)) << j) - ((4u + ((uint32_t)run_index & 3u)) << ((uint32_t)run_index >> 2)) : 0u;
+                        const uint32_t run = blocks + field(fits ? win >> (ones + 1u) : 0u, (int)j);
+                        const uint32_t used = fits ? ones + 1u + j : 0u; // bits of the run-length code (<= 21)
+                        const uint32_t taken = ((pp - pp_first) >> 3) + run + 1u; // samples of this call with the event
+                        const uint32_t budget = rest_of_line < (uint32_t)kStepsPerLoop ? rest_of_line : (uint32_t)kStepsPerLoop;
+                        fits = fits && run <= (uint32_t)G && taken <= budget;
+                        const int rb = (int)lds_load<S>(lm + ((fits ? run : 0u) + 1u) * kSz); // the sample above the interruption sample
+                        const int which = same_level(ra, rb) ? 1 : 0;
+                        RunCtx ctx = which ? ctx1 : ctx0;
+                        const uint32_t goal = (uint32_t)ctx.a + (uint32_t)(ctx.n >> 1) * (uint32_t)ctx.ritype;
+                        int kr = 0;
+                        if (goal > (uint32_t)ctx.n)
+                        {
+                            kr = (int)leading_zeros((uint32_t)ctx.n) - (int)leading_zeros(goal);
+                            kr += (((uint64_t)(uint32_t)ctx.n << kr) < goal) ? 1 : 0;
+                        }
+                        const uint32_t w3 = win >> used; // the bits behind the run-length code
+                        const uint32_t zeros = lowest_one(w3);
+                        const int escape_from = t.limit - (int)j - 1 - t.qbpp - 1;
+                        const int tail_bits = (int)zeros < escape_from ? kr : t.qbpp;
+                        const uint32_t event_bits = used + zeros + 1u + (uint32_t)tail_bits;
+                        fits = fits && kr <= 24 && zeros < 32u && event_bits <= 32u;
+                        const LaneMask served_m = lanes_where(fits);
+                        if (served_m != 0)
+                        {
+                            JLS_PATH(16); // run services inside the step loop
+                            const uint32_t tail = field(fits ? w3 >> ((zeros + 1u) & 31u) : 0u, fits ? tail_bits : 0);
+                            const int em = (int)zeros < escape_from ? ((int)zeros << kr) + (int)tail : (int)tail + 1;
+                            const int er = run_error_value(ctx, em + ctx.ritype, kr);
+                            run_update(ctx, er, em, t.reset);
+                            const int x = interruption_sample(which != 0, ra, rb, er);
+                            JLS_LOCKSTEP();
+                            if (fits)
+                            {
+                                if ((uint32_t)sub < run)
+                                    lds_store<S>(lm + ((uint32_t)sub + 1u) * kSz, (S)ra); // the lanes of the scan fill its run
+                                run_ctx[which] = ctx;
+                                a = x;
+                                u1 = event_bits;
+                                k_last = 0;
+                                t_mm = 0;
+                                where = records_address + 365u * 8u; // (its "context update" goes to the unused record)
+                                run_index = ri2 > 0 ? (int)ri2 - 1 : 0;
+                                lm += run * kSz;
+                                pp += run * 8u;
+                            }
+                            JLS_LOCKSTEP();
+                            ok_m |= served_m;
+                            // the count of steps left: no more than any served scan may still take
+                            const uint32_t may_take = fits ? budget - taken : ~0u;
+                            uint32_t left = 63u - (uint32_t)__builtin_clzll(ticker);
+                            for (LaneMask m = served_m; m != 0;)
+                            {
+                                const uint32_t v = value_of_lowest_lane(m, may_take);
+                                left = v < left ? v : left;
+                                m &= ~lanes_where(may_take == v);
+                            }
+                            ticker = 1ull << left;
+                        }
+                    }
+                }
                 // one exit: a one-hot counter that an event clears
                 ticker = tick(ticker, in_line_m, ok_m);
             } while (ticker != 0);
@@ -906,70 +986,15 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
         const bool slow = stopped && qs8 != 0 && !retry;
 
         // ---- run mode: reference src/scan_decoder_impl.hpp:264-337, src/scan_decoder_core.hpp:72-100
-        // Three run events in four are a run of length 0 -- the single bit 0 (and J zero bits) -- followed by its interruption
-        // sample, and everything such an event needs is in the registers its lane left the step loop with: the bit window
-        // (the lane consumed nothing in its last step) and Rb = the sample above the interruption sample.  What is left to
-        // fetch is the run context (both are read, ahead of knowing which).  The general handler below takes every other
-        // case, and all of them when the codes of one lane do not fit its window.
-#if defined(JLS_EMULATED) || defined(JLS_CXX_STEP_LOOP)
-        constexpr bool kEmptyRunsLeaveTheLoop = true;
-#else
-        constexpr bool kEmptyRunsLeaveTheLoop = false; // (the assembly loop serves them; what it leaves is rarely one: the handler below)
-#endif
-        bool empty_runs = false;
-        if (kEmptyRunsLeaveTheLoop && __any(in_run))
-        {
-            const RunCtx ctx0 = run_ctx[0], ctx1 = run_ctx[1];
-            const int j = run_j(run_index);
-            const uint32_t w2 = j >= 31 ? 0u : win_stopped >> (1 + j); // the bits behind the run-length code
-            const uint32_t avail = 31u - (uint32_t)j;
-            const int b_at = (int)entry_stopped.y; // prev[i]
-            const int which = same_level(a, b_at) ? 1 : 0;
-            RunCtx ctx = which ? ctx1 : ctx0;
-            const uint32_t goal = (uint32_t)ctx.a + (uint32_t)(ctx.n >> 1) * (uint32_t)ctx.ritype;
-            int k = 0;
-            if (goal > (uint32_t)ctx.n)
-            {
-                k = (int)leading_zeros((uint32_t)ctx.n) - (int)leading_zeros(goal);
-                k += (((uint64_t)(uint32_t)ctx.n << k) < goal) ? 1 : 0;
-            }
-            const uint32_t zeros = lowest_one(w2);
-            const int escape_from = t.limit - j - 1 - t.qbpp - 1;
-            const int tail_bits = (int)zeros < escape_from ? k : t.qbpp;
-            const uint32_t code_bits = zeros + 1u + (uint32_t)tail_bits;
-            const bool fits = (win_stopped & 1u) == 0 && field(win_stopped >> 1, j) == 0 && k <= 24 && zeros < 32u && code_bits <= avail &&
-                              i <= width;
-            empty_runs = __all(!in_run || fits);
-            if (empty_runs)
-            {
-                JLS_PATH(13); // run handlers with nothing but runs of length 0
-                const uint32_t tail = field(w2 >> ((zeros + 1u) & 31u), tail_bits);
-                const int em = (int)zeros < escape_from ? ((int)zeros << k) + (int)tail : (int)tail + 1;
-                const int e = run_error_value(ctx, em + ctx.ritype, k);
-                run_update(ctx, e, em, t.reset);
-                const int x = interruption_sample(which != 0, a, b_at, e);
-                JLS_LOCKSTEP();
-                if (in_run)
-                {
-                    run_ctx[which] = ctx;
-                    line[i] = (S)x;
-                    a = x;
-                    if (run_index > 0)
-                        --run_index;
-                    ++i;
-                    p += 1u + (uint32_t)j + code_bits;
-                    rc_over = b_at; // prev[i - 1] of the next sample, should it have no entry yet
-                }
-                JLS_LOCKSTEP();
-            }
-        }
+        // (what the step loop's own run service does not take; the handler for runs of length 0 that stood here from round 3 on --
+        // out of the registers the lane left the loop with -- has nothing left to do: those runs are served inside the loop)
         // A run of any length that is interrupted inside its line, with codes that fit 64 bits of the stream: ONE request for the
         // bits (three ring words), both run contexts read ahead of knowing which, the length of the run from the number of
         // leading ones in closed form (run_prefix) instead of bit by bit, and one dependent LDS trip -- the sample above the
         // interruption sample.  What does not fit -- a run that reaches the end of its line, RUNindex beyond the table, a code
         // longer than the window -- takes the handler below, bit by bit (round 3's).
         bool windowed_runs = false;
-        if (!empty_runs && __any(in_run))
+        if (__any(in_run))
         {
             const uint32_t remaining = width - (i - 1);
             const uint32_t wi = (p >> 5) & (kRingWords - 1);
@@ -1039,7 +1064,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 JLS_LOCKSTEP();
             }
         }
-        if (!empty_runs && !windowed_runs && __any(in_run))
+        if (!windowed_runs && __any(in_run))
         {
             JLS_PATH(6); // run handler
             const uint32_t remaining = width - (i - 1);

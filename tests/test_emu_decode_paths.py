@@ -16,7 +16,7 @@ import oracle_bind as ob
 from charls_amd import synth
 from test_emu_serial_kernels import _stream_copy
 
-ROUNDS, REFILLS, STEPS, GENERAL_RUNS, BYTEWISE, DELETE_TRIPS, EMPTY_RUNS, PREPARES, WINDOWED_RUNS = 0, 1, 5, 6, 11, 12, 13, 14, 15
+ROUNDS, REFILLS, STEP_LOOPS, STEPS, GENERAL_RUNS, BYTEWISE, DELETE_TRIPS, PREPARES, WINDOWED_RUNS, SERVED_IN_LOOP = 0, 1, 3, 5, 6, 11, 12, 14, 15, 16
 
 
 def _decode(frames, width, height, group):
@@ -53,17 +53,21 @@ def test_noise_streams_are_unstuffed_by_the_128_bit_refill(group):
     assert c[BYTEWISE] < c[REFILLS]
 
 
-def test_empty_runs_take_the_register_only_handler():
-    """The bench's frames: most run events are runs of length 0, and those do not enter the handlers for longer runs; runs that
-    are interrupted inside their line come out of one 64-bit window (round 6), not bit by bit.  (On the GPU the step loop serves
-    the empty runs itself; the CPU harness runs the C++ rendering, where they leave the loop for this handler.)"""
+def test_short_runs_are_served_inside_the_step_loop():
+    """The bench's frames and a natural image: nearly every run event -- runs of length 0 first of all -- is served by the step
+    loop itself (round 6), so that a wavefront enters the loop once per ~ 50 samples instead of once per event; what leaves the
+    loop comes out of one 64-bit window, and the bit-by-bit handler is for runs to the end of a line."""
     w, h = 1024, 6
     frames = [synth.frame_numpy(w, h, seed=1000 + f, bits=8, kind="gradient") for f in range(8)]
     c = _decode(frames, w, h, 8)
     assert c[STEPS] > 0 and c[ROUNDS] > 0
-    assert c[EMPTY_RUNS] > c[WINDOWED_RUNS] > 0
-    assert c[GENERAL_RUNS] <= c[WINDOWED_RUNS] // 8, "the bit-by-bit handler is for runs to the end of a line and codes beyond the window"
+    assert c[SERVED_IN_LOOP] > 8 * (c[WINDOWED_RUNS] + c[GENERAL_RUNS]) and c[SERVED_IN_LOOP] > 0
+    assert c[STEPS] > 20 * c[STEP_LOOPS], "a wavefront leaves the loop for events the loop should serve"
     assert 0 < c[PREPARES] <= c[ROUNDS]
+    tile, _ = common.read_pnm("tulips-gray-8bit-512-512.pgm")
+    frames = [np.ascontiguousarray(np.roll(tile, 31 * f, axis=1)[40 * f:40 * f + 8]) for f in range(4)]
+    c = _decode(frames, 512, 8, 16)
+    assert c[SERVED_IN_LOOP] > 8 * (c[WINDOWED_RUNS] + c[GENERAL_RUNS])
 
 
 def test_flat_frames_never_take_it():
@@ -71,11 +75,11 @@ def test_flat_frames_never_take_it():
     case the windowed handler leaves to the bit-by-bit one."""
     w, h = 200, 9
     c = _decode([np.zeros((h, w), dtype=np.uint8) for _ in range(2)], w, h, 32)
-    assert c[EMPTY_RUNS] == 0 and c[WINDOWED_RUNS] == 0 and c[GENERAL_RUNS] > 0
+    assert c[SERVED_IN_LOOP] == 0 and c[WINDOWED_RUNS] == 0 and c[GENERAL_RUNS] > 0
 
 
 def test_the_path_profile_tool_runs():
     out = subprocess.run([sys.executable, os.path.join(common.ROOT, "tools", "decode_path_profile.py"), "--width", "256", "--lines", "4",
                           "--group", "16"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "fast handler of empty runs" in out.stdout and "refills" in out.stdout
+    assert "run services inside the step loop" in out.stdout and "refills" in out.stdout

@@ -20,8 +20,8 @@ from test_emu_serial_kernels import _stream_copy  # noqa: E402
 
 NAMES = ["rounds", "refills", "line starts", "step loops", "trips of the step-count loop", "steps", "general run handler",
          "run-length code bits", "trips of the run fill", "unusual codes", "line ends", "refills byte by byte",
-         "trips of the refill's delete loop", "fast handler of empty runs", "calls of prepare (64 entries of the previous line)",
-         "run handler out of one 64-bit window"]
+         "trips of the refill's delete loop", "(retired: handler of empty runs)", "calls of prepare (64 entries of the previous line)",
+         "run handler out of one 64-bit window", "run services inside the step loop"]
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--width", type=int, default=4096)

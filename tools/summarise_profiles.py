@@ -13,7 +13,7 @@ DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 PMC_FRAMES = 64
 # the instantiation of the headline decoder that the bench's 4096-frame launch uses (runtime.hip: decode_group_plan)
-DOMINANT = os.environ.get("CHARLS_AMD_DOMINANT_INSTANTIATION", "<unsigned char, 16, 1, 4>")
+DOMINANT = os.environ.get("CHARLS_AMD_DOMINANT_INSTANTIATION", "<unsigned char, 16, 1, 4, false>")
 DOMINANT_KNOBS = "CHARLS_AMD_DECODE_GROUP=16 CHARLS_AMD_DECODE_WORKGROUP_WAVES=4"
 
 
