@@ -402,12 +402,17 @@ GroupPlan decode_group_plan(const ScanDesc& d, uint32_t count)
         if (group_lds_bytes(d, per_wave) > kGroupDecodeLds)
             break;
         fallback = lanes;
-        if ((count + per_wave - 1) / per_wave <= waves_per_cu * cus)
-            return {lanes, 1};
-        // four wavefronts per CU as ONE workgroup (it must be the only one its CU can hold: more than half of the LDS)
+        const uint32_t waves = (count + per_wave - 1) / per_wave;
+        if (waves <= cus)
+            return {lanes, 1}; // a CU per wavefront
+        // four wavefronts per CU as ONE workgroup (it must be the only one its CU can hold: more than half of the LDS): ahead of
+        // two one-wavefront workgroups per CU since round 6 -- 1024 frames at 32 lanes: 2.91 s against 3.03 s
+        // (profiles/r06_decode_launch_shapes.txt)
         const uint32_t per_group = 4 * per_wave;
         if (allow_workgroups && lanes >= 16 && group_lds_bytes(d, per_group) <= kGroupDecodeLds && (count + per_group - 1) / per_group <= cus)
             return {lanes, 4};
+        if (waves <= waves_per_cu * cus)
+            return {lanes, 1};
     }
     return {fallback, 1};
 }
