@@ -643,6 +643,29 @@ def data_sweep(lib, batch, torch, frames, streams, out, dev, mpix, count):
     return rows
 
 
+def near_lossless_row(lib, batch, torch, frames, streams, out, mpix, count, near=2):
+    """the same frames coded near-lossless (NEAR = 2).  Both directions are ONE chain per frame here (the
+    encoder predicts from reconstructed samples: scan_group_encode.hip; the decoder is decode_scans_group<.., kNear>), so the
+    figure is the number of frames in flight times a stream's rate.  One pass; every sample within NEAR of its source."""
+    src, dst = frames[:count], out[:count]
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    e = batch.encode_batch(src, bits_per_sample=BITS, near_lossless=near, streams=streams[:count], lib=lib)
+    torch.cuda.synchronize()
+    b = time.perf_counter()
+    _, errcs, _ = batch.decode_batch(e.streams, e.sizes, dst, lib=lib)
+    torch.cuda.synchronize()
+    c = time.perf_counter()
+    assert (e.errcs == 0).all() and (errcs == 0).all()
+    worst = 0
+    for f0 in range(0, count, 64):
+        worst = max(worst, int((dst[f0:f0 + 64].to(torch.int16) - src[f0:f0 + 64].to(torch.int16)).abs().max().item()))
+    assert worst <= near, f"near-lossless round trip: a sample is {worst} away from its source (NEAR = {near})"
+    return {"near": near, "frames": count, "encode_mpix_s": round(count * mpix / (b - a), 1), "decode_mpix_s": round(count * mpix / (c - b), 1),
+            "jls_bytes_per_frame": int(np.mean(e.sizes.astype(np.float64))), "largest_difference": worst,
+            "note": "one pass; |decoded - source| <= NEAR checked for every sample (tolerance = NEAR, ISO 14495-1); not part of `value`"}
+
+
 def extras(lib, batch, torch, frames, streams, out, enc, dev, mpix, pitch, args):
     """Context for `value` (never part of it): throughput against the number of frames in flight, one frame through the
     host-pointer C ABI (the literal reading of BASELINE configs[1]), a batch with the PCIe copies inside the clock, the
@@ -669,6 +692,11 @@ def extras(lib, batch, torch, frames, streams, out, enc, dev, mpix, pitch, args)
             result["data_sweep"] = data_sweep(lib, batch, torch, frames, streams, out, dev, mpix, min(1024, frames.shape[0] // 2))
         except Exception as e:  # noqa: BLE001 -- an extra must not take the bench line with it
             result["data_sweep"] = {"error": repr(e)}
+    if frames.shape[0] >= 1024:
+        try:
+            result["near_lossless"] = near_lossless_row(lib, batch, torch, frames, streams, out, mpix, 1024)
+        except Exception as e:  # noqa: BLE001
+            result["near_lossless"] = {"error": repr(e)}
     # ---- one frame through the host-pointer C ABI (handle created inside the clock, as cli/benchmark.cpp does); the
     # batch-sized work areas go first: giving ~90 GB back to the driver takes seconds and is not part of coding a frame
     batch.release_work_areas(lib)
