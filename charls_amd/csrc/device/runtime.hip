@@ -336,14 +336,6 @@ size_t group_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
                                  : grp::workgroup_lds_bytes<uint8_t>(d.width, scans_per_wave, group_lines(d));
 }
 
-// Lanes per scan of the speed path (scan_group_decode.hip) for a launch of `count` scans; 0 = the one-scan-per-wavefront
-// kernel (scan_fast_decode.hip).  A wavefront stops for every event of every one of its scans (run mode, end of line,
-// refill), so the fewer scans share a wavefront the less a sample costs: 3.45 s for the 16.8 M samples of a 4096 x 4096 frame
-// with 2 scans per wavefront, 3.65 s with 4, 4.14 s with 8 (profiles/r03_decode_sweep_lanes_per_scan.txt).  Against that, the
-// chip clocks down once more than two of a CU's four SIMDs run this kernel (2.3 -> 1.8 GHz with all four busy, and not on
-// every run: 4096 frames with 4 scans per wavefront took 3.94 s in one sweep and 5.01 s in the next), so the scans are packed
-// as densely as it takes to stay at two wavefronts per CU, and no denser.
-// CHARLS_AMD_DECODE_GROUP overrides (0, 4, 8, 16, 32).
 // Lanes per scan (G) and wavefronts per workgroup (W) of the speed path (scan_group_decode.hip) for a launch of `count` scans;
 // lanes 0 = the one-scan-per-wavefront kernel (scan_fast_decode.hip).
 //
@@ -352,8 +344,10 @@ size_t group_lds_bytes(const ScanDesc& d, uint32_t scans_per_wave)
 // as the wavefront has a SIMD TO ITSELF: two wavefronts of this kernel on one SIMD take a third longer each (4.8 s instead of
 // 3.6 s for a frame's 16.8 M samples: profiles/r05_decode_wavefronts_per_workgroup.txt).  So the rule is one wavefront per
 // SIMD, and the fewest scans per wavefront that allows:
-//  * up to two wavefronts per CU, one-wavefront workgroups find a SIMD each (W = 1: rounds 2 - 4);
-//  * beyond that the dispatcher doubles one-wavefront workgroups up on some SIMDs while others idle -- not in every launch:
+//  * up to ONE wavefront per CU, one-wavefront workgroups (W = 1); with two per CU they still find a SIMD each, but a workgroup
+//    of four is 4 % faster there too (1024 frames at 32 lanes: 2.91 s against 3.03 s, round 6), so W = 1 beyond one per CU is
+//    left to the scans that have no W = 4 instantiation (several lines per pixel row);
+//  * beyond two per CU the dispatcher doubles one-wavefront workgroups up on some SIMDs while others idle -- not in every launch:
 //    1024 of them decoded 4096 frames in 3.67 s in one call and in 4.89 s in others, at an unchanged 2.39 GHz
 //    (profiles/r05_pmc_decode_effective_clock.txt; rounds 3 and 4 took the slow launches for the chip clocking down and never
 //    went beyond two wavefronts per CU).  A workgroup of FOUR wavefronts that takes the whole LDS of its CU is dealt out one

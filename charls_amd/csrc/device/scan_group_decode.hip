@@ -1,25 +1,25 @@
-// scan_group_decode.hip -- speed path of the scan decoder for lossless single-component scans: SEVERAL scans per wavefront.
+// scan_group_decode.hip -- speed path of the scan decoder for single-component and line-interleaved scans, lossless and
+// near-lossless: SEVERAL scans per wavefront.
 //
 // Decoding one scan is one dependency chain (bit position -> k -> context -> reconstructed sample, reference
 // src/scan_decoder_core.hpp:38-69), so the only parallelism is the number of scans in flight, and what a wavefront pays
-// per decoded sample is the number of instructions it has to issue (a wavefront issues at most one instruction every
-// four cycles).  scan_fast_decode.hip spends a whole 64-lane instruction on the value of ONE scan; here the 64 lanes are
-// split into groups of G lanes and every group decodes a scan of its own, so one instruction advances 64 / G scans:
+// per decoded sample is the number of instructions it has to issue (one wavefront issues one instruction every four to five
+// cycles: tools/microbench/issue_ceiling.hip).  scan_fast_decode.hip spends a whole 64-lane instruction on the value of ONE
+// scan; here the 64 lanes are split into groups of G lanes and every group decodes a scan of its own, so one instruction
+// advances 64 / G scans:
 //
-//   * all per-scan state (window of the previous line, Ra, bit position, producer state) lives in vector registers,
-//     replicated over the G lanes of the group; nothing is wave-uniform, there is no scalar chain;
-//   * control flow stays convergent for the whole wavefront: every step all groups decode one regular-mode sample
-//     under a per-lane predicate; a group that meets anything else (run mode, an escape or long code, the end of its
-//     line, an empty bit ring) raises an event, the wavefront leaves the step loop, and the event is handled once, out
-//     of line, under the predicate of the groups that raised it;
-//   * the G lanes of a group share the bulk work of their scan: un-stuffing 16 coded bytes per lane into the dense
-//     bit ring, run fills, and the 16-byte row stores of every finished line;
-//   * what all scans of the wavefront wait for is written for instruction count as well: a refill handles a lane's 16
-//     bytes as one 128-bit number (refill), a run of length 0 and its interruption sample -- three run events in four --
-//     come out of the registers the lane left the step loop with (the handler in front of the general one);
-//   * LDS per scan: 365 context records (8 B), two run contexts, a 1 KB dense bit ring and ONE line of samples = 8.1 KB
-//     for 4096 8-bit samples; with the gradient table the scans of a wavefront share, 33 KB per wavefront at G = 16, 76 KB
-//     at G = 8 (two wavefronts per CU: the launch rule of runtime.hip: decode_group_lanes).
+//   * all per-scan state (Ra, bit position, pointers into the line and into the prepared entries, producer state) lives in
+//     vector registers, replicated over the G lanes of the group; nothing is wave-uniform, there is no scalar chain;
+//   * control flow stays convergent for the whole wavefront: every step all groups decode one regular-mode sample; what is
+//     rare -- a context whose N has reached RESET, run mode, an unusual code -- is ONE mask looked at once per step, the
+//     frequent run events are served inside the loop under the EXEC mask of their lanes (scan_group_step.inc), and for the rest
+//     (an escape or long code, a long run, the end of a line, an empty bit ring) the wavefront leaves the step loop and the event
+//     is handled once, out of line, under the predicate of the groups that raised it;
+//   * the G lanes of a group share the bulk work of their scan: un-stuffing 16 coded bytes per lane into the dense bit ring
+//     (a lane's 16 bytes as one 128-bit number: refill), preparing what the steps need of the previous line 64 samples ahead
+//     (prepare), run fills, and the 16-byte row stores of every finished line;
+//   * LDS per scan: 365 context records (8 B), two run contexts, a 1 KB dense bit ring, 192 prepared entries (8 B) and ONE line
+//     of samples = 9.7 KB for 4096 8-bit samples (the launch rule: runtime.hip, decode_group_plan).
 //
 // Like scan_fast_decode.hip this is not a restatement of the reference's bit reader: a result is accepted only when the
 // scan ends cleanly (all samples decoded inside the entropy-coded segment, zero padding, marker next); everything else
@@ -428,14 +428,11 @@ JLS_DEV int take_unary(const uint32_t* ring, uint32_t& p, int most)
 
 } // namespace grp
 
-// Dynamic LDS: (64 / G) * grp::region_bytes<S>(width).  `count` scans, 64 / G of them per workgroup of one wavefront.
+// Dynamic LDS: grp::workgroup_lds_bytes<S>(width, scans per workgroup, NL).  `count` scans, 64 / G of them per wavefront.
 //
-// A lone wavefront issues one instruction every 4.3 - 5 cycles whatever its kind or dependences, and an LDS read returns
-// after 48 cycles, hidden by eleven independent instructions (profiles/r02_microbench_latency.txt).  A step of the loop
-// below therefore costs its instruction count, and the loop is written for that count: the window of the previous line
-// is one packed register that slides with v_alignbit, the two gradients that depend on the previous line only are
-// carried as T = 9 Q1 + Q2, sign handling is three multiply-adds with +-1, the RESET halving is a rarely taken block, and
-// what an event needs (run mode or an unusual code) is worked out after the loop from the state it leaves behind.
+// The step loop is written for its instruction count (scan_group_step.inc has the budget and what was measured): what a step
+// needs of the previous line comes prepared ({Rc | T << 16, Rb} per sample), sign handling is multiply-adds with +-1, and what
+// an event needs is worked out after the loop from the state it leaves behind.
 //
 // NL = 1: a single-component scan.  NL = 2..4: a LINE-INTERLEAVED scan of NL components (reference
 // src/scan_decoder_impl.hpp:62-129): the lines of a pixel row are coded one component after the other, each against the
