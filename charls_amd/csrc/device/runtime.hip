@@ -422,12 +422,11 @@ constexpr uint32_t kPixelWaves = 512; // wavefronts a launch of the pixel kernel
 int pixel_group_lanes(const ScanDesc& d, uint32_t count)
 {
     const bool by_sample = d.interleave_mode == 2 && d.components >= 2 && d.components <= 4;
-    // (near-lossless single-component scans and line-interleaved scans of three components have decode_scans_group<.., kNear>
-    // since round 6; NEAR_DECODE_PIXELS=1 brings them back here: the A/B)
+    // (near-lossless single-component and line-interleaved scans have decode_scans_group<.., kNear> since round 6;
+    // NEAR_DECODE_PIXELS=1 brings them back here: the A/B)
     const bool near_here = knobs::get_or(knobs::kNearDecodePixels, 0) != 0;
     const bool near_planar = d.interleave_mode == 0 && d.components == 1 && d.near_lossless != 0 && near_here;
-    const bool near_by_line = d.interleave_mode == 1 && d.components >= 2 && d.components <= 4 && d.near_lossless != 0 &&
-                              (near_here || d.components != 3);
+    const bool near_by_line = d.interleave_mode == 1 && d.components >= 2 && d.components <= 4 && d.near_lossless != 0 && near_here;
     if ((!by_sample && !near_planar && !near_by_line) || !wave_decode_eligible(d))
         return 0;
     if (by_sample && d.bits_per_sample > 8 && ((reinterpret_cast<uintptr_t>(d.pixels) | d.pixel_stride) & 1u) != 0)
@@ -460,7 +459,7 @@ bool fast_decode_eligible(const ScanDesc& d)
     const bool by_line = d.interleave_mode == 1 && d.components >= 2 && d.components <= 4; // group kernel only
     // (near-lossless scans: the group kernel only)
     const bool near_ok = d.near_lossless == 0 ||
-                         (knobs::get_or(knobs::kNearDecodePixels, 0) == 0 && (planar || d.components == 3) && decode_group_lanes(d, 1) != 0);
+                         (knobs::get_or(knobs::kNearDecodePixels, 0) == 0 && decode_group_lanes(d, 1) != 0);
     return wave_decode_eligible(d) && near_ok && (planar || by_line) &&
            ((planar && fast_decode_lds(d) <= kMaxDynamicLds) || decode_group_lanes(d, 1) != 0) &&
            knobs::get_or(knobs::kExactDecoder, 0) == 0;
@@ -732,13 +731,15 @@ void launch_decode_plain(const ScanDesc& proto, const ScanDesc* d_descs, ScanRes
     } while (0)
         const bool wide = proto.bits_per_sample > 8;
         if (proto.near_lossless != 0)
-        { // near-lossless: single-component scans or three lines per pixel row (fast_decode_eligible), 8 / 16 / 32 lanes
+        { // near-lossless: 8 / 16 / 32 lanes
             const uint32_t nl = group_lines(proto);
 #define JLS_LAUNCH_NEAR(S, G, W)                                                                                         \
     do                                                                                                                   \
     {                                                                                                                    \
         if (nl == 1) JLS_LAUNCH_GROUP_NWK(S, G, 1, W, true);                                                             \
-        else JLS_LAUNCH_GROUP_NWK(S, G, 3, 1, true);                                                                     \
+        else if (nl == 2) JLS_LAUNCH_GROUP_NWK(S, G, 2, 1, true);                                                        \
+        else if (nl == 3) JLS_LAUNCH_GROUP_NWK(S, G, 3, 1, true);                                                        \
+        else JLS_LAUNCH_GROUP_NWK(S, G, 4, 1, true);                                                                     \
     } while (0)
             if (wg_waves == 4 && group == 16)
             {

@@ -138,10 +138,10 @@ int emu_decode_scans_group(const jls::ScanDesc* descs, jls::ScanResult* results,
     do                                                                                                                                    \
     {                                                                                                                                     \
         if (nl == 1) emu::launch(jls::decode_scans_group<S, G, 1, 1, true>, grid, dim3(64), lds, descs, results, (uint32_t)count);        \
-        else emu::launch(jls::decode_scans_group<S, G, 3, 1, true>, grid, dim3(64), lds, descs, results, (uint32_t)count);                \
+        else if (nl == 2) emu::launch(jls::decode_scans_group<S, G, 2, 1, true>, grid, dim3(64), lds, descs, results, (uint32_t)count);   \
+        else if (nl == 3) emu::launch(jls::decode_scans_group<S, G, 3, 1, true>, grid, dim3(64), lds, descs, results, (uint32_t)count);   \
+        else emu::launch(jls::decode_scans_group<S, G, 4, 1, true>, grid, dim3(64), lds, descs, results, (uint32_t)count);                \
     } while (0)
-        if (nl != 1 && nl != 3)
-            return -1;
         if (group == 8)
         {
             if (wide) EMU_GROUP_NEAR(uint16_t, 8); else EMU_GROUP_NEAR(uint8_t, 8);

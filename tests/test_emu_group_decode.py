@@ -335,13 +335,14 @@ def test_group_decoder_near_lossless_batches(group, w, h, bits, near, kind, coun
         assert outs[f].tobytes() == wants[f], f
 
 
-@pytest.mark.parametrize("group,w,h,bits,near,kind,count", _rotating(NEAR_GROUPS, [(40, 12, 8, 2, "mixed", 5), (300, 4, 8, 3, "noise", 3),
-                                                                                    (33, 7, 16, 5, "mixed", 3), (64, 6, 8, 1, "gradient", 3)]))
-def test_group_decoder_near_lossless_line_interleaved(group, w, h, bits, near, kind, count):
-    """Three lines per pixel row (ILV_LINE) of near-lossless components on the ONE set of contexts."""
+@pytest.mark.parametrize("group,w,h,bits,near,kind,count,comps", _rotating(NEAR_GROUPS, [(40, 12, 8, 2, "mixed", 5, 3), (300, 4, 8, 3, "noise", 3, 3),
+                                                                                          (33, 7, 16, 5, "mixed", 3, 3), (64, 6, 8, 1, "gradient", 3, 3),
+                                                                                          (50, 9, 8, 2, "mixed", 3, 2), (70, 5, 12, 4, "mixed", 3, 4)]))
+def test_group_decoder_near_lossless_line_interleaved(group, w, h, bits, near, kind, count, comps):
+    """Two to four lines per pixel row (ILV_LINE) of near-lossless components on the ONE set of contexts."""
     L = emu_bind.lib()
-    frames = [synth.frame_numpy(w, h, seed=19 * f + bits + near, bits=bits, components=3, kind=kind, interleaved=True) for f in range(count)]
-    descs, outs, wants, ends, keep = _near_descs(frames, w, h, bits, near, comps=3, ilv=1)
+    frames = [synth.frame_numpy(w, h, seed=19 * f + bits + near, bits=bits, components=comps, kind=kind, interleaved=True) for f in range(count)]
+    descs, outs, wants, ends, keep = _near_descs(frames, w, h, bits, near, comps=comps, ilv=1)
     res = _launch(L, descs, group)
     for f in range(count):
         assert (res[f].errc, res[f].flags, res[f].bytes) == (0, 0, ends[f]), f

@@ -448,3 +448,27 @@ def test_run_service_of_the_step_loop_against_the_exact_decoder(torch, knobs, gr
     assert (errcs == 0).all() and torch.equal(out, exact)
     got = out.cpu().numpy().view(host.dtype).astype(np.int64)
     assert np.abs(got - host.astype(np.int64)).max() <= near  # tolerance = NEAR, per ISO 14495-1 (0: lossless)
+
+
+@pytest.mark.parametrize("comps,bits,near", [(2, 8, 2), (3, 8, 3), (4, 8, 1), (3, 12, 2), (2, 16, 5)])
+def test_near_lossless_line_interleaved_scans_on_the_group_kernel(torch, knobs, comps, bits, near):
+    """Near-lossless ILV_LINE scans of two to four components decode on decode_scans_group<.., NL, 1, kNear> (round 6; before: the
+    pixel kernels): the speed path hands nothing to the exact decoder, agrees with it and with the oracle, and stays within NEAR."""
+    host = np.stack([synth.frame_numpy(129, 33, seed=7 * f + comps, bits=bits, components=comps, kind="mixed", interleaved=True) for f in range(6)])
+    frames = torch.from_numpy(host.view(np.int16) if bits > 8 else host).to("cuda:0")
+    enc = batch.encode_batch(frames, bits_per_sample=bits, component_count=comps, interleave_mode=1, near_lossless=near)
+    assert (enc.errcs == 0).all()
+    before = capi.engine_counters().get("exact_retry_scans", 0)
+    out = torch.zeros_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, out)
+    assert (errcs == 0).all()
+    assert capi.engine_counters().get("exact_retry_scans", 0) == before
+    knobs.set("EXACT_DECODER", 1)
+    exact = torch.zeros_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, exact)
+    assert (errcs == 0).all() and torch.equal(out, exact)
+    first = enc.streams[0, :int(enc.sizes[0])].cpu().numpy().tobytes()
+    assert first == ob.encode(host[0], width=129, height=33, bits_per_sample=bits, component_count=comps, interleave_mode=1, near_lossless=near)
+    assert out[0].cpu().numpy().tobytes() == ob.decode(first)[1].tobytes()
+    got = out.cpu().numpy().view(host.dtype).astype(np.int64)
+    assert np.abs(got - host.astype(np.int64)).max() <= near  # tolerance = NEAR, per ISO 14495-1
