@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -286,6 +287,14 @@ def load_product() -> CharLSLibrary:
             raise RuntimeError(
                 f"{PRODUCT_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). charls_amd has no CPU fallback.")
+        if "torch" not in sys.modules:
+            # torch brings a HIP runtime of its own under the SONAME this library links (/opt/rocm's libamdhip64); the one
+            # that is loaded first serves both, and torch does not find its device on the other one.  Every Python user of
+            # this binding (tests, bench, tools) uses torch for device memory sooner or later: it goes first.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         _product = CharLSLibrary(PRODUCT_LIB)
     return _product
 
