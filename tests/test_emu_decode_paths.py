@@ -1,6 +1,6 @@
 """Which paths of scan_group_decode.hip a decode takes (CPU harness with the kernel's path counters on, tests/emu/
-emu_profile_driver.cpp): the rewritten refill and the register-only run handler must be the paths that run on ordinary
-streams, with the byte-by-byte refill and the general handler left for what they are kept for.  Test infrastructure only."""
+emu_profile_driver.cpp): the 128-bit refill and the run service of the step loop must be the paths that run on ordinary
+streams, with the byte-by-byte refill and the handlers behind the loop left for what they are kept for.  Test infrastructure only."""
 import ctypes as C
 import os
 import subprocess
