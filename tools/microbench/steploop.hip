@@ -17,16 +17,18 @@
 #define UPDATE_FIRST JLS_STEP_ORDER_UPDATE_FIRST
 #define PREDICTOR_LATE JLS_STEP_ORDER_PREDICTOR_LATE
 // one step per trip: the one copy requests the next entry into its own pair (the predictor has to come before the request)
+#define RARE(SFX, ENEXT) JLS_STEP_RARE(SFX, "ds_read_u8", "ds_write_b8", "1", ENEXT, JLS_RUN_WHICH_LOSSLESS, JLS_RUN_RECON_LOSSLESS)
 #define LOOP1(ORDER, STORES, KSEEN)                                                                                               \
     JLS_STEP_PROLOGUE JLS_STEP_BODY_X("a", "s_branch L_stepa%=\n", "v118", "v119", "v[118:119]", "BYTE_0", "1",                   \
-                                      ORDER("BYTE_0", "1", "", "v118", "v119"), STORES, "", " offset:255", "", "", "", KSEEN)        \
-        JLS_STEP_RARE("a", "ds_read_u8", "1") JLS_STEP_EPILOGUE("")
+                                      ORDER("BYTE_0", "1", "", "v118", "v119"), STORES, "", " offset:255", "", "", "", KSEEN,       \
+                                      JLS_STEP_LOSSLESS)                                                                           \
+        RARE("a", "v[118:119]") JLS_STEP_EPILOGUE("")
 #define LOOP2(ORDER, STORES, KSEEN)                                                                                               \
     JLS_STEP_PROLOGUE JLS_STEP_BODY_X("a", "", "v118", "v119", "v[106:107]", "BYTE_0", "1", ORDER("BYTE_0", "1", "", "v118", "v119"), \
-                                      STORES, "", " offset:255", "", "", "", KSEEN)                                                 \
+                                      STORES, "", " offset:255", "", "", "", KSEEN, JLS_STEP_LOSSLESS)                              \
         JLS_STEP_BODY_X("b", "s_branch L_stepa%=\n", "v106", "v107", "v[118:119]", "BYTE_0", "1",                                  \
-                        ORDER("BYTE_0", "1", "", "v106", "v107"), STORES, "", " offset:255", "", "", "", KSEEN)                      \
-            JLS_STEP_RARE("a", "ds_read_u8", "1") JLS_STEP_RARE("b", "ds_read_u8", "1") JLS_STEP_EPILOGUE("")
+                        ORDER("BYTE_0", "1", "", "v106", "v107"), STORES, "", " offset:255", "", "", "", KSEEN, JLS_STEP_LOSSLESS)   \
+            RARE("a", "v[106:107]") RARE("b", "v[118:119]") JLS_STEP_EPILOGUE("")
 #define NO_STORES "", "1", "", "0"
 
 #define STEPLOOP_NAME_0 "one step per trip, both stores early"
@@ -47,7 +49,7 @@
 #define STEPLOOP_TEXT_7 LOOP2(PREDICTOR_LATE, JLS_STEP_STORES_LATE("ds_write_b8"), JLS_STEP_KSEEN)
 #define STEPLOOP_VARIANTS 8
 
-constexpr uint32_t kRegion = 9744, kRecords = 0, kRing = 2960, kPrep = 3992, kLine = 5568, kLut = 512;
+constexpr uint32_t kRegion = 9744, kRecords = 0, kRun = 2928, kRing = 2976, kPrep = 4008, kLine = 5584, kLut = 512;
 constexpr int kBurst = 60;
 
 __device__ __forceinline__ uint64_t now()
@@ -99,7 +101,8 @@ __device__ int quantize(int d)
         const uint32_t line_address = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(region + kLine);             \
         int a = 100, u_a = 0, u_n1 = 2, u_tb = 0, u_cc = 0;                                                                       \
         uint32_t p = 0, u1 = 0, k_last = 0, k_seen = 0, qsu8 = 0, win_now = 0, where = records_address + 365 * 8;                 \
-        const uint32_t limit_v = 23, reset_v = 64;                                                                                \
+        const uint32_t limit_v = 23, cfg_v = 22u | (8u << 8) | (64u << 16); /* escape_base | qbpp << 8 | RESET << 16 */           \
+        const uint32_t run_ctx_address = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(region + kRun);           \
         const int maxval_s = 255;                                                                                                 \
         int run_index = 0;                                                                                                        \
         const unsigned long long in_line_m = ~0ull;                                                                               \
@@ -115,9 +118,8 @@ __device__ int quantize(int d)
                            [un1] "+v"(u_n1), [utb] "+v"(u_tb), [cc] "+v"(u_cc), [u1] "+v"(u1), [k] "+v"(k_last),                   \
                            [kseen] "+v"(k_seen), [qsu] "+v"(qsu8), [win] "+v"(win_now), [cnt] "+s"(count), [fail] "=&s"(fail_m),    \
                            [ri] "+v"(run_index)                                                                                   \
-                         : [ring] "v"(ring_address), [recbase] "v"(records_address), [limitv] "v"(limit_v), [vreset] "v"(reset_v), \
-                           [inl] "s"(in_line_m), [smax] "s"(maxval_s), [rctx] "v"(records_address), [esc] "v"(limit_v),           \
-                           [qbpp] "v"(reset_v)                                                                                     \
+                         : [ring] "v"(ring_address), [recbase] "v"(records_address), [limitv] "v"(limit_v), [cfg] "v"(cfg_v),     \
+                           [inl] "s"(in_line_m), [smax] "s"(maxval_s), [rctx] "v"(run_ctx_address), [gl] "n"(16)                   \
                          : JLS_STEP_LOOP_CLOBBERS);                                                                                             \
             failed |= fail_m;                                                                                                     \
         }                                                                                                                         \
