@@ -3,7 +3,8 @@
 // trip, ...; round 6's first form and its ablations: tools/microbench/steploop_variants.py at commit 2de007a,
 // profiles/r06_steploop_v1_ablation.txt), with the
 // product's launch shape -- four wavefronts per workgroup (one per SIMD), four scans per wavefront, the product's LDS layout.
-// Not part of the product.  Build: see steploop_variants.py.  Run: tools/microbench/build/steploop [workgroups]
+// Not part of the product.  Build: hipcc --offload-arch=gfx950 -O2 -Icharls_amd/csrc/device tools/microbench/steploop.hip -o tools/microbench/build/steploop
+// Run: tools/microbench/build/steploop [workgroups]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
