@@ -621,7 +621,8 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
         // A wavefront whose scans are all inside a line with their bit rings filled needs nothing before its next steps but their
         // entries, and one whose scans all decoded to the end of the step loop nothing behind it: most rounds are such rounds (one
         // in 54 steps on the bench's frames, ~ 2000 cycles each), and they pay ONE test where the blocks below pay one each.
-        const bool look = !__all(phase == kInLine && (src.ended || src.produced - p >= kMarginBits));
+        // (Scans that are through -- or lane groups without a scan -- do not count, as long as one scan is still inside a line.)
+        const bool look = !__all(phase == kDone || (phase == kInLine && (src.ended || src.produced - p >= kMarginBits)));
         // ---- producer: keep kMarginBits ahead of the consumer; scans that finished their samples look for the marker
         {
             const uint32_t ahead = src.produced - p;
@@ -986,7 +987,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
         const bool in_run = stopped && qs8 == 0 && !retry;
         const bool slow = stopped && qs8 != 0 && !retry;
         // (nothing stopped, no line ended, nothing to hand back: the next round)
-        if (__all(in_line && !stopped && !retry && i <= width && !(kChecked && a_seen >= (1u << 24))))
+        if (in_line_m != 0 && __all(phase == kDone || (in_line && !stopped && !retry && i <= width && !(kChecked && a_seen >= (1u << 24)))))
             continue;
 
         // ---- run mode: reference src/scan_decoder_impl.hpp:264-337, src/scan_decoder_core.hpp:72-100
