@@ -26,7 +26,8 @@ lib = capi.load_product()
 
 shapes = [(64, 64, 8, 1, 0, 0, 0), (300, 200, 8, 1, 0, 0, 0), (1024, 768, 8, 1, 0, 0, 0), (2048, 512, 8, 1, 0, 0, 0), (4096, 64, 8, 1, 0, 0, 0),
           (200, 144, 16, 1, 0, 0, 0), (640, 480, 12, 1, 0, 0, 0), (160, 120, 8, 3, 2, 0, 1), (256, 128, 8, 3, 1, 0, 0), (128, 96, 8, 3, 0, 0, 0),
-          (256, 128, 8, 1, 0, 2, 0), (200, 100, 8, 3, 2, 3, 0), (9000, 3, 8, 1, 0, 0, 0)]
+          (256, 128, 8, 1, 0, 2, 0), (200, 100, 8, 3, 2, 3, 0), (9000, 3, 8, 1, 0, 0, 0), (333, 77, 8, 3, 1, 2, 0), (640, 100, 12, 1, 0, 3, 0),
+          (512, 64, 8, 4, 1, 1, 0)]
 cases = []
 for i, (w, h, bits, comps, ilv, near, ct) in enumerate(shapes):
     for v in range(2):
