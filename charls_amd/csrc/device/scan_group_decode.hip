@@ -911,7 +911,7 @@ __global__ void __launch_bounds__(64 * W) decode_scans_group(const ScanDesc* __r
                 ticker = tick(ticker, in_line_m, ok_m);
             } while (ticker != 0);
 #else
-            // The same loop, written out for gfx950: 73 instructions per step for 8-bit samples (the compiler's rendering of the
+            // The same loop, written out for gfx950: 72 instructions per step for 8-bit samples (the compiler's rendering of the
             // C++ above: 88), scheduled by hand so that the three LDS round trips of the chain (Q3 <- the gradient table,
             // the context record, and before them the prepared entry, which is requested one step ahead) are covered by the
             // previous step's context update, the bit window and the predictor.  Lanes outside their line are switched off
