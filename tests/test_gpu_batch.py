@@ -472,3 +472,17 @@ def test_near_lossless_line_interleaved_scans_on_the_group_kernel(torch, knobs, 
     assert out[0].cpu().numpy().tobytes() == ob.decode(first)[1].tobytes()
     got = out.cpu().numpy().view(host.dtype).astype(np.int64)
     assert np.abs(got - host.astype(np.int64)).max() <= near  # tolerance = NEAR, per ISO 14495-1
+
+
+def test_near_lossless_decode_knob_keeps_the_pixel_kernels_alive(torch, knobs):
+    """NEAR_DECODE_PIXELS=1 (the A/B of round 6): near-lossless single-component scans back on decode_pixels_group -- same pixels."""
+    frames = synth.frames_torch(5, 300, 40, seed0=21, kind="mixed", device="cuda:0")
+    enc = batch.encode_batch(frames, near_lossless=3)
+    a = torch.zeros_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, a)
+    assert (errcs == 0).all()
+    knobs.set("NEAR_DECODE_PIXELS", 1)
+    b = torch.zeros_like(frames)
+    _, errcs, _ = batch.decode_batch(enc.streams, enc.sizes, b)
+    assert (errcs == 0).all() and torch.equal(a, b)
+    assert int((a.to(torch.int16) - frames.to(torch.int16)).abs().max()) <= 3  # tolerance = NEAR

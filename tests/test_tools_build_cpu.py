@@ -19,3 +19,10 @@ def test_microbenchmarks_compile(source, tmp_path):
     out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O2", "-I" + os.path.join(common.ROOT, "charls_amd", "csrc", "device"), "-c", src,
                           "-o", str(tmp_path / "probe.o")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
+
+
+def test_design_tables_tool_reads_the_committed_profiles():
+    out = subprocess.run([os.environ.get("PYTHON", "python"), os.path.join(common.ROOT, "tools", "design_tables.py"), "r06"], capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "| `value` |" in out.stdout and "### 6.3" in out.stdout and "near-lossless gray (6)" in out.stdout
